@@ -1,0 +1,122 @@
+/* include/asg_hip.h -- C ABI of libasg_hip.so: the MI355X (gfx950) ASG forward-backward hot path.
+ *
+ * Drop-in boundary for the native layer of zh217/torch-asg.  The reference binds its native code
+ * through a pybind11 module `torch_asg_native` with seven functions
+ * (/root/reference/torch_asg/native/extension.cpp:15-29); each entry point below names the one it
+ * replaces.  Differences from the reference ABI, by design:
+ *   - plain C: raw DEVICE pointers, explicit element strides, explicit sizes, explicit stream;
+ *     no torch / ATen / pybind types anywhere;
+ *   - the CALLER owns every buffer (state, scratch, outputs); the library never allocates device
+ *     memory and never touches the thread's current stream;
+ *   - no path_contrib tensors: the O(T*B*N*N) buffer of fully_connected_lattice.cpp:77 is never
+ *     materialised -- the saved state is O(T*B*(N+S));
+ *   - returns an int status (0 = ok) instead of throwing.
+ *
+ * All device pointers must be valid on the current HIP device.  Lengths/targets are int64
+ * (the reference asserts kLong: utils.cpp:28,46).  `dtype` selects float32 / float64 for every
+ * floating-point buffer of the call (utils.h:33-39 dispatch).
+ */
+#ifndef ASG_HIP_H
+#define ASG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ASG_HIP_VERSION 100
+
+#define ASG_DTYPE_F32 0
+#define ASG_DTYPE_F64 1
+
+/* status codes */
+#define ASG_OK 0
+#define ASG_ERR_INVALID 1       /* null pointer / bad dtype / negative size */
+#define ASG_ERR_UNSUPPORTED 2   /* shape outside what this build supports */
+#define ASG_ERR_WORKSPACE 3     /* state/scratch buffer too small */
+#define ASG_ERR_HIP_BASE 1000   /* 1000 + hipError_t */
+
+/* flags */
+#define ASG_FLAG_STREAMS 1          /* run the full-lattice and force-aligned passes on two HIP streams
+                                       (the reference's multi-stream route, streamlined_fast_gpu.cpp:104-230);
+                                       without it everything is issued on `stream` in order
+                                       (= ASGLoss(gpu_no_stream_impl=True), asg.py:124) */
+#define ASG_FLAG_SINGLE_LAUNCH 2    /* all four recursions in ONE kernel launch (blockIdx.y = pass) */
+#define ASG_FLAG_MATVEC_READLANE 4  /* tuning: broadcast the previous frame with v_readlane instead of LDS */
+#define ASG_FLAG_ALPHA_SCORES 8     /* debugging: forward also writes the scores obtained from the alpha passes
+                                       into full_scores[B..2B) / aligned_scores[B..2B) */
+
+/* One batch of utterances, as the reference's ASGLoss.forward receives it (asg.py:109). */
+typedef struct asg_problem {
+    const void *inputs;            /* [T,B,N] emissions (time-major), element strides below       */
+    int64_t inputs_strides[3];
+    const void *transition;        /* [N,N]; transition[i][j] = score of going from label j to i  */
+    int64_t transition_strides[2];
+    const int64_t *targets;        /* [B,S] int64                                                  */
+    int64_t targets_strides[2];
+    const int64_t *input_lengths;  /* [B] int64, or NULL = all T   (asg.py:116-117)               */
+    const int64_t *target_lengths; /* [B] int64, or NULL = all S   (asg.py:113-114)               */
+    int64_t T, B, N, S;
+    int32_t dtype;                 /* ASG_DTYPE_*                                                  */
+    int32_t reserved;
+} asg_problem;
+
+/* Opaque per-module context: side stream + events for ASG_FLAG_STREAMS. Not thread-safe: use one
+ * per calling thread/module (the reference keeps none: it borrows streams from the CUDA stream pool,
+ * streamlined_fast_gpu.cpp:121-129). */
+typedef struct asg_ctx asg_ctx;
+
+int asg_hip_version(void);
+const char *asg_hip_strerror(int status);
+
+int asg_ctx_create(asg_ctx **out);
+int asg_ctx_destroy(asg_ctx *ctx);
+
+/* Bytes of saved lattice state (forward -> backward) and of backward scratch for a problem shape.
+ * Only T,B,N,S,dtype of `p` are read. */
+size_t asg_state_bytes(const asg_problem *p);
+size_t asg_scratch_bytes(const asg_problem *p);
+
+/* ---- granular entry points: the reference's "serial" route (asg.py:124-128) ------------------- */
+
+/* replaces torch_asg_native.fully_connected_forward (extension.cpp:16, fully_connected_lattice.cpp:65-91):
+ * alpha+beta recursions of the fully-connected lattice; scores[B] = S_full. */
+int asg_full_forward(const asg_problem *p, void *state, size_t state_bytes, void *scores, int flags, void *stream);
+
+/* replaces torch_asg_native.fully_connected_backward (extension.cpp:17, fully_connected_lattice.cpp:93-105):
+ * grad_transition[N,N], grad_inputs[T,B,N] (both contiguous, fully overwritten). */
+int asg_full_backward(const asg_problem *p, const void *state, size_t state_bytes, const void *grad_out,
+                      void *scratch, size_t scratch_bytes, void *grad_transition, void *grad_inputs, void *stream);
+
+/* replaces torch_asg_native.force_aligned_forward (extension.cpp:18, force_aligned_lattice.cpp:266-319). */
+int asg_aligned_forward(const asg_problem *p, void *state, size_t state_bytes, void *scores, int flags, void *stream);
+
+/* replaces torch_asg_native.force_aligned_backward (extension.cpp:19, force_aligned_lattice.cpp:321-356). */
+int asg_aligned_backward(const asg_problem *p, const void *state, size_t state_bytes, const void *grad_out,
+                         void *scratch, size_t scratch_bytes, void *grad_transition, void *grad_inputs, void *stream);
+
+/* ---- fused entry points: the reference's GPU fast route (asg.py:129-136) ---------------------- */
+
+/* replaces torch_asg_native.fast_asg_gpu_forward (extension.cpp:25, streamlined_fast_gpu.cpp:104-230):
+ * all four recursions; full_scores[B], aligned_scores[B] ([2B] each with ASG_FLAG_ALPHA_SCORES). */
+int asg_forward(asg_ctx *ctx, const asg_problem *p, void *state, size_t state_bytes,
+                void *full_scores, void *aligned_scores, int flags, void *stream);
+
+/* replaces torch_asg_native.fast_asg_gpu_forward_only (extension.cpp:23, streamlined_fast_gpu.cpp:24-94):
+ * beta recursions only, nothing saved.  `state` is only used as scratch by the large-alphabet path
+ * (N > 64: the normalised transition matrices live there); it may be NULL when N <= 64 and S <= 64. */
+int asg_forward_only(asg_ctx *ctx, const asg_problem *p, void *state, size_t state_bytes,
+                     void *full_scores, void *aligned_scores, int flags, void *stream);
+
+/* replaces torch_asg_native.fast_asg_gpu_backward (extension.cpp:27, streamlined_fast_gpu.cpp:236-297):
+ * non-recursive gradient assembly for loss-side gradients grad_full[B], grad_aligned[B]. */
+int asg_backward(asg_ctx *ctx, const asg_problem *p, const void *state, size_t state_bytes,
+                 const void *grad_full, const void *grad_aligned, void *scratch, size_t scratch_bytes,
+                 void *grad_transition, void *grad_inputs, int flags, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ASG_HIP_H */

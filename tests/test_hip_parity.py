@@ -1,0 +1,332 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against
+(a) golden fixtures from the real reference, (b) the CPU oracle on seeded random inputs,
+(c) the reference's own known-answer tests re-typed, (d) size-independent properties.
+
+Tolerance: max|x - ref| <= 1e-4 * max(1, max|ref|) in fp32 -- applied against the
+reference's fp64 results (the reference's own fp32 path is noisier than that at T=400);
+1e-9 in fp64.  Against the reference's fp32 fixtures the same rule plus the fixture's own fp32-vs-fp64 gap.
+"""
+import numpy as np
+import pytest
+import torch
+
+import util
+from oracle import asg_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+MODES = [dict(launch_mode="streams"), dict(launch_mode="single"), dict(launch_mode="serial"),
+         dict(gpu_no_stream_impl=True)]
+
+
+def _asg():
+    import torch_asg_amd
+    return torch_asg_amd
+
+
+def run_hip(x, tg, tr, il, tl, reduction, dtype=torch.float32, pass_lengths=True, **kw):
+    """x [T,B,N] (any strides, torch CPU), returns dict of numpy arrays."""
+    A = _asg()
+    N = tr.shape[0]
+    m = A.ASGLoss(N, reduction=reduction, **kw).to(DEV).to(dtype)
+    with torch.no_grad():
+        m.transition.copy_(torch.as_tensor(tr).to(dtype))
+    xd = torch.as_tensor(x).to(dtype).to(DEV).requires_grad_(True)
+    tgd = torch.as_tensor(tg).to(DEV)
+    if pass_lengths:
+        loss = m(xd, tgd, torch.as_tensor(il).to(DEV), torch.as_tensor(tl).to(DEV))
+    else:
+        loss = m(xd, tgd)
+    loss.sum().backward()
+    torch.cuda.synchronize()
+    return dict(loss=loss.detach().cpu().numpy(), grad_inputs=xd.grad.cpu().numpy(),
+                grad_transition=m.transition.grad.cpu().numpy())
+
+
+# ------------------------------------------------------------------ golden, small + edge cases
+@pytest.mark.parametrize("name", util.SMALL)
+@pytest.mark.parametrize("mode", range(len(MODES)))
+def test_golden_small_f32(name, mode):
+    g = util.load(name)
+    r = run_hip(g["inputs"], g["targets"], g["transition"], g["input_lengths"], g["target_lengths"],
+                str(g["reduction"]), torch.float32, bool(g["pass_lengths"]), **MODES[mode])
+    for k in ("loss", "grad_inputs", "grad_transition"):
+        util.assert_close(r[k], g["f64_" + k], 1e-4, "%s/%s vs ref f64" % (name, k))
+        util.assert_close(r[k], g["f32_" + k], 1e-4, "%s/%s vs ref f32" % (name, k))
+    assert not np.isnan(r["grad_inputs"]).any() and not np.isnan(r["grad_transition"]).any()
+
+
+@pytest.mark.parametrize("name", util.SMALL)
+def test_golden_small_f64(name):
+    g = util.load(name)
+    r = run_hip(g["inputs"], g["targets"], g["transition"], g["input_lengths"], g["target_lengths"],
+                str(g["reduction"]), torch.float64, bool(g["pass_lengths"]))
+    for k in ("loss", "grad_inputs", "grad_transition"):
+        util.assert_close(r[k], g["f64_" + k], 1e-9, "%s/%s" % (name, k))
+
+
+def test_noncontiguous_inputs():
+    # permuted [B,T,N] view as in /root/reference/torch_asg/test/test_asg.py:454
+    g = util.load("edge_noncontig")
+    xb = torch.from_numpy(g["inputs"]).permute(1, 0, 2).contiguous()     # [B,T,N]
+    A = _asg()
+    m = A.ASGLoss(g["transition"].shape[0], reduction="none").to(DEV)
+    with torch.no_grad():
+        m.transition.copy_(torch.from_numpy(g["transition"]))
+    xo = xb.to(DEV).requires_grad_(True)
+    x = xo.permute(1, 0, 2)
+    assert not x.is_contiguous()
+    loss = m(x, torch.from_numpy(g["targets"]).to(DEV), torch.from_numpy(g["input_lengths"]).to(DEV),
+             torch.from_numpy(g["target_lengths"]).to(DEV))
+    loss.sum().backward()
+    util.assert_close(loss.detach().cpu().numpy(), g["f64_loss"], 1e-4, "loss")
+    util.assert_close(xo.grad.permute(1, 0, 2).cpu().numpy(), g["f64_grad_inputs"], 1e-4, "gin")
+    util.assert_close(m.transition.grad.cpu().numpy(), g["f64_grad_transition"], 1e-4, "gtr")
+
+
+# ------------------------------------------------------------------ golden, BASELINE configs
+@pytest.mark.parametrize("name", ["cfg2", "cfg2_var", "cfg3", "cfg3_var"])
+@pytest.mark.parametrize("mode", [0, 1, 3])
+def test_golden_configs_f32(name, mode):
+    g = util.load(name)
+    tr, x, tg, il, tl = util.synth(int(g["T"]), int(g["B"]), int(g["N"]), int(g["L"]), int(g["seed"]),
+                                   bool(g["variable"]))
+    assert abs(float(x.double().sum()) - float(g["inputs_checksum"])) < 1e-6
+    r = run_hip(x, tg, tr, il, tl, str(g["reduction"]), torch.float32, **MODES[mode])
+    checks = [("loss", r["loss"], "loss"), ("grad_transition", r["grad_transition"], "grad_transition"),
+              ("grad_inputs_sample", r["grad_inputs"][::7, ::3, :], "grad_inputs_sample"),
+              ("grad_inputs_sum_t", r["grad_inputs"].sum(0), "grad_inputs_sum_t")]
+    for what, val, key in checks:
+        # hard gate: within 1e-4 (magnitude-relative) of the reference's fp64 answer
+        util.assert_close(val, g["f64_" + key], 1e-4, "%s/%s vs ref f64" % (name, what))
+        # vs the reference's fp32 answer: 1e-4 plus the reference's own fp32 noise on this quantity
+        ok, noise = util.tol_ok(g["f32_" + key], g["f64_" + key], np.inf)
+        util.assert_close(val, g["f32_" + key], 1e-4 + noise, "%s/%s vs ref f32" % (name, what))
+
+
+@pytest.mark.parametrize("name", ["cfg2_var", "cfg3_var"])
+def test_golden_configs_f64(name):
+    g = util.load(name)
+    tr, x, tg, il, tl = util.synth(int(g["T"]), int(g["B"]), int(g["N"]), int(g["L"]), int(g["seed"]),
+                                   bool(g["variable"]), torch.float64)
+    r = run_hip(x, tg, tr, il, tl, "mean", torch.float64)
+    util.assert_close(r["loss"], g["f64_loss"], 1e-10, "loss")
+    util.assert_close(r["grad_transition"], g["f64_grad_transition"], 1e-9, "gtr")
+    util.assert_close(r["grad_inputs"][::7, ::3, :], g["f64_grad_inputs_sample"], 1e-9, "gin")
+
+
+# ------------------------------------------------------------------ random shapes vs the oracle
+@pytest.mark.parametrize("seed", range(12))
+def test_random_vs_oracle(seed):
+    rng = np.random.default_rng(100 + seed)
+    T = int(rng.integers(1, 70))
+    B = int(rng.integers(1, 9))
+    N = int(rng.integers(1, 65))
+    L = int(rng.integers(1, min(64, T) + 1))
+    tr, x, tg, _, _ = util.synth(T, B, N, L, seed)
+    il = rng.integers(1, T + 1, B)
+    tl = np.minimum(rng.integers(1, L + 1, B), il)
+    red = ["mean", "sum", "none"][seed % 3]
+    o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il, tl, red)
+    r = run_hip(x, tg, tr, il, tl, red, torch.float32, **MODES[seed % len(MODES)])
+    for k in ("loss", "grad_inputs", "grad_transition"):
+        util.assert_close(r[k], o[k], 1e-4, "seed%d/%s T%d B%d N%d L%d" % (seed, k, T, B, N, L))
+
+
+@pytest.mark.parametrize("N", [1, 2, 8, 9, 16, 17, 31, 33, 40, 47, 49, 57, 64])
+def test_every_alphabet_tile(N):
+    T, B, L = 23, 3, min(7, 23)
+    tr, x, tg, il, tl = util.synth(T, B, N, L, N, True)
+    o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il.numpy(), tl.numpy(), "sum")
+    r = run_hip(x, tg, tr, il, tl, "sum")
+    for k in ("loss", "grad_inputs", "grad_transition"):
+        util.assert_close(r[k], o[k], 1e-4, "N%d/%s" % (N, k))
+
+
+def test_alpha_and_beta_scores_agree_and_matvec_variants():
+    A = _asg()
+    from torch_asg_amd import _lib
+    tr, x, tg, il, tl = util.synth(150, 16, 30, 20, 0, True)
+    o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il.numpy(), tl.numpy(), "none",
+                     need_grad=False)
+    be = A.asg.native()
+    outs = []
+    for extra in (0, _lib.FLAG_MATVEC_READLANE):
+        full, ali, _ = be.forward(x.to(DEV), tg.to(DEV), tr.to(DEV), il.to(DEV), tl.to(DEV),
+                                  _lib.FLAG_ALPHA_SCORES | extra)
+        full, ali = full.cpu().numpy(), ali.cpu().numpy()
+        B = 16
+        util.assert_close(full[:B], o["full_scores"], 1e-5, "full beta")
+        util.assert_close(full[B:], o["full_scores"], 1e-5, "full alpha")
+        util.assert_close(ali[:B], o["aligned_scores"], 1e-5, "aligned beta")
+        util.assert_close(ali[B:], o["aligned_scores"], 1e-5, "aligned alpha")
+        outs.append((full, ali))
+    util.assert_close(outs[0][0], outs[1][0], 1e-6, "matvec variants")
+
+
+# ------------------------------------------------------------------ routes
+def test_forward_only_and_eval_routes():
+    A = _asg()
+    tr, x, tg, il, tl = util.synth(60, 5, 21, 9, 3, True)
+    ref = run_hip(x, tg, tr, il, tl, "none")["loss"]
+    for kw, train in ((dict(forward_only=True), True), (dict(), False)):
+        m = A.ASGLoss(21, reduction="none", **kw).to(DEV)
+        with torch.no_grad():
+            m.transition.copy_(tr)
+        m.train(train)
+        out = m(x.to(DEV).requires_grad_(True), tg.to(DEV), il.to(DEV), tl.to(DEV))
+        assert not out.requires_grad            # no backward support on this route (asg.py:66-68)
+        util.assert_close(out.cpu().numpy(), ref, 1e-6, "forward-only")
+
+
+def test_fcc_fac_functions_direct():
+    # the reference's tests call FCC / FAC directly with CPU length tensors (test_asg.py:67,219)
+    A = _asg()
+    tr, x, tg, il, tl = util.synth(20, 4, 11, 6, 5, True)
+    o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il.numpy(), tl.numpy(), "none")
+    xd = x.to(DEV).requires_grad_(True)
+    trd = tr.to(DEV).requires_grad_(True)
+    full = A.FCC.apply(trd, xd, tg.to(DEV), il, tl)
+    ali = A.FAC.apply(trd, xd, tg.to(DEV), il, tl)
+    util.assert_close(full.detach().cpu().numpy(), o["full_scores"], 1e-5, "FCC")
+    util.assert_close(ali.detach().cpu().numpy(), o["aligned_scores"], 1e-5, "FAC")
+    (full - ali).sum().backward()
+    util.assert_close(xd.grad.cpu().numpy(), o["grad_inputs"], 1e-4, "gin")
+    util.assert_close(trd.grad.cpu().numpy(), o["grad_transition"], 1e-4, "gtr")
+    # each Function alone returns exactly its own part
+    xd2 = x.to(DEV).requires_grad_(True)
+    A.FCC.apply(tr.to(DEV), xd2, tg.to(DEV), il, tl).sum().backward()
+    util.assert_close(xd2.grad.cpu().numpy(), o["grad_inputs_full"], 1e-4, "gin full only")
+    xd3 = x.to(DEV).requires_grad_(True)
+    (-A.FAC.apply(tr.to(DEV), xd3, tg.to(DEV), il, tl)).sum().backward()
+    util.assert_close(xd3.grad.cpu().numpy(), o["grad_inputs_aligned"], 1e-4, "gin aligned only")
+
+
+def test_determinism_and_mode_equality():
+    tr, x, tg, il, tl = util.synth(150, 16, 30, 20, 0, True)
+    base = run_hip(x, tg, tr, il, tl, "mean")
+    again = run_hip(x, tg, tr, il, tl, "mean")
+    for k in base:
+        assert np.array_equal(base[k], again[k]), "run-to-run " + k
+    for kw in MODES[1:]:
+        r = run_hip(x, tg, tr, il, tl, "mean", **kw)
+        for k in base:
+            assert np.array_equal(base[k], r[k]), "%s differs in mode %s" % (k, kw)
+
+
+def test_transition_grad_accumulates_like_a_parameter():
+    A = _asg()
+    tr, x, tg, il, tl = util.synth(12, 3, 6, 4, 1, True)
+    m = A.ASGLoss(6).to(DEV)
+    with torch.no_grad():
+        m.transition.copy_(tr)
+    m(x.to(DEV), tg.to(DEV), il.to(DEV), tl.to(DEV)).backward()
+    g1 = m.transition.grad.clone()
+    m(x.to(DEV), tg.to(DEV), il.to(DEV), tl.to(DEV)).backward()
+    assert torch.allclose(m.transition.grad, 2 * g1, rtol=1e-6, atol=1e-7)
+    assert "transition" in m.state_dict()
+
+
+# ------------------------------------------------------------------ reference's own tests, re-typed
+def test_reference_known_answers_on_gpu():
+    import math
+    import test_oracle as to
+    A = _asg()
+    xb, tg, il, tl, loss, gi, gt = to.ASG4()
+    for dtype, tol in ((torch.float64, 1e-4), (torch.float32, 1e-4)):
+        xo = torch.from_numpy(xb).to(dtype).to(DEV).requires_grad_(True)
+        m = A.ASGLoss(6, reduction="none").to(DEV).to(dtype)
+        out = m(xo.permute(1, 0, 2), torch.from_numpy(tg).to(DEV), torch.from_numpy(il).to(DEV),
+                torch.from_numpy(tl).to(DEV))
+        out.sum().backward()
+        assert (out.detach().cpu().double().numpy() - loss).__abs__().sum() < 1e-3       # test_asg.py:462
+        assert np.abs(xo.grad.cpu().double().numpy() - gi).max() < tol                      # :463
+        assert np.abs(m.transition.grad.cpu().double().numpy() - gt).max() < tol            # :464
+    # test_asg_2 (:324-351): log 32 ; test_fac_2 (:227-254): -log 32 ; test_fcc_3 (:100-128): S_full = 0
+    x = torch.full((3, 1, 4), math.log(0.25), dtype=torch.float64, device=DEV)
+    m = A.ASGLoss(4).to(DEV).double()
+    assert abs(float(m(x, torch.tensor([[0, 1]], device=DEV), torch.tensor([3]), torch.tensor([2]))) - math.log(32.0)) < 1e-10
+    s = A.FAC.apply(torch.zeros(4, 4, dtype=torch.float64, device=DEV), x, torch.tensor([[0, 1]], device=DEV),
+                    torch.tensor([3]), torch.tensor([2]))
+    assert abs(float(s) + math.log(32.0)) < 1e-10
+    g = torch.Generator().manual_seed(0)
+    p = torch.rand(3, 300, 40, generator=g)
+    xx = torch.log(p / p.sum(-1, keepdim=True)).permute(1, 0, 2).to(DEV)
+    s = A.FCC.apply(torch.zeros(40, 40, device=DEV), xx, torch.zeros(3, 50, dtype=torch.long, device=DEV),
+                    torch.tensor([300] * 3), torch.tensor([50] * 3))
+    assert float(s.abs().sum()) < 1e-4
+
+
+def test_truncation_and_determinism_asg_3():
+    # test_asg.py:354-376: S=4 > T=3 exercises asg.py:119-122; same call twice -> same loss
+    import math
+    A = _asg()
+    x = torch.full((3, 1, 4), math.log(0.25), device=DEV)
+    tg = torch.tensor([[0, 1, 1, 1]], device=DEV)
+    m = A.ASGLoss(4).to(DEV)
+    l1 = m(x, tg, torch.tensor([3], device=DEV), torch.tensor([4], device=DEV))
+    l2 = m(x, tg, torch.tensor([3], device=DEV), torch.tensor([4], device=DEV))
+    assert float((l1 - l2).abs()) < 1e-10 and math.isfinite(float(l1))
+
+
+def test_gradcheck_fp64_on_gpu():
+    # test_asg.py:131-186,257-288 re-run on the device fp64 kernels
+    from torch.autograd import gradcheck
+    A = _asg()
+    g = torch.Generator().manual_seed(7)
+    T, B, N, S = 6, 2, 5, 3
+    x = torch.randn(T, B, N, generator=g, dtype=torch.float64).to(DEV).requires_grad_(True)
+    tr = torch.rand(N, N, generator=g, dtype=torch.float64).to(DEV).requires_grad_(True)
+    tg = torch.randint(0, N, (B, S), generator=g).to(DEV)
+    il, tl = torch.tensor([6, 4]), torch.tensor([3, 2])
+    assert gradcheck(lambda a, b: A.FCC.apply(b, a, tg, il, tl).sum(), (x, tr))
+    assert gradcheck(lambda a, b: A.FAC.apply(b, a, tg, il, tl).sum(), (x, tr))
+    assert gradcheck(lambda a, b: torch.stack(A.ASGGPUFast.apply(a, b, tg, il.to(DEV), tl.to(DEV))).sum(0), (x, tr))
+
+
+# ------------------------------------------------------------------ error behaviour
+def test_error_behaviour():
+    A = _asg()
+    m = A.ASGLoss(4)
+    with pytest.raises(RuntimeError):                       # CPU tensors: no fallback
+        m(torch.randn(3, 1, 4), torch.zeros(1, 2, dtype=torch.long))
+    m = m.to(DEV)
+    x = torch.randn(3, 1, 4, device=DEV)
+    with pytest.raises(RuntimeError, match="Long"):         # int32 lengths (utils.cpp:28,46)
+        m(x, torch.zeros(1, 2, dtype=torch.long, device=DEV), torch.tensor([3], dtype=torch.int32),
+          torch.tensor([2], dtype=torch.int32))
+    with pytest.raises(RuntimeError):                       # fp16 unsupported
+        m.half()(x.half(), torch.zeros(1, 2, dtype=torch.long, device=DEV))
+
+
+# ------------------------------------------------------------------ properties at full size
+def test_cfg3_properties():
+    tr, x, tg, il, tl = util.synth(400, 64, 40, 30, 0, True)
+    r = run_hip(x, tg, tr, il, tl, "sum")
+    gi = r["grad_inputs"]
+    ilv = il.numpy()
+    for b in range(64):
+        assert np.all(gi[ilv[b]:, b, :] == 0), "padded frames must have exactly-zero grads"
+        assert np.abs(gi[:ilv[b], b, :].sum(-1)).max() < 2e-5, "posteriors of full and aligned cancel per frame"
+    assert abs(r["grad_transition"].astype(np.float64).sum()) <= 1e-5 * np.abs(r["grad_transition"]).sum()
+    assert np.isfinite(r["loss"]).all()
+
+
+def test_cfg4_shard_equals_whole():
+    # cfg 4: B=512 = 8 shards of 64; sharded sum of grads == unsharded
+    A = _asg()
+    T, B, N, L = 400, 128, 40, 30
+    tr, x, tg, il, tl = util.synth(T, B, N, L, 2, True)
+    whole = run_hip(x, tg, tr, il, tl, "sum")
+    acc = np.zeros((N, N), np.float64)
+    loss = 0.0
+    for r in range(4):
+        xs, tgs, ils, tls = A.shard_batch(x, tg, il, tl, r, 4)
+        part = run_hip(xs, tgs, tr, ils, tls, "sum")
+        acc += part["grad_transition"]
+        loss += float(part["loss"])
+        lo, hi = r * 32, (r + 1) * 32
+        assert np.array_equal(part["grad_inputs"], whole["grad_inputs"][:, lo:hi])
+    util.assert_close(acc, whole["grad_transition"], 1e-5, "sharded gtr")
+    assert abs(loss - float(whole["loss"])) < 1e-4 * abs(float(whole["loss"]))

@@ -1,0 +1,70 @@
+"""ctypes binding of libasg_hip.so (C ABI: include/asg_hip.h).
+
+There is NO fallback: if the HIP library is missing or fails to load, importing this module's
+`lib()` raises.  The product path never routes through oracle/ or any CPU implementation.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libasg_hip.so")
+
+ASG_DTYPE_F32, ASG_DTYPE_F64 = 0, 1
+FLAG_STREAMS, FLAG_SINGLE_LAUNCH, FLAG_MATVEC_READLANE, FLAG_ALPHA_SCORES = 1, 2, 4, 8
+
+# every symbol include/asg_hip.h declares
+SYMBOLS = ["asg_hip_version", "asg_hip_strerror", "asg_ctx_create", "asg_ctx_destroy", "asg_state_bytes",
+           "asg_scratch_bytes", "asg_full_forward", "asg_full_backward", "asg_aligned_forward",
+           "asg_aligned_backward", "asg_forward", "asg_forward_only", "asg_backward"]
+
+
+class AsgProblem(ctypes.Structure):
+    _fields_ = [("inputs", ctypes.c_void_p), ("inputs_strides", ctypes.c_int64 * 3),
+                ("transition", ctypes.c_void_p), ("transition_strides", ctypes.c_int64 * 2),
+                ("targets", ctypes.c_void_p), ("targets_strides", ctypes.c_int64 * 2),
+                ("input_lengths", ctypes.c_void_p), ("target_lengths", ctypes.c_void_p),
+                ("T", ctypes.c_int64), ("B", ctypes.c_int64), ("N", ctypes.c_int64), ("S", ctypes.c_int64),
+                ("dtype", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+_LIB = None
+
+
+def lib():
+    """Load libasg_hip.so once; fail loudly if it is not there."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "torch_asg_amd: %s not found. Build it with `python torch_asg_amd/csrc/build.py` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+    pp = ctypes.POINTER(AsgProblem)
+    L.asg_hip_version.restype = ci
+    L.asg_hip_strerror.restype = ctypes.c_char_p
+    L.asg_hip_strerror.argtypes = [ci]
+    L.asg_ctx_create.argtypes = [ctypes.POINTER(vp)]
+    L.asg_ctx_destroy.argtypes = [vp]
+    L.asg_state_bytes.restype = sz
+    L.asg_state_bytes.argtypes = [pp]
+    L.asg_scratch_bytes.restype = sz
+    L.asg_scratch_bytes.argtypes = [pp]
+    L.asg_full_forward.argtypes = [pp, vp, sz, vp, ci, vp]
+    L.asg_aligned_forward.argtypes = [pp, vp, sz, vp, ci, vp]
+    L.asg_full_backward.argtypes = [pp, vp, sz, vp, vp, sz, vp, vp, vp]
+    L.asg_aligned_backward.argtypes = [pp, vp, sz, vp, vp, sz, vp, vp, vp]
+    L.asg_forward.argtypes = [vp, pp, vp, sz, vp, vp, ci, vp]
+    L.asg_forward_only.argtypes = [vp, pp, vp, sz, vp, vp, ci, vp]
+    L.asg_backward.argtypes = [vp, pp, vp, sz, vp, vp, vp, sz, vp, vp, ci, vp]
+    for name in SYMBOLS:
+        getattr(L, name)
+    _LIB = L
+    return L
+
+
+def check(status, what):
+    if status != 0:
+        msg = lib().asg_hip_strerror(int(status)).decode()
+        raise RuntimeError("torch_asg_amd: %s failed: %s (status %d)" % (what, msg, status))

@@ -1,0 +1,330 @@
+"""ASGLoss / autograd surface for the MI355X-native ASG hot path.
+
+Mirrors the reference's Python interface (/root/reference/torch_asg/asg.py) so it is a drop-in:
+
+    ASGLoss(num_labels, reduction='mean', forward_only=False, gpu_no_stream_impl=False)   asg.py:100-107
+    .forward(inputs[T,B,N], targets[B,S], input_lengths=None, target_lengths=None)        asg.py:109-142
+    .transition : nn.Parameter[N,N], zero-initialised, transition[i,j] = score of j -> i  asg.py:105
+    FCC, FAC, ASGGPUFast, ASGGPUFastForwardOnly autograd Functions                         asg.py:7-97
+    (same argument orders, same (grad_transition, grad_inputs, None...) return conventions)
+
+All numerical work happens in hand-written HIP kernels behind the C ABI of include/asg_hip.h.
+CPU tensors are rejected: this package has no CPU fallback by design.
+"""
+import ctypes
+
+import torch
+import torch.autograd
+import torch.nn as nn
+
+from . import _lib
+
+
+class HipBackend:
+    """Thin tensor <-> C-ABI adapter.  Every method launches HIP kernels on the current stream."""
+
+    def __init__(self):
+        self._ctx = {}
+
+    # -- helpers ---------------------------------------------------------------------------
+    @staticmethod
+    def _check(inputs, transition, targets, input_lengths, target_lengths):
+        if not inputs.is_cuda:
+            raise RuntimeError("torch_asg_amd: inputs must live on a ROCm device (got %s); "
+                               "there is no CPU implementation in this package" % inputs.device)
+        if inputs.dtype not in (torch.float32, torch.float64):
+            raise RuntimeError("torch_asg_amd: expected scalar type Float or Double but found %s" % inputs.dtype)
+        if inputs.dim() != 3:
+            raise RuntimeError("torch_asg_amd: inputs must be [T,B,N]")
+        if transition.dtype != inputs.dtype or transition.device != inputs.device:
+            raise RuntimeError("torch_asg_amd: transition must have the dtype/device of inputs")
+        N = inputs.shape[2]
+        if tuple(transition.shape) != (N, N):
+            raise RuntimeError("torch_asg_amd: transition must be [%d,%d]" % (N, N))
+        for name, t in (("targets", targets), ("input_lengths", input_lengths), ("target_lengths", target_lengths)):
+            if t is not None and t.dtype != torch.int64:
+                # the reference asserts kLong (utils.cpp:28,46) and uses accessor<int64_t>
+                raise RuntimeError("torch_asg_amd: expected scalar type Long but found %s for %s" % (t.dtype, name))
+
+    @staticmethod
+    def _problem(inputs, transition, targets, input_lengths, target_lengths):
+        T, B, N = inputs.shape
+        dev = inputs.device
+        p = _lib.AsgProblem()
+        p.inputs = inputs.data_ptr()
+        p.inputs_strides[:] = list(inputs.stride())
+        p.transition = transition.data_ptr()
+        p.transition_strides[:] = list(transition.stride())
+        keep = [inputs, transition]
+        if targets is not None:
+            targets = targets.to(dev, non_blocking=True)
+            p.targets = targets.data_ptr()
+            p.targets_strides[:] = list(targets.stride())
+            p.S = targets.shape[1]
+            keep.append(targets)
+        else:
+            p.targets = None
+            p.S = 1
+        for name, t in (("input_lengths", input_lengths), ("target_lengths", target_lengths)):
+            if t is not None:
+                t = t.to(dev, non_blocking=True).contiguous()
+                if t.shape != (B,):
+                    raise RuntimeError("torch_asg_amd: %s must have shape [%d]" % (name, B))
+                keep.append(t)
+                setattr(p, name, t.data_ptr())
+            else:
+                setattr(p, name, None)
+        p.T, p.B, p.N = T, B, N
+        p.dtype = _lib.ASG_DTYPE_F32 if inputs.dtype == torch.float32 else _lib.ASG_DTYPE_F64
+        return p, keep
+
+    def _context(self, device):
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        h = self._ctx.get(idx)
+        if h is None:
+            h = ctypes.c_void_p()
+            with torch.cuda.device(idx):
+                _lib.check(_lib.lib().asg_ctx_create(ctypes.byref(h)), "asg_ctx_create")
+            self._ctx[idx] = h
+        return h
+
+    @staticmethod
+    def _stream(device):
+        return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+    @staticmethod
+    def _buf(nbytes, device):
+        return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+    # -- granular (reference "serial" route) ---------------------------------------------------
+    def full_forward(self, inputs, transition, input_lengths, flags=0):
+        self._check(inputs, transition, None, input_lengths, None)
+        L = _lib.lib()
+        with torch.cuda.device(inputs.device):
+            p, keep = self._problem(inputs, transition, None, input_lengths, None)
+            state = self._buf(L.asg_state_bytes(ctypes.byref(p)), inputs.device)
+            scores = torch.empty(inputs.shape[1], dtype=inputs.dtype, device=inputs.device)
+            _lib.check(L.asg_full_forward(ctypes.byref(p), state.data_ptr(), state.numel(), scores.data_ptr(),
+                                          flags, self._stream(inputs.device)), "asg_full_forward")
+        return scores, state
+
+    def full_backward(self, state, grad_out, inputs, transition, input_lengths):
+        L = _lib.lib()
+        T, B, N = inputs.shape
+        with torch.cuda.device(inputs.device):
+            p, keep = self._problem(inputs, transition, None, input_lengths, None)
+            g = grad_out.to(inputs.dtype).contiguous()
+            scratch = self._buf(L.asg_scratch_bytes(ctypes.byref(p)), inputs.device)
+            gtr = torch.empty(N, N, dtype=inputs.dtype, device=inputs.device)
+            gin = torch.empty(T, B, N, dtype=inputs.dtype, device=inputs.device)
+            _lib.check(L.asg_full_backward(ctypes.byref(p), state.data_ptr(), state.numel(), g.data_ptr(),
+                                           scratch.data_ptr(), scratch.numel(), gtr.data_ptr(), gin.data_ptr(),
+                                           self._stream(inputs.device)), "asg_full_backward")
+        return gtr, gin
+
+    def aligned_forward(self, inputs, targets, transition, input_lengths, target_lengths, flags=0):
+        self._check(inputs, transition, targets, input_lengths, target_lengths)
+        L = _lib.lib()
+        with torch.cuda.device(inputs.device):
+            p, keep = self._problem(inputs, transition, targets, input_lengths, target_lengths)
+            state = self._buf(L.asg_state_bytes(ctypes.byref(p)), inputs.device)
+            scores = torch.empty(inputs.shape[1], dtype=inputs.dtype, device=inputs.device)
+            _lib.check(L.asg_aligned_forward(ctypes.byref(p), state.data_ptr(), state.numel(), scores.data_ptr(),
+                                             flags, self._stream(inputs.device)), "asg_aligned_forward")
+        return scores, state
+
+    def aligned_backward(self, state, grad_out, inputs, targets, transition, input_lengths, target_lengths):
+        L = _lib.lib()
+        T, B, N = inputs.shape
+        with torch.cuda.device(inputs.device):
+            p, keep = self._problem(inputs, transition, targets, input_lengths, target_lengths)
+            g = grad_out.to(inputs.dtype).contiguous()
+            scratch = self._buf(L.asg_scratch_bytes(ctypes.byref(p)), inputs.device)
+            gtr = torch.empty(N, N, dtype=inputs.dtype, device=inputs.device)
+            gin = torch.empty(T, B, N, dtype=inputs.dtype, device=inputs.device)
+            _lib.check(L.asg_aligned_backward(ctypes.byref(p), state.data_ptr(), state.numel(), g.data_ptr(),
+                                              scratch.data_ptr(), scratch.numel(), gtr.data_ptr(), gin.data_ptr(),
+                                              self._stream(inputs.device)), "asg_aligned_backward")
+        return gtr, gin
+
+    # -- fused (reference GPU fast route) --------------------------------------------------------
+    def forward(self, inputs, targets, transition, input_lengths, target_lengths, flags=_lib.FLAG_STREAMS):
+        self._check(inputs, transition, targets, input_lengths, target_lengths)
+        L = _lib.lib()
+        B = inputs.shape[1]
+        k = 2 if flags & _lib.FLAG_ALPHA_SCORES else 1
+        with torch.cuda.device(inputs.device):
+            p, keep = self._problem(inputs, transition, targets, input_lengths, target_lengths)
+            state = self._buf(L.asg_state_bytes(ctypes.byref(p)), inputs.device)
+            scores = torch.empty(2, k * B, dtype=inputs.dtype, device=inputs.device)
+            _lib.check(L.asg_forward(self._context(inputs.device), ctypes.byref(p), state.data_ptr(), state.numel(),
+                                     scores[0].data_ptr(), scores[1].data_ptr(), flags,
+                                     self._stream(inputs.device)), "asg_forward")
+        return scores[0], scores[1], state
+
+    def forward_only(self, inputs, targets, transition, input_lengths, target_lengths, flags=_lib.FLAG_STREAMS):
+        self._check(inputs, transition, targets, input_lengths, target_lengths)
+        L = _lib.lib()
+        T, B, N = inputs.shape
+        with torch.cuda.device(inputs.device):
+            p, keep = self._problem(inputs, transition, targets, input_lengths, target_lengths)
+            state = None
+            if N > 64 or p.S > 64:
+                state = self._buf(L.asg_state_bytes(ctypes.byref(p)), inputs.device)
+            scores = torch.empty(2, B, dtype=inputs.dtype, device=inputs.device)
+            _lib.check(L.asg_forward_only(self._context(inputs.device), ctypes.byref(p),
+                                          state.data_ptr() if state is not None else None,
+                                          state.numel() if state is not None else 0,
+                                          scores[0].data_ptr(), scores[1].data_ptr(), flags,
+                                          self._stream(inputs.device)), "asg_forward_only")
+        return scores[0], scores[1]
+
+    def backward(self, state, grad_full, grad_aligned, inputs, targets, transition, input_lengths, target_lengths,
+                 flags=0):
+        L = _lib.lib()
+        T, B, N = inputs.shape
+        with torch.cuda.device(inputs.device):
+            p, keep = self._problem(inputs, transition, targets, input_lengths, target_lengths)
+            g = torch.stack([grad_full.to(inputs.dtype), grad_aligned.to(inputs.dtype)]).contiguous()
+            scratch = self._buf(L.asg_scratch_bytes(ctypes.byref(p)), inputs.device)
+            gtr = torch.empty(N, N, dtype=inputs.dtype, device=inputs.device)
+            gin = torch.empty(T, B, N, dtype=inputs.dtype, device=inputs.device)
+            _lib.check(L.asg_backward(self._context(inputs.device), ctypes.byref(p), state.data_ptr(), state.numel(),
+                                      g[0].data_ptr(), g[1].data_ptr(), scratch.data_ptr(), scratch.numel(),
+                                      gtr.data_ptr(), gin.data_ptr(), flags, self._stream(inputs.device)),
+                       "asg_backward")
+        return gtr, gin
+
+
+_backend = None
+
+
+def native():
+    """The native binding used by the autograd Functions (the HIP library; nothing else ships)."""
+    global _backend
+    if _backend is None:
+        _lib.lib()            # fail loudly here if libasg_hip.so is missing
+        _backend = HipBackend()
+    return _backend
+
+
+class FAC(torch.autograd.Function):
+    """Force-aligned lattice score S_aligned[b]; same signature as the reference's FAC (asg.py:7-34)."""
+
+    @staticmethod
+    def forward(ctx, transition, inputs, targets, input_lengths, target_lengths):
+        scores, state = native().aligned_forward(inputs, targets, transition, input_lengths, target_lengths)
+        ctx.save_for_backward(state, inputs, targets, input_lengths, target_lengths, transition)
+        return scores
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        state, inputs, targets, input_lengths, target_lengths, transition = ctx.saved_tensors
+        grad_transition, grad_inputs = native().aligned_backward(state, grad_out, inputs, targets, transition,
+                                                                 input_lengths, target_lengths)
+        return grad_transition, grad_inputs, None, None, None
+
+
+class FCC(torch.autograd.Function):
+    """Fully-connected lattice score S_full[b]; same signature as the reference's FCC (asg.py:37-55)."""
+
+    @staticmethod
+    def forward(ctx, transition, inputs, targets, input_lengths, target_lengths):
+        scores, state = native().full_forward(inputs, transition, input_lengths)
+        ctx.save_for_backward(state, inputs, input_lengths, transition)
+        return scores
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        state, inputs, input_lengths, transition = ctx.saved_tensors
+        grad_transition, grad_inputs = native().full_backward(state, grad_out, inputs, transition, input_lengths)
+        return grad_transition, grad_inputs, None, None, None
+
+
+class ASGGPUFastForwardOnly(torch.autograd.Function):
+    """beta-only evaluation route (asg.py:58-68): returns full - aligned, no gradient."""
+
+    @staticmethod
+    def forward(ctx, inputs, outputs, transition, input_lengths, output_lengths, flags=_lib.FLAG_STREAMS):
+        full, aligned = native().forward_only(inputs, outputs, transition, input_lengths, output_lengths, flags)
+        result = full - aligned
+        ctx.mark_non_differentiable(result)
+        return result
+
+    @staticmethod
+    def backward(ctx, *grad_outputs):
+        return None
+
+
+class ASGGPUFast(torch.autograd.Function):
+    """Fused training route (asg.py:71-97): (full_scores, aligned_scores), gradients assembled non-recursively."""
+
+    @staticmethod
+    def forward(ctx, inputs, transition, outputs, input_lengths, output_lengths, flags=_lib.FLAG_STREAMS):
+        full, aligned, state = native().forward(inputs, outputs, transition, input_lengths, output_lengths, flags)
+        ctx.save_for_backward(state, inputs, outputs, input_lengths, output_lengths, transition)
+        return full, aligned
+
+    @staticmethod
+    def backward(ctx, grad_full, grad_aligned):
+        state, inputs, outputs, input_lengths, output_lengths, transition = ctx.saved_tensors
+        grad_transition, grad_inputs = native().backward(state, grad_full, grad_aligned, inputs, outputs, transition,
+                                                         input_lengths, output_lengths)
+        return grad_inputs, grad_transition, None, None, None, None
+
+
+class ASGLoss(nn.Module):
+    """Auto Segmentation Criterion loss; constructor and forward signature as asg.py:100-142.
+
+    launch_mode (extra, optional): how the fused route issues the four recursions --
+      'streams' (default)  full-lattice and force-aligned passes overlapped on two HIP streams
+      'single'             one kernel launch, blockIdx.y = pass
+      'serial'             two launches on the caller's stream
+    gpu_no_stream_impl=True selects the reference's "serial" route: separate FAC and FCC Functions.
+    """
+
+    def __init__(self, num_labels, reduction='mean', forward_only=False, gpu_no_stream_impl=False,
+                 launch_mode='streams'):
+        super().__init__()
+        self.num_labels = num_labels
+        self.reduction = reduction  # mean, sum, none
+        self.transition = nn.Parameter(torch.zeros(num_labels, num_labels))
+        self.forward_only = forward_only
+        self.gpu_no_stream_impl = gpu_no_stream_impl
+        self.launch_mode = launch_mode
+
+    def _flags(self):
+        return {'streams': _lib.FLAG_STREAMS, 'single': _lib.FLAG_SINGLE_LAUNCH, 'serial': 0}[self.launch_mode]
+
+    def forward(self, inputs, targets, input_lengths=None, target_lengths=None):
+        batch_input_len, num_batches, num_labels = inputs.shape
+        _, batch_output_len = targets.shape
+
+        if target_lengths is None:                                   # asg.py:113-114
+            target_lengths = targets.new_full((num_batches,), batch_output_len)
+        if input_lengths is None:                                    # asg.py:116-117
+            input_lengths = target_lengths.new_full((num_batches,), batch_input_len)
+
+        if batch_output_len > batch_input_len:                       # asg.py:119-122
+            batch_output_len = batch_input_len
+            targets = targets[:, :batch_output_len]
+            target_lengths = torch.clamp(target_lengths, max=batch_output_len)
+
+        if self.gpu_no_stream_impl:
+            # the reference's "serial" route (asg.py:124-128)
+            fac_result = FAC.apply(self.transition, inputs, targets, input_lengths, target_lengths)
+            fcc_result = FCC.apply(self.transition, inputs, targets, input_lengths, target_lengths)
+            result = fcc_result - fac_result
+        elif self.forward_only or not self.training:
+            result = ASGGPUFastForwardOnly.apply(inputs, targets, self.transition, input_lengths, target_lengths,
+                                                 self._flags())
+        else:
+            full_scores, aligned_scores = ASGGPUFast.apply(inputs, self.transition, targets, input_lengths,
+                                                           target_lengths, self._flags())
+            result = full_scores - aligned_scores
+        if self.reduction == 'sum':
+            return result.sum()
+        elif self.reduction == 'mean':
+            return result.mean()
+        else:
+            return result

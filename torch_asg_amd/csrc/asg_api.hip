@@ -1,0 +1,324 @@
+// torch_asg_amd/csrc/asg_api.hip -- the C ABI declared in include/asg_hip.h.
+// Argument validation, state/scratch layout, path selection (small / generic), stream fork-join.
+// No torch, no pybind: plain HIP runtime calls only.
+#include "../../include/asg_hip.h"
+#include "asg_kernels.h"
+
+#include <hip/hip_runtime.h>
+#include <new>
+
+using namespace asg;
+
+struct asg_ctx {
+    hipStream_t side;
+    hipEvent_t fork, join;
+    int device;
+};
+
+namespace {
+
+inline int hip_status(hipError_t e) { return e == hipSuccess ? ASG_OK : ASG_ERR_HIP_BASE + (int) e; }
+
+inline size_t align_up(size_t x) { return (x + 255) & ~(size_t) 255; }
+
+struct Layout {
+    size_t ah, bh, msh, ab, bb, ehat, fhat, rmax, cmax, total;
+    int np4;
+};
+
+inline bool small_full(int64_t N) { return N <= 64; }
+inline bool small_aligned(int64_t S) { return S <= 64; }
+
+Layout make_layout(const asg_problem *p) {
+    Layout L{};
+    const size_t e = p->dtype == ASG_DTYPE_F64 ? 8 : 4;
+    const size_t T = p->T, B = p->B, N = p->N, S = p->S < 1 ? 1 : p->S;
+    size_t off = 0;
+    L.ah = off; off = align_up(off + B * T * N * e);
+    L.bh = off; off = align_up(off + B * T * N * e);
+    L.msh = off; off = align_up(off + B * T * e);
+    L.ab = off; off = align_up(off + B * T * S * e);
+    L.bb = off; off = align_up(off + B * T * S * e);
+    L.np4 = (int) ((N + 3) / 4 * 4);
+    if (!small_full(p->N)) {
+        L.ehat = off; off = align_up(off + N * L.np4 * e);
+        L.fhat = off; off = align_up(off + N * L.np4 * e);
+        L.rmax = off; off = align_up(off + N * e);
+        L.cmax = off; off = align_up(off + N * e);
+    }
+    L.total = off;
+    return L;
+}
+
+int check_problem(const asg_problem *p, bool need_targets) {
+    if (!p) return ASG_ERR_INVALID;
+    if (p->dtype != ASG_DTYPE_F32 && p->dtype != ASG_DTYPE_F64) return ASG_ERR_INVALID;
+    if (p->T < 1 || p->B < 1 || p->N < 1) return ASG_ERR_INVALID;
+    if (!p->inputs || !p->transition) return ASG_ERR_INVALID;
+    if (need_targets && (p->S < 1 || !p->targets)) return ASG_ERR_INVALID;
+    if (p->T > (1 << 30) || p->B > (1 << 30) || p->N > (1 << 30) || p->S > (1 << 30)) return ASG_ERR_UNSUPPORTED;
+    return ASG_OK;
+}
+
+Problem to_problem(const asg_problem *p) {
+    Problem P{};
+    P.inputs = p->inputs;
+    P.is0 = p->inputs_strides[0]; P.is1 = p->inputs_strides[1]; P.is2 = p->inputs_strides[2];
+    P.transition = p->transition;
+    P.ts0 = p->transition_strides[0]; P.ts1 = p->transition_strides[1];
+    P.targets = p->targets;
+    P.gs0 = p->targets_strides[0]; P.gs1 = p->targets_strides[1];
+    P.in_len = p->input_lengths;
+    P.tg_len = p->target_lengths;
+    P.T = (int) p->T; P.B = (int) p->B; P.N = (int) p->N; P.S = (int) (p->S < 1 ? 1 : p->S);
+    return P;
+}
+
+State to_state(const asg_problem *p, const void *state) {
+    Layout L = make_layout(p);
+    char *base = (char *) state;
+    State W{};
+    if (base) {
+        W.ah = base + L.ah; W.bh = base + L.bh; W.msh = base + L.msh; W.ab = base + L.ab; W.bb = base + L.bb;
+        if (!small_full(p->N)) {
+            W.ehat = base + L.ehat; W.fhat = base + L.fhat; W.rmax = base + L.rmax; W.cmax = base + L.cmax;
+        }
+    }
+    W.np4 = L.np4;
+    return W;
+}
+
+template <typename R>
+int run_forward(asg_ctx *ctx, const asg_problem *p, void *state, void *full_scores, void *aligned_scores,
+                int mask, bool store, int flags, hipStream_t stream) {
+    Problem P = to_problem(p);
+    State W = to_state(p, state);
+    FwdOut O{};
+    O.full_scores = full_scores;
+    O.aligned_scores = aligned_scores;
+    if ((flags & ASG_FLAG_ALPHA_SCORES) && store) {
+        if (full_scores) O.full_scores_alpha = (R *) full_scores + p->B;
+        if (aligned_scores) O.aligned_scores_alpha = (R *) aligned_scores + p->B;
+    }
+    const int mv = (flags & ASG_FLAG_MATVEC_READLANE) ? 1 : 0;
+    const int full_mask = mask & (kFullAlpha | kFullBeta);
+    const int ali_mask = mask & (kAlignedAlpha | kAlignedBeta);
+    const bool sf = small_full(p->N), sa = small_aligned(p->S);
+    if ((full_mask && !sf) || (ali_mask && !sa)) {
+        // generic path (any N / S up to 1024)
+        hipError_t e = hipSuccess;
+        if (full_mask && !sf) {
+            e = launch_prep_generic<R>(P, W, stream);
+            if (e != hipSuccess) return hip_status(e);
+        }
+        bool two = (flags & ASG_FLAG_STREAMS) && ctx && full_mask && ali_mask;
+        hipStream_t s2 = two ? ctx->side : stream;
+        if (two) {
+            if ((e = hipEventRecord(ctx->fork, stream)) != hipSuccess) return hip_status(e);
+            if ((e = hipStreamWaitEvent(s2, ctx->fork, 0)) != hipSuccess) return hip_status(e);
+        }
+        if (full_mask) {
+            e = sf ? launch_fwd_small<R>(P, W, O, full_mask, store, mv, stream)
+                   : launch_fwd_generic<R>(P, W, O, full_mask, store, stream);
+            if (e != hipSuccess) return hip_status(e);
+        }
+        if (ali_mask) {
+            e = sa ? launch_fwd_small<R>(P, W, O, ali_mask, store, mv, s2)
+                   : launch_fwd_generic<R>(P, W, O, ali_mask, store, s2);
+            if (e != hipSuccess) return hip_status(e);
+        }
+        if (two) {
+            if ((e = hipEventRecord(ctx->join, s2)) != hipSuccess) return hip_status(e);
+            if ((e = hipStreamWaitEvent(stream, ctx->join, 0)) != hipSuccess) return hip_status(e);
+        }
+        return ASG_OK;
+    }
+    hipError_t e;
+    if ((flags & ASG_FLAG_STREAMS) && ctx && full_mask && ali_mask) {
+        // fork: aligned passes on the side stream, full passes on the caller's stream; join back.
+        if ((e = hipEventRecord(ctx->fork, stream)) != hipSuccess) return hip_status(e);
+        if ((e = hipStreamWaitEvent(ctx->side, ctx->fork, 0)) != hipSuccess) return hip_status(e);
+        if ((e = launch_fwd_small<R>(P, W, O, full_mask, store, mv, stream)) != hipSuccess) return hip_status(e);
+        if ((e = launch_fwd_small<R>(P, W, O, ali_mask, store, mv, ctx->side)) != hipSuccess) return hip_status(e);
+        if ((e = hipEventRecord(ctx->join, ctx->side)) != hipSuccess) return hip_status(e);
+        if ((e = hipStreamWaitEvent(stream, ctx->join, 0)) != hipSuccess) return hip_status(e);
+        return ASG_OK;
+    }
+    if (flags & ASG_FLAG_SINGLE_LAUNCH) return hip_status(launch_fwd_small<R>(P, W, O, mask, store, mv, stream));
+    if (full_mask && (e = launch_fwd_small<R>(P, W, O, full_mask, store, mv, stream)) != hipSuccess) return hip_status(e);
+    if (ali_mask && (e = launch_fwd_small<R>(P, W, O, ali_mask, store, mv, stream)) != hipSuccess) return hip_status(e);
+    return ASG_OK;
+}
+
+template <typename R>
+int run_backward(const asg_problem *p, const void *state, const void *grad_full, const void *grad_aligned,
+                 void *scratch, size_t scratch_bytes, void *grad_transition, void *grad_inputs, int parts,
+                 hipStream_t stream) {
+    Problem P = to_problem(p);
+    State W = to_state(p, state);
+    BwdArgs A{};
+    A.grad_full = grad_full;
+    A.grad_aligned = grad_aligned;
+    A.grad_inputs = grad_inputs;
+    A.grad_transition = grad_transition;
+    A.scratch = scratch;
+    if (scratch_bytes < asg_scratch_bytes(p)) return ASG_ERR_WORKSPACE;
+    const bool sf = small_full(p->N), sa = small_aligned(p->S);
+    if (sf && (sa || !(parts & 2))) {
+        bwd_scratch_bytes_small((int) sizeof(R), P.T, P.B, P.N, P.S, &A.chunk, &A.nchunks);
+        return hip_status(launch_bwd_small<R>(P, W, A, parts, stream));
+    }
+    return hip_status(launch_bwd_generic<R>(P, W, A, parts, stream));
+}
+
+}  // namespace
+
+extern "C" {
+
+int asg_hip_version(void) { return ASG_HIP_VERSION; }
+
+const char *asg_hip_strerror(int status) {
+    switch (status) {
+        case ASG_OK: return "ok";
+        case ASG_ERR_INVALID: return "invalid argument";
+        case ASG_ERR_UNSUPPORTED: return "unsupported problem shape";
+        case ASG_ERR_WORKSPACE: return "state or scratch buffer too small";
+        default: break;
+    }
+    if (status >= ASG_ERR_HIP_BASE) return hipGetErrorString((hipError_t) (status - ASG_ERR_HIP_BASE));
+    return "unknown error";
+}
+
+int asg_ctx_create(asg_ctx **out) {
+    if (!out) return ASG_ERR_INVALID;
+    asg_ctx *c = new (std::nothrow) asg_ctx();
+    if (!c) return ASG_ERR_INVALID;
+    hipError_t e = hipGetDevice(&c->device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->join, hipEventDisableTiming);
+    if (e != hipSuccess) { delete c; return hip_status(e); }
+    *out = c;
+    return ASG_OK;
+}
+
+int asg_ctx_destroy(asg_ctx *c) {
+    if (!c) return ASG_OK;
+    hipEventDestroy(c->fork);
+    hipEventDestroy(c->join);
+    hipStreamDestroy(c->side);
+    delete c;
+    return ASG_OK;
+}
+
+size_t asg_state_bytes(const asg_problem *p) {
+    if (!p || p->T < 1 || p->B < 1 || p->N < 1) return 0;
+    asg_problem q = *p;
+    if (q.S < 1) q.S = 1;
+    return make_layout(&q).total;
+}
+
+size_t asg_scratch_bytes(const asg_problem *p) {
+    if (!p || p->T < 1 || p->B < 1 || p->N < 1) return 0;
+    const int e = p->dtype == ASG_DTYPE_F64 ? 8 : 4;
+    const int S = (int) (p->S < 1 ? 1 : p->S);
+    size_t a = 256;
+    if (small_full(p->N)) {
+        size_t s = bwd_scratch_bytes_small(e, (int) p->T, (int) p->B, (int) p->N, S, nullptr, nullptr);
+        if (s > a) a = s;
+    }
+    if (!small_full(p->N) || !small_aligned(S)) {
+        size_t s = bwd_scratch_bytes_generic(e, (int) p->T, (int) p->B, (int) p->N, S);
+        if (s > a) a = s;
+    }
+    return a;
+}
+
+#define ASG_DISPATCH(p, call_f32, call_f64) ((p)->dtype == ASG_DTYPE_F32 ? (call_f32) : (call_f64))
+
+int asg_full_forward(const asg_problem *p, void *state, size_t state_bytes, void *scores, int flags, void *stream) {
+    int rc = check_problem(p, false);
+    if (rc) return rc;
+    if (!state || !scores) return ASG_ERR_INVALID;
+    if (state_bytes < asg_state_bytes(p)) return ASG_ERR_WORKSPACE;
+    flags &= ~(ASG_FLAG_STREAMS | ASG_FLAG_SINGLE_LAUNCH);
+    return ASG_DISPATCH(p,
+        run_forward<float>(nullptr, p, state, scores, nullptr, kFullAlpha | kFullBeta, true, flags, (hipStream_t) stream),
+        run_forward<double>(nullptr, p, state, scores, nullptr, kFullAlpha | kFullBeta, true, flags, (hipStream_t) stream));
+}
+
+int asg_aligned_forward(const asg_problem *p, void *state, size_t state_bytes, void *scores, int flags, void *stream) {
+    int rc = check_problem(p, true);
+    if (rc) return rc;
+    if (!state || !scores) return ASG_ERR_INVALID;
+    if (state_bytes < asg_state_bytes(p)) return ASG_ERR_WORKSPACE;
+    flags &= ~(ASG_FLAG_STREAMS | ASG_FLAG_SINGLE_LAUNCH);
+    return ASG_DISPATCH(p,
+        run_forward<float>(nullptr, p, state, nullptr, scores, kAlignedAlpha | kAlignedBeta, true, flags, (hipStream_t) stream),
+        run_forward<double>(nullptr, p, state, nullptr, scores, kAlignedAlpha | kAlignedBeta, true, flags, (hipStream_t) stream));
+}
+
+int asg_full_backward(const asg_problem *p, const void *state, size_t state_bytes, const void *grad_out,
+                      void *scratch, size_t scratch_bytes, void *grad_transition, void *grad_inputs, void *stream) {
+    int rc = check_problem(p, false);
+    if (rc) return rc;
+    if (!state || !grad_out || !scratch || !grad_transition || !grad_inputs) return ASG_ERR_INVALID;
+    if (state_bytes < asg_state_bytes(p)) return ASG_ERR_WORKSPACE;
+    return ASG_DISPATCH(p,
+        run_backward<float>(p, state, grad_out, nullptr, scratch, scratch_bytes, grad_transition, grad_inputs, 1, (hipStream_t) stream),
+        run_backward<double>(p, state, grad_out, nullptr, scratch, scratch_bytes, grad_transition, grad_inputs, 1, (hipStream_t) stream));
+}
+
+int asg_aligned_backward(const asg_problem *p, const void *state, size_t state_bytes, const void *grad_out,
+                         void *scratch, size_t scratch_bytes, void *grad_transition, void *grad_inputs, void *stream) {
+    int rc = check_problem(p, true);
+    if (rc) return rc;
+    if (!state || !grad_out || !scratch || !grad_transition || !grad_inputs) return ASG_ERR_INVALID;
+    if (state_bytes < asg_state_bytes(p)) return ASG_ERR_WORKSPACE;
+    return ASG_DISPATCH(p,
+        run_backward<float>(p, state, nullptr, grad_out, scratch, scratch_bytes, grad_transition, grad_inputs, 2, (hipStream_t) stream),
+        run_backward<double>(p, state, nullptr, grad_out, scratch, scratch_bytes, grad_transition, grad_inputs, 2, (hipStream_t) stream));
+}
+
+int asg_forward(asg_ctx *ctx, const asg_problem *p, void *state, size_t state_bytes,
+                void *full_scores, void *aligned_scores, int flags, void *stream) {
+    int rc = check_problem(p, true);
+    if (rc) return rc;
+    if (!state || !full_scores || !aligned_scores) return ASG_ERR_INVALID;
+    if (state_bytes < asg_state_bytes(p)) return ASG_ERR_WORKSPACE;
+    return ASG_DISPATCH(p,
+        run_forward<float>(ctx, p, state, full_scores, aligned_scores, 15, true, flags, (hipStream_t) stream),
+        run_forward<double>(ctx, p, state, full_scores, aligned_scores, 15, true, flags, (hipStream_t) stream));
+}
+
+int asg_forward_only(asg_ctx *ctx, const asg_problem *p, void *state, size_t state_bytes,
+                     void *full_scores, void *aligned_scores, int flags, void *stream) {
+    int rc = check_problem(p, true);
+    if (rc) return rc;
+    if (!full_scores || !aligned_scores) return ASG_ERR_INVALID;
+    if (!small_full(p->N) || !small_aligned(p->S)) {
+        if (!state) return ASG_ERR_INVALID;
+        if (state_bytes < asg_state_bytes(p)) return ASG_ERR_WORKSPACE;
+    } else {
+        state = nullptr;
+    }
+    flags &= ~ASG_FLAG_ALPHA_SCORES;
+    return ASG_DISPATCH(p,
+        run_forward<float>(ctx, p, state, full_scores, aligned_scores, kFullBeta | kAlignedBeta, false, flags, (hipStream_t) stream),
+        run_forward<double>(ctx, p, state, full_scores, aligned_scores, kFullBeta | kAlignedBeta, false, flags, (hipStream_t) stream));
+}
+
+int asg_backward(asg_ctx *ctx, const asg_problem *p, const void *state, size_t state_bytes,
+                 const void *grad_full, const void *grad_aligned, void *scratch, size_t scratch_bytes,
+                 void *grad_transition, void *grad_inputs, int flags, void *stream) {
+    (void) ctx; (void) flags;
+    int rc = check_problem(p, true);
+    if (rc) return rc;
+    if (!state || !grad_full || !grad_aligned || !scratch || !grad_transition || !grad_inputs) return ASG_ERR_INVALID;
+    if (state_bytes < asg_state_bytes(p)) return ASG_ERR_WORKSPACE;
+    return ASG_DISPATCH(p,
+        run_backward<float>(p, state, grad_full, grad_aligned, scratch, scratch_bytes, grad_transition, grad_inputs, 3, (hipStream_t) stream),
+        run_backward<double>(p, state, grad_full, grad_aligned, scratch, scratch_bytes, grad_transition, grad_inputs, 3, (hipStream_t) stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,74 @@
+// torch_asg_amd/csrc/asg_kernels.h -- parameter blocks + launch prototypes shared by the
+// kernel translation units and the C-ABI (asg_api.hip).  Internal; the public surface is
+// include/asg_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace asg {
+
+// One ASG problem instance as the caller handed it over (device pointers, element strides).
+struct Problem {
+    const void *inputs;          // [T,B,N] emissions, any strides
+    int64_t is0, is1, is2;
+    const void *transition;      // [N,N], transition[i][j] = score of j -> i
+    int64_t ts0, ts1;
+    const int64_t *targets;      // [B,S]
+    int64_t gs0, gs1;
+    const int64_t *in_len;       // [B] or nullptr (= T)
+    const int64_t *tg_len;       // [B] or nullptr (= S)
+    int T, B, N, S;
+};
+
+// Saved lattice state (forward -> backward), all in log2 units and RELATIVE per frame.
+//   ah  [B][T][N]  full-lattice alpha-hat (max over labels == 0 per frame)
+//   bh  [B][T][N]  full-lattice beta-hat
+//   msh [B][T]     per-frame shift removed from alpha (needed to rebuild the row sums)
+//   ab  [B][T][S]  aligned alpha-bar,  bb [B][T][S] aligned beta-bar
+struct State {
+    void *ah, *bh, *msh, *ab, *bb;
+    // large-N path only: row/column-normalised exp2 of the transition matrix
+    void *ehat, *fhat, *rmax, *cmax;   // [N][NP4], [N][NP4], [N], [N]
+    int np4;
+};
+
+struct FwdOut {
+    void *full_scores;           // [B]  from the beta pass (as the reference: fully_connected_lattice.cpp:89)
+    void *aligned_scores;        // [B]  from the beta pass (force_aligned_lattice.cpp:316)
+    void *full_scores_alpha;     // [B] or nullptr: same score from the alpha pass (cross-check)
+    void *aligned_scores_alpha;  // [B] or nullptr
+};
+
+struct BwdArgs {
+    const void *grad_full;       // [B] d(loss)/d(full_scores)
+    const void *grad_aligned;    // [B] d(loss)/d(aligned_scores)
+    void *grad_inputs;           // [T,B,N] contiguous
+    void *grad_transition;       // [N,N] contiguous
+    void *scratch;               // partial tiles etc.
+    int chunk;                   // frames per workgroup (small path)
+    int nchunks;
+};
+
+enum ChainBits { kFullAlpha = 1, kFullBeta = 2, kAlignedAlpha = 4, kAlignedBeta = 8 };
+
+// ---- small path: N <= 64, S <= 64, one wavefront per chain -------------------------------
+// chain_mask selects which of the four recursions this launch runs.
+template <typename R>
+hipError_t launch_fwd_small(const Problem &P, const State &W, const FwdOut &O, int chain_mask, bool store,
+                            int matvec_variant, hipStream_t stream);
+template <typename R>
+hipError_t launch_bwd_small(const Problem &P, const State &W, const BwdArgs &A, int parts, hipStream_t stream);
+
+// ---- generic path: any N (p-vector in LDS), S <= 1024 ----------------------------------
+template <typename R>
+hipError_t launch_prep_generic(const Problem &P, const State &W, hipStream_t stream);
+template <typename R>
+hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O, int chain_mask, bool store,
+                              hipStream_t stream);
+template <typename R>
+hipError_t launch_bwd_generic(const Problem &P, const State &W, const BwdArgs &A, int parts, hipStream_t stream);
+
+size_t bwd_scratch_bytes_small(int elem, int T, int B, int N, int S, int *chunk, int *nchunks);
+size_t bwd_scratch_bytes_generic(int elem, int T, int B, int N, int S);
+
+}  // namespace asg

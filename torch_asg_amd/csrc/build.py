@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Build libasg_hip.so for gfx950 with hipcc (no torch headers, no cmake).
+
+    python torch_asg_amd/csrc/build.py [--force] [--verbose]
+
+Each .hip translation unit is compiled to an object in parallel, then linked into
+torch_asg_amd/csrc/libasg_hip.so (git-ignored; travels to the GPU box with the snapshot).
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SOURCES = ["asg_small.hip", "asg_generic.hip", "asg_api.hip"]
+HEADERS = ["asg_common.h", "asg_kernels.h", os.path.join("..", "..", "include", "asg_hip.h")]
+OUT = os.path.join(HERE, "libasg_hip.so")
+ARCH = os.environ.get("ASG_HIP_ARCH", "gfx950")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+CFLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
+          "-ffp-contract=off"]
+
+
+def _mtime(p):
+    return os.path.getmtime(p) if os.path.exists(p) else 0.0
+
+
+def build(force=False, verbose=False):
+    hdr_t = max(_mtime(os.path.join(HERE, h)) for h in HEADERS)
+    hdr_t = max(hdr_t, _mtime(__file__))
+    procs, objs = [], []
+    for s in SOURCES:
+        src = os.path.join(HERE, s)
+        obj = os.path.join(HERE, s.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _mtime(obj) < max(_mtime(src), hdr_t):
+            cmd = [HIPCC] + CFLAGS + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((s, subprocess.Popen(cmd)))
+    for s, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("hipcc failed on %s" % s)
+    if procs or not os.path.exists(OUT):
+        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", OUT] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv))
