@@ -209,10 +209,13 @@ def test_determinism_and_mode_equality():
     again = run_hip(x, tg, tr, il, tl, "mean")
     for k in base:
         assert np.array_equal(base[k], again[k]), "run-to-run " + k
-    for kw in MODES[1:]:
+    for kw in MODES[1:3]:     # same kernels, different launch arrangement: bit-identical
         r = run_hip(x, tg, tr, il, tl, "mean", **kw)
         for k in base:
             assert np.array_equal(base[k], r[k]), "%s differs in mode %s" % (k, kw)
+    r = run_hip(x, tg, tr, il, tl, "mean", **MODES[3])   # FCC + FAC summed by autograd: equal to rounding
+    for k in base:
+        util.assert_close(r[k], base[k], 1e-6, "serial route " + k)
 
 
 def test_transition_grad_accumulates_like_a_parameter():

@@ -5,7 +5,9 @@
 //    transcendental is a bare v_exp_f32 / v_log_f32;
 //  * a wavefront is 64 lanes; cross-lane traffic uses DPP / v_readlane, never ds_bpermute;
 //  * per-frame state is stored RELATIVE to a running offset (kept in double), which is
-//    what gives better-than-reference fp32 accuracy for long utterances.
+//    what gives better-than-reference fp32 accuracy for long utterances;
+//  * "log zero" inside the recursions is any value <= kLogZero (-1e30): it absorbs finite addends,
+//    never produces NaN in (a - b), and is mapped back to -inf at the API boundary.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -13,6 +15,7 @@
 namespace asg {
 
 constexpr int kWave = 64;
+constexpr double kLn2 = 0.6931471805599453;
 
 template <typename R> struct Num;
 
@@ -21,9 +24,9 @@ template <> struct Num<float> {
     static __device__ __forceinline__ float exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32
     static __device__ __forceinline__ float log2(float x) { return __builtin_amdgcn_logf(x); }    // v_log_f32
     static __device__ __forceinline__ float log2e() { return 1.4426950408889634f; }
-    static __device__ __forceinline__ float tiny() { return 1e-30f; }     // below this the exp-domain sum is re-done exactly
-    static __device__ __forceinline__ float ls_floor() { return -100.0f; }
-    static constexpr double kFix = 1099511627776.0;                       // 2^40 fixed-point scale
+    static __device__ __forceinline__ float logzero() { return -1e30f; }
+    static __device__ __forceinline__ float lg_limit() { return 100.0f; }   // |log2(row sum)| beyond this -> exact path
+    static constexpr double kFix = 1099511627776.0;                        // 2^40 fixed-point scale
 };
 
 template <> struct Num<double> {
@@ -31,24 +34,21 @@ template <> struct Num<double> {
     static __device__ __forceinline__ double exp2(double x) { return ::exp2(x); }
     static __device__ __forceinline__ double log2(double x) { return ::log2(x); }
     static __device__ __forceinline__ double log2e() { return 1.4426950408889634; }
-    static __device__ __forceinline__ double tiny() { return 1e-280; }
-    static __device__ __forceinline__ double ls_floor() { return -900.0; }
-    static constexpr double kFix = 17592186044416.0;                      // 2^44
+    static __device__ __forceinline__ double logzero() { return -1e300; }
+    static __device__ __forceinline__ double lg_limit() { return 900.0; }
+    static constexpr double kFix = 17592186044416.0;                       // 2^44
 };
 
-constexpr double kLn2 = 0.6931471805599453;
-
 // ---- DPP moves -----------------------------------------------------------
-// update_dpp(old, src, ctrl, row_mask, bank_mask, bound_ctrl=false): lanes whose source
-// is out of range keep `old`.
-template <int CTRL>
+// BC = bound_ctrl: lanes whose source lane does not exist read 0 (BC) or keep `oldv` (!BC).
+template <int CTRL, bool BC = false>
 __device__ __forceinline__ float dpp_mov(float oldv, float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(oldv), __float_as_int(v), CTRL, 0xF, 0xF, false));
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(oldv), __float_as_int(v), CTRL, 0xF, 0xF, BC));
 }
-template <int CTRL>
+template <int CTRL, bool BC = false>
 __device__ __forceinline__ double dpp_mov(double oldv, double v) {
-    int lo = __builtin_amdgcn_update_dpp(__double2loint(oldv), __double2loint(v), CTRL, 0xF, 0xF, false);
-    int hi = __builtin_amdgcn_update_dpp(__double2hiint(oldv), __double2hiint(v), CTRL, 0xF, 0xF, false);
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(oldv), __double2loint(v), CTRL, 0xF, 0xF, BC);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(oldv), __double2hiint(v), CTRL, 0xF, 0xF, BC);
     return __hiloint2double(hi, lo);
 }
 
@@ -68,44 +68,87 @@ __device__ __forceinline__ double readlane(double v, int l) {
     return __hiloint2double(hi, lo);
 }
 
-// value of lane i-1 (lane 0 gets `fill`) / lane i+1 (lane 63 gets `fill`)
-template <typename R> __device__ __forceinline__ R from_prev_lane(R v, R fill) { return dpp_mov<kDppWaveShr1>(fill, v); }
-template <typename R> __device__ __forceinline__ R from_next_lane(R v, R fill) { return dpp_mov<kDppWaveShl1>(fill, v); }
+// value of lane i-1 (lane 0 reads 0) / lane i+1 (lane 63 reads 0); fuses into the consuming VALU op
+template <typename R> __device__ __forceinline__ R prev_lane_or_zero(R v) { return dpp_mov<kDppWaveShr1, true>(R(0), v); }
+template <typename R> __device__ __forceinline__ R next_lane_or_zero(R v) { return dpp_mov<kDppWaveShl1, true>(R(0), v); }
 
-// All-lanes max / sum of one value per lane over the first ROWS*16 lanes (lanes beyond
-// must hold the identity).  4 DPP steps inside each 16-lane row, then v_readlane per row.
-template <int ROWS, typename R>
-__device__ __forceinline__ R wave_allmax(R v) {
+// ---- wave-wide reductions, result uniform (SGPR) -------------------------
+// fp32: six DPP-fused VALU ops (each needs 2 wait states after the VALU write it reads: s_nop 1;
+// hipcc inserts nothing inside an asm block) + one v_readlane.
+__device__ __forceinline__ float wave_allmax(float v) {
+    float r;
+    asm volatile(
+        "s_nop 1\n"
+        "v_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+        "s_nop 1\n"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+        "s_nop 1\n"
+        "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n"
+        "s_nop 1\n"
+        "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n"
+        "s_nop 1\n"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
+        "s_nop 1\n"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
+        "s_nop 1\n"
+        : "=&v"(r) : "v"(v));
+    return readlane(r, 63);
+}
+__device__ __forceinline__ float wave_allsum(float v) {
+    float r;
+    asm volatile(
+        "s_nop 1\n"
+        "v_add_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+        "s_nop 1\n"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+        "s_nop 1\n"
+        "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n"
+        "s_nop 1\n"
+        "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n"
+        "s_nop 1\n"
+        "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
+        "s_nop 1\n"
+        "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
+        "s_nop 1\n"
+        : "=&v"(r) : "v"(v));
+    return readlane(r, 63);
+}
+// fp64: plain DPP moves (correctness path, not tuned)
+__device__ __forceinline__ double wave_allmax(double v) {
     v = fmax(v, dpp_mov<kDppXor1>(v, v));
     v = fmax(v, dpp_mov<kDppXor2>(v, v));
     v = fmax(v, dpp_mov<kDppHalfMirror>(v, v));
     v = fmax(v, dpp_mov<kDppMirror>(v, v));
-    R r = readlane(v, 0);
-    if (ROWS > 1) r = fmax(r, readlane(v, 16));
-    if (ROWS > 2) r = fmax(r, readlane(v, 32));
-    if (ROWS > 3) r = fmax(r, readlane(v, 48));
-    return r;
+    return fmax(fmax(readlane(v, 0), readlane(v, 16)), fmax(readlane(v, 32), readlane(v, 48)));
 }
-template <int ROWS, typename R>
-__device__ __forceinline__ R wave_allsum(R v) {
+__device__ __forceinline__ double wave_allsum(double v) {
     v += dpp_mov<kDppXor1>(v, v);
     v += dpp_mov<kDppXor2>(v, v);
     v += dpp_mov<kDppHalfMirror>(v, v);
     v += dpp_mov<kDppMirror>(v, v);
-    R r = readlane(v, 0);
-    if (ROWS > 1) r += readlane(v, 16);
-    if (ROWS > 2) r += readlane(v, 32);
-    if (ROWS > 3) r += readlane(v, 48);
-    return r;
+    return (readlane(v, 0) + readlane(v, 16)) + (readlane(v, 32) + readlane(v, 48));
 }
 
-// log2(2^a + 2^b); (-inf,-inf) -> -inf
+// log2(2^a + 2^b) for a, b finite or <= logzero (never NaN): max + log2(1 + 2^-(|a-b|))
 template <typename R>
 __device__ __forceinline__ R lse2(R a, R b) {
     R m = fmax(a, b);
-    R d = fmin(a, b) - m;                       // <= 0, NaN when both are -inf
-    R r = m + Num<R>::log2(R(1) + Num<R>::exp2(d));
-    return (m == Num<R>::ninf()) ? m : r;
+    R d = fmin(a, b) - m;
+    return m + Num<R>::log2(R(1) + Num<R>::exp2(d));
+}
+
+// ---- raw buffer stores: hardware bounds check instead of EXEC masking ------
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(void *p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(p, 0, bytes, 0x00020000);
+}
+constexpr unsigned kOobOffset = 0x80000000u;   // voffset of lanes that must not store
+__device__ __forceinline__ void buf_store(float v, __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, voff, soff, 0);
+}
+__device__ __forceinline__ void buf_store(double v, __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    u2 w = {(unsigned) __double2loint(v), (unsigned) __double2hiint(v)};
+    __builtin_amdgcn_raw_buffer_store_b64(w, rs, voff, soff, 0);
 }
 
 // fixed-point helpers for deterministic LDS scatter-adds (integer adds commute)

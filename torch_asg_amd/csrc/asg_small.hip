@@ -23,45 +23,71 @@ namespace asg {
 
 namespace {
 
-constexpr int kPF = 16;   // emission prefetch depth (frames), register ring
+constexpr int kPF = 16;     // emission prefetch depth (frames), register ring; also the unroll of one block
+constexpr int kRenorm = 4;  // full lattice: subtract the frame max every kRenorm steps (must divide kPF)
 
-template <typename R> struct Vec4 { R x, y, z, w; };
+template <typename R> using V2 = R __attribute__((ext_vector_type(2)));
+template <typename R> using V4 = R __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int clampi(int64_t v, int lo, int hi) {
     return v < lo ? lo : (v > hi ? hi : (int) v);
 }
 
+template <typename R> __device__ __forceinline__ V2<R> fma2(V2<R> a, V2<R> b, V2<R> c) {
+    return __builtin_elementwise_fma(a, b, c);
+}
+
+// Row (or column) `lane` of the transition matrix in log2 units, max-normalised and exponentiated:
+// e2[j] = exp2(Tr2[.] - mx).  All loads are unconditional (clamped indices) so they pipeline.
+template <typename R, int NP>
+__device__ __forceinline__ void load_norm_row(const R *base, int64_t stride, int N, bool act,
+                                              V2<R> (&e2)[NP / 2], R &mx) {
+    const R NINF = Num<R>::ninf(), L2E = Num<R>::log2e();
+    R raw[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) raw[j] = base[(int64_t) (j < N ? j : 0) * stride];
+    mx = NINF;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        raw[j] = (act && j < N) ? raw[j] * L2E : NINF;
+        mx = fmax(mx, raw[j]);
+    }
+    if (mx == NINF) mx = 0;
+#pragma unroll
+    for (int j = 0; j < NP; j += 2) {
+        e2[j / 2].x = Num<R>::exp2(raw[j] - mx);
+        e2[j / 2].y = Num<R>::exp2(raw[j + 1] - mx);
+    }
+}
+
 // s_i = sum_j e[j] * p_j with p_j living in lane j.
 template <typename R, int NP, int MV>
-__device__ __forceinline__ R matvec(const R (&e)[NP], R p, R *lds, int lane) {
-    R s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+__device__ __forceinline__ R matvec(const V2<R> (&e2)[NP / 2], R p, R *lds, int lane) {
+    V2<R> a0 = {0, 0}, a1 = {0, 0};
     if (MV == 0) {
         // LDS broadcast: one ds_write_b32 per lane, then every lane reads the whole vector with
         // wide same-address (broadcast, conflict-free) reads.  A single wavefront owns `lds`, and the
-        // LDS executes one wave's DS ops in order, so no barrier is needed -- only a compiler fence.
+        // LDS executes one wave's DS ops in order, so no s_barrier is needed -- only compiler ordering.
         lds[lane] = p;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
         for (int j = 0; j < NP; j += 4) {
-            Vec4<R> v = *reinterpret_cast<const Vec4<R> *>(lds + j);
-            s0 = fma(e[j + 0], v.x, s0);
-            s1 = fma(e[j + 1], v.y, s1);
-            s2 = fma(e[j + 2], v.z, s2);
-            s3 = fma(e[j + 3], v.w, s3);
+            V4<R> v = *reinterpret_cast<const V4<R> *>(lds + j);
+            a0 = fma2<R>(e2[j / 2], v.xy, a0);
+            a1 = fma2<R>(e2[j / 2 + 1], v.zw, a1);
         }
         __builtin_amdgcn_wave_barrier();
     } else {
 #pragma unroll
         for (int j = 0; j < NP; j += 4) {
-            s0 = fma(e[j + 0], readlane(p, j + 0), s0);
-            s1 = fma(e[j + 1], readlane(p, j + 1), s1);
-            s2 = fma(e[j + 2], readlane(p, j + 2), s2);
-            s3 = fma(e[j + 3], readlane(p, j + 3), s3);
+            V2<R> v0 = {readlane(p, j + 0), readlane(p, j + 1)};
+            V2<R> v1 = {readlane(p, j + 2), readlane(p, j + 3)};
+            a0 = fma2<R>(e2[j / 2], v0, a0);
+            a1 = fma2<R>(e2[j / 2 + 1], v1, a1);
         }
     }
-    return (s0 + s1) + (s2 + s3);
+    V2<R> a = a0 + a1;
+    return a.x + a.y;
 }
 
 // Exact log2-sum-exp2 over j of (trow[j*tstride]*log2e + v_j), v_j in lane j.  Rare path.
@@ -71,247 +97,324 @@ __device__ __noinline__ R exact_lse_row(const R *trow, int64_t tstride, R v, int
     R mx = NINF;
     for (int j = 0; j < N; ++j) {
         R vj = readlane(v, j);
-        R x = act ? trow[j * tstride] * L2E + vj : NINF;
-        mx = fmax(mx, x);
+        R x = trow[j * tstride] * L2E + vj;
+        mx = fmax(mx, (act && x == x) ? x : NINF);
     }
     R sm = 0;
     for (int j = 0; j < N; ++j) {
         R vj = readlane(v, j);
-        R x = act ? trow[j * tstride] * L2E + vj : NINF;
-        sm += (mx == NINF) ? R(0) : Num<R>::exp2(x - mx);
+        R x = trow[j * tstride] * L2E + vj;
+        sm += (mx == NINF || !act || x != x) ? R(0) : Num<R>::exp2(x - mx);
     }
     return (mx == NINF) ? NINF : mx + Num<R>::log2(sm);
 }
 
+template <typename R> __device__ __forceinline__ R score_out(double s2) {
+    // log2-domain score -> natural log; anything at/below "log zero" is reported as -inf
+    return (s2 < -1e29) ? Num<R>::ninf() : (R) (s2 * kLn2);
+}
+
 // ------------------------------------------------------------------ full lattice, alpha
+// State per lane i: ah = alpha_t[i] in log2 units relative to the running offset C (double).
+// Every kRenorm-th step the frame max is folded into C so that p = exp2(ah) stays in range; in between
+// ah drifts by at most kRenorm-1 frames.  A row sum s whose |log2 s| > lg_limit (underflow, overflow,
+// zero, NaN) is re-done by exact_lse_row from the log-domain state, so the result is always a true LSE.
+template <typename R, int NP, int MV, bool STORE, bool GUARD>
+__device__ __forceinline__ void full_alpha_block(const R (&cur)[kPF], int nsteps, unsigned soff0, unsigned row_bytes,
+                                                 const V2<R> (&e2)[NP / 2], R RiX, const R *trow, int64_t ts1,
+                                                 int N, bool act, unsigned long long actmask, R *lds, int lane,
+                                                 __amdgpu_buffer_rsrc_t rs, unsigned voff, R &ah, double &C) {
+    const R L2E = Num<R>::log2e();
+#pragma unroll
+    for (int k = 0; k < kPF; ++k) {
+        if (!GUARD || k < nsteps) {
+            R p = Num<R>::exp2(ah);                      // lanes >= N hold -inf -> 0
+            R s = matvec<R, NP, MV>(e2, p, lds, lane);
+            R lg = Num<R>::log2(s);
+            R x = fma(cur[k], L2E, RiX) + lg;            // RiX = -inf on lanes >= N
+            unsigned long long bad = __ballot(!(fabs(lg) < Num<R>::lg_limit())) & actmask;
+            if (bad) {
+                R ex = exact_lse_row<R>(trow, ts1, ah, N, act);
+                if ((bad >> lane) & 1) x = fma(cur[k], L2E, R(0)) + ex;
+            }
+            if ((k % kRenorm) == kRenorm - 1) {
+                R m = fmax(wave_allmax(x), Num<R>::logzero());
+                ah = x - m;
+                C += (double) m;
+            } else {
+                ah = x;
+            }
+            if (STORE) buf_store(ah, rs, voff, soff0 + (unsigned) k * row_bytes);
+        }
+    }
+}
+
 template <typename R, int NP, int MV, bool STORE>
 __device__ void full_alpha_chain(const Problem &P, const State &W, const FwdOut &O, int b, R *lds) {
-    constexpr int ROWS = (NP + 15) / 16;
     const int lane = threadIdx.x & 63;
     const int N = P.N, T = P.T;
     const int len = P.in_len ? clampi(P.in_len[b], 0, T) : T;
     const R NINF = Num<R>::ninf(), L2E = Num<R>::log2e();
     const bool act = lane < N;
-    const R *tr = (const R *) P.transition;
-    const R *trow = tr + (act ? (int64_t) lane * P.ts0 : 0);
+    const unsigned long long actmask = __ballot(act);
+    const int lc = act ? lane : 0;
+    const R *trow = (const R *) P.transition + (int64_t) lc * P.ts0;
 
-    R e[NP];
-    R Ri = NINF;
-#pragma unroll
-    for (int j = 0; j < NP; ++j) {
-        R v = (act && j < N) ? trow[(int64_t) j * P.ts1] * L2E : NINF;
-        e[j] = v;
-        Ri = fmax(Ri, v);
-    }
-    if (Ri == NINF) Ri = 0;
-#pragma unroll
-    for (int j = 0; j < NP; ++j) e[j] = Num<R>::exp2(e[j] - Ri);
+    V2<R> e2[NP / 2];
+    R Ri;
+    load_norm_row<R, NP>(trow, P.ts1, N, act, e2, Ri);
+    const R RiX = act ? Ri : NINF;
 
-    const R *in = (const R *) P.inputs + (int64_t) b * P.is1 + (act ? (int64_t) lane * P.is2 : 0);
-    R *ah_out = (R *) W.ah + (int64_t) b * T * N + lane;
-    R *msh_out = (R *) W.msh + (int64_t) b * T;
-
-    R cur[kPF], nxt[kPF];
-#pragma unroll
-    for (int k = 0; k < kPF; ++k) cur[k] = (act && k < len) ? in[(int64_t) k * P.is0] * L2E : NINF;
+    const R *in = (const R *) P.inputs + (int64_t) b * P.is1 + (int64_t) lc * P.is2;
+    const unsigned row_bytes = (unsigned) N * sizeof(R);
+    __amdgpu_buffer_rsrc_t rs = make_rsrc((R *) W.ah + (int64_t) b * T * N, STORE ? (unsigned) T * row_bytes : 0u);
+    const unsigned voff = act ? (unsigned) lane * sizeof(R) : kOobOffset;
 
     double C = 0.0;
     R ah = NINF;
-    for (int tb = 0; tb < len; tb += kPF) {
-#pragma unroll
-        for (int k = 0; k < kPF; ++k) {
-            int tt = tb + kPF + k;
-            nxt[k] = (act && tt < len) ? in[(int64_t) tt * P.is0] * L2E : NINF;
+    if (len >= 1) {
+        // frame 0: alpha_0 = I_0
+        {
+            R x = act ? in[0] * L2E : NINF;
+            R m = fmax(wave_allmax(x), Num<R>::logzero());
+            ah = x - m;
+            C = (double) m;
+            if (STORE) buf_store(ah, rs, voff, 0u);
         }
+        // frames 1 .. len-1 in blocks of kPF, emissions prefetched one block ahead
+        const int nst = len - 1;
+        R cur[kPF], nxt[kPF];
 #pragma unroll
-        for (int k = 0; k < kPF; ++k) {
-            const int t = tb + k;
-            if (t >= len) break;
-            R x;
-            if (t == 0) {
-                x = cur[k];
-            } else {
-                R p = Num<R>::exp2(ah);                      // lanes >= N hold -inf -> 0
-                R s = matvec<R, NP, MV>(e, p, lds, lane);
-                x = cur[k] + Ri + Num<R>::log2(s);
-                bool bad = act && !(s >= Num<R>::tiny());
-                if (__any(bad)) {
-                    R ex = exact_lse_row<R>(trow, P.ts1, ah, N, act);
-                    if (bad) x = cur[k] + ex;
-                }
-            }
-            R m = wave_allmax<ROWS>(x);
-            if (m == NINF) { ah = NINF; C = -__builtin_inf(); m = 0; }
-            else { ah = x - m; C += (double) m; }
-            if (STORE) {
-                if (act) ah_out[(int64_t) t * N] = ah;
-                if (lane == 0) msh_out[t] = m;
-            }
+        for (int k = 0; k < kPF; ++k) cur[k] = in[(int64_t) min(1 + k, len - 1) * P.is0];
+        int done = 0;
+        for (; done + kPF <= nst; done += kPF) {
+#pragma unroll
+            for (int k = 0; k < kPF; ++k) nxt[k] = in[(int64_t) min(1 + done + kPF + k, len - 1) * P.is0];
+            full_alpha_block<R, NP, MV, STORE, false>(cur, kPF, (unsigned) (1 + done) * row_bytes, row_bytes, e2, RiX,
+                                                      trow, P.ts1, N, act, actmask, lds, lane, rs, voff, ah, C);
+#pragma unroll
+            for (int k = 0; k < kPF; ++k) cur[k] = nxt[k];
         }
-#pragma unroll
-        for (int k = 0; k < kPF; ++k) cur[k] = nxt[k];
+        if (done < nst)
+            full_alpha_block<R, NP, MV, STORE, true>(cur, nst - done, (unsigned) (1 + done) * row_bytes, row_bytes, e2,
+                                                     RiX, trow, P.ts1, N, act, actmask, lds, lane, rs, voff, ah, C);
     }
     if (O.full_scores_alpha) {
-        R sm = wave_allsum<ROWS>(Num<R>::exp2(ah));
-        double sc = (len >= 1) ? (C + (double) Num<R>::log2(sm)) * kLn2 : -__builtin_inf();
-        if (lane == 0) ((R *) O.full_scores_alpha)[b] = (R) sc;
+        R mx = fmax(wave_allmax(ah), Num<R>::logzero());
+        R sm = wave_allsum(Num<R>::exp2(ah - mx));
+        double sc = (len >= 1) ? C + (double) mx + (double) Num<R>::log2(sm) : -1e300;
+        if (lane == 0) ((R *) O.full_scores_alpha)[b] = score_out<R>(sc);
     }
 }
 
 // ------------------------------------------------------------------ full lattice, beta
+// Iteration n handles frame t = len-1-n: y = I2[t] + bh[t]; it produces bh[t-1] = LSE_j(Tr[j][.] + y_j).
+template <typename R, int NP, int MV, bool STORE, bool GUARD>
+__device__ __forceinline__ void full_beta_block(const R (&cur)[kPF], int nsteps, unsigned soff0, unsigned row_bytes,
+                                                const V2<R> (&f2)[NP / 2], R CiX, const R *tcol, int64_t ts0,
+                                                int N, bool act, unsigned long long actmask, R *lds, int lane,
+                                                __amdgpu_buffer_rsrc_t rs, unsigned voff, R &bh, double &C) {
+    const R L2E = Num<R>::log2e();
+#pragma unroll
+    for (int k = 0; k < kPF; ++k) {
+        if (!GUARD || k < nsteps) {
+            R y = fma(cur[k], L2E, bh);                  // lanes >= N: bh = -inf
+            R m = R(0);
+            if ((k % kRenorm) == 0) {
+                m = fmax(wave_allmax(y), Num<R>::logzero());
+                C += (double) m;
+                y -= m;
+            }
+            R p = Num<R>::exp2(y);
+            R s = matvec<R, NP, MV>(f2, p, lds, lane);
+            R lg = Num<R>::log2(s);
+            bh = CiX + lg;
+            unsigned long long bad = __ballot(!(fabs(lg) < Num<R>::lg_limit())) & actmask;
+            if (bad) {
+                R ex = exact_lse_row<R>(tcol, ts0, y, N, act);
+                if ((bad >> lane) & 1) bh = ex;
+            }
+            if (STORE) buf_store(bh, rs, voff, soff0 - (unsigned) k * row_bytes);
+        }
+    }
+}
+
 template <typename R, int NP, int MV, bool STORE>
 __device__ void full_beta_chain(const Problem &P, const State &W, const FwdOut &O, int b, R *lds) {
-    constexpr int ROWS = (NP + 15) / 16;
     const int lane = threadIdx.x & 63;
     const int N = P.N, T = P.T;
     const int len = P.in_len ? clampi(P.in_len[b], 0, T) : T;
     const R NINF = Num<R>::ninf(), L2E = Num<R>::log2e();
     const bool act = lane < N;
-    const R *tr = (const R *) P.transition;
-    const R *tcol = tr + (act ? (int64_t) lane * P.ts1 : 0);      // column `lane`: Tr[j][lane]
+    const unsigned long long actmask = __ballot(act);
+    const int lc = act ? lane : 0;
+    const R *tcol = (const R *) P.transition + (int64_t) lc * P.ts1;      // column `lane`: Tr[j][lane]
 
-    R f[NP];
-    R Ci = NINF;
-#pragma unroll
-    for (int j = 0; j < NP; ++j) {
-        R v = (act && j < N) ? tcol[(int64_t) j * P.ts0] * L2E : NINF;
-        f[j] = v;
-        Ci = fmax(Ci, v);
-    }
-    if (Ci == NINF) Ci = 0;
-#pragma unroll
-    for (int j = 0; j < NP; ++j) f[j] = Num<R>::exp2(f[j] - Ci);
+    V2<R> f2[NP / 2];
+    R Ci;
+    load_norm_row<R, NP>(tcol, P.ts0, N, act, f2, Ci);
+    const R CiX = act ? Ci : NINF;
 
-    const R *in = (const R *) P.inputs + (int64_t) b * P.is1 + (act ? (int64_t) lane * P.is2 : 0);
-    R *bh_out = (R *) W.bh + (int64_t) b * T * N + lane;
+    const R *in = (const R *) P.inputs + (int64_t) b * P.is1 + (int64_t) lc * P.is2;
+    const unsigned row_bytes = (unsigned) N * sizeof(R);
+    __amdgpu_buffer_rsrc_t rs = make_rsrc((R *) W.bh + (int64_t) b * T * N, STORE ? (unsigned) T * row_bytes : 0u);
+    const unsigned voff = act ? (unsigned) lane * sizeof(R) : kOobOffset;
 
     if (len < 1) {
         if (lane == 0) ((R *) O.full_scores)[b] = NINF;
         return;
     }
-    // iteration n handles frame t = len-1-n: y = I2[t] + bh[t], then produces bh[t-1]
-    R cur[kPF], nxt[kPF];
-#pragma unroll
-    for (int k = 0; k < kPF; ++k) {
-        int t = len - 1 - k;
-        cur[k] = (act && t >= 0) ? in[(int64_t) t * P.is0] * L2E : NINF;
-    }
     double C = 0.0;
     R bh = act ? R(0) : NINF;
-    if (STORE && act) bh_out[(int64_t) (len - 1) * N] = bh;
-    for (int nb = 0; nb < len; nb += kPF) {
+    if (STORE) buf_store(bh, rs, voff, (unsigned) (len - 1) * row_bytes);
+    // steps n = 0 .. len-2 consume frames t = len-1 .. 1 and write bh[t-1]
+    const int nst = len - 1;
+    R cur[kPF], nxt[kPF];
 #pragma unroll
-        for (int k = 0; k < kPF; ++k) {
-            int t = len - 1 - (nb + kPF + k);
-            nxt[k] = (act && t >= 0) ? in[(int64_t) t * P.is0] * L2E : NINF;
-        }
+    for (int k = 0; k < kPF; ++k) cur[k] = in[(int64_t) max(len - 1 - k, 0) * P.is0];
+    int done = 0;
+    for (; done + kPF <= nst; done += kPF) {
 #pragma unroll
-        for (int k = 0; k < kPF; ++k) {
-            const int t = len - 1 - (nb + k);
-            if (t < 0) break;
-            R y = cur[k] + bh;
-            R my = wave_allmax<ROWS>(y);
-            if (t == 0) {
-                R sm = wave_allsum<ROWS>((my == NINF) ? R(0) : Num<R>::exp2(y - my));
-                double sc = (my == NINF) ? -__builtin_inf() : (C + (double) my + (double) Num<R>::log2(sm)) * kLn2;
-                if (lane == 0) ((R *) O.full_scores)[b] = (R) sc;
-                break;
-            }
-            if (my == NINF) {
-                bh = NINF; C = -__builtin_inf();
-            } else {
-                R p = Num<R>::exp2(y - my);
-                R s = matvec<R, NP, MV>(f, p, lds, lane);
-                bh = Ci + Num<R>::log2(s);
-                bool bad = act && !(s >= Num<R>::tiny());
-                if (__any(bad)) {
-                    R ex = exact_lse_row<R>(tcol, P.ts0, y, N, act);
-                    if (bad) bh = ex - my;
-                }
-                if (!act) bh = NINF;
-                C += (double) my;
-            }
-            if (STORE && act) bh_out[(int64_t) (t - 1) * N] = bh;
-        }
+        for (int k = 0; k < kPF; ++k) nxt[k] = in[(int64_t) max(len - 1 - (done + kPF + k), 0) * P.is0];
+        full_beta_block<R, NP, MV, STORE, false>(cur, kPF, (unsigned) (len - 2 - done) * row_bytes, row_bytes, f2, CiX,
+                                                 tcol, P.ts0, N, act, actmask, lds, lane, rs, voff, bh, C);
 #pragma unroll
         for (int k = 0; k < kPF; ++k) cur[k] = nxt[k];
     }
+    R last_raw = cur[0];
+    if (done < nst) {
+        full_beta_block<R, NP, MV, STORE, true>(cur, nst - done, (unsigned) (len - 2 - done) * row_bytes, row_bytes, f2,
+                                                CiX, tcol, P.ts0, N, act, actmask, lds, lane, rs, voff, bh, C);
+        // the frame-0 emission sits right after the last consumed ring slot
+        const int r = nst - done;
+        last_raw = cur[0];
+#pragma unroll
+        for (int k = 1; k < kPF; ++k) last_raw = (k == r) ? cur[k] : last_raw;
+    }
+    // frame 0: S_full = LSE_i(I_0[i] + beta_0[i])   (fully_connected_lattice.cpp:89)
+    R y = fma(last_raw, L2E, bh);
+    R my = fmax(wave_allmax(y), Num<R>::logzero());
+    R sm = wave_allsum(Num<R>::exp2(y - my));
+    if (lane == 0) ((R *) O.full_scores)[b] = score_out<R>(C + (double) my + (double) Num<R>::log2(sm));
 }
 
 // ------------------------------------------------------------------ aligned lattice
 template <typename R>
 struct AlignedSetup {
-    int len, ol, tgt;
+    int len, ol, tgt, prv;
     bool act;
     R H2;      // Tr2[O_s][O_s]
-    R Dprev;   // Tr2[O_s][O_{s-1}]   (edge s-1 -> s), 0 for s == 0
-    R Dnext;   // Tr2[O_{s+1}][O_s]   (edge s -> s+1), 0 for s >= ol-1
+    R Dprev;   // Tr2[O_s][O_{s-1}]   (edge s-1 -> s); log-zero for s == 0 and inactive lanes
+    R Dnext;   // Tr2[O_{s+1}][O_s]   (edge s -> s+1); log-zero for s >= ol-1
+    R ebias;   // 0 on active lanes, log-zero otherwise: em = fma(raw, log2e, ebias)
     const R *in;   // &inputs[0][b][O_s]
 };
 
 template <typename R>
-__device__ __forceinline__ AlignedSetup<R> aligned_setup(const Problem &P, int b, int lane) {
+__device__ __forceinline__ AlignedSetup<R> aligned_setup(const Problem &P, int b, int lane, bool valid = true) {
     AlignedSetup<R> A;
-    const R L2E = Num<R>::log2e();
+    const R L2E = Num<R>::log2e(), LZ = Num<R>::logzero();
+    valid = valid && P.targets != nullptr;
     A.len = P.in_len ? clampi(P.in_len[b], 0, P.T) : P.T;
-    A.ol = P.tg_len ? clampi(P.tg_len[b], 0, P.S) : P.S;
+    A.ol = valid ? (P.tg_len ? clampi(P.tg_len[b], 0, P.S) : P.S) : 0;
     A.act = lane < A.ol;
-    const int64_t *tg = P.targets + (int64_t) b * P.gs0;
-    int cur = A.act ? clampi(tg[(int64_t) lane * P.gs1], 0, P.N - 1) : 0;
-    int prv = (A.act && lane >= 1) ? clampi(tg[(int64_t) (lane - 1) * P.gs1], 0, P.N - 1) : 0;
-    int nxt = (lane + 1 < A.ol) ? clampi(tg[(int64_t) (lane + 1) * P.gs1], 0, P.N - 1) : 0;
+    // unconditional, clamped loads (inactive lanes re-read position 0 / label 0)
+    const int sc = A.act ? lane : 0;
+    const int sp = (A.act && lane >= 1) ? lane - 1 : 0;
+    const int sn = (lane + 1 < A.ol) ? lane + 1 : 0;
+    int cur = 0, prv = 0, nxt = 0;
+    if (valid) {
+        const int64_t *tg = P.targets + (int64_t) b * P.gs0;
+        cur = clampi(tg[(int64_t) sc * P.gs1], 0, P.N - 1);
+        prv = clampi(tg[(int64_t) sp * P.gs1], 0, P.N - 1);
+        nxt = clampi(tg[(int64_t) sn * P.gs1], 0, P.N - 1);
+    }
     const R *tr = (const R *) P.transition;
+    R h = tr[(int64_t) cur * P.ts0 + (int64_t) cur * P.ts1];
+    R dp = tr[(int64_t) cur * P.ts0 + (int64_t) prv * P.ts1];
+    R dn = tr[(int64_t) nxt * P.ts0 + (int64_t) cur * P.ts1];
     A.tgt = cur;
-    A.H2 = A.act ? tr[(int64_t) cur * P.ts0 + (int64_t) cur * P.ts1] * L2E : R(0);
-    A.Dprev = (A.act && lane >= 1) ? tr[(int64_t) cur * P.ts0 + (int64_t) prv * P.ts1] * L2E : R(0);
-    A.Dnext = (lane + 1 < A.ol) ? tr[(int64_t) nxt * P.ts0 + (int64_t) cur * P.ts1] * L2E : R(0);
+    A.prv = prv;
+    A.H2 = A.act ? fmax(h * L2E, LZ) : R(0);
+    A.Dprev = (A.act && lane >= 1) ? fmax(dp * L2E, LZ) : LZ;
+    A.Dnext = (lane + 1 < A.ol) ? fmax(dn * L2E, LZ) : LZ;
+    A.ebias = A.act ? R(0) : LZ;
     A.in = (const R *) P.inputs + (int64_t) b * P.is1 + (int64_t) cur * P.is2;
     return A;
+}
+
+template <typename R, bool STORE, bool GUARD>
+__device__ __forceinline__ void aligned_alpha_block(const R (&cur)[kPF], int nsteps, unsigned soff0, unsigned row_bytes,
+                                                    const AlignedSetup<R> &A, __amdgpu_buffer_rsrc_t rs, unsigned voff,
+                                                    R &ab) {
+    const R L2E = Num<R>::log2e(), LZ = Num<R>::logzero();
+#pragma unroll
+    for (int k = 0; k < kPF; ++k) {
+        if (!GUARD || k < nsteps) {
+            R em = fma(cur[k], L2E, A.ebias);
+            R stay = ab + A.H2;
+            R come = prev_lane_or_zero<R>(ab) + A.Dprev;      // v_add_f32_dpp wave_shr:1; lane 0: 0 + logzero
+            ab = fmax(em + lse2<R>(stay, come), LZ);
+            if (STORE) buf_store(ab, rs, voff, soff0 + (unsigned) k * row_bytes);
+        }
+    }
 }
 
 template <typename R, bool STORE>
 __device__ void aligned_alpha_chain(const Problem &P, const State &W, const FwdOut &O, int b) {
     const int lane = threadIdx.x & 63;
     const int T = P.T, S = P.S;
-    const R NINF = Num<R>::ninf(), L2E = Num<R>::log2e();
+    const R L2E = Num<R>::log2e(), LZ = Num<R>::logzero();
     const AlignedSetup<R> A = aligned_setup<R>(P, b, lane);
     const int len = A.len;
-    R *ab_out = (R *) W.ab + (int64_t) b * T * S + lane;
-    const bool st = STORE && lane < S;
+    const unsigned row_bytes = (unsigned) S * sizeof(R);
+    __amdgpu_buffer_rsrc_t rs = make_rsrc((R *) W.ab + (int64_t) b * T * S, STORE ? (unsigned) T * row_bytes : 0u);
+    const unsigned voff = lane < S ? (unsigned) lane * sizeof(R) : kOobOffset;
 
-    R cur[kPF], nxt[kPF];
-#pragma unroll
-    for (int k = 0; k < kPF; ++k) cur[k] = (A.act && k < len) ? A.in[(int64_t) k * P.is0] * L2E : NINF;
     double C = 0.0;
-    R ab = NINF;
-    for (int tb = 0; tb < len; tb += kPF) {
+    R ab = LZ;
+    if (len >= 1) {
+        ab = (lane == 0) ? fmax(fma(A.in[0], L2E, A.ebias), LZ) : LZ;
+        if (STORE) buf_store(ab, rs, voff, 0u);
+        const int nst = len - 1;
+        R cur[kPF], nxt[kPF];
 #pragma unroll
-        for (int k = 0; k < kPF; ++k) {
-            int tt = tb + kPF + k;
-            nxt[k] = (A.act && tt < len) ? A.in[(int64_t) tt * P.is0] * L2E : NINF;
-        }
-        if (tb > 0) {   // renormalise once per block: log domain is offset-free, this only bounds magnitudes
-            R m = wave_allmax<4>(ab);
-            if (m != NINF) { ab -= m; C += (double) m; }
-        }
+        for (int k = 0; k < kPF; ++k) cur[k] = A.in[(int64_t) min(1 + k, len - 1) * P.is0];
+        int done = 0;
+        for (; done + kPF <= nst; done += kPF) {
 #pragma unroll
-        for (int k = 0; k < kPF; ++k) {
-            const int t = tb + k;
-            if (t >= len) break;
-            if (t == 0) {
-                ab = (lane == 0) ? cur[k] : NINF;
-            } else {
-                R left = from_prev_lane<R>(ab, NINF);
-                ab = cur[k] + lse2<R>(ab + A.H2, left + A.Dprev);
-            }
-            if (st) ab_out[(int64_t) t * S] = ab;
-        }
+            for (int k = 0; k < kPF; ++k) nxt[k] = A.in[(int64_t) min(1 + done + kPF + k, len - 1) * P.is0];
+            // renormalise once per block: the log domain is offset-free, this only bounds magnitudes
+            R m = wave_allmax(ab);
+            if (m > R(-1e29)) { ab = fmax(ab - m, LZ); C += (double) m; }
+            aligned_alpha_block<R, STORE, false>(cur, kPF, (unsigned) (1 + done) * row_bytes, row_bytes, A, rs, voff, ab);
 #pragma unroll
-        for (int k = 0; k < kPF; ++k) cur[k] = nxt[k];
+            for (int k = 0; k < kPF; ++k) cur[k] = nxt[k];
+        }
+        if (done < nst)
+            aligned_alpha_block<R, STORE, true>(cur, nst - done, (unsigned) (1 + done) * row_bytes, row_bytes, A, rs,
+                                                voff, ab);
     }
     if (O.aligned_scores_alpha) {
-        R last = (A.ol >= 1 && len >= 1) ? readlane(ab, A.ol - 1) : NINF;
-        if (lane == 0) ((R *) O.aligned_scores_alpha)[b] = (R) ((C + (double) last) * kLn2);
+        R last = (A.ol >= 1 && len >= 1) ? readlane(ab, A.ol - 1) : LZ;
+        if (lane == 0) ((R *) O.aligned_scores_alpha)[b] = score_out<R>(C + (double) last);
+    }
+}
+
+template <typename R, bool STORE, bool GUARD>
+__device__ __forceinline__ void aligned_beta_block(const R (&cur)[kPF], int nsteps, unsigned soff0, unsigned row_bytes,
+                                                   const AlignedSetup<R> &A, __amdgpu_buffer_rsrc_t rs, unsigned voff,
+                                                   R &bb) {
+    const R L2E = Num<R>::log2e(), LZ = Num<R>::logzero();
+#pragma unroll
+    for (int k = 0; k < kPF; ++k) {
+        if (!GUARD || k < nsteps) {
+            R y = fmax(fma(cur[k], L2E, A.ebias) + bb, LZ);
+            R stay = y + A.H2;
+            R go = next_lane_or_zero<R>(y) + A.Dnext;          // v_add_f32_dpp wave_shl:1
+            bb = fmax(lse2<R>(stay, go), LZ);
+            if (STORE) buf_store(bb, rs, voff, soff0 - (unsigned) k * row_bytes);
+        }
     }
 }
 
@@ -319,51 +422,45 @@ template <typename R, bool STORE>
 __device__ void aligned_beta_chain(const Problem &P, const State &W, const FwdOut &O, int b) {
     const int lane = threadIdx.x & 63;
     const int T = P.T, S = P.S;
-    const R NINF = Num<R>::ninf(), L2E = Num<R>::log2e();
+    const R NINF = Num<R>::ninf(), L2E = Num<R>::log2e(), LZ = Num<R>::logzero();
     const AlignedSetup<R> A = aligned_setup<R>(P, b, lane);
     const int len = A.len;
-    R *bb_out = (R *) W.bb + (int64_t) b * T * S + lane;
-    const bool st = STORE && lane < S;
+    const unsigned row_bytes = (unsigned) S * sizeof(R);
+    __amdgpu_buffer_rsrc_t rs = make_rsrc((R *) W.bb + (int64_t) b * T * S, STORE ? (unsigned) T * row_bytes : 0u);
+    const unsigned voff = lane < S ? (unsigned) lane * sizeof(R) : kOobOffset;
     if (len < 1 || A.ol < 1) {
         if (lane == 0) ((R *) O.aligned_scores)[b] = NINF;
         return;
     }
+    double C = 0.0;
+    R bb = (lane == A.ol - 1) ? R(0) : LZ;
+    if (STORE) buf_store(bb, rs, voff, (unsigned) (len - 1) * row_bytes);
+    const int nst = len - 1;
     R cur[kPF], nxt[kPF];
 #pragma unroll
-    for (int k = 0; k < kPF; ++k) {
-        int t = len - 1 - k;
-        cur[k] = (A.act && t >= 0) ? A.in[(int64_t) t * P.is0] * L2E : NINF;
-    }
-    double C = 0.0;
-    R bb = (lane == A.ol - 1) ? R(0) : NINF;
-    if (st) bb_out[(int64_t) (len - 1) * S] = bb;
-    for (int nb = 0; nb < len; nb += kPF) {
+    for (int k = 0; k < kPF; ++k) cur[k] = A.in[(int64_t) max(len - 1 - k, 0) * P.is0];
+    int done = 0;
+    for (; done + kPF <= nst; done += kPF) {
 #pragma unroll
-        for (int k = 0; k < kPF; ++k) {
-            int t = len - 1 - (nb + kPF + k);
-            nxt[k] = (A.act && t >= 0) ? A.in[(int64_t) t * P.is0] * L2E : NINF;
-        }
-        if (nb > 0) {
-            R m = wave_allmax<4>(bb);
-            if (m != NINF) { bb -= m; C += (double) m; }
-        }
-#pragma unroll
-        for (int k = 0; k < kPF; ++k) {
-            const int t = len - 1 - (nb + k);
-            if (t < 0) break;
-            R y = cur[k] + bb;
-            if (t == 0) {
-                R y0 = readlane(y, 0);
-                if (lane == 0) ((R *) O.aligned_scores)[b] = (R) ((C + (double) y0) * kLn2);
-                break;
-            }
-            R right = from_next_lane<R>(y, NINF);
-            bb = lse2<R>(A.H2 + y, A.Dnext + right);
-            if (st) bb_out[(int64_t) (t - 1) * S] = bb;
-        }
+        for (int k = 0; k < kPF; ++k) nxt[k] = A.in[(int64_t) max(len - 1 - (done + kPF + k), 0) * P.is0];
+        R m = wave_allmax(bb);
+        if (m > R(-1e29)) { bb = fmax(bb - m, LZ); C += (double) m; }
+        aligned_beta_block<R, STORE, false>(cur, kPF, (unsigned) (len - 2 - done) * row_bytes, row_bytes, A, rs, voff, bb);
 #pragma unroll
         for (int k = 0; k < kPF; ++k) cur[k] = nxt[k];
     }
+    R last_raw = cur[0];
+    if (done < nst) {
+        aligned_beta_block<R, STORE, true>(cur, nst - done, (unsigned) (len - 2 - done) * row_bytes, row_bytes, A, rs,
+                                           voff, bb);
+        const int r = nst - done;
+#pragma unroll
+        for (int k = 1; k < kPF; ++k) last_raw = (k == r) ? cur[k] : last_raw;
+    }
+    // S_aligned = beta_0[0] + I~_0[0]   (force_aligned_lattice.cpp:316)
+    R y = fma(last_raw, L2E, A.ebias) + bb;
+    R y0 = readlane(y, 0);
+    if (lane == 0) ((R *) O.aligned_scores)[b] = score_out<R>(C + (double) y0);
 }
 
 // ------------------------------------------------------------------ forward kernel
@@ -373,7 +470,6 @@ template <typename R, int NP, int MV, bool STORE>
 __global__ void __launch_bounds__(64) fwd_small_kernel(Problem P, State W, FwdOut O, int chain_mask) {
     __shared__ __attribute__((aligned(16))) R lds[64];
     int which = 0, seen = 0;
-#pragma unroll
     for (int c = 0; c < 4; ++c) {
         if (chain_mask & (1 << c)) {
             if (seen == (int) blockIdx.y) which = 1 << c;
@@ -389,25 +485,31 @@ __global__ void __launch_bounds__(64) fwd_small_kernel(Problem P, State W, FwdOu
 
 // ------------------------------------------------------------------ backward (gradient assembly)
 // grid = (B, nchunks), block = 256 (4 waves).  Wave w of chunk c owns frames t = c*chunk + w, +4, ...
-// Per frame: full-lattice posterior -> grad_inputs, outer-product accumulation of the transition
-// gradient in registers (lane i holds row i), aligned posterior scattered back to labels with
-// fixed-point LDS adds (deterministic), horizontal/diagonal edge posteriors accumulated per lane.
+// Per frame (non-recursive, every frame independent):
+//   full:    posterior_i = softmax_i(alpha_hat + beta_hat)                    -> grad_inputs row
+//            p_j = exp2(alpha_hat_{t-1}[j] - max), s_i = sum_j E[i][j] p_j    (row sums recomputed here, so the
+//            forward pass has nothing to save but alpha_hat / beta_hat), u_i = g * posterior_i / s_i,
+//            acc[i][j] += u_i * p_j   (lane i keeps row i in registers; scaled by E[i][j] once at the end)
+//   aligned: posterior_s = softmax_s(alpha_bar + beta_bar), scattered back to labels with fixed-point
+//            LDS adds (integer adds commute -> deterministic), stay/advance edge posteriors per lane.
 // Output: grad_inputs rows for its frames, one partial [N][N] tile per workgroup.
 template <typename R, int NP>
 __global__ void __launch_bounds__(256) bwd_small_kernel(Problem P, State W, BwdArgs A, int parts) {
-    constexpr int ROWS = (NP + 15) / 16;
+    constexpr bool kWide = sizeof(R) == 4;       // fp32: one LDS tile per wave; fp64: shared tile, serial rounds
     __shared__ __attribute__((aligned(16))) R pbuf[4][64];
     __shared__ unsigned long long fxI[4][64];
     __shared__ unsigned long long fxT[64 * 64];
-    __shared__ R tileF[64 * NP];
+    __shared__ __attribute__((aligned(16))) R tileF[(kWide ? 4 : 1) * 64 * NP];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.x, chunk = blockIdx.y;
     const int N = P.N, T = P.T, S = P.S;
-    const R NINF = Num<R>::ninf(), L2E = Num<R>::log2e();
+    const R NINF = Num<R>::ninf(), L2E = Num<R>::log2e(), LZ = Num<R>::logzero();
     const bool do_full = parts & 1, do_ali = parts & 2;
     const int len = P.in_len ? clampi(P.in_len[b], 0, T) : T;
     const bool act = lane < N;
+    const unsigned long long actmask = __ballot(act);
+    const int lc = act ? lane : 0;
 
     for (int k = threadIdx.x; k < N * N; k += 256) fxT[k] = 0;
     fxI[wave][lane] = 0;
@@ -416,33 +518,27 @@ __global__ void __launch_bounds__(256) bwd_small_kernel(Problem P, State W, BwdA
     const R ga = do_ali ? ((const R *) A.grad_aligned)[b] : R(0);
 
     // full: row i of exp2(Tr2 - rowmax)
-    const R *tr = (const R *) P.transition;
-    const R *trow = tr + (act ? (int64_t) lane * P.ts0 : 0);
-    R e[NP];
-    R Ri = NINF;
+    const R *trow = (const R *) P.transition + (int64_t) lc * P.ts0;
+    V2<R> e2[NP / 2];
+    R Ri;
+    load_norm_row<R, NP>(trow, P.ts1, N, act, e2, Ri);
+    V2<R> acc[NP / 2], accx[NP / 2];
 #pragma unroll
-    for (int j = 0; j < NP; ++j) {
-        R v = (act && j < N) ? trow[(int64_t) j * P.ts1] * L2E : NINF;
-        e[j] = v;
-        Ri = fmax(Ri, v);
-    }
-    if (Ri == NINF) Ri = 0;
-#pragma unroll
-    for (int j = 0; j < NP; ++j) e[j] = Num<R>::exp2(e[j] - Ri);
-    R acc[NP], accx[NP];
-#pragma unroll
-    for (int j = 0; j < NP; ++j) { acc[j] = 0; accx[j] = 0; }
+    for (int j = 0; j < NP / 2; ++j) { acc[j] = V2<R>{0, 0}; accx[j] = V2<R>{0, 0}; }
 
-    const AlignedSetup<R> AS = aligned_setup<R>(P, b, lane);
+    const AlignedSetup<R> AS = aligned_setup<R>(P, b, lane, do_ali);
     R accH = 0, accD = 0;    // unscaled edge posteriors: stay on s ; arrive at s from s-1
 
-    const R *in = (const R *) P.inputs + (int64_t) b * P.is1 + (act ? (int64_t) lane * P.is2 : 0);
-    const R *ahp = (const R *) W.ah + (int64_t) b * T * N + lane;
-    const R *bhp = (const R *) W.bh + (int64_t) b * T * N + lane;
-    const R *mshp = (const R *) W.msh + (int64_t) b * T;
-    const R *abp = (const R *) W.ab + (int64_t) b * T * S + lane;
-    const R *bbp = (const R *) W.bb + (int64_t) b * T * S + lane;
-    R *gin = (R *) A.grad_inputs + (int64_t) b * N + lane;
+    const bool sl = lane < S;
+    const int ls_ = sl ? lane : 0;
+    const R *ahp = (const R *) W.ah + (int64_t) b * T * N + lc;
+    const R *bhp = (const R *) W.bh + (int64_t) b * T * N + lc;
+    const R *abp = (const R *) W.ab + (int64_t) b * T * S + ls_;
+    const R *bbp = (const R *) W.bb + (int64_t) b * T * S + ls_;
+    __amdgpu_buffer_rsrc_t rs_g = make_rsrc((R *) A.grad_inputs + (int64_t) b * N,
+                                            (unsigned) ((int64_t) (T - 1) * P.B * N + N) * (unsigned) sizeof(R));
+    const unsigned voff = act ? (unsigned) lane * sizeof(R) : kOobOffset;
+    const unsigned grow_bytes = (unsigned) P.B * N * sizeof(R);
     __syncthreads();
 
     const int t0 = chunk * A.chunk;
@@ -450,64 +546,73 @@ __global__ void __launch_bounds__(256) bwd_small_kernel(Problem P, State W, BwdA
     for (int t = t0 + wave; t < t1; t += 4) {
         R gi = 0;
         if (t < len) {
+            const int tp = t >= 1 ? t - 1 : 0;
             if (do_full) {
-                R ahv = act ? ahp[(int64_t) t * N] : NINF;
-                R bhv = act ? bhp[(int64_t) t * N] : NINF;
-                R gam = ahv + bhv;
-                R mg = wave_allmax<ROWS>(gam);
-                R w = (mg == NINF) ? R(0) : Num<R>::exp2(gam - mg);
-                R Z = wave_allsum<ROWS>(w);
+                R ahv = ahp[(int64_t) t * N], bhv = bhp[(int64_t) t * N], ahprev = ahp[(int64_t) tp * N];
+                ahv = act ? ahv : NINF;
+                ahprev = act ? ahprev : NINF;
+                R gam = ahv + bhv;                         // lanes >= N: -inf
+                R mg = fmax(wave_allmax(gam), LZ);
+                R w = Num<R>::exp2(gam - mg);
+                R Z = wave_allsum(w);
                 gi = (Z > 0) ? gf * (w / Z) : R(0);
                 if (t >= 1) {
-                    R ahprev = act ? ahp[(int64_t) (t - 1) * N] : NINF;
-                    R p = Num<R>::exp2(ahprev);
-                    R i2 = act ? in[(int64_t) t * P.is0] * L2E : R(0);
-                    R ls = ahv + mshp[t] - i2 - Ri;           // log2 of this row's mat-vec sum in the forward pass
-                    bool live = act && gi != R(0);
-                    bool bad = live && !(ls >= Num<R>::ls_floor());
-                    R u = (live && !bad) ? gi * Num<R>::exp2(-ls) : R(0);
-                    if (__any(bad)) {
-                        // exact rare path (the forward pass re-did this node with an exact LSE):
-                        // xi[i][j] = gi * exp2(Tr2[i][j] + ah_{t-1}[j] - (ah_t[i] + m_t - I2_t[i])), kept in accx (not scaled by e[j])
-                        R base = ahv + mshp[t] - i2;
-                        for (int j = 0; j < N; ++j) {
-                            R aj = readlane(ahprev, j);
-                            R x = bad ? gi * Num<R>::exp2(trow[(int64_t) j * P.ts1] * L2E + aj - base) : R(0);
-#pragma unroll
-                            for (int q = 0; q < NP; ++q) accx[q] += (q == j) ? x : R(0);
-                        }
-                    }
-                    // acc[j] += u * p_j
+                    R mp = fmax(wave_allmax(ahprev), LZ);
+                    R p = Num<R>::exp2(ahprev - mp);
                     R *lds = pbuf[wave];
                     lds[lane] = p;
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    V4<R> pv[NP / 4];
 #pragma unroll
-                    for (int j = 0; j < NP; j += 4) {
-                        Vec4<R> v = *reinterpret_cast<const Vec4<R> *>(lds + j);
-                        acc[j + 0] = fma(u, v.x, acc[j + 0]);
-                        acc[j + 1] = fma(u, v.y, acc[j + 1]);
-                        acc[j + 2] = fma(u, v.z, acc[j + 2]);
-                        acc[j + 3] = fma(u, v.w, acc[j + 3]);
-                    }
+                    for (int j = 0; j < NP / 4; ++j) pv[j] = *reinterpret_cast<const V4<R> *>(lds + 4 * j);
                     __builtin_amdgcn_wave_barrier();
+                    V2<R> a0 = {0, 0}, a1 = {0, 0};
+#pragma unroll
+                    for (int j = 0; j < NP / 4; ++j) {
+                        a0 = fma2<R>(e2[2 * j], pv[j].xy, a0);
+                        a1 = fma2<R>(e2[2 * j + 1], pv[j].zw, a1);
+                    }
+                    V2<R> a = a0 + a1;
+                    R sden = a.x + a.y;                    // row sum of the forward mat-vec (up to the common scale of p)
+                    bool live = gi != R(0);
+                    unsigned long long bad = __ballot(live && !(fabs(Num<R>::log2(sden)) < Num<R>::lg_limit())) & actmask;
+                    bool mybad = (bad >> lane) & 1;
+                    R u = (live && !mybad) ? gi / sden : R(0);
+                    if (bad) {
+                        // exact rare path: xi[i][j] = gi * softmax_j(Tr2[i][j] + ah_{t-1}[j]), kept unscaled in accx
+                        R lse = exact_lse_row<R>(trow, P.ts1, ahprev, N, act);
+                        for (int j = 0; j < N; ++j) {
+                            R aj = readlane(ahprev, j);
+                            R x = mybad ? gi * Num<R>::exp2(trow[(int64_t) j * P.ts1] * L2E + aj - lse) : R(0);
+                            x = (x == x) ? x : R(0);
+#pragma unroll
+                            for (int q = 0; q < NP / 2; ++q) {
+                                accx[q].x += (2 * q == j) ? x : R(0);
+                                accx[q].y += (2 * q + 1 == j) ? x : R(0);
+                            }
+                        }
+                    }
+                    const V2<R> u2 = {u, u};
+#pragma unroll
+                    for (int j = 0; j < NP / 4; ++j) {
+                        acc[2 * j] = fma2<R>(u2, pv[j].xy, acc[2 * j]);
+                        acc[2 * j + 1] = fma2<R>(u2, pv[j].zw, acc[2 * j + 1]);
+                    }
                 }
             }
             if (do_ali) {
-                const bool sl = lane < S;
-                R abv = sl ? abp[(int64_t) t * S] : NINF;
-                R bbv = sl ? bbp[(int64_t) t * S] : NINF;
+                R abv = abp[(int64_t) t * S], bbv = bbp[(int64_t) t * S], abprev = abp[(int64_t) tp * S];
+                abv = sl ? abv : LZ;
+                bbv = sl ? bbv : LZ;
+                abprev = sl ? abprev : LZ;
                 R gam = abv + bbv;
-                R mg = wave_allmax<4>(gam);
-                R w = (mg == NINF) ? R(0) : Num<R>::exp2(gam - mg);
-                R Z = wave_allsum<4>(w);
+                R mg = wave_allmax(gam);
+                R w = (mg > R(-1e29)) ? Num<R>::exp2(gam - mg) : R(0);   // infeasible alignment -> no posterior
+                R Z = wave_allsum(w);
                 R post = (Z > 0) ? w / Z : R(0);            // unscaled state posterior, 0 for s >= ol
                 if (AS.act && post != R(0))
                     atomicAdd(&fxI[wave][AS.tgt], to_fix<R>(post));
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 unsigned long long fv = fxI[wave][lane];
                 if (fv != 0) {
                     gi += ga * from_fix<R>(fv);
@@ -515,67 +620,86 @@ __global__ void __launch_bounds__(256) bwd_small_kernel(Problem P, State W, BwdA
                 }
                 __builtin_amdgcn_wave_barrier();
                 if (t >= 1) {
-                    R abprev = sl ? abp[(int64_t) (t - 1) * S] : NINF;
-                    R left = from_prev_lane<R>(abprev, NINF);
-                    R pc0 = abprev + AS.H2, pc1 = left + AS.Dprev;
+                    R pc0 = abprev + AS.H2;
+                    R pc1 = prev_lane_or_zero<R>(abprev) + AS.Dprev;
                     R l = lse2<R>(pc0, pc1);
-                    R hori = (pc0 == NINF) ? R(0) : Num<R>::exp2(pc0 - l);
-                    R diag = (pc1 == NINF) ? R(0) : Num<R>::exp2(pc1 - l);
-                    accH += post * hori;
-                    accD += post * diag;
+                    accH += post * Num<R>::exp2(pc0 - l);
+                    accD += post * Num<R>::exp2(pc1 - l);
                 }
             }
         }
-        if (act) gin[(int64_t) t * P.B * N] = gi;
+        buf_store(gi, rs_g, voff, (unsigned) t * grow_bytes);
     }
 
     // ---- epilogue: one partial [N][N] tile per workgroup
 #pragma unroll
-    for (int j = 0; j < NP; ++j) acc[j] = fma(acc[j], e[j], accx[j]);
-    for (int w = 0; w < 4; ++w) {
-        if (wave == w && act) {
+    for (int j = 0; j < NP / 2; ++j) acc[j] = fma2<R>(acc[j], e2[j], accx[j]);
+    if (kWide) {
+        if (act) {
 #pragma unroll
-            for (int j = 0; j < NP; ++j) {
-                R prev = (w == 0) ? R(0) : tileF[lane * NP + j];
-                tileF[lane * NP + j] = prev + acc[j];
-            }
+            for (int j = 0; j < NP / 2; ++j)
+                *reinterpret_cast<V2<R> *>(&tileF[(wave * 64 + lane) * NP + 2 * j]) = acc[j];
         }
-        __syncthreads();
+    } else {
+        for (int w = 0; w < 4; ++w) {
+            if (wave == w && act) {
+#pragma unroll
+                for (int j = 0; j < NP / 2; ++j) {
+                    V2<R> *dst = reinterpret_cast<V2<R> *>(&tileF[lane * NP + 2 * j]);
+                    V2<R> prev = (w == 0) ? V2<R>{0, 0} : *dst;
+                    *dst = prev + acc[j];
+                }
+            }
+            __syncthreads();
+        }
     }
     if (do_ali && AS.act) {
         if (accH != R(0)) atomicAdd(&fxT[AS.tgt * N + AS.tgt], to_fix<R>(accH));
-        if (lane >= 1 && accD != R(0)) {
-            const int64_t *tg = P.targets + (int64_t) b * P.gs0;
-            int prv = clampi(tg[(int64_t) (lane - 1) * P.gs1], 0, N - 1);
-            atomicAdd(&fxT[AS.tgt * N + prv], to_fix<R>(accD));
-        }
+        if (lane >= 1 && accD != R(0)) atomicAdd(&fxT[AS.tgt * N + AS.prv], to_fix<R>(accD));
     }
     __syncthreads();
     R *tile_out = (R *) A.scratch + ((int64_t) b * A.nchunks + chunk) * N * N;
     for (int k = threadIdx.x; k < N * N; k += 256) {
         int i = k / N, j = k - i * N;
-        R v = do_full ? tileF[i * NP + j] : R(0);
+        R v = R(0);
+        if (do_full) {
+            if (kWide) v = (tileF[(0 * 64 + i) * NP + j] + tileF[(1 * 64 + i) * NP + j]) +
+                           (tileF[(2 * 64 + i) * NP + j] + tileF[(3 * 64 + i) * NP + j]);
+            else v = tileF[i * NP + j];
+        }
         unsigned long long fv = fxT[k];
         if (fv != 0) v += ga * from_fix<R>(fv);
         tile_out[k] = v;
     }
 }
 
-// sum G partial tiles in a fixed order -> deterministic grad_transition
+// Sum G partial tiles in a fixed order -> deterministic grad_transition.
+// block = 256 threads = 32 elements x 8 tile-groups; each thread sums every 8th tile, then a fixed-order
+// LDS combine over the 8 groups.
 template <typename R>
 __global__ void __launch_bounds__(256) reduce_tiles_kernel(const R *tiles, int G, int n, R *out) {
-    int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= n) return;
+    __shared__ R part[8][32];
+    const int e = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int k = blockIdx.x * 32 + e;
     R s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    int g = 0;
-    for (; g + 3 < G; g += 4) {
-        s0 += tiles[(int64_t) (g + 0) * n + k];
-        s1 += tiles[(int64_t) (g + 1) * n + k];
-        s2 += tiles[(int64_t) (g + 2) * n + k];
-        s3 += tiles[(int64_t) (g + 3) * n + k];
+    if (k < n) {
+        int g = grp;
+        for (; g + 24 < G; g += 32) {
+            s0 += tiles[(int64_t) (g + 0) * n + k];
+            s1 += tiles[(int64_t) (g + 8) * n + k];
+            s2 += tiles[(int64_t) (g + 16) * n + k];
+            s3 += tiles[(int64_t) (g + 24) * n + k];
+        }
+        for (; g < G; g += 8) s0 += tiles[(int64_t) g * n + k];
     }
-    for (; g < G; ++g) s0 += tiles[(int64_t) g * n + k];
-    out[k] = (s0 + s1) + (s2 + s3);
+    part[grp][e] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (grp == 0 && k < n) {
+        R s = part[0][e];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) s += part[q][e];
+        out[k] = s;
+    }
 }
 
 template <typename R, int NP, int MV>
@@ -606,7 +730,7 @@ hipError_t launch_bwd_np(const Problem &P, const State &W, const BwdArgs &A, int
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int n = P.N * P.N, G = P.B * A.nchunks;
-    hipLaunchKernelGGL((reduce_tiles_kernel<R>), dim3((n + 255) / 256), dim3(256), 0, st,
+    hipLaunchKernelGGL((reduce_tiles_kernel<R>), dim3((n + 31) / 32), dim3(256), 0, st,
                        (const R *) A.scratch, G, n, (R *) A.grad_transition);
     return hipGetLastError();
 }
