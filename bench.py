@@ -1,0 +1,290 @@
+#!/usr/bin/env python3
+"""bench.py -- utterances/s of the ASG forward+backward hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode graph|eager] [--launch single|streams|serial]
+
+One "step" = ASGLoss(inputs, targets, input_lengths, target_lengths) + loss.backward() on one batch of
+synthetic utterances already resident in HBM (SURVEY.md 8d inputs: cfg 3, T=400 B=64 N=40 L=30, fp32).
+With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank owns its own B=64 shard of a
+B=64*N batch (= cfg 4 at N=8), and the step ends with the single RCCL all-reduce of transition.grad
+(SURVEY.md 8e): weak scaling, no other collective.
+
+Rank 0 prints ONE JSON line.  Besides the driver's contract fields it carries
+  roofline     -- dominant kernel (the recursion kernel): algorithmic bytes / measured kernel time vs HBM peak
+  cpu_baseline -- the reference's own compiled CPU path (oracle/_ref) timed on this box's host cores (N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch                      # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+T, B, N, L = 400, 64, 40, 30          # BASELINE.json configs[2] ("cfg 3"), per GPU
+HBM_PEAK_GBS = 8000.0                 # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def algorithmic_bytes(T, B, N, L, w=4):
+    """read inputs once + write grad_inputs once; Tr + grad_Tr; targets, lengths, loss."""
+    return 2 * T * B * N * w + 2 * N * N * w + B * (8 * L + 16 + w)
+
+
+def synth(seed, device):
+    g = torch.Generator().manual_seed(seed)
+    transition = torch.rand(N, N, generator=g)
+    inputs = torch.randn(T, B, N, generator=g)
+    targets = torch.randint(0, N, (B, L), generator=g)
+    il = torch.full((B,), T, dtype=torch.int64)
+    tl = torch.full((B,), L, dtype=torch.int64)
+    return [t.to(device) for t in (transition, inputs, targets, il, tl)]
+
+
+def cpu_baseline(budget_s=24.0):
+    """Time the reference CPU path on this host: the real reference C++ (oracle/_ref) when present,
+    else the plain-C oracle port.  Bounded sample of the SAME workload (cfg 3 batches).
+
+    The reference is op-dispatch-bound, so on a many-core host its default thread count is
+    far from its best; a small sweep over thread counts is timed and the BEST one is reported (cores = that
+    thread count), the others are listed in `sample`."""
+    tr, x, tg, il, tl = synth(0, "cpu")
+    ncpu = os.cpu_count() or 1
+    try:
+        from oracle import ref_runner
+        if not ref_runner.available():
+            raise RuntimeError("no _ref")
+        kind = "reference"
+
+        def step():
+            ref_runner.asg_loss(x, tg, tr, il, tl, "mean")
+
+        def set_threads(n):
+            torch.set_num_threads(n)
+            os.environ["OMP_NUM_THREADS"] = str(n)
+    except Exception:
+        from oracle import asg_oracle as orc
+        kind = "port"
+        xn, tgn, trn, iln, tln = x.numpy(), tg.numpy(), tr.numpy(), il.numpy(), tl.numpy()
+
+        def step():
+            orc.asg_loss(xn, tgn, trn, iln, tln, "mean")
+
+        def set_threads(n):
+            import ctypes
+            try:
+                ctypes.CDLL("libgomp.so.1").omp_set_num_threads(int(n))
+            except Exception:
+                pass
+    default_threads = torch.get_num_threads()
+    cands = sorted({n for n in (8, 16, 32, default_threads) if 1 <= n <= ncpu})
+    results = {}
+    per = budget_s / len(cands)
+    for n in cands:
+        set_threads(n)
+        step()                               # warm-up
+        t0 = time.perf_counter()
+        reps = 0
+        while reps < 2 or (time.perf_counter() - t0 < per and reps < 50):
+            step()
+            reps += 1
+        results[n] = ((time.perf_counter() - t0) / reps, reps)
+    set_threads(default_threads)
+    best = min(results, key=lambda n: results[n][0])
+    dt, reps = results[best]
+    return {"value": B / dt, "unit": "utterances/s", "cores": int(best), "kind": kind,
+            "ms_per_step": dt * 1e3,
+            "sample": "fwd+bwd passes over the cfg-3 batch (T=%d B=%d N=%d L=%d fp32), 1 warm-up + >=2 timed reps per "
+                      "thread count, %s, host cpu_count=%d; ms/step by threads: %s (default threads=%d)"
+                      % (T, B, N, L, "oracle/_ref = the reference's C++ CPU path built -fopenmp -Ofast"
+                         if kind == "reference" else "oracle/asg_oracle.c (OpenMP)", ncpu,
+                         ", ".join("%d:%.0f" % (n, results[n][0] * 1e3) for n in cands), default_threads)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--mode", choices=["graph", "eager"], default="graph")
+    ap.add_argument("--launch", choices=["single", "streams", "serial"], default="single")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="init the process group even with one rank (testing)")
+    args = ap.parse_args()
+
+    # keep stdout clean for the ONE JSON line: anything libraries print (RCCL banners etc.) goes to stderr
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
+                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ..." % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import torch_asg_amd
+    from torch_asg_amd import asg as asg_mod
+
+    tr, x, tg, il, tl = synth(1000 + rank, dev)          # every rank: its own B=64 shard
+    loss_mod = torch_asg_amd.ASGLoss(N, reduction="mean", launch_mode=args.launch).to(dev)
+    with torch.no_grad():
+        loss_mod.transition.copy_(synth(0, dev)[0])      # replicated transition matrix
+    x.requires_grad_(True)
+    global_batch = B * world
+
+    # ---- kernel timing hook: HIP events around the recursion-kernel launch, on the launch stream
+    ev_pairs = []
+    be = asg_mod.native()
+    orig_forward = be.forward
+
+    def timed_forward(*a, **k):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = orig_forward(*a, **k)
+        e1.record()
+        ev_pairs.append((e0, e1))
+        return out
+
+    def one_step():
+        loss_mod.transition.grad = None
+        x.grad = None
+        # local mean over B and division by world == mean over the global batch (equal shards)
+        loss = loss_mod(x, tg, il, tl) / world
+        loss.backward()
+        return loss
+
+    def sync_grads():
+        if use_dist:
+            dist.all_reduce(loss_mod.transition.grad, op=dist.ReduceOp.SUM)   # the one collective of the step
+
+    # ---- optional hipGraph capture of the compute part of the step (static shapes)
+    graph = None
+    mode = args.mode
+    if mode == "graph":
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    one_step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_loss = one_step()
+            graph.replay()
+            torch.cuda.synchronize()
+        except Exception as e:           # capture unsupported in this environment: fall back, say so
+            sys.stderr.write("[bench] hipGraph capture failed (%s); running eager\n" % (e,))
+            graph = None
+            mode = "eager"
+
+    def step():
+        if graph is not None:
+            graph.replay()
+        else:
+            one_step()
+        sync_grads()
+
+    def fence():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if use_dist:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # ---- dominant-kernel duration, measured live with HIP events on eager launches of the same step
+    # (events cannot be read back out of a replayed graph, so this leg always launches eagerly; the GPU is
+    # kept busy by queuing all launches before the first sync, so the events bracket kernel time, not host time)
+    be.forward = timed_forward
+    for _ in range(5):
+        one_step()
+    torch.cuda.synchronize()
+    ev_pairs.clear()
+    nk = min(max(args.steps, 20), 200)
+    for _ in range(nk):
+        torch.cuda._sleep(400000)      # ~0.2 ms spin kernel: lets the host run ahead so the queue never drains
+        one_step()
+    torch.cuda.synchronize()
+    be.forward = orig_forward
+    kern_ms = sorted(e0.elapsed_time(e1) for e0, e1 in ev_pairs)
+    kern_ms_avg = sum(kern_ms) / len(kern_ms)
+    kern_ms_med = kern_ms[len(kern_ms) // 2]
+
+    if rank == 0:
+        a_alg = algorithmic_bytes(T, B, N, L)
+        ms_per_step = dt / args.steps * 1e3
+        value = global_batch * args.steps / dt
+        achieved = a_alg / (kern_ms_med * 1e-3) / 1e9
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_cfg3.json")
+        if os.path.exists(pmc_path):
+            try:
+                with open(pmc_path) as f:
+                    traffic = json.load(f).get("recursion_kernel_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "utterances/sec fwd+bwd, T=400 B=64 N=40; achieved HBM GB/s vs roofline",
+            "value": value,
+            "unit": "utterances/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "cfg3 per GPU: T=%d B=%d N=%d L=%d fp32, full lengths, ASGLoss(reduction=mean) "
+                                   "forward+backward%s" % (T, B, N, L, "" if world == 1 else
+                                                            "; global batch %d sharded over %d GPUs, one RCCL "
+                                                            "all-reduce of transition.grad per step" % (global_batch, world)),
+                       "global_batch": global_batch, "per_gpu_batch": B, "T": T, "N": N, "L": L,
+                       "step_mode": mode, "launch_mode": args.launch,
+                       "parallelism": "batch-sharded x%d" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "fwd_small_kernel (alpha/beta recursions, all four passes in one launch)"
+                                   if args.launch == "single" else "asg_forward launches (recursion kernels)",
+                         "kernel_ms": kern_ms_med, "kernel_ms_avg": kern_ms_avg,
+                         "algorithmic_bytes_per_launch": a_alg,
+                         "step_achieved": a_alg / (ms_per_step * 1e-3) / 1e9,
+                         "note": "serial-latency-bound scan: 400 dependent steps x 64 utterances; see DESIGN.md"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
