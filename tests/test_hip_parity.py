@@ -165,6 +165,36 @@ def test_alpha_and_beta_scores_agree_and_matvec_variants():
     util.assert_close(outs[0][0], outs[1][0], 1e-6, "matvec variants")
 
 
+@pytest.mark.parametrize("case", ["wide_transitions", "neginf_transitions", "huge_emission_range", "logit_scale"])
+def test_exact_fallback_paths(case):
+    """Inputs that push row sums of the exp-domain mat-vec out of fp32 range, so the kernels must take their
+    exact log-sum-exp path (forward) / exact softmax path (backward); checked against the fp64 oracle."""
+    g = torch.Generator().manual_seed(42)
+    T, B, N, L = 37, 3, 19, 6
+    tr = torch.rand(N, N, generator=g)
+    x = torch.randn(T, B, N, generator=g)
+    if case == "wide_transitions":
+        tr = 60.0 * torch.randn(N, N, generator=g)                    # span >> 69 nats
+    elif case == "neginf_transitions":
+        tr = torch.where(torch.rand(N, N, generator=g) < 0.6, torch.full((N, N), float("-inf")), tr)
+        tr.fill_diagonal_(0.1)                                        # self loops keep every state alive
+        tr[:, 0] = 0.2                                                # and label 0 can go anywhere
+    elif case == "huge_emission_range":
+        x = 40.0 * torch.randn(T, B, N, generator=g)
+    elif case == "logit_scale":
+        x = 25.0 + 30.0 * torch.rand(T, B, N, generator=g)            # large positive scores every frame
+    tg = torch.randint(0, N, (B, L), generator=g)
+    if case == "neginf_transitions":
+        tg = torch.zeros(B, L, dtype=torch.long)                      # an alignment that is certainly feasible
+    il = torch.tensor([37, 30, 21])
+    tl = torch.tensor([6, 4, 5])
+    o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il.numpy(), tl.numpy(), "none")
+    assert np.isfinite(o["loss"]).all()
+    r = run_hip(x, tg, tr, il, tl, "none")
+    for k in ("loss", "grad_inputs", "grad_transition"):
+        util.assert_close(r[k], o[k], 1e-4, "%s/%s" % (case, k))
+
+
 # ------------------------------------------------------------------ routes
 def test_forward_only_and_eval_routes():
     A = _asg()

@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libasg_hip.so")
+LIB_PATH = os.environ.get("ASG_HIP_LIB") or os.path.join(_HERE, "csrc", "libasg_hip.so")
 
 ASG_DTYPE_F32, ASG_DTYPE_F64 = 0, 1
 FLAG_STREAMS, FLAG_SINGLE_LAUNCH, FLAG_MATVEC_READLANE, FLAG_ALPHA_SCORES = 1, 2, 4, 8

@@ -6,6 +6,7 @@
 
 #include <hip/hip_runtime.h>
 #include <new>
+#include <cstdlib>
 
 using namespace asg;
 
@@ -101,6 +102,7 @@ int run_forward(asg_ctx *ctx, const asg_problem *p, void *state, void *full_scor
         if (aligned_scores) O.aligned_scores_alpha = (R *) aligned_scores + p->B;
     }
     const int mv = (flags & ASG_FLAG_MATVEC_READLANE) ? 1 : 0;
+    if (const char *dm = getenv("ASG_DEBUG_MASK")) mask &= atoi(dm);      // developer probe: time single passes
     const int full_mask = mask & (kFullAlpha | kFullBeta);
     const int ali_mask = mask & (kAlignedAlpha | kAlignedBeta);
     const bool sf = small_full(p->N), sa = small_aligned(p->S);

@@ -70,11 +70,17 @@ __device__ __forceinline__ R matvec(const V2<R> (&e2)[NP / 2], R p, R *lds, int 
         // LDS executes one wave's DS ops in order, so no s_barrier is needed -- only compiler ordering.
         lds[lane] = p;
         __builtin_amdgcn_wave_barrier();
+        // Issue ALL broadcast reads back to back, then the FMAs (lgkmcnt(NP/4-1 .. 0) peels them off as
+        // they land): one LDS round trip per step.  Left alone, hipcc's register-pressure scheduler
+        // interleaves reads and FMAs 3-4 at a time and the step pays the LDS latency 3-4 times.
+        V4<R> pv[NP / 4];
 #pragma unroll
-        for (int j = 0; j < NP; j += 4) {
-            V4<R> v = *reinterpret_cast<const V4<R> *>(lds + j);
-            a0 = fma2<R>(e2[j / 2], v.xy, a0);
-            a1 = fma2<R>(e2[j / 2 + 1], v.zw, a1);
+        for (int j = 0; j < NP / 4; ++j) pv[j] = *reinterpret_cast<const V4<R> *>(lds + 4 * j);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NP / 4; ++j) {
+            a0 = fma2<R>(e2[2 * j], pv[j].xy, a0);
+            a1 = fma2<R>(e2[2 * j + 1], pv[j].zw, a1);
         }
         __builtin_amdgcn_wave_barrier();
     } else {
@@ -91,8 +97,10 @@ __device__ __forceinline__ R matvec(const V2<R> (&e2)[NP / 2], R p, R *lds, int 
 }
 
 // Exact log2-sum-exp2 over j of (trow[j*tstride]*log2e + v_j), v_j in lane j.  Rare path.
+// Deliberately inlined (small rolled loops): an out-of-line call gives the kernel a stack (scratch),
+// and a kernel that needs scratch pays ~20 us of extra dispatch cost on this stack.
 template <typename R>
-__device__ __noinline__ R exact_lse_row(const R *trow, int64_t tstride, R v, int N, bool act) {
+__device__ __forceinline__ R exact_lse_row(const R *trow, int64_t tstride, R v, int N, bool act) {
     const R NINF = Num<R>::ninf(), L2E = Num<R>::log2e();
     R mx = NINF;
     for (int j = 0; j < N; ++j) {
@@ -117,14 +125,29 @@ template <typename R> __device__ __forceinline__ R score_out(double s2) {
 // ------------------------------------------------------------------ full lattice, alpha
 // State per lane i: ah = alpha_t[i] in log2 units relative to the running offset C (double).
 // Every kRenorm-th step the frame max is folded into C so that p = exp2(ah) stays in range; in between
-// ah drifts by at most kRenorm-1 frames.  A row sum s whose |log2 s| > lg_limit (underflow, overflow,
-// zero, NaN) is re-done by exact_lse_row from the log-domain state, so the result is always a true LSE.
+// ah drifts by at most kRenorm-1 frames.
+//
+// Exactness guard without a branch on the critical path: every step ORs-in |log2 s| (as an unsigned bit
+// pattern: finite < inf < NaN) into a per-lane sticky VGPR; after the 16-step block ONE test decides whether
+// any row sum left the safe range (underflow, overflow, zero, NaN).  If so the chain rewinds to the state at
+// block entry and redoes the block with `slow_full_steps` (exact max-shifted log-sum-exp per node), whose
+// stores simply overwrite the fast attempt's.
+template <typename R> struct ChainState { R v; double C; };
+
+template <typename R> __device__ __forceinline__ unsigned abs_bits(float x) { return __float_as_uint(x) & 0x7fffffffu; }
+template <typename R> __device__ __forceinline__ unsigned abs_bits(double x) {
+    // order-preserving 32-bit summary of |x|: clamp to float range first
+    float f = (float) fmin(fabs(x), 3.0e38);
+    return (x != x) ? 0x7fc00000u : __float_as_uint(f);
+}
+
 template <typename R, int NP, int MV, bool STORE, bool GUARD>
-__device__ __forceinline__ void full_alpha_block(const R (&cur)[kPF], int nsteps, unsigned soff0, unsigned row_bytes,
-                                                 const V2<R> (&e2)[NP / 2], R RiX, const R *trow, int64_t ts1,
-                                                 int N, bool act, unsigned long long actmask, R *lds, int lane,
-                                                 __amdgpu_buffer_rsrc_t rs, unsigned voff, R &ah, double &C) {
+__device__ __forceinline__ bool full_alpha_block(const R (&cur)[kPF], int nsteps, unsigned soff0, unsigned row_bytes,
+                                                 const V2<R> (&e2)[NP / 2], R RiX, unsigned long long actmask,
+                                                 R *lds, int lane, __amdgpu_buffer_rsrc_t rs, unsigned voff,
+                                                 R &ah, double &C) {
     const R L2E = Num<R>::log2e();
+    unsigned worst = 0;                                  // max over the block of bits(|log2 s|)
 #pragma unroll
     for (int k = 0; k < kPF; ++k) {
         if (!GUARD || k < nsteps) {
@@ -132,11 +155,7 @@ __device__ __forceinline__ void full_alpha_block(const R (&cur)[kPF], int nsteps
             R s = matvec<R, NP, MV>(e2, p, lds, lane);
             R lg = Num<R>::log2(s);
             R x = fma(cur[k], L2E, RiX) + lg;            // RiX = -inf on lanes >= N
-            unsigned long long bad = __ballot(!(fabs(lg) < Num<R>::lg_limit())) & actmask;
-            if (bad) {
-                R ex = exact_lse_row<R>(trow, ts1, ah, N, act);
-                if ((bad >> lane) & 1) x = fma(cur[k], L2E, R(0)) + ex;
-            }
+            worst = max(worst, abs_bits<R>(lg));
             if ((k % kRenorm) == kRenorm - 1) {
                 R m = fmax(wave_allmax(x), Num<R>::logzero());
                 ah = x - m;
@@ -147,6 +166,41 @@ __device__ __forceinline__ void full_alpha_block(const R (&cur)[kPF], int nsteps
             if (STORE) buf_store(ah, rs, voff, soff0 + (unsigned) k * row_bytes);
         }
     }
+    return (__ballot(worst >= __float_as_uint((float) Num<R>::lg_limit())) & actmask) != 0;
+}
+
+// Exact (slow, rare) recursion for `nsteps` frames starting at frame t_first: alpha or beta direction.
+//   alpha (BETA=false): x_i = I2[t][i] + LSE_j(Tr2[i][j] + v_j),   v <- x - max, C += max
+//   beta  (BETA=true):  y_j = I2[t][j] + v_j, C += max(y), y -= max, v_i <- LSE_j(Tr2[j][i] + y_j)   (writes frame t-1)
+template <typename R, bool BETA>
+__device__ __forceinline__ ChainState<R> slow_full_steps(const R *in, int64_t is0, const R *tline, int64_t tstride,
+                                                      int N, int lane, int t_first, int nsteps, R v, double C,
+                                                      R *out, int64_t out_stride, bool store) {
+    const R NINF = Num<R>::ninf(), L2E = Num<R>::log2e(), LZ = Num<R>::logzero();
+    const bool act = lane < N;
+    for (int n = 0; n < nsteps; ++n) {
+        const int t = BETA ? t_first - n : t_first + n;
+        R em = act ? in[(int64_t) t * is0] * L2E : NINF;
+        if (!BETA) {
+            R x = em + exact_lse_row<R>(tline, tstride, v, N, act);
+            R m = fmax(wave_allmax(x), LZ);
+            v = x - m;
+            C += (double) m;
+            if (store && act) out[(int64_t) t * out_stride] = v;
+        } else {
+            R y = em + v;
+            R m = fmax(wave_allmax(y), LZ);
+            y -= m;
+            C += (double) m;
+            v = exact_lse_row<R>(tline, tstride, y, N, act);
+            if (!act) v = NINF;
+            if (store && act) out[(int64_t) (t - 1) * out_stride] = v;
+        }
+    }
+    ChainState<R> r;
+    r.v = v;
+    r.C = C;
+    return r;
 }
 
 template <typename R, int NP, int MV, bool STORE>
@@ -186,18 +240,46 @@ __device__ void full_alpha_chain(const Problem &P, const State &W, const FwdOut 
         R cur[kPF], nxt[kPF];
 #pragma unroll
         for (int k = 0; k < kPF; ++k) cur[k] = in[(int64_t) min(1 + k, len - 1) * P.is0];
+        // enter the block loop with no load in flight, so the loop-head wait state is the steady-state one
+        // (otherwise hipcc sizes the head-of-loop vmcnt for this first entry and drains the store queue every block)
+        __builtin_amdgcn_s_waitcnt(0x0F70);
         int done = 0;
         for (; done + kPF <= nst; done += kPF) {
 #pragma unroll
             for (int k = 0; k < kPF; ++k) nxt[k] = in[(int64_t) min(1 + done + kPF + k, len - 1) * P.is0];
-            full_alpha_block<R, NP, MV, STORE, false>(cur, kPF, (unsigned) (1 + done) * row_bytes, row_bytes, e2, RiX,
-                                                      trow, P.ts1, N, act, actmask, lds, lane, rs, voff, ah, C);
+            {
+                const R ah0 = ah;
+                const double C0 = C;
+                const bool redo = full_alpha_block<R, NP, MV, STORE, false>(cur, kPF, (unsigned) (1 + done) * row_bytes,
+                                                                            row_bytes, e2, RiX, actmask, lds, lane, rs,
+                                                                            voff, ah, C);
+                // consume the prefetched frames BEFORE the (rare) branch: the load-completion wait is then an
+                // exact vmcnt(#stores) here, instead of a conservative drain of the store queue after the merge
+                // The 16 prefetch loads were issued before this block's 16 stores: "at most 16 VMEM ops outstanding"
+                // == all loads have landed.  Saying so explicitly keeps hipcc from draining the store queue
+                // (vmcnt(0/1)) at the loop head, where it has lost the exact count behind the branch below.
+                __builtin_amdgcn_s_waitcnt(STORE ? 0x4F70 : 0x0F70);
 #pragma unroll
-            for (int k = 0; k < kPF; ++k) cur[k] = nxt[k];
+                for (int k = 0; k < kPF; ++k) cur[k] = nxt[k];
+                if (redo) {
+                    ChainState<R> r = slow_full_steps<R, false>(in, P.is0, trow, P.ts1, N, lane, 1 + done, kPF, ah0, C0,
+                                                                (R *) W.ah + (int64_t) b * T * N + lc, N, STORE);
+                    ah = r.v;
+                    C = r.C;
+                }
+            }
         }
-        if (done < nst)
-            full_alpha_block<R, NP, MV, STORE, true>(cur, nst - done, (unsigned) (1 + done) * row_bytes, row_bytes, e2,
-                                                     RiX, trow, P.ts1, N, act, actmask, lds, lane, rs, voff, ah, C);
+        if (done < nst) {
+            const R ah0 = ah;
+            const double C0 = C;
+            if (full_alpha_block<R, NP, MV, STORE, true>(cur, nst - done, (unsigned) (1 + done) * row_bytes, row_bytes, e2,
+                                                         RiX, actmask, lds, lane, rs, voff, ah, C)) {
+                ChainState<R> r = slow_full_steps<R, false>(in, P.is0, trow, P.ts1, N, lane, 1 + done, nst - done, ah0,
+                                                            C0, (R *) W.ah + (int64_t) b * T * N + lc, N, STORE);
+                ah = r.v;
+                C = r.C;
+            }
+        }
     }
     if (O.full_scores_alpha) {
         R mx = fmax(wave_allmax(ah), Num<R>::logzero());
@@ -210,18 +292,18 @@ __device__ void full_alpha_chain(const Problem &P, const State &W, const FwdOut 
 // ------------------------------------------------------------------ full lattice, beta
 // Iteration n handles frame t = len-1-n: y = I2[t] + bh[t]; it produces bh[t-1] = LSE_j(Tr[j][.] + y_j).
 template <typename R, int NP, int MV, bool STORE, bool GUARD>
-__device__ __forceinline__ void full_beta_block(const R (&cur)[kPF], int nsteps, unsigned soff0, unsigned row_bytes,
-                                                const V2<R> (&f2)[NP / 2], R CiX, const R *tcol, int64_t ts0,
-                                                int N, bool act, unsigned long long actmask, R *lds, int lane,
-                                                __amdgpu_buffer_rsrc_t rs, unsigned voff, R &bh, double &C) {
+__device__ __forceinline__ bool full_beta_block(const R (&cur)[kPF], int nsteps, unsigned soff0, unsigned row_bytes,
+                                                const V2<R> (&f2)[NP / 2], R CiX, unsigned long long actmask,
+                                                R *lds, int lane, __amdgpu_buffer_rsrc_t rs, unsigned voff,
+                                                R &bh, double &C) {
     const R L2E = Num<R>::log2e();
+    unsigned worst = 0;
 #pragma unroll
     for (int k = 0; k < kPF; ++k) {
         if (!GUARD || k < nsteps) {
             R y = fma(cur[k], L2E, bh);                  // lanes >= N: bh = -inf
-            R m = R(0);
             if ((k % kRenorm) == 0) {
-                m = fmax(wave_allmax(y), Num<R>::logzero());
+                R m = fmax(wave_allmax(y), Num<R>::logzero());
                 C += (double) m;
                 y -= m;
             }
@@ -229,14 +311,11 @@ __device__ __forceinline__ void full_beta_block(const R (&cur)[kPF], int nsteps,
             R s = matvec<R, NP, MV>(f2, p, lds, lane);
             R lg = Num<R>::log2(s);
             bh = CiX + lg;
-            unsigned long long bad = __ballot(!(fabs(lg) < Num<R>::lg_limit())) & actmask;
-            if (bad) {
-                R ex = exact_lse_row<R>(tcol, ts0, y, N, act);
-                if ((bad >> lane) & 1) bh = ex;
-            }
+            worst = max(worst, abs_bits<R>(lg));
             if (STORE) buf_store(bh, rs, voff, soff0 - (unsigned) k * row_bytes);
         }
     }
+    return (__ballot(worst >= __float_as_uint((float) Num<R>::lg_limit())) & actmask) != 0;
 }
 
 template <typename R, int NP, int MV, bool STORE>
@@ -272,19 +351,41 @@ __device__ void full_beta_chain(const Problem &P, const State &W, const FwdOut &
     R cur[kPF], nxt[kPF];
 #pragma unroll
     for (int k = 0; k < kPF; ++k) cur[k] = in[(int64_t) max(len - 1 - k, 0) * P.is0];
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // see full_alpha_chain
     int done = 0;
     for (; done + kPF <= nst; done += kPF) {
 #pragma unroll
         for (int k = 0; k < kPF; ++k) nxt[k] = in[(int64_t) max(len - 1 - (done + kPF + k), 0) * P.is0];
-        full_beta_block<R, NP, MV, STORE, false>(cur, kPF, (unsigned) (len - 2 - done) * row_bytes, row_bytes, f2, CiX,
-                                                 tcol, P.ts0, N, act, actmask, lds, lane, rs, voff, bh, C);
+        {
+            const R bh0 = bh;
+            const double C0 = C;
+            const bool redo = full_beta_block<R, NP, MV, STORE, false>(cur, kPF, (unsigned) (len - 2 - done) * row_bytes,
+                                                                       row_bytes, f2, CiX, actmask, lds, lane, rs, voff,
+                                                                       bh, C);
+            __builtin_amdgcn_s_waitcnt(STORE ? 0x4F70 : 0x0F70);    // see full_alpha_chain
 #pragma unroll
-        for (int k = 0; k < kPF; ++k) cur[k] = nxt[k];
+            for (int k = 0; k < kPF; ++k) cur[k] = nxt[k];
+            if (redo) {
+                ChainState<R> r = slow_full_steps<R, true>(in, P.is0, tcol, P.ts0, N, lane, len - 1 - done, kPF, bh0, C0,
+                                                           (R *) W.bh + (int64_t) b * T * N + lc, N, STORE);
+                bh = r.v;
+                C = r.C;
+            }
+        }
     }
     R last_raw = cur[0];
     if (done < nst) {
-        full_beta_block<R, NP, MV, STORE, true>(cur, nst - done, (unsigned) (len - 2 - done) * row_bytes, row_bytes, f2,
-                                                CiX, tcol, P.ts0, N, act, actmask, lds, lane, rs, voff, bh, C);
+        {
+            const R bh0 = bh;
+            const double C0 = C;
+            if (full_beta_block<R, NP, MV, STORE, true>(cur, nst - done, (unsigned) (len - 2 - done) * row_bytes, row_bytes,
+                                                        f2, CiX, actmask, lds, lane, rs, voff, bh, C)) {
+                ChainState<R> r = slow_full_steps<R, true>(in, P.is0, tcol, P.ts0, N, lane, len - 1 - done, nst - done, bh0,
+                                                           C0, (R *) W.bh + (int64_t) b * T * N + lc, N, STORE);
+                bh = r.v;
+                C = r.C;
+            }
+        }
         // the frame-0 emission sits right after the last consumed ring slot
         const int r = nst - done;
         last_raw = cur[0];
@@ -466,8 +567,11 @@ __device__ void aligned_beta_chain(const Problem &P, const State &W, const FwdOu
 // ------------------------------------------------------------------ forward kernel
 // grid = (B, popcount(chain_mask)), block = 64.  blockIdx.y walks the set bits of chain_mask
 // low to high, so the long full-lattice chains are dispatched first.
+// launch_bounds(64, 1): one wave per SIMD is all this latency-bound kernel ever has (one chain per CU at cfg 3);
+// without the explicit 1 hipcc schedules for 4 waves/SIMD (<=128 VGPRs) and serialises the LDS broadcast reads
+// of the mat-vec into 3-4 dependent groups per step (+45% step latency) as soon as a few more values are live.
 template <typename R, int NP, int MV, bool STORE>
-__global__ void __launch_bounds__(64) fwd_small_kernel(Problem P, State W, FwdOut O, int chain_mask) {
+__global__ void __launch_bounds__(64, 1) fwd_small_kernel(Problem P, State W, FwdOut O, int chain_mask) {
     __shared__ __attribute__((aligned(16))) R lds[64];
     int which = 0, seen = 0;
     for (int c = 0; c < 4; ++c) {
@@ -494,7 +598,7 @@ __global__ void __launch_bounds__(64) fwd_small_kernel(Problem P, State W, FwdOu
 //            LDS adds (integer adds commute -> deterministic), stay/advance edge posteriors per lane.
 // Output: grad_inputs rows for its frames, one partial [N][N] tile per workgroup.
 template <typename R, int NP>
-__global__ void __launch_bounds__(256) bwd_small_kernel(Problem P, State W, BwdArgs A, int parts) {
+__global__ void __launch_bounds__(256, 1) bwd_small_kernel(Problem P, State W, BwdArgs A, int parts) {
     constexpr bool kWide = sizeof(R) == 4;       // fp32: one LDS tile per wave; fp64: shared tile, serial rounds
     __shared__ __attribute__((aligned(16))) R pbuf[4][64];
     __shared__ unsigned long long fxI[4][64];
@@ -543,12 +647,24 @@ __global__ void __launch_bounds__(256) bwd_small_kernel(Problem P, State W, BwdA
 
     const int t0 = chunk * A.chunk;
     const int t1 = min(T, t0 + A.chunk);
+    // software prefetch: the six state values of the NEXT frame are loaded before the current one is processed
+    R n_ah, n_bh, n_ahp, n_ab, n_bb, n_abp;
+    {
+        const int tq = min(t0 + wave, T - 1), tqp = tq >= 1 ? tq - 1 : 0;
+        n_ah = ahp[(int64_t) tq * N]; n_bh = bhp[(int64_t) tq * N]; n_ahp = ahp[(int64_t) tqp * N];
+        n_ab = abp[(int64_t) tq * S]; n_bb = bbp[(int64_t) tq * S]; n_abp = abp[(int64_t) tqp * S];
+    }
     for (int t = t0 + wave; t < t1; t += 4) {
         R gi = 0;
+        const R c_ah = n_ah, c_bh = n_bh, c_ahp = n_ahp, c_ab = n_ab, c_bb = n_bb, c_abp = n_abp;
+        {
+            const int tq = min(t + 4, T - 1), tqp = tq >= 1 ? tq - 1 : 0;
+            n_ah = ahp[(int64_t) tq * N]; n_bh = bhp[(int64_t) tq * N]; n_ahp = ahp[(int64_t) tqp * N];
+            n_ab = abp[(int64_t) tq * S]; n_bb = bbp[(int64_t) tq * S]; n_abp = abp[(int64_t) tqp * S];
+        }
         if (t < len) {
-            const int tp = t >= 1 ? t - 1 : 0;
             if (do_full) {
-                R ahv = ahp[(int64_t) t * N], bhv = bhp[(int64_t) t * N], ahprev = ahp[(int64_t) tp * N];
+                R ahv = c_ah, bhv = c_bh, ahprev = c_ahp;
                 ahv = act ? ahv : NINF;
                 ahprev = act ? ahprev : NINF;
                 R gam = ahv + bhv;                         // lanes >= N: -inf
@@ -601,7 +717,7 @@ __global__ void __launch_bounds__(256) bwd_small_kernel(Problem P, State W, BwdA
                 }
             }
             if (do_ali) {
-                R abv = abp[(int64_t) t * S], bbv = bbp[(int64_t) t * S], abprev = abp[(int64_t) tp * S];
+                R abv = c_ab, bbv = c_bb, abprev = c_abp;
                 abv = sl ? abv : LZ;
                 bbv = sl ? bbv : LZ;
                 abprev = sl ? abprev : LZ;

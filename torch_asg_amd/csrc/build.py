@@ -24,7 +24,23 @@ def _mtime(p):
     return os.path.getmtime(p) if os.path.exists(p) else 0.0
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, defines=(), out=None):
+    """defines/out: developer experiments -- build a variant library next to the real one."""
+    global OUT
+    if defines or out:
+        import tempfile
+        odir = tempfile.mkdtemp(prefix="asgvar_")
+        objs = []
+        procs = []
+        for s in SOURCES:
+            obj = os.path.join(odir, s.replace(".hip", ".o"))
+            objs.append(obj)
+            procs.append(subprocess.Popen([HIPCC] + CFLAGS + ["-D" + d for d in defines] + ["-c", os.path.join(HERE, s), "-o", obj],
+                                          stderr=subprocess.DEVNULL))
+        for p in procs:
+            assert p.wait() == 0
+        subprocess.check_call([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", out] + objs)
+        return out
     hdr_t = max(_mtime(os.path.join(HERE, h)) for h in HEADERS)
     hdr_t = max(hdr_t, _mtime(__file__))
     procs, objs = [], []
@@ -49,4 +65,9 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
+    if "--define" in sys.argv:
+        i = sys.argv.index("--define")
+        defs = sys.argv[i + 1].split(",")
+        print(build(defines=[d for d in defs if d], out=sys.argv[sys.argv.index("--out") + 1]))
+        sys.exit(0)
     print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv))
