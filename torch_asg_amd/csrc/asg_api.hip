@@ -23,8 +23,8 @@ inline int hip_status(hipError_t e) { return e == hipSuccess ? ASG_OK : ASG_ERR_
 inline size_t align_up(size_t x) { return (x + 255) & ~(size_t) 255; }
 
 struct Layout {
-    size_t ah, bh, msh, ab, bb, ehat, fhat, rmax, cmax, total;
-    int np4;
+    size_t ah, bh, ab, bb, ehat, fhat, rmax, cmax, asu, asi, dbg, total;
+    int npad;
 };
 
 inline bool small_full(int64_t N) { return N <= 64; }
@@ -37,16 +37,18 @@ Layout make_layout(const asg_problem *p) {
     size_t off = 0;
     L.ah = off; off = align_up(off + B * T * N * e);
     L.bh = off; off = align_up(off + B * T * N * e);
-    L.msh = off; off = align_up(off + B * T * e);
     L.ab = off; off = align_up(off + B * T * S * e);
     L.bb = off; off = align_up(off + B * T * S * e);
-    L.np4 = (int) ((N + 3) / 4 * 4);
+    L.npad = small_full(p->N) ? (int) ((N + 7) / 8 * 8) : (int) ((N + 3) / 4 * 4);
+    L.ehat = off; off = align_up(off + N * L.npad * e);
+    L.rmax = off; off = align_up(off + N * e);
     if (!small_full(p->N)) {
-        L.ehat = off; off = align_up(off + N * L.np4 * e);
-        L.fhat = off; off = align_up(off + N * L.np4 * e);
-        L.rmax = off; off = align_up(off + N * e);
+        L.fhat = off; off = align_up(off + N * L.npad * e);
         L.cmax = off; off = align_up(off + N * e);
     }
+    L.asu = off; off = align_up(off + B * S * 2 * e);
+    L.asi = off; off = align_up(off + B * S * 2 * sizeof(int));
+    L.dbg = off; off = align_up(off + 512);      // developer timing stamps (ASG_TIMING builds only)
     L.total = off;
     return L;
 }
@@ -80,12 +82,13 @@ State to_state(const asg_problem *p, const void *state) {
     char *base = (char *) state;
     State W{};
     if (base) {
-        W.ah = base + L.ah; W.bh = base + L.bh; W.msh = base + L.msh; W.ab = base + L.ab; W.bb = base + L.bb;
-        if (!small_full(p->N)) {
-            W.ehat = base + L.ehat; W.fhat = base + L.fhat; W.rmax = base + L.rmax; W.cmax = base + L.cmax;
-        }
+        W.ah = base + L.ah; W.bh = base + L.bh; W.ab = base + L.ab; W.bb = base + L.bb;
+        W.ehat = base + L.ehat; W.rmax = base + L.rmax;
+        if (!small_full(p->N)) { W.fhat = base + L.fhat; W.cmax = base + L.cmax; }
+        W.asu = base + L.asu; W.asi = (int *) (base + L.asi);
+        W.dbg = base + L.dbg;
     }
-    W.np4 = L.np4;
+    W.npad = L.npad;
     return W;
 }
 

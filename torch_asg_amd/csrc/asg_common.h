@@ -113,6 +113,47 @@ __device__ __forceinline__ float wave_allsum(float v) {
         : "=&v"(r) : "v"(v));
     return readlane(r, 63);
 }
+// Two / three independent reductions interleaved in one block: the DPP wait states of one are filled by the
+// other(s), so the latency is that of a single reduction.
+#define ASG_DPP_STEP2(op, ctl) \
+    op " %0, %0, %0 " ctl "\n" op " %1, %1, %1 " ctl "\n" "s_nop 0\n"
+__device__ __forceinline__ void wave_allmax2(float &a, float &b) {
+    float ra, rb;
+    asm volatile(
+        "s_nop 1\n"
+        "v_max_f32_dpp %0, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+        "v_max_f32_dpp %1, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+        "s_nop 0\n"
+        ASG_DPP_STEP2("v_max_f32_dpp", "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+        ASG_DPP_STEP2("v_max_f32_dpp", "row_half_mirror row_mask:0xf bank_mask:0xf")
+        ASG_DPP_STEP2("v_max_f32_dpp", "row_mirror row_mask:0xf bank_mask:0xf")
+        ASG_DPP_STEP2("v_max_f32_dpp", "row_bcast:15 row_mask:0xa bank_mask:0xf")
+        ASG_DPP_STEP2("v_max_f32_dpp", "row_bcast:31 row_mask:0xc bank_mask:0xf")
+        "s_nop 0\n"
+        : "=&v"(ra), "=&v"(rb) : "v"(a), "v"(b));
+    a = readlane(ra, 63);
+    b = readlane(rb, 63);
+}
+__device__ __forceinline__ void wave_allsum2(float &a, float &b) {
+    float ra, rb;
+    asm volatile(
+        "s_nop 1\n"
+        "v_add_f32_dpp %0, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %1, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+        "s_nop 0\n"
+        ASG_DPP_STEP2("v_add_f32_dpp", "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+        ASG_DPP_STEP2("v_add_f32_dpp", "row_half_mirror row_mask:0xf bank_mask:0xf")
+        ASG_DPP_STEP2("v_add_f32_dpp", "row_mirror row_mask:0xf bank_mask:0xf")
+        ASG_DPP_STEP2("v_add_f32_dpp", "row_bcast:15 row_mask:0xa bank_mask:0xf")
+        ASG_DPP_STEP2("v_add_f32_dpp", "row_bcast:31 row_mask:0xc bank_mask:0xf")
+        "s_nop 0\n"
+        : "=&v"(ra), "=&v"(rb) : "v"(a), "v"(b));
+    a = readlane(ra, 63);
+    b = readlane(rb, 63);
+}
+__device__ __forceinline__ void wave_allmax2(double &a, double &b);
+__device__ __forceinline__ void wave_allsum2(double &a, double &b);
+
 // fp64: plain DPP moves (correctness path, not tuned)
 __device__ __forceinline__ double wave_allmax(double v) {
     v = fmax(v, dpp_mov<kDppXor1>(v, v));
@@ -128,6 +169,9 @@ __device__ __forceinline__ double wave_allsum(double v) {
     v += dpp_mov<kDppMirror>(v, v);
     return (readlane(v, 0) + readlane(v, 16)) + (readlane(v, 32) + readlane(v, 48));
 }
+
+__device__ __forceinline__ void wave_allmax2(double &a, double &b) { a = wave_allmax(a); b = wave_allmax(b); }
+__device__ __forceinline__ void wave_allsum2(double &a, double &b) { a = wave_allsum(a); b = wave_allsum(b); }
 
 // log2(2^a + 2^b) for a, b finite or <= logzero (never NaN): max + log2(1 + 2^-(|a-b|))
 template <typename R>

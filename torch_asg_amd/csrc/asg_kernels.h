@@ -21,15 +21,20 @@ struct Problem {
 };
 
 // Saved lattice state (forward -> backward), all in log2 units and RELATIVE per frame.
-//   ah  [B][T][N]  full-lattice alpha-hat (max over labels == 0 per frame)
-//   bh  [B][T][N]  full-lattice beta-hat
-//   msh [B][T]     per-frame shift removed from alpha (needed to rebuild the row sums)
-//   ab  [B][T][S]  aligned alpha-bar,  bb [B][T][S] aligned beta-bar
+//   ah  [B][T][N]  full-lattice alpha-hat          bh  [B][T][N]  full-lattice beta-hat
+//   ab  [B][T][S]  aligned alpha-bar               bb  [B][T][S]  aligned beta-bar
+//   ehat [N][npad] row-normalised exp2 of the transition matrix (written once per forward by the alpha pass of
+//                  utterance 0; npad = N rounded up to 8 on the small path, to 4 on the generic path), rmax [N]
+//   fhat/cmax      column-normalised twin (generic path only)
+//   asu [B][S][2]  per target position: {Tr2[O_s][O_s], Tr2[O_s][O_{s-1}]}  (log-zero where undefined)
+//   asi [B][S][2]  int32 {O_s, O_{s-1}}
 struct State {
-    void *ah, *bh, *msh, *ab, *bb;
-    // large-N path only: row/column-normalised exp2 of the transition matrix
-    void *ehat, *fhat, *rmax, *cmax;   // [N][NP4], [N][NP4], [N], [N]
-    int np4;
+    void *ah, *bh, *ab, *bb;
+    void *ehat, *fhat, *rmax, *cmax;
+    void *asu;
+    int *asi;
+    void *dbg;
+    int npad;
 };
 
 struct FwdOut {

@@ -218,6 +218,14 @@ __device__ void full_alpha_chain(const Problem &P, const State &W, const FwdOut 
     R Ri;
     load_norm_row<R, NP>(trow, P.ts1, N, act, e2, Ri);
     const R RiX = act ? Ri : NINF;
+    if (STORE && b == 0 && act) {
+        // publish the normalised transition rows once per forward: the gradient-assembly kernel reads them
+        // instead of redoing N loads + N exp2 in every one of its wavefronts
+        V2<R> *erow = reinterpret_cast<V2<R> *>((R *) W.ehat + (int64_t) lane * W.npad);
+#pragma unroll
+        for (int j = 0; j < NP / 2; ++j) erow[j] = e2[j];
+        ((R *) W.rmax)[lane] = Ri;
+    }
 
     const R *in = (const R *) P.inputs + (int64_t) b * P.is1 + (int64_t) lc * P.is2;
     const unsigned row_bytes = (unsigned) N * sizeof(R);
@@ -472,6 +480,12 @@ __device__ void aligned_alpha_chain(const Problem &P, const State &W, const FwdO
     __amdgpu_buffer_rsrc_t rs = make_rsrc((R *) W.ab + (int64_t) b * T * S, STORE ? (unsigned) T * row_bytes : 0u);
     const unsigned voff = lane < S ? (unsigned) lane * sizeof(R) : kOobOffset;
 
+    if (STORE && lane < S) {
+        V2<R> u = {A.H2, A.Dprev};
+        reinterpret_cast<V2<R> *>(W.asu)[(int64_t) b * S + lane] = u;
+        int2 ii = {A.tgt, A.prv};
+        reinterpret_cast<int2 *>(W.asi)[(int64_t) b * S + lane] = ii;
+    }
     double C = 0.0;
     R ab = LZ;
     if (len >= 1) {
@@ -596,45 +610,65 @@ __global__ void __launch_bounds__(64, 1) fwd_small_kernel(Problem P, State W, Fw
 //            acc[i][j] += u_i * p_j   (lane i keeps row i in registers; scaled by E[i][j] once at the end)
 //   aligned: posterior_s = softmax_s(alpha_bar + beta_bar), scattered back to labels with fixed-point
 //            LDS adds (integer adds commute -> deterministic), stay/advance edge posteriors per lane.
+// Rows whose recomputed sum is outside the safe range are skipped on the fast path (sticky flag) and handled
+// by an exact second pass over the wave's frames into a fixed-point LDS tile -- rare, off the fast path.
 // Output: grad_inputs rows for its frames, one partial [N][N] tile per workgroup.
 template <typename R, int NP>
-__global__ void __launch_bounds__(256, 1) bwd_small_kernel(Problem P, State W, BwdArgs A, int parts) {
-    constexpr bool kWide = sizeof(R) == 4;       // fp32: one LDS tile per wave; fp64: shared tile, serial rounds
+__global__ void __launch_bounds__(256) bwd_small_kernel(Problem P, State W, BwdArgs A, int parts) {
     __shared__ __attribute__((aligned(16))) R pbuf[4][64];
     __shared__ unsigned long long fxI[4][64];
-    __shared__ unsigned long long fxT[64 * 64];
-    __shared__ __attribute__((aligned(16))) R tileF[(kWide ? 4 : 1) * 64 * NP];
+    __shared__ unsigned long long fxT[NP * NP];      // aligned edge posteriors (unscaled)
+    __shared__ unsigned long long fxX[NP * NP];      // exact-path full-lattice edge posteriors (unscaled)
+    __shared__ __attribute__((aligned(16))) R tileF[64 * NP];
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    // wave index made provably uniform: otherwise every frame index, pointer and store offset derived from it is
+    // treated as divergent (EXEC-masked loop control, waterfall loop around the buffer store)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.x, chunk = blockIdx.y;
     const int N = P.N, T = P.T, S = P.S;
     const R NINF = Num<R>::ninf(), L2E = Num<R>::log2e(), LZ = Num<R>::logzero();
     const bool do_full = parts & 1, do_ali = parts & 2;
     const int len = P.in_len ? clampi(P.in_len[b], 0, T) : T;
-    const bool act = lane < N;
-    const unsigned long long actmask = __ballot(act);
-    const int lc = act ? lane : 0;
+    const int ol = (do_ali && P.targets) ? (P.tg_len ? clampi(P.tg_len[b], 0, S) : S) : 0;
+    const bool act = lane < N, sl = lane < S, sact = lane < ol;
+    const int lc = act ? lane : 0, ls_ = sl ? lane : 0;
 
-    for (int k = threadIdx.x; k < N * N; k += 256) fxT[k] = 0;
-    fxI[wave][lane] = 0;
-
+    // ---- prologue: everything below is ONE round of independent loads
     const R gf = do_full ? ((const R *) A.grad_full)[b] : R(0);
     const R ga = do_ali ? ((const R *) A.grad_aligned)[b] : R(0);
-
-    // full: row i of exp2(Tr2 - rowmax)
-    const R *trow = (const R *) P.transition + (int64_t) lc * P.ts0;
     V2<R> e2[NP / 2];
-    R Ri;
-    load_norm_row<R, NP>(trow, P.ts1, N, act, e2, Ri);
-    V2<R> acc[NP / 2], accx[NP / 2];
+    if (do_full) {
+        const V4<R> *erow = reinterpret_cast<const V4<R> *>((const R *) W.ehat + (int64_t) lc * W.npad);
 #pragma unroll
-    for (int j = 0; j < NP / 2; ++j) { acc[j] = V2<R>{0, 0}; accx[j] = V2<R>{0, 0}; }
+        for (int j = 0; j < NP / 4; ++j) {
+            V4<R> v = erow[j];
+            e2[2 * j] = v.xy;
+            e2[2 * j + 1] = v.zw;
+        }
+        if (!act) {
+#pragma unroll
+            for (int j = 0; j < NP / 2; ++j) e2[j] = V2<R>{0, 0};
+        }
+    }
+    V2<R> hd = {0, 0};
+    int2 tp = {0, 0};
+    if (do_ali) {
+        hd = reinterpret_cast<const V2<R> *>(W.asu)[(int64_t) b * S + ls_];
+        tp = reinterpret_cast<const int2 *>(W.asi)[(int64_t) b * S + ls_];
+    }
+    const R H2 = hd.x, Dprev = hd.y;
+    const int tgt = tp.x, prv = tp.y;
 
-    const AlignedSetup<R> AS = aligned_setup<R>(P, b, lane, do_ali);
+    for (int k = threadIdx.x; k < N * N; k += 256) { fxT[k] = 0; fxX[k] = 0; }
+    fxI[wave][lane] = 0;
+
+    V2<R> acc[NP / 2];
+#pragma unroll
+    for (int j = 0; j < NP / 2; ++j) acc[j] = V2<R>{0, 0};
     R accH = 0, accD = 0;    // unscaled edge posteriors: stay on s ; arrive at s from s-1
+    bool any_bad = false;
 
-    const bool sl = lane < S;
-    const int ls_ = sl ? lane : 0;
     const R *ahp = (const R *) W.ah + (int64_t) b * T * N + lc;
     const R *bhp = (const R *) W.bh + (int64_t) b * T * N + lc;
     const R *abp = (const R *) W.ab + (int64_t) b * T * S + ls_;
@@ -663,128 +697,131 @@ __global__ void __launch_bounds__(256, 1) bwd_small_kernel(Problem P, State W, B
             n_ab = abp[(int64_t) tq * S]; n_bb = bbp[(int64_t) tq * S]; n_abp = abp[(int64_t) tqp * S];
         }
         if (t < len) {
-            if (do_full) {
-                R ahv = c_ah, bhv = c_bh, ahprev = c_ahp;
-                ahv = act ? ahv : NINF;
-                ahprev = act ? ahprev : NINF;
-                R gam = ahv + bhv;                         // lanes >= N: -inf
-                R mg = fmax(wave_allmax(gam), LZ);
-                R w = Num<R>::exp2(gam - mg);
-                R Z = wave_allsum(w);
-                gi = (Z > 0) ? gf * (w / Z) : R(0);
-                if (t >= 1) {
-                    R mp = fmax(wave_allmax(ahprev), LZ);
-                    R p = Num<R>::exp2(ahprev - mp);
-                    R *lds = pbuf[wave];
-                    lds[lane] = p;
-                    __builtin_amdgcn_wave_barrier();
-                    V4<R> pv[NP / 4];
+            // the three maxima (full gamma, previous alpha, aligned gamma) in one interleaved reduction pass
+            R gam = act ? c_ah + c_bh : NINF;
+            R ahprev = act ? c_ahp : NINF;
+            R gam2 = sl ? c_ab + c_bb : LZ;
+            R abprev = sl ? c_abp : LZ;
+            R mg = gam, mp = ahprev;
+            wave_allmax2(mg, mp);
+            R mg2 = wave_allmax(gam2);
+            mg = fmax(mg, LZ);
+            mp = fmax(mp, LZ);
+            R w = do_full ? Num<R>::exp2(gam - mg) : R(0);
+            R w2 = (do_ali && mg2 > R(-1e29)) ? Num<R>::exp2(gam2 - mg2) : R(0);   // infeasible alignment -> no posterior
+            R p = Num<R>::exp2(ahprev - mp);
+            R *lds = pbuf[wave];
+            if (do_full && t >= 1) {
+                lds[lane] = p;
+                __builtin_amdgcn_wave_barrier();
+            }
+            R Z = w, Z2 = w2;
+            wave_allsum2(Z, Z2);
+            R post2 = (Z2 > 0) ? w2 / Z2 : R(0);            // unscaled aligned state posterior, 0 for s >= ol
+            gi = (Z > 0) ? gf * (w / Z) : R(0);
+            if (do_full && t >= 1) {
+                V4<R> pv[NP / 4];
 #pragma unroll
-                    for (int j = 0; j < NP / 4; ++j) pv[j] = *reinterpret_cast<const V4<R> *>(lds + 4 * j);
-                    __builtin_amdgcn_wave_barrier();
-                    V2<R> a0 = {0, 0}, a1 = {0, 0};
+                for (int j = 0; j < NP / 4; ++j) pv[j] = *reinterpret_cast<const V4<R> *>(lds + 4 * j);
+                __builtin_amdgcn_sched_barrier(0);
+                V2<R> a0 = {0, 0}, a1 = {0, 0};
 #pragma unroll
-                    for (int j = 0; j < NP / 4; ++j) {
-                        a0 = fma2<R>(e2[2 * j], pv[j].xy, a0);
-                        a1 = fma2<R>(e2[2 * j + 1], pv[j].zw, a1);
-                    }
-                    V2<R> a = a0 + a1;
-                    R sden = a.x + a.y;                    // row sum of the forward mat-vec (up to the common scale of p)
-                    bool live = gi != R(0);
-                    unsigned long long bad = __ballot(live && !(fabs(Num<R>::log2(sden)) < Num<R>::lg_limit())) & actmask;
-                    bool mybad = (bad >> lane) & 1;
-                    R u = (live && !mybad) ? gi / sden : R(0);
-                    if (bad) {
-                        // exact rare path: xi[i][j] = gi * softmax_j(Tr2[i][j] + ah_{t-1}[j]), kept unscaled in accx
-                        R lse = exact_lse_row<R>(trow, P.ts1, ahprev, N, act);
-                        for (int j = 0; j < N; ++j) {
-                            R aj = readlane(ahprev, j);
-                            R x = mybad ? gi * Num<R>::exp2(trow[(int64_t) j * P.ts1] * L2E + aj - lse) : R(0);
-                            x = (x == x) ? x : R(0);
-#pragma unroll
-                            for (int q = 0; q < NP / 2; ++q) {
-                                accx[q].x += (2 * q == j) ? x : R(0);
-                                accx[q].y += (2 * q + 1 == j) ? x : R(0);
-                            }
-                        }
-                    }
-                    const V2<R> u2 = {u, u};
-#pragma unroll
-                    for (int j = 0; j < NP / 4; ++j) {
-                        acc[2 * j] = fma2<R>(u2, pv[j].xy, acc[2 * j]);
-                        acc[2 * j + 1] = fma2<R>(u2, pv[j].zw, acc[2 * j + 1]);
-                    }
+                for (int j = 0; j < NP / 4; ++j) {
+                    a0 = fma2<R>(e2[2 * j], pv[j].xy, a0);
+                    a1 = fma2<R>(e2[2 * j + 1], pv[j].zw, a1);
                 }
+                V2<R> a = a0 + a1;
+                R sden = a.x + a.y;                    // row sum of the forward mat-vec (up to the common scale of p)
+                bool ok = fabs(Num<R>::log2(sden)) < Num<R>::lg_limit();
+                any_bad |= (gi != R(0)) && !ok;
+                R u = ok ? gi / sden : R(0);
+                const V2<R> u2 = {u, u};
+#pragma unroll
+                for (int j = 0; j < NP / 4; ++j) {
+                    acc[2 * j] = fma2<R>(u2, pv[j].xy, acc[2 * j]);
+                    acc[2 * j + 1] = fma2<R>(u2, pv[j].zw, acc[2 * j + 1]);
+                }
+                __builtin_amdgcn_wave_barrier();
             }
             if (do_ali) {
-                R abv = c_ab, bbv = c_bb, abprev = c_abp;
-                abv = sl ? abv : LZ;
-                bbv = sl ? bbv : LZ;
-                abprev = sl ? abprev : LZ;
-                R gam = abv + bbv;
-                R mg = wave_allmax(gam);
-                R w = (mg > R(-1e29)) ? Num<R>::exp2(gam - mg) : R(0);   // infeasible alignment -> no posterior
-                R Z = wave_allsum(w);
-                R post = (Z > 0) ? w / Z : R(0);            // unscaled state posterior, 0 for s >= ol
-                if (AS.act && post != R(0))
-                    atomicAdd(&fxI[wave][AS.tgt], to_fix<R>(post));
+                if (sact && post2 != R(0)) atomicAdd(&fxI[wave][tgt], to_fix<R>(post2));
                 __builtin_amdgcn_wave_barrier();
+                if (t >= 1) {
+                    R pc0 = abprev + H2;
+                    R pc1 = prev_lane_or_zero<R>(abprev) + Dprev;
+                    R l = lse2<R>(pc0, pc1);
+                    accH += post2 * Num<R>::exp2(pc0 - l);
+                    accD += post2 * Num<R>::exp2(pc1 - l);
+                }
                 unsigned long long fv = fxI[wave][lane];
                 if (fv != 0) {
                     gi += ga * from_fix<R>(fv);
                     fxI[wave][lane] = 0;
                 }
                 __builtin_amdgcn_wave_barrier();
-                if (t >= 1) {
-                    R pc0 = abprev + AS.H2;
-                    R pc1 = prev_lane_or_zero<R>(abprev) + AS.Dprev;
-                    R l = lse2<R>(pc0, pc1);
-                    accH += post * Num<R>::exp2(pc0 - l);
-                    accD += post * Num<R>::exp2(pc1 - l);
-                }
             }
         }
         buf_store(gi, rs_g, voff, (unsigned) t * grow_bytes);
     }
 
-    // ---- epilogue: one partial [N][N] tile per workgroup
+    // ---- rare exact pass: rows whose recomputed sum was unusable (forward took its exact path there too)
+    if (do_full && __any(any_bad)) {
+        const R *trow = (const R *) P.transition + (int64_t) lc * P.ts0;
+        for (int t = max(t0 + wave, 1); t < min(t1, len); t += 4) {
+            R ahv = act ? ahp[(int64_t) t * N] : NINF, bhv = act ? bhp[(int64_t) t * N] : NINF;
+            R ahprev = act ? ahp[(int64_t) (t - 1) * N] : NINF;
+            R gam = ahv + bhv;
+            R mg = fmax(wave_allmax(gam), LZ);
+            R w = Num<R>::exp2(gam - mg);
+            R Z = wave_allsum(w);
+            R post = (Z > 0) ? w / Z : R(0);
+            R mp = fmax(wave_allmax(ahprev), LZ);
+            R p = Num<R>::exp2(ahprev - mp);
+            R sden = 0;
+            for (int j = 0; j < N; ++j) {
+                R ej = R(0);
 #pragma unroll
-    for (int j = 0; j < NP / 2; ++j) acc[j] = fma2<R>(acc[j], e2[j], accx[j]);
-    if (kWide) {
-        if (act) {
-#pragma unroll
-            for (int j = 0; j < NP / 2; ++j)
-                *reinterpret_cast<V2<R> *>(&tileF[(wave * 64 + lane) * NP + 2 * j]) = acc[j];
-        }
-    } else {
-        for (int w = 0; w < 4; ++w) {
-            if (wave == w && act) {
-#pragma unroll
-                for (int j = 0; j < NP / 2; ++j) {
-                    V2<R> *dst = reinterpret_cast<V2<R> *>(&tileF[lane * NP + 2 * j]);
-                    V2<R> prev = (w == 0) ? V2<R>{0, 0} : *dst;
-                    *dst = prev + acc[j];
+                for (int q = 0; q < NP / 2; ++q) { ej = (2 * q == j) ? e2[q].x : ej; ej = (2 * q + 1 == j) ? e2[q].y : ej; }
+                sden = fma(ej, readlane(p, j), sden);
+            }
+            bool bad = act && post != R(0) && !(fabs(Num<R>::log2(sden)) < Num<R>::lg_limit());
+            if (__any(bad)) {
+                R lse = exact_lse_row<R>(trow, P.ts1, ahprev, N, act);
+                for (int j = 0; j < N; ++j) {
+                    R aj = readlane(ahprev, j);
+                    R x = bad ? post * Num<R>::exp2(trow[(int64_t) j * P.ts1] * L2E + aj - lse) : R(0);
+                    if (x == x && x != R(0)) atomicAdd(&fxX[lane * N + j], to_fix<R>(x));
                 }
             }
-            __syncthreads();
         }
     }
-    if (do_ali && AS.act) {
-        if (accH != R(0)) atomicAdd(&fxT[AS.tgt * N + AS.tgt], to_fix<R>(accH));
-        if (lane >= 1 && accD != R(0)) atomicAdd(&fxT[AS.tgt * N + AS.prv], to_fix<R>(accD));
+
+    // ---- epilogue: one partial [N][N] tile per workgroup
+#pragma unroll
+    for (int j = 0; j < NP / 2; ++j) acc[j] = acc[j] * e2[j];
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w && act) {
+#pragma unroll
+            for (int j = 0; j < NP / 2; ++j) {
+                V2<R> *dst = reinterpret_cast<V2<R> *>(&tileF[lane * NP + 2 * j]);
+                V2<R> prev = (w == 0) ? V2<R>{0, 0} : *dst;
+                *dst = prev + acc[j];
+            }
+        }
+        __syncthreads();
+    }
+    if (do_ali && sact) {
+        if (accH != R(0)) atomicAdd(&fxT[tgt * N + tgt], to_fix<R>(accH));
+        if (lane >= 1 && accD != R(0)) atomicAdd(&fxT[tgt * N + prv], to_fix<R>(accD));
     }
     __syncthreads();
     R *tile_out = (R *) A.scratch + ((int64_t) b * A.nchunks + chunk) * N * N;
     for (int k = threadIdx.x; k < N * N; k += 256) {
         int i = k / N, j = k - i * N;
-        R v = R(0);
-        if (do_full) {
-            if (kWide) v = (tileF[(0 * 64 + i) * NP + j] + tileF[(1 * 64 + i) * NP + j]) +
-                           (tileF[(2 * 64 + i) * NP + j] + tileF[(3 * 64 + i) * NP + j]);
-            else v = tileF[i * NP + j];
-        }
-        unsigned long long fv = fxT[k];
+        R v = do_full ? tileF[i * NP + j] : R(0);
+        unsigned long long fv = fxT[k], fx = fxX[k];
         if (fv != 0) v += ga * from_fix<R>(fv);
+        if (fx != 0) v += gf * from_fix<R>(fx);
         tile_out[k] = v;
     }
 }
@@ -875,8 +912,8 @@ hipError_t launch_bwd_small(const Problem &P, const State &W, const BwdArgs &A, 
 }
 
 size_t bwd_scratch_bytes_small(int elem, int T, int B, int N, int S, int *chunk, int *nchunks) {
-    // aim for ~512 workgroups (2 per CU) but at least 16 frames per workgroup
-    int nch = (512 + B - 1) / B;
+    // aim for ~768 workgroups (3 per CU, 12 waves per CU) but at least 16 frames per workgroup
+    int nch = (768 + B - 1) / B;
     if (nch < 1) nch = 1;
     int ch = (T + nch - 1) / nch;
     if (ch < 16) ch = 16;
