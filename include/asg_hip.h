@@ -116,6 +116,24 @@ int asg_backward(asg_ctx *ctx, const asg_problem *p, const void *state, size_t s
                  const void *grad_full, const void *grad_aligned, void *scratch, size_t scratch_bytes,
                  void *grad_transition, void *grad_inputs, int flags, void *stream);
 
+/* ---- whole-loss entry points (no counterpart in the reference's native layer: they fold the Python-side
+ * `full - aligned` and reduction of asg.py:128,136-142 and their autograd into the kernels, so one ASGLoss
+ * step is 2 + 2 kernel launches with no PyTorch glue kernels in between) ------------------------------------ */
+
+#define ASG_REDUCTION_NONE 0
+#define ASG_REDUCTION_SUM 1
+#define ASG_REDUCTION_MEAN 2
+
+/* loss = reduce_b(full[b] - aligned[b]); `loss` is [B] (none) or [1]; `scores` is a [2][B] work buffer that
+ * receives full_scores then aligned_scores. */
+int asg_loss_forward(asg_ctx *ctx, const asg_problem *p, void *state, size_t state_bytes, int reduction,
+                     void *loss, void *scores, int flags, void *stream);
+
+/* gradients of the reduced loss: grad_loss is [B] (none) or [1]. */
+int asg_loss_backward(asg_ctx *ctx, const asg_problem *p, const void *state, size_t state_bytes, int reduction,
+                      const void *grad_loss, void *scratch, size_t scratch_bytes, void *grad_transition,
+                      void *grad_inputs, int flags, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -58,3 +58,18 @@ class OracleBackend:
         g1, i1 = self.full_backward(fstate, grad_full, inputs, transition, input_lengths)
         g2, i2 = self.aligned_backward(astate, grad_aligned, inputs, targets, transition, input_lengths, target_lengths)
         return g1 + g2, i1 + i2
+
+    def loss_forward(self, inputs, targets, transition, input_lengths, target_lengths, reduction, flags=0):
+        fs, as_, state = self.forward(inputs, targets, transition, input_lengths, target_lengths)
+        per = fs - as_
+        loss = per if reduction == "none" else (per.sum() if reduction == "sum" else per.mean())
+        return loss, state
+
+    def loss_backward(self, state, grad_loss, inputs, targets, transition, input_lengths, target_lengths,
+                      reduction, flags=0):
+        B = inputs.shape[1]
+        g = grad_loss.reshape(-1).to(inputs.dtype)
+        if reduction != "none":
+            g = g.expand(B) * (1.0 / B if reduction == "mean" else 1.0)
+        g = g.contiguous()
+        return self.backward(state, g, -g, inputs, targets, transition, input_lengths, target_lengths)

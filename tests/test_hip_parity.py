@@ -248,6 +248,28 @@ def test_determinism_and_mode_equality():
         util.assert_close(r[k], base[k], 1e-6, "serial route " + k)
 
 
+def test_fused_loss_function_equals_reference_style_composition():
+    """ASGLoss' fused route (ASGLossFunction) vs the reference-style composition ASGGPUFast + torch ops."""
+    A = _asg()
+    tr, x, tg, il, tl = util.synth(70, 6, 23, 9, 11, True)
+    for red in ("mean", "sum", "none"):
+        outs = []
+        for fused in (True, False):
+            xd = x.to(DEV).requires_grad_(True)
+            trd = tr.to(DEV).requires_grad_(True)
+            if fused:
+                loss = A.ASGLossFunction.apply(xd, trd, tg.to(DEV), il.to(DEV), tl.to(DEV), red, 1)
+            else:
+                f, a = A.ASGGPUFast.apply(xd, trd, tg.to(DEV), il.to(DEV), tl.to(DEV))
+                per = f - a
+                loss = per if red == "none" else (per.sum() if red == "sum" else per.mean())
+            w = torch.linspace(0.5, 1.5, loss.numel(), device=DEV).reshape(loss.shape)
+            (loss * w).sum().backward()
+            outs.append((loss.detach().cpu().numpy(), xd.grad.cpu().numpy(), trd.grad.cpu().numpy()))
+        for a, b in zip(outs[0], outs[1]):
+            util.assert_close(a, b, 2e-6, "fused vs composed (%s)" % red)
+
+
 def test_transition_grad_accumulates_like_a_parameter():
     A = _asg()
     tr, x, tg, il, tl = util.synth(12, 3, 6, 4, 1, True)

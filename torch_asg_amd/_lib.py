@@ -15,7 +15,8 @@ FLAG_STREAMS, FLAG_SINGLE_LAUNCH, FLAG_MATVEC_READLANE, FLAG_ALPHA_SCORES = 1, 2
 # every symbol include/asg_hip.h declares
 SYMBOLS = ["asg_hip_version", "asg_hip_strerror", "asg_ctx_create", "asg_ctx_destroy", "asg_state_bytes",
            "asg_scratch_bytes", "asg_full_forward", "asg_full_backward", "asg_aligned_forward",
-           "asg_aligned_backward", "asg_forward", "asg_forward_only", "asg_backward"]
+           "asg_aligned_backward", "asg_forward", "asg_forward_only", "asg_backward", "asg_loss_forward",
+           "asg_loss_backward"]
 
 
 class AsgProblem(ctypes.Structure):
@@ -58,6 +59,8 @@ def lib():
     L.asg_forward.argtypes = [vp, pp, vp, sz, vp, vp, ci, vp]
     L.asg_forward_only.argtypes = [vp, pp, vp, sz, vp, vp, ci, vp]
     L.asg_backward.argtypes = [vp, pp, vp, sz, vp, vp, vp, sz, vp, vp, ci, vp]
+    L.asg_loss_forward.argtypes = [vp, pp, vp, sz, ci, vp, vp, ci, vp]
+    L.asg_loss_backward.argtypes = [vp, pp, vp, sz, ci, vp, vp, sz, vp, vp, ci, vp]
     for name in SYMBOLS:
         getattr(L, name)
     _LIB = L

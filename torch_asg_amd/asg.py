@@ -196,6 +196,43 @@ class HipBackend:
         return gtr, gin
 
 
+    # -- whole loss: full - aligned, reduction and their gradients inside the kernels -----------------------
+    _RED = {"none": 0, "sum": 1, "mean": 2}
+
+    def loss_forward(self, inputs, targets, transition, input_lengths, target_lengths, reduction,
+                     flags=_lib.FLAG_STREAMS):
+        self._check(inputs, transition, targets, input_lengths, target_lengths)
+        L = _lib.lib()
+        B = inputs.shape[1]
+        red = self._RED[reduction]
+        with torch.cuda.device(inputs.device):
+            p, keep = self._problem(inputs, transition, targets, input_lengths, target_lengths)
+            state = self._buf(L.asg_state_bytes(ctypes.byref(p)), inputs.device)
+            scores = torch.empty(2, B, dtype=inputs.dtype, device=inputs.device)
+            loss = torch.empty((B,) if red == 0 else (), dtype=inputs.dtype, device=inputs.device)
+            _lib.check(L.asg_loss_forward(self._context(inputs.device), ctypes.byref(p), state.data_ptr(),
+                                          state.numel(), red, loss.data_ptr(), scores.data_ptr(),
+                                          flags & ~_lib.FLAG_ALPHA_SCORES, self._stream(inputs.device)),
+                       "asg_loss_forward")
+        return loss, state
+
+    def loss_backward(self, state, grad_loss, inputs, targets, transition, input_lengths, target_lengths,
+                      reduction, flags=0):
+        L = _lib.lib()
+        T, B, N = inputs.shape
+        with torch.cuda.device(inputs.device):
+            p, keep = self._problem(inputs, transition, targets, input_lengths, target_lengths)
+            g = grad_loss.to(inputs.dtype).contiguous()
+            scratch = self._buf(L.asg_scratch_bytes(ctypes.byref(p)), inputs.device)
+            gtr = torch.empty(N, N, dtype=inputs.dtype, device=inputs.device)
+            gin = torch.empty(T, B, N, dtype=inputs.dtype, device=inputs.device)
+            _lib.check(L.asg_loss_backward(self._context(inputs.device), ctypes.byref(p), state.data_ptr(),
+                                           state.numel(), self._RED[reduction], g.data_ptr(), scratch.data_ptr(),
+                                           scratch.numel(), gtr.data_ptr(), gin.data_ptr(), flags,
+                                           self._stream(inputs.device)), "asg_loss_backward")
+        return gtr, gin
+
+
 _backend = None
 
 
@@ -273,6 +310,26 @@ class ASGGPUFast(torch.autograd.Function):
         return grad_inputs, grad_transition, None, None, None, None
 
 
+class ASGLossFunction(torch.autograd.Function):
+    """The whole criterion in one Function: loss = reduce(full - aligned) (asg.py:128,136-142) with the
+    subtraction, the reduction and their gradients done inside the kernels (no PyTorch glue launches)."""
+
+    @staticmethod
+    def forward(ctx, inputs, transition, outputs, input_lengths, output_lengths, reduction, flags):
+        loss, state = native().loss_forward(inputs, outputs, transition, input_lengths, output_lengths, reduction,
+                                            flags)
+        ctx.save_for_backward(state, inputs, outputs, input_lengths, output_lengths, transition)
+        ctx.reduction = reduction
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        state, inputs, outputs, input_lengths, output_lengths, transition = ctx.saved_tensors
+        grad_transition, grad_inputs = native().loss_backward(state, grad_loss, inputs, outputs, transition,
+                                                              input_lengths, output_lengths, ctx.reduction)
+        return grad_inputs, grad_transition, None, None, None, None, None
+
+
 class ASGLoss(nn.Module):
     """Auto Segmentation Criterion loss; constructor and forward signature as asg.py:100-142.
 
@@ -318,6 +375,10 @@ class ASGLoss(nn.Module):
         elif self.forward_only or not self.training:
             result = ASGGPUFastForwardOnly.apply(inputs, targets, self.transition, input_lengths, target_lengths,
                                                  self._flags())
+        elif self.reduction in ('sum', 'mean', 'none'):
+            # fused training route: the reference's ASGGPUFast + (full - aligned) + reduction (asg.py:133-142)
+            return ASGLossFunction.apply(inputs, self.transition, targets, input_lengths, target_lengths,
+                                         self.reduction, self._flags())
         else:
             full_scores, aligned_scores = ASGGPUFast.apply(inputs, self.transition, targets, input_lengths,
                                                            target_lengths, self._flags())

@@ -158,12 +158,15 @@ int run_forward(asg_ctx *ctx, const asg_problem *p, void *state, void *full_scor
 template <typename R>
 int run_backward(const asg_problem *p, const void *state, const void *grad_full, const void *grad_aligned,
                  void *scratch, size_t scratch_bytes, void *grad_transition, void *grad_inputs, int parts,
-                 hipStream_t stream) {
+                 hipStream_t stream, int gstride = 1, double gscale = 1.0, int neg_aligned = 0) {
     Problem P = to_problem(p);
     State W = to_state(p, state);
     BwdArgs A{};
-    A.grad_full = grad_full;
+    A.grad_full = grad_full ? grad_full : grad_aligned;
     A.grad_aligned = grad_aligned;
+    A.gstride = gstride;
+    A.gscale = gscale;
+    A.neg_aligned = neg_aligned;
     A.grad_inputs = grad_inputs;
     A.grad_transition = grad_transition;
     A.scratch = scratch;
@@ -324,6 +327,34 @@ int asg_backward(asg_ctx *ctx, const asg_problem *p, const void *state, size_t s
     return ASG_DISPATCH(p,
         run_backward<float>(p, state, grad_full, grad_aligned, scratch, scratch_bytes, grad_transition, grad_inputs, 3, (hipStream_t) stream),
         run_backward<double>(p, state, grad_full, grad_aligned, scratch, scratch_bytes, grad_transition, grad_inputs, 3, (hipStream_t) stream));
+}
+
+int asg_loss_forward(asg_ctx *ctx, const asg_problem *p, void *state, size_t state_bytes, int reduction,
+                     void *loss, void *scores, int flags, void *stream) {
+    if (reduction < 0 || reduction > 2 || !loss || !scores) return ASG_ERR_INVALID;
+    const size_t e = p && p->dtype == ASG_DTYPE_F64 ? 8 : 4;
+    char *sc = (char *) scores;
+    int rc = asg_forward(ctx, p, state, state_bytes, sc, sc + (size_t) (p ? p->B : 0) * e, flags & ~ASG_FLAG_ALPHA_SCORES, stream);
+    if (rc) return rc;
+    return hip_status(ASG_DISPATCH(p,
+        launch_loss_reduce<float>(sc, sc + (size_t) p->B * e, (int) p->B, reduction, loss, (hipStream_t) stream),
+        launch_loss_reduce<double>(sc, sc + (size_t) p->B * e, (int) p->B, reduction, loss, (hipStream_t) stream)));
+}
+
+int asg_loss_backward(asg_ctx *ctx, const asg_problem *p, const void *state, size_t state_bytes, int reduction,
+                      const void *grad_loss, void *scratch, size_t scratch_bytes, void *grad_transition,
+                      void *grad_inputs, int flags, void *stream) {
+    (void) ctx; (void) flags;
+    int rc = check_problem(p, true);
+    if (rc) return rc;
+    if (reduction < 0 || reduction > 2) return ASG_ERR_INVALID;
+    if (!state || !grad_loss || !scratch || !grad_transition || !grad_inputs) return ASG_ERR_INVALID;
+    if (state_bytes < asg_state_bytes(p)) return ASG_ERR_WORKSPACE;
+    const int gstride = reduction == 0 ? 1 : 0;
+    const double gscale = reduction == 2 ? 1.0 / (double) p->B : 1.0;
+    return ASG_DISPATCH(p,
+        run_backward<float>(p, state, grad_loss, nullptr, scratch, scratch_bytes, grad_transition, grad_inputs, 3, (hipStream_t) stream, gstride, gscale, 1),
+        run_backward<double>(p, state, grad_loss, nullptr, scratch, scratch_bytes, grad_transition, grad_inputs, 3, (hipStream_t) stream, gstride, gscale, 1));
 }
 
 }  // extern "C"

@@ -45,8 +45,11 @@ struct FwdOut {
 };
 
 struct BwdArgs {
-    const void *grad_full;       // [B] d(loss)/d(full_scores)
-    const void *grad_aligned;    // [B] d(loss)/d(aligned_scores)
+    const void *grad_full;       // d(loss)/d(full_scores):    element b read at index b*gstride, times gscale
+    const void *grad_aligned;    // d(loss)/d(aligned_scores); nullptr + neg_aligned: = -grad_full (ASG loss)
+    int gstride;                 // 1 = per-utterance gradients, 0 = one scalar broadcast (reduced loss)
+    int neg_aligned;
+    double gscale;               // 1, or 1/B for reduction='mean' 
     void *grad_inputs;           // [T,B,N] contiguous
     void *grad_transition;       // [N,N] contiguous
     void *scratch;               // partial tiles etc.
@@ -63,6 +66,9 @@ hipError_t launch_fwd_small(const Problem &P, const State &W, const FwdOut &O, i
                             int matvec_variant, hipStream_t stream);
 template <typename R>
 hipError_t launch_bwd_small(const Problem &P, const State &W, const BwdArgs &A, int parts, hipStream_t stream);
+// loss[b] = full[b] - aligned[b], reduced: 0 = none ([B] out), 1 = sum, 2 = mean ([1] out); fixed-order tree
+template <typename R>
+hipError_t launch_loss_reduce(const void *full, const void *aligned, int B, int reduction, void *out, hipStream_t stream);
 
 // ---- generic path: any N (p-vector in LDS), S <= 1024 ----------------------------------
 template <typename R>

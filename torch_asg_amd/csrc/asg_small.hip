@@ -635,8 +635,11 @@ __global__ void __launch_bounds__(256) bwd_small_kernel(Problem P, State W, BwdA
     const int lc = act ? lane : 0, ls_ = sl ? lane : 0;
 
     // ---- prologue: everything below is ONE round of independent loads
-    const R gf = do_full ? ((const R *) A.grad_full)[b] : R(0);
-    const R ga = do_ali ? ((const R *) A.grad_aligned)[b] : R(0);
+    const R g0 = A.grad_full ? (R) ((double) ((const R *) A.grad_full)[(int64_t) b * A.gstride] * A.gscale) : R(0);
+    const R gf = do_full ? g0 : R(0);
+    const R ga = do_ali ? (A.neg_aligned ? -g0
+                                         : (R) ((double) ((const R *) A.grad_aligned)[(int64_t) b * A.gstride] * A.gscale))
+                        : R(0);
     V2<R> e2[NP / 2];
     if (do_full) {
         const V4<R> *erow = reinterpret_cast<const V4<R> *>((const R *) W.ehat + (int64_t) lc * W.npad);
@@ -827,32 +830,60 @@ __global__ void __launch_bounds__(256) bwd_small_kernel(Problem P, State W, BwdA
 }
 
 // Sum G partial tiles in a fixed order -> deterministic grad_transition.
-// block = 256 threads = 32 elements x 8 tile-groups; each thread sums every 8th tile, then a fixed-order
-// LDS combine over the 8 groups.
+// block = 256 threads = 32 elements x 8 tile-groups; thread (e, grp) sums tiles grp, grp+8, ... with 16
+// independent accumulators (16 loads in flight: the kernel is pure L2 latency), then a fixed-order LDS
+// combine over the 8 groups.
 template <typename R>
 __global__ void __launch_bounds__(256) reduce_tiles_kernel(const R *tiles, int G, int n, R *out) {
     __shared__ R part[8][32];
     const int e = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    const int k = blockIdx.x * 32 + e;
-    R s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    if (k < n) {
-        int g = grp;
-        for (; g + 24 < G; g += 32) {
-            s0 += tiles[(int64_t) (g + 0) * n + k];
-            s1 += tiles[(int64_t) (g + 8) * n + k];
-            s2 += tiles[(int64_t) (g + 16) * n + k];
-            s3 += tiles[(int64_t) (g + 24) * n + k];
-        }
-        for (; g < G; g += 8) s0 += tiles[(int64_t) g * n + k];
-    }
-    part[grp][e] = (s0 + s1) + (s2 + s3);
-    __syncthreads();
-    if (grp == 0 && k < n) {
-        R s = part[0][e];
+    const int k = min(blockIdx.x * 32 + e, n - 1);
+    R acc[16];
 #pragma unroll
-        for (int q = 1; q < 8; ++q) s += part[q][e];
-        out[k] = s;
+    for (int q = 0; q < 16; ++q) acc[q] = 0;
+    int g = grp;
+    for (; g + 8 * 15 < G; g += 8 * 16) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] += tiles[(int64_t) (g + 8 * q) * n + k];
     }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        int gg = g + 8 * q;
+        R v = tiles[(int64_t) min(gg, G - 1) * n + k];        // unconditional load, masked add
+        acc[q] += (gg < G) ? v : R(0);
+    }
+    R s = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) s += acc[q];
+    part[grp][e] = s;
+    __syncthreads();
+    if (grp == 0 && blockIdx.x * 32 + e < n) {
+        R t = part[0][e];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) t += part[q][e];
+        out[k] = t;
+    }
+}
+
+// loss[b] = full[b] - aligned[b]  (asg.py:128,136) and its reduction (asg.py:137-142), one workgroup,
+// fixed-order tree -> deterministic.
+template <typename R>
+__global__ void __launch_bounds__(256) loss_reduce_kernel(const R *full, const R *aligned, int B, int reduction, R *out) {
+    __shared__ double part[256];
+    double s = 0;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        R l = full[b] - aligned[b];
+        if (reduction == 0) out[b] = l;
+        s += (double) l;
+    }
+    if (reduction == 0) return;
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {
+        if ((int) threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (R) (reduction == 2 ? part[0] / B : part[0]);
 }
 
 template <typename R, int NP, int MV>
@@ -927,6 +958,15 @@ size_t bwd_scratch_bytes_small(int elem, int T, int B, int N, int S, int *chunk,
 
 template hipError_t launch_fwd_small<float>(const Problem &, const State &, const FwdOut &, int, bool, int, hipStream_t);
 template hipError_t launch_fwd_small<double>(const Problem &, const State &, const FwdOut &, int, bool, int, hipStream_t);
+template <typename R>
+hipError_t launch_loss_reduce(const void *full, const void *aligned, int B, int reduction, void *out, hipStream_t stream) {
+    hipLaunchKernelGGL((loss_reduce_kernel<R>), dim3(1), dim3(256), 0, stream, (const R *) full, (const R *) aligned, B,
+                       reduction, (R *) out);
+    return hipGetLastError();
+}
+template hipError_t launch_loss_reduce<float>(const void *, const void *, int, int, void *, hipStream_t);
+template hipError_t launch_loss_reduce<double>(const void *, const void *, int, int, void *, hipStream_t);
+
 template hipError_t launch_bwd_small<float>(const Problem &, const State &, const BwdArgs &, int, hipStream_t);
 template hipError_t launch_bwd_small<double>(const Problem &, const State &, const BwdArgs &, int, hipStream_t);
 
