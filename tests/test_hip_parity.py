@@ -195,6 +195,53 @@ def test_exact_fallback_paths(case):
         util.assert_close(r[k], o[k], 1e-4, "%s/%s" % (case, k))
 
 
+# ------------------------------------------------------------------ generic path (N > 64 and / or S > 64)
+@pytest.mark.parametrize("T,B,N,L", [(20, 3, 100, 7), (33, 5, 257, 12), (150, 2, 12, 100), (100, 3, 130, 80),
+                                       (9, 2, 65, 3), (40, 17, 70, 65)])
+@pytest.mark.parametrize("dtype,rtol", [(torch.float32, 1e-4), (torch.float64, 1e-9)])
+def test_generic_path_vs_oracle(T, B, N, L, dtype, rtol):
+    rng = np.random.default_rng(T * 1000 + N)
+    tr, x, tg, _, _ = util.synth(T, B, N, L, N + L)
+    il = rng.integers(max(1, T // 2), T + 1, B)
+    tl = np.minimum(rng.integers(1, L + 1, B), il)
+    red = ["mean", "sum", "none"][(T + N) % 3]
+    o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il, tl, red)
+    for kw in (MODES[0], MODES[3]):
+        r = run_hip(x, tg, tr, il, tl, red, dtype, **kw)
+        for k in ("loss", "grad_inputs", "grad_transition"):
+            util.assert_close(r[k], o[k], rtol, "generic T%d B%d N%d L%d %s/%s" % (T, B, N, L, kw, k))
+
+
+def test_golden_cfg5_reduced_large_alphabet():
+    # BASELINE.json configs[4] at the size the reference can still run: T=64 B=4 N=1024 L=16, variable lengths
+    g = util.load("cfg5_reduced")
+    tr, x, tg, il, tl = util.synth(64, 4, 1024, 16, 0, True)
+    r = run_hip(x, tg, tr, il, tl, "mean")
+    util.assert_close(r["loss"], g["f64_loss"], 1e-4, "loss")
+    gt = r["grad_transition"]
+    util.assert_close(gt[::8, ::8], g["f64_grad_transition_sample"], 1e-4, "gtr sample")
+    util.assert_close(gt.sum(1), g["f64_grad_transition_rowsum"], 1e-4, "gtr rowsum")
+    util.assert_close(gt.sum(0), g["f64_grad_transition_colsum"], 1e-4, "gtr colsum")
+    util.assert_close(np.diag(gt), g["f64_grad_transition_diag"], 1e-4, "gtr diag")
+    util.assert_close(r["grad_inputs"][::7, ::3, :], g["f64_grad_inputs_sample"], 1e-4, "gin sample")
+    util.assert_close(r["grad_inputs"].sum(0), g["f64_grad_inputs_sum_t"], 1e-4, "gin sum")
+
+
+def test_generic_forward_only_and_determinism():
+    A = _asg()
+    tr, x, tg, il, tl = util.synth(30, 3, 90, 70, 4, True)
+    tl = torch.minimum(tl, il)
+    ref = run_hip(x, tg, tr, il, tl, "none")
+    again = run_hip(x, tg, tr, il, tl, "none")
+    for k in ref:
+        assert np.array_equal(ref[k], again[k]), "generic path run-to-run " + k
+    m = A.ASGLoss(90, reduction="none", forward_only=True).to(DEV)
+    with torch.no_grad():
+        m.transition.copy_(tr)
+    out = m(x.to(DEV), tg.to(DEV), il.to(DEV), tl.to(DEV))
+    util.assert_close(out.cpu().numpy(), ref["loss"], 1e-5, "generic forward-only")
+
+
 # ------------------------------------------------------------------ routes
 def test_forward_only_and_eval_routes():
     A = _asg()

@@ -23,7 +23,7 @@ inline int hip_status(hipError_t e) { return e == hipSuccess ? ASG_OK : ASG_ERR_
 inline size_t align_up(size_t x) { return (x + 255) & ~(size_t) 255; }
 
 struct Layout {
-    size_t ah, bh, ab, bb, ehat, fhat, rmax, cmax, asu, asi, dbg, total;
+    size_t ah, bh, ab, bb, ehat, fhat, rmax, cmax, asu, asi, dbg, work, total;
     int npad;
 };
 
@@ -49,6 +49,7 @@ Layout make_layout(const asg_problem *p) {
     L.asu = off; off = align_up(off + B * S * 2 * e);
     L.asi = off; off = align_up(off + B * S * 2 * sizeof(int));
     L.dbg = off; off = align_up(off + 512);      // developer timing stamps (ASG_TIMING builds only)
+    if (!small_full(p->N)) { L.work = off; off = align_up(off + fwd_work_bytes_generic((int) e, (int) T, (int) B, (int) N)); }
     L.total = off;
     return L;
 }
@@ -87,6 +88,7 @@ State to_state(const asg_problem *p, const void *state) {
         if (!small_full(p->N)) { W.fhat = base + L.fhat; W.cmax = base + L.cmax; }
         W.asu = base + L.asu; W.asi = (int *) (base + L.asi);
         W.dbg = base + L.dbg;
+        if (!small_full(p->N)) W.work = base + L.work;
     }
     W.npad = L.npad;
     return W;
@@ -172,11 +174,21 @@ int run_backward(const asg_problem *p, const void *state, const void *grad_full,
     A.scratch = scratch;
     if (scratch_bytes < asg_scratch_bytes(p)) return ASG_ERR_WORKSPACE;
     const bool sf = small_full(p->N), sa = small_aligned(p->S);
-    if (sf && (sa || !(parts & 2))) {
-        bwd_scratch_bytes_small((int) sizeof(R), P.T, P.B, P.N, P.S, &A.chunk, &A.nchunks);
-        return hip_status(launch_bwd_small<R>(P, W, A, parts, stream));
+    bwd_scratch_bytes_small((int) sizeof(R), P.T, P.B, P.N, P.S, &A.chunk, &A.nchunks);
+    if (sf && (sa || !(parts & 2))) return hip_status(launch_bwd_small<R>(P, W, A, parts, stream));
+    // mixed / generic: full-lattice part by whichever path owns N, aligned part by the generic kernels
+    hipError_t e = hipSuccess;
+    int gparts = 0;
+    if (parts & 1) {
+        if (sf) {
+            if ((e = launch_bwd_small<R>(P, W, A, 1, stream)) != hipSuccess) return hip_status(e);
+            gparts |= 4;
+        } else {
+            gparts |= 1;
+        }
     }
-    return hip_status(launch_bwd_generic<R>(P, W, A, parts, stream));
+    if (parts & 2) gparts |= 2;
+    return hip_status(launch_bwd_generic<R>(P, W, A, gparts, stream));
 }
 
 }  // namespace

@@ -17,6 +17,9 @@ namespace asg {
 constexpr int kWave = 64;
 constexpr double kLn2 = 0.6931471805599453;
 
+template <typename R> using V2 = R __attribute__((ext_vector_type(2)));
+template <typename R> using V4 = R __attribute__((ext_vector_type(4)));
+
 template <typename R> struct Num;
 
 template <> struct Num<float> {

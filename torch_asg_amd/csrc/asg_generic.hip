@@ -1,17 +1,789 @@
-// torch_asg_amd/csrc/asg_generic.hip -- generic (large alphabet / long target) path. STUB for now.
+// torch_asg_amd/csrc/asg_generic.hip -- generic ASG path: large alphabets (N > 64) and/or long targets
+// (S > 64).  Same maths and same saved state as the small path (asg_small.hip), different parallelisation:
+//
+//  * full lattice, forward: TIME-SYNCHRONOUS and BATCH-COOPERATIVE.  One kernel launch per frame and
+//    direction computes, for ALL utterances at once, s[i][b] = sum_j E[i][j] * p[b][j] as an LDS-tiled
+//    [N x N] x [N x B] product (every tile of the normalised transition matrix E is read once per frame and
+//    reused by the whole batch), then the per-node epilogue (log2, emission, lagged normaliser, exp2 for
+//    the next frame).  This is the reference's per-time-step ATen loop
+//    (/root/reference/torch_asg/native/fully_connected_lattice.cpp:22-28,44-46) with its ~10 launches per
+//    step collapsed into one and its [B,N,N] temporaries never materialised.
+//  * full lattice, gradient: two tiled products -- row sums for every (b,t) at once, then the outer-product
+//    accumulation  gradTr = E o (U^T P)  -- instead of the reference's softmax over path_contrib
+//    (fully_connected_lattice.cpp:49-63; that tensor would be 25.6 TB at T=2000 B=32 N=10000).
+//  * aligned lattice: one workgroup per (utterance, direction), target axis spread over up to 16 waves,
+//    neighbour exchange through LDS; gradient kernel per (utterance, frame-chunk).
+//
+// VALU only (no MFMA), fp32 or fp64.  Not tuned to the level of the small path; see DESIGN.md.
 #include "asg_common.h"
 #include "asg_kernels.h"
 
 namespace asg {
 
-template <typename R>
-hipError_t launch_prep_generic(const Problem &, const State &, hipStream_t) { return hipErrorNotSupported; }
-template <typename R>
-hipError_t launch_fwd_generic(const Problem &, const State &, const FwdOut &, int, bool, hipStream_t) { return hipErrorNotSupported; }
-template <typename R>
-hipError_t launch_bwd_generic(const Problem &, const State &, const BwdArgs &, int, hipStream_t) { return hipErrorNotSupported; }
+namespace {
 
-size_t bwd_scratch_bytes_generic(int, int, int, int, int) { return 256; }
+__device__ __forceinline__ int gclampi(int64_t v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : (int) v); }
+
+// order-preserving float <-> uint key (for atomicMax of a float-valued normaliser)
+__device__ __forceinline__ unsigned fkey(float f) {
+    unsigned b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float funkey(unsigned k) {
+    unsigned b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(b);
+}
+
+template <typename R>
+__device__ __forceinline__ R block_reduce_max(R v, R *red) {   // 256 threads; red[4]
+    v = wave_allmax(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    R r = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    return r;
+}
+template <typename R>
+__device__ __forceinline__ R block_reduce_sum(R v, R *red) {
+    v = wave_allsum(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    R r = (red[0] + red[1]) + (red[2] + red[3]);
+    return r;
+}
+
+// ------------------------------------------------------------------ transition prep
+// grid = N, block = 256.  Row i of out = exp2(Tr2[i][:] - rowmax) (COLS=false) or the same for column i
+// (COLS=true: out[i][j] = exp2(Tr2[j][i] - colmax_i)).
+template <typename R, bool COLS>
+__global__ void __launch_bounds__(256) prep_kernel(const R *tr, int64_t ts0, int64_t ts1, int N, int npad, R *out, R *mx) {
+    __shared__ R red[4];
+    const int i = blockIdx.x;
+    const R L2E = Num<R>::log2e(), NINF = Num<R>::ninf();
+    const int64_t sa = COLS ? ts1 : ts0, sb = COLS ? ts0 : ts1;     // element (i,j) at i*sa + j*sb
+    R m = NINF;
+    for (int j = threadIdx.x; j < N; j += 256) m = fmax(m, tr[(int64_t) i * sa + (int64_t) j * sb] * L2E);
+    m = block_reduce_max<R>(m, red);
+    if (m == NINF) m = 0;
+    for (int j = threadIdx.x; j < npad; j += 256)
+        out[(int64_t) i * npad + j] = j < N ? Num<R>::exp2(tr[(int64_t) i * sa + (int64_t) j * sb] * L2E - m) : R(0);
+    if (threadIdx.x == 0) mx[i] = m;
+}
+
+// per-frame emission maximum: emax[t][b] = max_i I2[t][b][i]   (grid = (T, B), block = 256)
+template <typename R>
+__global__ void __launch_bounds__(256) emax_kernel(Problem P, R *emax) {
+    __shared__ R red[4];
+    const int t = blockIdx.x, b = blockIdx.y;
+    const R *in = (const R *) P.inputs + (int64_t) t * P.is0 + (int64_t) b * P.is1;
+    R m = Num<R>::ninf();
+    for (int i = threadIdx.x; i < P.N; i += 256) m = fmax(m, in[(int64_t) i * P.is2] * Num<R>::log2e());
+    m = block_reduce_max<R>(m, red);
+    if (threadIdx.x == 0) emax[(int64_t) t * P.B + b] = fmax(m, Num<R>::logzero());
+}
+
+// ------------------------------------------------------------------ forward stepping state
+template <typename R>
+struct StepBuf {
+    R *pbuf;          // [2][B][npad]  p = exp2(q) of the frame being consumed / produced
+    unsigned *mu;     // [3][B]        key(max q) per utterance, triple buffered
+    double *off;      // [B]           running absolute offset
+    const R *emax;    // [T][B]
+    R *state;         // ah or bh  [B][T][N]
+    const R *ehat;    // [N][npad] (alpha: rows, beta: columns)
+    const R *hmax;    // [N]
+    int npad;
+};
+
+// init: alpha at frame 0 / beta at frame len-1.  grid = B, block = 256.
+template <typename R, bool BETA>
+__global__ void __launch_bounds__(256) fwd_init_kernel(Problem P, StepBuf<R> S) {
+    const int b = blockIdx.x;
+    const int N = P.N, T = P.T;
+    const int len = P.in_len ? gclampi(P.in_len[b], 0, T) : T;
+    const R L2E = Num<R>::log2e();
+    if (threadIdx.x == 0) {
+        S.mu[0 * P.B + b] = fkey(0.0f);
+        S.mu[1 * P.B + b] = fkey(-__builtin_inff());
+        S.mu[2 * P.B + b] = fkey(-__builtin_inff());
+    }
+    if (len < 1) { if (threadIdx.x == 0) S.off[b] = -1e300; return; }
+    const int t = BETA ? len - 1 : 0;
+    const R em = S.emax[(int64_t) t * P.B + b];
+    const R *in = (const R *) P.inputs + (int64_t) t * P.is0 + (int64_t) b * P.is1;
+    R *st = S.state + ((int64_t) b * T + t) * N;
+    R *pb = S.pbuf + (int64_t) b * S.npad;
+    for (int i = threadIdx.x; i < S.npad; i += 256) {
+        if (i < N) {
+            R q = in[(int64_t) i * P.is2] * L2E - em;          // max over i is exactly 0
+            st[i] = BETA ? R(0) : q;
+            pb[i] = Num<R>::exp2(q);
+        } else {
+            pb[i] = 0;
+        }
+    }
+    if (threadIdx.x == 0) S.off[b] = (double) em;
+}
+
+// One frame of the recursion for all utterances.  grid = (ceil(N/64), ceil(B/16)), block = 256.
+// Thread (r = tid & 63, ug = tid >> 6) owns row i = 64*bx + r and the four utterances 16*by + 4*ug .. +3.
+// step n: alpha consumes q_{t-1} (t = n) and writes ah[t]; beta consumes q_t (t = len-1-n) and writes bh[t-1].
+template <typename R, bool BETA>
+__global__ void __launch_bounds__(256) fwd_step_kernel(Problem P, StepBuf<R> S, int n) {
+    constexpr int KT = 32;
+    __shared__ R Es[KT][64 + 1];
+    __shared__ __attribute__((aligned(16))) R Ps[KT][16];
+    const int N = P.N, T = P.T, B = P.B, npad = S.npad;
+    const int r = threadIdx.x & 63, ug = threadIdx.x >> 6;
+    const int i0 = blockIdx.x * 64, b0 = blockIdx.y * 16;
+    const int i = i0 + r;
+    const R *pcur = S.pbuf + (int64_t) (n & 1) * B * npad;
+    R *pnext = S.pbuf + (int64_t) ((n + 1) & 1) * B * npad;
+
+    R acc[4] = {0, 0, 0, 0};
+    for (int k0 = 0; k0 < npad; k0 += KT) {
+        // E tile: 64 rows x KT cols, coalesced along k
+        for (int e = threadIdx.x; e < 64 * KT; e += 256) {
+            int rr = e / KT, kk = e - rr * KT;
+            int ii = i0 + rr, jj = k0 + kk;
+            Es[kk][rr] = (ii < N && jj < npad) ? S.ehat[(int64_t) ii * npad + jj] : R(0);
+        }
+        for (int e = threadIdx.x; e < 16 * KT; e += 256) {
+            int uu = e / KT, kk = e - uu * KT;
+            int bb = b0 + uu, jj = k0 + kk;
+            Ps[kk][uu] = (bb < B && jj < npad) ? pcur[(int64_t) bb * npad + jj] : R(0);
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int kk = 0; kk < KT; ++kk) {
+            R ev = Es[kk][r];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = fma(ev, Ps[kk][4 * ug + u], acc[u]);
+        }
+        __syncthreads();
+    }
+    // ---- epilogue
+    const R L2E = Num<R>::log2e(), LZ = Num<R>::logzero();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int b = b0 + 4 * ug + u;
+        if (b >= B || i >= N) continue;
+        const int len = P.in_len ? gclampi(P.in_len[b], 0, T) : T;
+        const int t = BETA ? len - 1 - n : n + 1;          // frame whose q is consumed (beta) / produced (alpha)
+        const bool active = BETA ? (t >= 1) : (t < len);
+        if (!active) continue;
+        const R muprev = fmax((R) funkey(S.mu[(n % 3) * B + b]), LZ);
+        R lg = Num<R>::log2(acc[u]);
+        R rr = S.hmax[i] + lg;
+        if (!(fabs(lg) < Num<R>::lg_limit())) {
+            // exact rare path: log2-sum-exp2 over j of (Tr2[.][.] + q_j) from the log-domain state
+            const R *tr = (const R *) P.transition;
+            const int tq = BETA ? t : t - 1;
+            const R *stq = S.state + ((int64_t) b * T + tq) * N;
+            const R *inq = (const R *) P.inputs + (int64_t) tq * P.is0 + (int64_t) b * P.is1;
+            const R emq = S.emax[(int64_t) tq * B + b];
+            R mx = Num<R>::ninf();
+            for (int j = 0; j < N; ++j) {
+                R qj = BETA ? inq[(int64_t) j * P.is2] * L2E - emq + stq[j] : stq[j];
+                R trv = BETA ? tr[(int64_t) j * P.ts0 + (int64_t) i * P.ts1] : tr[(int64_t) i * P.ts0 + (int64_t) j * P.ts1];
+                R v = trv * L2E + qj;
+                mx = (v == v) ? fmax(mx, v) : mx;
+            }
+            R sm = 0;
+            for (int j = 0; j < N; ++j) {
+                R qj = BETA ? inq[(int64_t) j * P.is2] * L2E - emq + stq[j] : stq[j];
+                R trv = BETA ? tr[(int64_t) j * P.ts0 + (int64_t) i * P.ts1] : tr[(int64_t) i * P.ts0 + (int64_t) j * P.ts1];
+                R v = trv * L2E + qj;
+                sm += (v == v && mx != Num<R>::ninf()) ? Num<R>::exp2(v - mx) : R(0);
+            }
+            rr = (mx == Num<R>::ninf()) ? mx : mx + Num<R>::log2(sm);
+        }
+        const int tw = BETA ? t - 1 : t;                   // frame written
+        const R emw = S.emax[(int64_t) tw * B + b];
+        const R emis = ((const R *) P.inputs)[(int64_t) tw * P.is0 + (int64_t) b * P.is1 + (int64_t) i * P.is2] * L2E - emw;
+        R stv, q;
+        if (BETA) { stv = rr - muprev; q = emis + stv; }
+        else { stv = emis + rr - muprev; q = stv; }
+        S.state[((int64_t) b * T + tw) * N + i] = stv;
+        pnext[(int64_t) b * npad + i] = Num<R>::exp2(q);
+        atomicMax(&S.mu[((n + 1) % 3) * B + b], fkey((float) q));
+        if (i == 0) {
+            S.off[b] += (double) muprev + (double) emw;
+            S.mu[((n + 2) % 3) * B + b] = fkey(-__builtin_inff());
+        }
+    }
+}
+
+// scores: grid = B, block = 256.  alpha: A + LSE_i(ah[len-1]);  beta: C_0 + LSE_i(q_0), q_0 = I2[0]-emax[0]+bh[0]
+template <typename R, bool BETA>
+__global__ void __launch_bounds__(256) fwd_score_kernel(Problem P, StepBuf<R> S, R *scores) {
+    __shared__ R red[4];
+    const int b = blockIdx.x, N = P.N, T = P.T;
+    const int len = P.in_len ? gclampi(P.in_len[b], 0, T) : T;
+    if (len < 1) { if (threadIdx.x == 0) scores[b] = Num<R>::ninf(); return; }
+    const int t = BETA ? 0 : len - 1;
+    const R *st = S.state + ((int64_t) b * T + t) * N;
+    const R *in = (const R *) P.inputs + (int64_t) t * P.is0 + (int64_t) b * P.is1;
+    const R em = S.emax[(int64_t) t * P.B + b];
+    R m = Num<R>::ninf();
+    for (int i = threadIdx.x; i < N; i += 256) {
+        R q = BETA ? in[(int64_t) i * P.is2] * Num<R>::log2e() - em + st[i] : st[i];
+        m = fmax(m, q);
+    }
+    m = fmax(block_reduce_max<R>(m, red), Num<R>::logzero());
+    R s = 0;
+    for (int i = threadIdx.x; i < N; i += 256) {
+        R q = BETA ? in[(int64_t) i * P.is2] * Num<R>::log2e() - em + st[i] : st[i];
+        s += Num<R>::exp2(q - m);
+    }
+    s = block_reduce_sum<R>(s, red);
+    if (threadIdx.x == 0) {
+        double sc = S.off[b] + (double) m + (double) Num<R>::log2(s);
+        scores[b] = (sc < -1e29) ? Num<R>::ninf() : (R) (sc * kLn2);
+    }
+}
+
+// ------------------------------------------------------------------ aligned lattice, wide targets
+// grid = (B, 2), block = 64 * ceil(S/64) (<= 1024).  blockIdx.y: 0 = alpha, 1 = beta.  Thread s owns target
+// position s; the neighbour's value travels through a double-buffered LDS row (one barrier per frame).
+template <typename R, bool STORE>
+__global__ void __launch_bounds__(1024) aligned_wide_kernel(Problem P, State W, FwdOut O, int mask) {
+    __shared__ R row[2][1024 + 2];
+    __shared__ R red[16];
+    const int b = blockIdx.x;
+    const bool beta = (mask == kAlignedBeta) || (mask == (kAlignedAlpha | kAlignedBeta) && blockIdx.y == 1);
+    const int s = threadIdx.x, S = P.S, T = P.T, N = P.N;
+    const R L2E = Num<R>::log2e(), LZ = Num<R>::logzero();
+    const int len = P.in_len ? gclampi(P.in_len[b], 0, T) : T;
+    const int ol = P.tg_len ? gclampi(P.tg_len[b], 0, S) : S;
+    const bool act = s < ol;
+    const int64_t *tg = P.targets + (int64_t) b * P.gs0;
+    const int cur = act ? gclampi(tg[(int64_t) s * P.gs1], 0, N - 1) : 0;
+    const int prv = (act && s >= 1) ? gclampi(tg[(int64_t) (s - 1) * P.gs1], 0, N - 1) : 0;
+    const int nxt = (s + 1 < ol) ? gclampi(tg[(int64_t) (s + 1) * P.gs1], 0, N - 1) : 0;
+    const R *tr = (const R *) P.transition;
+    const R H2 = act ? fmax(tr[(int64_t) cur * P.ts0 + (int64_t) cur * P.ts1] * L2E, LZ) : R(0);
+    const R Dprev = (act && s >= 1) ? fmax(tr[(int64_t) cur * P.ts0 + (int64_t) prv * P.ts1] * L2E, LZ) : LZ;
+    const R Dnext = (s + 1 < ol) ? fmax(tr[(int64_t) nxt * P.ts0 + (int64_t) cur * P.ts1] * L2E, LZ) : LZ;
+    const R *in = (const R *) P.inputs + (int64_t) b * P.is1 + (int64_t) cur * P.is2;
+    R *out = (R *) (beta ? W.bb : W.ab) + (int64_t) b * T * S;
+    if (STORE && !beta && s < S) {
+        V2<R> u = {H2, Dprev};
+        reinterpret_cast<V2<R> *>(W.asu)[(int64_t) b * S + s] = u;
+        int2 ii = {cur, prv};
+        reinterpret_cast<int2 *>(W.asi)[(int64_t) b * S + s] = ii;
+    }
+    R *score_out = (R *) (beta ? O.aligned_scores : O.aligned_scores_alpha);
+    if (len < 1 || ol < 1) {
+        if (s == 0 && score_out) score_out[b] = Num<R>::ninf();
+        return;
+    }
+    double C = 0.0;
+    R v;
+    if (!beta) {
+        v = (s == 0) ? fmax(in[0] * L2E, LZ) : LZ;
+        if (!act) v = LZ;
+        if (STORE && s < S) out[s] = v;
+        for (int t = 1; t < len; ++t) {
+            R *rw = row[t & 1];
+            rw[s + 1] = v;
+            if (s == 0) rw[0] = LZ;
+            __syncthreads();
+            R em = act ? in[(int64_t) t * P.is0] * L2E : LZ;
+            R left = rw[s];
+            v = fmax(em + lse2<R>(v + H2, left + Dprev), LZ);
+            if ((t & 15) == 0) {            // renormalise now and then: log domain is offset free
+                R m = v;
+                m = wave_allmax(m);
+                if ((s & 63) == 0) red[s >> 6] = m;
+                __syncthreads();
+                R mm = red[0];
+                for (int w = 1; w < (int) (blockDim.x >> 6); ++w) mm = fmax(mm, red[w]);
+                if (mm > R(-1e29)) { v = fmax(v - mm, LZ); C += (double) mm; }
+                __syncthreads();
+            }
+            if (STORE && s < S) out[(int64_t) t * S + s] = v;
+        }
+        if (score_out) {
+            row[0][s] = v;
+            __syncthreads();
+            if (s == 0) {
+                double sc = C + (double) row[0][ol - 1];
+                score_out[b] = (sc < -1e29) ? Num<R>::ninf() : (R) (sc * kLn2);
+            }
+        }
+    } else {
+        v = (s == ol - 1) ? R(0) : LZ;
+        if (STORE && s < S) out[(int64_t) (len - 1) * S + s] = v;
+        for (int t = len - 1; t >= 1; --t) {
+            R em = act ? in[(int64_t) t * P.is0] * L2E : LZ;
+            R y = fmax(em + v, LZ);
+            R *rw = row[t & 1];
+            rw[s] = y;
+            if (s == (int) blockDim.x - 1) rw[blockDim.x] = LZ;
+            __syncthreads();
+            R right = rw[s + 1];
+            v = fmax(lse2<R>(y + H2, right + Dnext), LZ);
+            if ((t & 15) == 0) {
+                R m = wave_allmax(v);
+                if ((s & 63) == 0) red[s >> 6] = m;
+                __syncthreads();
+                R mm = red[0];
+                for (int w = 1; w < (int) (blockDim.x >> 6); ++w) mm = fmax(mm, red[w]);
+                if (mm > R(-1e29)) { v = fmax(v - mm, LZ); C += (double) mm; }
+                __syncthreads();
+            }
+            if (STORE && s < S) out[(int64_t) (t - 1) * S + s] = v;
+        }
+        if (score_out) {
+            R em = act ? in[0] * L2E : LZ;
+            if (s == 0) {
+                double sc = C + (double) (em + v);
+                score_out[b] = (sc < -1e29) ? Num<R>::ninf() : (R) (sc * kLn2);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ gradient: full lattice
+// per (b,t) posterior + exp-domain previous frame.  grid = (T, B), block = 256.
+//   grad_inputs[t][b][:] = g_b * softmax(ah+bh)      (zeros for t >= len; the aligned part is added later)
+//   Pm[(b,t)][:] = exp2(ah[t-1] - max)  (t>=1, else 0)     Gm[(b,t)][:] = g_b * softmax   (t>=1 rows used)
+template <typename R>
+__global__ void __launch_bounds__(256) bwd_post_kernel(Problem P, State W, BwdArgs A, R *Pm, R *Gm, int npad) {
+    __shared__ R red[4];
+    const int t = blockIdx.x, b = blockIdx.y, N = P.N, T = P.T;
+    const int len = P.in_len ? gclampi(P.in_len[b], 0, T) : T;
+    const R LZ = Num<R>::logzero();
+    R *gin = (R *) A.grad_inputs + ((int64_t) t * P.B + b) * N;
+    R *pm = Pm + ((int64_t) b * T + t) * npad, *gm = Gm + ((int64_t) b * T + t) * npad;
+    if (t >= len) {
+        for (int i = threadIdx.x; i < N; i += 256) gin[i] = 0;
+        for (int i = threadIdx.x; i < npad; i += 256) { pm[i] = 0; gm[i] = 0; }
+        return;
+    }
+    const R gf = (R) ((double) ((const R *) A.grad_full)[(int64_t) b * A.gstride] * A.gscale);
+    const R *ah = (const R *) W.ah + ((int64_t) b * T + t) * N;
+    const R *bh = (const R *) W.bh + ((int64_t) b * T + t) * N;
+    R m = Num<R>::ninf();
+    for (int i = threadIdx.x; i < N; i += 256) m = fmax(m, ah[i] + bh[i]);
+    m = fmax(block_reduce_max<R>(m, red), LZ);
+    R z = 0;
+    for (int i = threadIdx.x; i < N; i += 256) z += Num<R>::exp2(ah[i] + bh[i] - m);
+    z = block_reduce_sum<R>(z, red);
+    R mp = Num<R>::ninf();
+    if (t >= 1) {
+        for (int i = threadIdx.x; i < N; i += 256) mp = fmax(mp, ah[i - N]);
+        mp = fmax(block_reduce_max<R>(mp, red), LZ);
+    }
+    for (int i = threadIdx.x; i < npad; i += 256) {
+        R g = 0, pv = 0;
+        if (i < N) {
+            g = (z > 0) ? gf * Num<R>::exp2(ah[i] + bh[i] - m) / z : R(0);
+            gin[i] = g;
+            if (t >= 1) pv = Num<R>::exp2(ah[i - N] - mp);
+        }
+        pm[i] = pv;
+        gm[i] = (t >= 1) ? g : R(0);
+    }
+}
+
+// LDS-tiled product C[m][n] = sum_k A(m,k) * B(k,n), 64x64 tile, 4x4 per thread, BK = 16.
+//   MODE 0 (row sums):   A = ehat[m][k] (k contiguous), B(k,n) = Pm[n][k] (k contiguous), epilogue
+//                        Gm[n][m] <- (ok) ? Gm[n][m] / C : 0          (U overwrites G in place)
+//   MODE 1 (outer prod): A(m,k) = Gm[k][m] (m contiguous), B(k,n) = Pm[k][n] (n contiguous), epilogue
+//                        out[m][n] = C * ehat[m][n]
+template <typename R, int MODE>
+__global__ void __launch_bounds__(256) bwd_gemm_kernel(const R *ehat, const R *Pm, R *Gm, R *out, int N, int npad, int K,
+                                                       int *anybad) {
+    constexpr int BK = 16;
+    __shared__ __attribute__((aligned(16))) R As[BK][64 + 4];
+    __shared__ __attribute__((aligned(16))) R Bs[BK][64 + 4];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+    const int Mdim = N, Ndim = MODE == 0 ? K : N, Kdim = MODE == 0 ? npad : K;
+    R acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[a][c] = 0;
+    for (int k0 = 0; k0 < Kdim; k0 += BK) {
+        for (int e = threadIdx.x; e < 64 * BK; e += 256) {
+            if (MODE == 0) {
+                int mm = e / BK, kk = e - mm * BK;
+                int gm_ = m0 + mm, gk = k0 + kk;
+                As[kk][mm] = (gm_ < Mdim && gk < Kdim) ? ehat[(int64_t) gm_ * npad + gk] : R(0);
+                int nn = mm;
+                int gn = n0 + nn;
+                Bs[kk][nn] = (gn < Ndim && gk < Kdim) ? Pm[(int64_t) gn * npad + gk] : R(0);
+            } else {
+                int kk = e / 64, mm = e - kk * 64;
+                int gk = k0 + kk, gm_ = m0 + mm, gn = n0 + mm;
+                R gv = (gk < Kdim && gm_ < Mdim) ? Gm[(int64_t) gk * npad + gm_] : R(0);
+                As[kk][mm] = (gv == Num<R>::ninf()) ? R(0) : gv;
+                Bs[kk][mm] = (gk < Kdim && gn < Ndim) ? Pm[(int64_t) gk * npad + gn] : R(0);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < BK; ++kk) {
+            R av[4], bv[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) av[a] = As[kk][ty * 4 + a];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) bv[c] = Bs[kk][tx * 4 + c];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[a][c] = fma(av[a], bv[c], acc[a][c]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            int gm_ = m0 + ty * 4 + a, gn = n0 + tx * 4 + c;
+            if (gm_ >= Mdim || gn >= Ndim) continue;
+            if (MODE == 0) {
+                R g = Gm[(int64_t) gn * npad + gm_];
+                R sden = acc[a][c];
+                bool ok = fabs(Num<R>::log2(sden)) < Num<R>::lg_limit();
+                // rows outside the safe range are marked -inf for the exact fix-up kernel (which recomputes
+                // their posterior); the outer-product pass reads markers as 0
+                const bool mark = !ok && g != R(0);
+                Gm[(int64_t) gn * npad + gm_] = ok ? g / sden : (mark ? Num<R>::ninf() : R(0));
+                if (mark) *anybad = 1;
+            } else {
+                out[(int64_t) gm_ * N + gn] = acc[a][c] * ehat[(int64_t) gm_ * npad + gn];
+            }
+        }
+}
+
+// exact fix-up of marked rows (rare; exits at once unless the row-sum pass raised `anybad`).
+// grid = (T, B), block = 256: recomputes the posterior of each marked (b,t,i) and adds
+// gi * softmax_j(Tr2[i][j] + ah[t-1][j]) into grad_transition.  Different (b,t) can hit the same (i,j), so this
+// path uses a float atomicAdd: it only runs for degenerate inputs (transition spans > 69 nats) and is the one
+// place whose summation ORDER is not fixed.
+template <typename R>
+__global__ void __launch_bounds__(256) bwd_fix_kernel(Problem P, State W, BwdArgs A, R *Gm, R *out, int npad, const int *anybad) {
+    __shared__ R red[4];
+    if (!*anybad) return;
+    const int t = blockIdx.x, b = blockIdx.y, N = P.N, T = P.T;
+    const int len = P.in_len ? gclampi(P.in_len[b], 0, T) : T;
+    if (t < 1 || t >= len) return;
+    R *gm = Gm + ((int64_t) b * T + t) * npad;
+    const R *ah = (const R *) W.ah + ((int64_t) b * T + t) * N;
+    const R *bh = (const R *) W.bh + ((int64_t) b * T + t) * N;
+    const R *ahp = ah - N;
+    const R *tr = (const R *) P.transition;
+    const R L2E = Num<R>::log2e(), LZ = Num<R>::logzero();
+    const R gf = (R) ((double) ((const R *) A.grad_full)[(int64_t) b * A.gstride] * A.gscale);
+    R m = Num<R>::ninf();
+    for (int i = threadIdx.x; i < N; i += 256) m = fmax(m, ah[i] + bh[i]);
+    m = fmax(block_reduce_max<R>(m, red), LZ);
+    R z = 0;
+    for (int i = threadIdx.x; i < N; i += 256) z += Num<R>::exp2(ah[i] + bh[i] - m);
+    z = block_reduce_sum<R>(z, red);
+    for (int i = 0; i < N; ++i) {
+        if (!(gm[i] == Num<R>::ninf())) continue;             // uniform: every thread reads the same element
+        R g = (z > 0) ? gf * Num<R>::exp2(ah[i] + bh[i] - m) / z : R(0);
+        R mx = Num<R>::ninf();
+        for (int j = threadIdx.x; j < N; j += 256) {
+            R v = tr[(int64_t) i * P.ts0 + (int64_t) j * P.ts1] * L2E + ahp[j];
+            mx = (v == v) ? fmax(mx, v) : mx;
+        }
+        mx = block_reduce_max<R>(mx, red);
+        if (mx == Num<R>::ninf()) continue;
+        R sm = 0;
+        for (int j = threadIdx.x; j < N; j += 256) {
+            R v = tr[(int64_t) i * P.ts0 + (int64_t) j * P.ts1] * L2E + ahp[j];
+            sm += (v == v) ? Num<R>::exp2(v - mx) : R(0);
+        }
+        sm = block_reduce_sum<R>(sm, red);
+        for (int j = threadIdx.x; j < N; j += 256) {
+            R v = tr[(int64_t) i * P.ts0 + (int64_t) j * P.ts1] * L2E + ahp[j];
+            R x = (v == v) ? g * Num<R>::exp2(v - mx) / sm : R(0);
+            if (x != R(0)) atomicAdd(&out[(int64_t) i * N + j], x);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ gradient: aligned lattice (any N, S <= 1024)
+// grid = (B, nchunks), block = 256.  Wave w handles frames t0+w, t0+w+4, ...; lane l covers target positions
+// l, l+64, ...  Duplicate labels inside an utterance are folded onto their FIRST occurrence in a fixed order,
+// so the read-modify-write of grad_inputs needs no atomics and is deterministic.
+// Edge posteriors are written per (b, chunk) to gHD[(b*nchunks+chunk)][2][S].
+template <typename R>
+__global__ void __launch_bounds__(256) bwd_aligned_kernel(Problem P, State W, BwdArgs A, R *gHD, int add_to_inputs) {
+    constexpr int MAXK = 16;                       // S <= 1024
+    __shared__ R post_s[4][1024];
+    __shared__ int first_s[1024];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.x, chunk = blockIdx.y;
+    const int S = P.S, T = P.T, N = P.N;
+    const R LZ = Num<R>::logzero();
+    const int len = P.in_len ? gclampi(P.in_len[b], 0, T) : T;
+    const int ol = P.tg_len ? gclampi(P.tg_len[b], 0, S) : S;
+    const R g0 = (R) ((double) ((const R *) (A.grad_aligned ? A.grad_aligned : A.grad_full))[(int64_t) b * A.gstride] * A.gscale);
+    const R ga = (A.grad_aligned || !A.neg_aligned) ? g0 : -g0;
+    const int K = (S + 63) / 64;
+    const int2 *asi = reinterpret_cast<const int2 *>(W.asi) + (int64_t) b * S;
+    const V2<R> *asu = reinterpret_cast<const V2<R> *>(W.asu) + (int64_t) b * S;
+    // first occurrence of each position's label (fixed order -> deterministic)
+    for (int s = threadIdx.x; s < S; s += 256) {
+        int f = s;
+        if (s < ol) {
+            const int lab = asi[s].x;
+            for (int q = 0; q < s; ++q) if (asi[q].x == lab) { f = q; break; }
+        }
+        first_s[s] = f;
+    }
+    __syncthreads();
+    R H2[MAXK], Dp[MAXK], accH[MAXK], accD[MAXK];
+    int tgt[MAXK];
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) {
+        int s = lane + 64 * k;
+        bool v = k < K && s < S;
+        V2<R> u = v ? asu[s] : V2<R>{0, LZ};
+        H2[k] = u.x; Dp[k] = u.y;
+        tgt[k] = v ? asi[s].x : 0;
+        accH[k] = 0; accD[k] = 0;
+    }
+    const R *abp = (const R *) W.ab + (int64_t) b * T * S;
+    const R *bbp = (const R *) W.bb + (int64_t) b * T * S;
+    const int t0 = chunk * A.chunk, t1 = min(T, t0 + A.chunk);
+    for (int t = t0 + wave; t < t1; t += 4) {
+        if (t >= len) continue;
+        R gam[MAXK], m = LZ;
+#pragma unroll
+        for (int k = 0; k < MAXK; ++k) {
+            int s = lane + 64 * k;
+            gam[k] = (k < K && s < S) ? abp[(int64_t) t * S + s] + bbp[(int64_t) t * S + s] : LZ;
+            m = fmax(m, gam[k]);
+        }
+        m = wave_allmax(m);
+        R z = 0;
+#pragma unroll
+        for (int k = 0; k < MAXK; ++k) {
+            gam[k] = (k < K && m > R(-1e29)) ? Num<R>::exp2(gam[k] - m) : R(0);
+            z += gam[k];
+        }
+        z = wave_allsum(z);
+#pragma unroll
+        for (int k = 0; k < MAXK; ++k) {
+            int s = lane + 64 * k;
+            R post = (z > 0 && k < K && s < ol) ? gam[k] / z : R(0);
+            if (k < K && s < S) post_s[wave][s] = post;
+            if (t >= 1 && k < K && s < ol) {
+                R ap = abp[(int64_t) (t - 1) * S + s];
+                R al = s >= 1 ? abp[(int64_t) (t - 1) * S + s - 1] : R(0);
+                R pc0 = ap + H2[k], pc1 = al + Dp[k];
+                R l = lse2<R>(pc0, pc1);
+                accH[k] += post * Num<R>::exp2(pc0 - l);
+                accD[k] += post * Num<R>::exp2(pc1 - l);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // owner (first occurrence) sums its duplicates in ascending order and updates grad_inputs[t][b][label]
+        R *gin = (R *) A.grad_inputs + ((int64_t) t * P.B + b) * N;
+#pragma unroll
+        for (int k = 0; k < MAXK; ++k) {
+            int s = lane + 64 * k;
+            if (k < K && s < ol && first_s[s] == s) {
+                R sum = post_s[wave][s];
+                for (int q = s + 1; q < ol; ++q) if (first_s[q] == s) sum += post_s[wave][q];
+                R add = ga * sum;
+                gin[tgt[k]] = add_to_inputs ? gin[tgt[k]] + add : add;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // reduce the 4 waves' edge posteriors and write this chunk's slice
+    __syncthreads();
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+        for (int k = 0; k < MAXK; ++k) {
+            int s = lane + 64 * k;
+            if (k < K && s < S) post_s[wave][s] = pass == 0 ? accH[k] : accD[k];
+        }
+        __syncthreads();
+        R *dst = gHD + (((int64_t) b * A.nchunks + chunk) * 2 + pass) * S;
+        for (int s = threadIdx.x; s < S; s += 256)
+            dst[s] = (post_s[0][s] + post_s[1][s]) + (post_s[2][s] + post_s[3][s]);
+        __syncthreads();
+    }
+}
+
+// scatter the aligned edge posteriors into grad_transition: ONE workgroup, utterances in order, duplicates
+// of an (i,j) key inside an utterance folded onto the first occurrence -> deterministic, no atomics.
+// keys: stay  (O_s, O_s)      <- gH[s]   for s < ol
+//       enter (O_s, O_{s-1})  <- gD[s]   for 1 <= s < ol
+template <typename R>
+__global__ void __launch_bounds__(1024) aligned_tr_scatter_kernel(Problem P, State W, BwdArgs A, const R *gHD, R *out, int accumulate) {
+    __shared__ long long key_s[2048];
+    __shared__ R val_s[2048];
+    const int S = P.S, N = P.N, B = P.B;
+    if (!accumulate) {
+        for (int64_t k = threadIdx.x; k < (int64_t) N * N; k += blockDim.x) out[k] = 0;
+        __syncthreads();
+    }
+    for (int b = 0; b < B; ++b) {
+        const int ol = P.tg_len ? gclampi(P.tg_len[b], 0, S) : S;
+        const R g0 = (R) ((double) ((const R *) (A.grad_aligned ? A.grad_aligned : A.grad_full))[(int64_t) b * A.gstride] * A.gscale);
+        const R ga = (A.grad_aligned || !A.neg_aligned) ? g0 : -g0;
+        const int2 *asi = reinterpret_cast<const int2 *>(W.asi) + (int64_t) b * S;
+        for (int e = threadIdx.x; e < 2 * S; e += blockDim.x) {
+            int pass = e / S, s = e - pass * S;
+            R v = 0;
+            for (int c = 0; c < A.nchunks; ++c) v += gHD[(((int64_t) b * A.nchunks + c) * 2 + pass) * S + s];
+            bool valid = pass == 0 ? (s < ol) : (s >= 1 && s < ol);
+            int2 ii = s < S ? asi[s] : int2{0, 0};
+            key_s[e] = valid ? ((long long) ii.x * N + (pass == 0 ? ii.x : ii.y)) : -1;
+            val_s[e] = valid ? ga * v : R(0);
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < 2 * S; e += blockDim.x) {
+            long long k = key_s[e];
+            if (k < 0) continue;
+            bool first = true;
+            for (int q = 0; q < e; ++q) if (key_s[q] == k) { first = false; break; }
+            if (!first) continue;
+            R sum = val_s[e];
+            for (int q = e + 1; q < 2 * S; ++q) if (key_s[q] == k) sum += val_s[q];
+            out[k] += sum;
+        }
+        __syncthreads();
+    }
+}
+
+inline size_t au(size_t x) { return (x + 255) & ~(size_t) 255; }
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------- host side
+template <typename R>
+hipError_t launch_prep_generic(const Problem &P, const State &W, hipStream_t stream) {
+    hipLaunchKernelGGL((prep_kernel<R, false>), dim3(P.N), dim3(256), 0, stream, (const R *) P.transition, P.ts0, P.ts1,
+                       P.N, W.npad, (R *) W.ehat, (R *) W.rmax);
+    hipLaunchKernelGGL((prep_kernel<R, true>), dim3(P.N), dim3(256), 0, stream, (const R *) P.transition, P.ts0, P.ts1,
+                       P.N, W.npad, (R *) W.fhat, (R *) W.cmax);
+    return hipGetLastError();
+}
+
+// forward work buffers live behind the saved state (see fwd_work_bytes_generic): emax, pbuf x2 dirs, mu, off
+size_t fwd_work_bytes_generic(int elem, int T, int B, int N) {
+    const size_t npad = (size_t) (N + 3) / 4 * 4;
+    return au((size_t) T * B * elem) + 2 * au(2 * (size_t) B * npad * elem) + 2 * au(3 * (size_t) B * 4) + 2 * au((size_t) B * 8);
+}
+
+template <typename R>
+hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O, int chain_mask, bool store,
+                              hipStream_t stream) {
+    const int full_mask = chain_mask & (kFullAlpha | kFullBeta);
+    const int ali_mask = chain_mask & (kAlignedAlpha | kAlignedBeta);
+    if (ali_mask) {
+        const int threads = ((P.S + 63) / 64) * 64;
+        if (threads > 1024) return hipErrorInvalidValue;
+        dim3 grid(P.B, __builtin_popcount(ali_mask));
+        if (store) hipLaunchKernelGGL((aligned_wide_kernel<R, true>), grid, dim3(threads), 0, stream, P, W, O, ali_mask);
+        else hipLaunchKernelGGL((aligned_wide_kernel<R, false>), grid, dim3(threads), 0, stream, P, W, O, ali_mask);
+    }
+    if (full_mask) {
+        if (!W.work) return hipErrorInvalidValue;
+        char *wk = (char *) W.work;
+        const size_t e = sizeof(R);
+        R *emax = (R *) wk; wk += au((size_t) P.T * P.B * e);
+        hipLaunchKernelGGL((emax_kernel<R>), dim3(P.T, P.B), dim3(256), 0, stream, P, emax);
+        // the p vectors are npad wide: their pad columns must be (and stay) zero
+        hipMemsetAsync(wk, 0, 2 * (au(2 * (size_t) P.B * W.npad * e) + au(3 * (size_t) P.B * 4) + au((size_t) P.B * 8)), stream);
+        for (int dir = 0; dir < 2; ++dir) {
+            StepBuf<R> S{};
+            S.pbuf = (R *) wk; wk += au(2 * (size_t) P.B * W.npad * e);
+            S.mu = (unsigned *) wk; wk += au(3 * (size_t) P.B * 4);
+            S.off = (double *) wk; wk += au((size_t) P.B * 8);
+            S.emax = emax;
+            S.npad = W.npad;
+            const bool beta = dir == 1;
+            if (!(full_mask & (beta ? kFullBeta : kFullAlpha))) continue;
+            S.state = (R *) (beta ? W.bh : W.ah);
+            S.ehat = (const R *) (beta ? W.fhat : W.ehat);
+            S.hmax = (const R *) (beta ? W.cmax : W.rmax);
+            dim3 sgrid((P.N + 63) / 64, (P.B + 15) / 16);
+            if (beta) {
+                hipLaunchKernelGGL((fwd_init_kernel<R, true>), dim3(P.B), dim3(256), 0, stream, P, S);
+                for (int n = 0; n + 1 < P.T; ++n)
+                    hipLaunchKernelGGL((fwd_step_kernel<R, true>), sgrid, dim3(256), 0, stream, P, S, n);
+                hipLaunchKernelGGL((fwd_score_kernel<R, true>), dim3(P.B), dim3(256), 0, stream, P, S, (R *) O.full_scores);
+            } else {
+                hipLaunchKernelGGL((fwd_init_kernel<R, false>), dim3(P.B), dim3(256), 0, stream, P, S);
+                for (int n = 0; n + 1 < P.T; ++n)
+                    hipLaunchKernelGGL((fwd_step_kernel<R, false>), sgrid, dim3(256), 0, stream, P, S, n);
+                if (O.full_scores_alpha)
+                    hipLaunchKernelGGL((fwd_score_kernel<R, false>), dim3(P.B), dim3(256), 0, stream, P, S,
+                                       (R *) O.full_scores_alpha);
+            }
+        }
+    }
+    (void) store;
+    return hipGetLastError();
+}
+
+static void generic_chunks(int T, int B, int *chunk, int *nchunks) {
+    int nch = (512 + B - 1) / B;
+    if (nch < 1) nch = 1;
+    int ch = (T + nch - 1) / nch;
+    if (ch < 16) ch = 16;
+    ch = (ch + 3) / 4 * 4;
+    *chunk = ch;
+    *nchunks = (T + ch - 1) / ch;
+}
+
+size_t bwd_scratch_bytes_generic(int elem, int T, int B, int N, int S) {
+    const size_t npad = (size_t) (N + 3) / 4 * 4;
+    int ch, nch;
+    generic_chunks(T, B, &ch, &nch);
+    return 2 * au((size_t) B * T * npad * elem) + au((size_t) B * nch * 2 * S * elem) + 512;
+}
+
+template <typename R>
+hipError_t launch_bwd_generic(const Problem &P, const State &W, const BwdArgs &A0, int parts, hipStream_t stream) {
+    BwdArgs A = A0;
+    generic_chunks(P.T, P.B, &A.chunk, &A.nchunks);
+    const size_t e = sizeof(R);
+    const int npad = (P.N + 3) / 4 * 4;
+    char *sc = (char *) A.scratch;
+    R *Pm = (R *) sc; sc += au((size_t) P.B * P.T * npad * e);
+    R *Gm = (R *) sc; sc += au((size_t) P.B * P.T * npad * e);
+    R *gHD = (R *) sc; sc += au((size_t) P.B * A.nchunks * 2 * P.S * e);
+    int *anybad = (int *) sc;
+    const bool do_full = parts & 1, do_ali = parts & 2, have_full = (parts & 5) != 0;
+    R *gtr = (R *) A.grad_transition;
+    if (do_full) {
+        if (P.N <= 64) return hipErrorInvalidValue;      // the small kernel owns this case
+        const int K = P.B * P.T;
+        hipMemsetAsync(anybad, 0, sizeof(int), stream);
+        hipLaunchKernelGGL((bwd_post_kernel<R>), dim3(P.T, P.B), dim3(256), 0, stream, P, W, A, Pm, Gm, npad);
+        hipLaunchKernelGGL((bwd_gemm_kernel<R, 0>), dim3((P.N + 63) / 64, (K + 63) / 64), dim3(256), 0, stream,
+                           (const R *) W.ehat, Pm, Gm, gtr, P.N, npad, K, anybad);
+        hipLaunchKernelGGL((bwd_gemm_kernel<R, 1>), dim3((P.N + 63) / 64, (P.N + 63) / 64), dim3(256), 0, stream,
+                           (const R *) W.ehat, Pm, Gm, gtr, P.N, npad, K, anybad);
+        hipLaunchKernelGGL((bwd_fix_kernel<R>), dim3(P.T, P.B), dim3(256), 0, stream, P, W, A, Gm, gtr, npad, anybad);
+    }
+    if (do_ali) {
+        if (P.S > 1024) return hipErrorInvalidValue;
+        if (!have_full) hipMemsetAsync(A.grad_inputs, 0, (size_t) P.T * P.B * P.N * e, stream);
+        hipLaunchKernelGGL((bwd_aligned_kernel<R>), dim3(P.B, A.nchunks), dim3(256), 0, stream, P, W, A, gHD, 1);
+        hipLaunchKernelGGL((aligned_tr_scatter_kernel<R>), dim3(1), dim3(1024), 0, stream, P, W, A, gHD, gtr,
+                           have_full ? 1 : 0);
+    }
+    return hipGetLastError();
+}
 
 template hipError_t launch_prep_generic<float>(const Problem &, const State &, hipStream_t);
 template hipError_t launch_prep_generic<double>(const Problem &, const State &, hipStream_t);

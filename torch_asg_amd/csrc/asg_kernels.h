@@ -34,6 +34,7 @@ struct State {
     void *asu;
     int *asi;
     void *dbg;
+    void *work;      // generic path: forward work buffers (emission maxima, p vectors, normalisers, offsets)
     int npad;
 };
 
@@ -76,10 +77,12 @@ hipError_t launch_prep_generic(const Problem &P, const State &W, hipStream_t str
 template <typename R>
 hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O, int chain_mask, bool store,
                               hipStream_t stream);
+// parts: 1 = full lattice (N > 64), 2 = aligned lattice, 4 = grad buffers already hold the full-lattice part
 template <typename R>
 hipError_t launch_bwd_generic(const Problem &P, const State &W, const BwdArgs &A, int parts, hipStream_t stream);
 
 size_t bwd_scratch_bytes_small(int elem, int T, int B, int N, int S, int *chunk, int *nchunks);
 size_t bwd_scratch_bytes_generic(int elem, int T, int B, int N, int S);
+size_t fwd_work_bytes_generic(int elem, int T, int B, int N);
 
 }  // namespace asg

@@ -26,8 +26,6 @@ namespace {
 constexpr int kPF = 16;     // emission prefetch depth (frames), register ring; also the unroll of one block
 constexpr int kRenorm = 4;  // full lattice: subtract the frame max every kRenorm steps (must divide kPF)
 
-template <typename R> using V2 = R __attribute__((ext_vector_type(2)));
-template <typename R> using V4 = R __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int clampi(int64_t v, int lo, int hi) {
     return v < lo ? lo : (v > hi ? hi : (int) v);
