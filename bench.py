@@ -148,12 +148,15 @@ def main():
     # ---- kernel timing hook: HIP events around the recursion-kernel launch, on the launch stream
     ev_pairs = []
     be = asg_mod.native()
+    # local mean over B times 1/world == mean over the global batch (equal shards); the factor enters as the
+    # incoming gradient of backward(), i.e. inside the assembly kernel, not as extra elementwise launches
+    gscale = torch.full((), 1.0 / world, device=dev)
+
     def one_step():
         loss_mod.transition.grad = None
         x.grad = None
-        # local mean over B and division by world == mean over the global batch (equal shards)
-        loss = loss_mod(x, tg, il, tl) / world
-        loss.backward()
+        loss = loss_mod(x, tg, il, tl)
+        loss.backward(gscale)
         return loss
 
     def sync_grads():

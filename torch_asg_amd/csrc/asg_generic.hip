@@ -128,93 +128,122 @@ __global__ void __launch_bounds__(256) fwd_init_kernel(Problem P, StepBuf<R> S) 
     if (threadIdx.x == 0) S.off[b] = (double) em;
 }
 
-// One frame of the recursion for all utterances.  grid = (ceil(N/64), ceil(B/16)), block = 256.
-// Thread (r = tid & 63, ug = tid >> 6) owns row i = 64*bx + r and the four utterances 16*by + 4*ug .. +3.
-// step n: alpha consumes q_{t-1} (t = n) and writes ah[t]; beta consumes q_t (t = len-1-n) and writes bh[t-1].
+// One frame of the recursion for all utterances.  grid = (ceil(N/64), ceil(B/32)), block = 256.
+// Thread (r = tid & 63, ug = tid >> 6) owns row i = 64*bx + r and the eight utterances 32*by + 8*ug .. +7, so with
+// B <= 32 every tile of E is fetched exactly once per frame.  Tiles are staged global -> registers -> LDS with
+// 16-byte loads, the next tile's loads in flight while the current one is consumed.
+// step n: alpha consumes q_{t-1} (t = n+1) and writes ah[t]; beta consumes q_t (t = len-1-n) and writes bh[t-1].
 template <typename R, bool BETA>
-__global__ void __launch_bounds__(256) fwd_step_kernel(Problem P, StepBuf<R> S, int n) {
-    constexpr int KT = 32;
-    __shared__ R Es[KT][64 + 1];
-    __shared__ __attribute__((aligned(16))) R Ps[KT][16];
+__device__ __forceinline__ void fwd_step_body(const Problem &P, const StepBuf<R> &S, int n) {
+    constexpr int KT = 32, NU = 8;
+    __shared__ __attribute__((aligned(16))) R Es[KT][64 + 4];
+    __shared__ __attribute__((aligned(16))) R Ps[KT][32];
     const int N = P.N, T = P.T, B = P.B, npad = S.npad;
     const int r = threadIdx.x & 63, ug = threadIdx.x >> 6;
-    const int i0 = blockIdx.x * 64, b0 = blockIdx.y * 16;
+    const int i0 = blockIdx.x * 64, b0 = blockIdx.y * 32;
     const int i = i0 + r;
     const R *pcur = S.pbuf + (int64_t) (n & 1) * B * npad;
     R *pnext = S.pbuf + (int64_t) ((n + 1) & 1) * B * npad;
 
-    R acc[4] = {0, 0, 0, 0};
+    // staging assignment: E tile = 64 rows x 8 float4 -> 2 float4 per thread; P tile = 32 utt x 8 float4 -> 1
+    const int er0 = threadIdx.x >> 3, ec = threadIdx.x & 7;          // rows er0 and er0 + 32, float4 column ec
+    const int pu = threadIdx.x >> 3, pc = threadIdx.x & 7;
+    const V4<R> zero4 = {0, 0, 0, 0};
+    auto ldE = [&](int k0, int rr) -> V4<R> {
+        int ii = i0 + rr, jj = k0 + 4 * ec;
+        return (ii < N && jj < npad) ? *reinterpret_cast<const V4<R> *>(S.ehat + (int64_t) ii * npad + jj) : zero4;
+    };
+    auto ldP = [&](int k0) -> V4<R> {
+        int bb = b0 + pu, jj = k0 + 4 * pc;
+        return (bb < B && jj < npad) ? *reinterpret_cast<const V4<R> *>(pcur + (int64_t) bb * npad + jj) : zero4;
+    };
+    V4<R> e_a = ldE(0, er0), e_b = ldE(0, er0 + 32), p_a = ldP(0);
+
+    R acc[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) acc[u] = 0;
     for (int k0 = 0; k0 < npad; k0 += KT) {
-        // E tile: 64 rows x KT cols, coalesced along k
-        for (int e = threadIdx.x; e < 64 * KT; e += 256) {
-            int rr = e / KT, kk = e - rr * KT;
-            int ii = i0 + rr, jj = k0 + kk;
-            Es[kk][rr] = (ii < N && jj < npad) ? S.ehat[(int64_t) ii * npad + jj] : R(0);
-        }
-        for (int e = threadIdx.x; e < 16 * KT; e += 256) {
-            int uu = e / KT, kk = e - uu * KT;
-            int bb = b0 + uu, jj = k0 + kk;
-            Ps[kk][uu] = (bb < B && jj < npad) ? pcur[(int64_t) bb * npad + jj] : R(0);
-        }
         __syncthreads();
+        Es[4 * ec + 0][er0] = e_a.x; Es[4 * ec + 1][er0] = e_a.y; Es[4 * ec + 2][er0] = e_a.z; Es[4 * ec + 3][er0] = e_a.w;
+        Es[4 * ec + 0][er0 + 32] = e_b.x; Es[4 * ec + 1][er0 + 32] = e_b.y; Es[4 * ec + 2][er0 + 32] = e_b.z; Es[4 * ec + 3][er0 + 32] = e_b.w;
+        Ps[4 * pc + 0][pu] = p_a.x; Ps[4 * pc + 1][pu] = p_a.y; Ps[4 * pc + 2][pu] = p_a.z; Ps[4 * pc + 3][pu] = p_a.w;
+        __syncthreads();
+        if (k0 + KT < npad) { e_a = ldE(k0 + KT, er0); e_b = ldE(k0 + KT, er0 + 32); p_a = ldP(k0 + KT); }
 #pragma unroll 8
         for (int kk = 0; kk < KT; ++kk) {
-            R ev = Es[kk][r];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) acc[u] = fma(ev, Ps[kk][4 * ug + u], acc[u]);
+            const R ev = Es[kk][r];
+            const V4<R> q0 = *reinterpret_cast<const V4<R> *>(&Ps[kk][NU * ug]);
+            const V4<R> q1 = *reinterpret_cast<const V4<R> *>(&Ps[kk][NU * ug + 4]);
+            acc[0] = fma(ev, q0.x, acc[0]); acc[1] = fma(ev, q0.y, acc[1]);
+            acc[2] = fma(ev, q0.z, acc[2]); acc[3] = fma(ev, q0.w, acc[3]);
+            acc[4] = fma(ev, q1.x, acc[4]); acc[5] = fma(ev, q1.y, acc[5]);
+            acc[6] = fma(ev, q1.z, acc[6]); acc[7] = fma(ev, q1.w, acc[7]);
         }
-        __syncthreads();
     }
     // ---- epilogue
     const R L2E = Num<R>::log2e(), LZ = Num<R>::logzero();
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int b = b0 + 4 * ug + u;
-        if (b >= B || i >= N) continue;
+    for (int u = 0; u < NU; ++u) {
+        const int b = b0 + NU * ug + u;            // wave-uniform: all 64 lanes of a wave share ug
+        if (b >= B) continue;
         const int len = P.in_len ? gclampi(P.in_len[b], 0, T) : T;
         const int t = BETA ? len - 1 - n : n + 1;          // frame whose q is consumed (beta) / produced (alpha)
         const bool active = BETA ? (t >= 1) : (t < len);
-        if (!active) continue;
+        if (!active) continue;                             // wave-uniform
         const R muprev = fmax((R) funkey(S.mu[(n % 3) * B + b]), LZ);
-        R lg = Num<R>::log2(acc[u]);
-        R rr = S.hmax[i] + lg;
-        if (!(fabs(lg) < Num<R>::lg_limit())) {
-            // exact rare path: log2-sum-exp2 over j of (Tr2[.][.] + q_j) from the log-domain state
-            const R *tr = (const R *) P.transition;
-            const int tq = BETA ? t : t - 1;
-            const R *stq = S.state + ((int64_t) b * T + tq) * N;
-            const R *inq = (const R *) P.inputs + (int64_t) tq * P.is0 + (int64_t) b * P.is1;
-            const R emq = S.emax[(int64_t) tq * B + b];
-            R mx = Num<R>::ninf();
-            for (int j = 0; j < N; ++j) {
-                R qj = BETA ? inq[(int64_t) j * P.is2] * L2E - emq + stq[j] : stq[j];
-                R trv = BETA ? tr[(int64_t) j * P.ts0 + (int64_t) i * P.ts1] : tr[(int64_t) i * P.ts0 + (int64_t) j * P.ts1];
-                R v = trv * L2E + qj;
-                mx = (v == v) ? fmax(mx, v) : mx;
-            }
-            R sm = 0;
-            for (int j = 0; j < N; ++j) {
-                R qj = BETA ? inq[(int64_t) j * P.is2] * L2E - emq + stq[j] : stq[j];
-                R trv = BETA ? tr[(int64_t) j * P.ts0 + (int64_t) i * P.ts1] : tr[(int64_t) i * P.ts0 + (int64_t) j * P.ts1];
-                R v = trv * L2E + qj;
-                sm += (v == v && mx != Num<R>::ninf()) ? Num<R>::exp2(v - mx) : R(0);
-            }
-            rr = (mx == Num<R>::ninf()) ? mx : mx + Num<R>::log2(sm);
-        }
         const int tw = BETA ? t - 1 : t;                   // frame written
         const R emw = S.emax[(int64_t) tw * B + b];
-        const R emis = ((const R *) P.inputs)[(int64_t) tw * P.is0 + (int64_t) b * P.is1 + (int64_t) i * P.is2] * L2E - emw;
-        R stv, q;
-        if (BETA) { stv = rr - muprev; q = emis + stv; }
-        else { stv = emis + rr - muprev; q = stv; }
-        S.state[((int64_t) b * T + tw) * N + i] = stv;
-        pnext[(int64_t) b * npad + i] = Num<R>::exp2(q);
-        atomicMax(&S.mu[((n + 1) % 3) * B + b], fkey((float) q));
+        float qkey = -__builtin_inff();
+        if (i < N) {
+            R lg = Num<R>::log2(acc[u]);
+            R rr = S.hmax[i] + lg;
+            if (!(fabs(lg) < Num<R>::lg_limit())) {
+                // exact rare path: log2-sum-exp2 over j of (Tr2[.][.] + q_j) from the log-domain state
+                const R *tr = (const R *) P.transition;
+                const int tq = BETA ? t : t - 1;
+                const R *stq = S.state + ((int64_t) b * T + tq) * N;
+                const R *inq = (const R *) P.inputs + (int64_t) tq * P.is0 + (int64_t) b * P.is1;
+                const R emq = S.emax[(int64_t) tq * B + b];
+                R mx = Num<R>::ninf();
+                for (int j = 0; j < N; ++j) {
+                    R qj = BETA ? inq[(int64_t) j * P.is2] * L2E - emq + stq[j] : stq[j];
+                    R trv = BETA ? tr[(int64_t) j * P.ts0 + (int64_t) i * P.ts1] : tr[(int64_t) i * P.ts0 + (int64_t) j * P.ts1];
+                    R v = trv * L2E + qj;
+                    mx = (v == v) ? fmax(mx, v) : mx;
+                }
+                R sm = 0;
+                for (int j = 0; j < N; ++j) {
+                    R qj = BETA ? inq[(int64_t) j * P.is2] * L2E - emq + stq[j] : stq[j];
+                    R trv = BETA ? tr[(int64_t) j * P.ts0 + (int64_t) i * P.ts1] : tr[(int64_t) i * P.ts0 + (int64_t) j * P.ts1];
+                    R v = trv * L2E + qj;
+                    sm += (v == v && mx != Num<R>::ninf()) ? Num<R>::exp2(v - mx) : R(0);
+                }
+                rr = (mx == Num<R>::ninf()) ? mx : mx + Num<R>::log2(sm);
+            }
+            const R emis = ((const R *) P.inputs)[(int64_t) tw * P.is0 + (int64_t) b * P.is1 + (int64_t) i * P.is2] * L2E - emw;
+            R stv, q;
+            if (BETA) { stv = rr - muprev; q = emis + stv; }
+            else { stv = emis + rr - muprev; q = stv; }
+            S.state[((int64_t) b * T + tw) * N + i] = stv;
+            pnext[(int64_t) b * npad + i] = Num<R>::exp2(q);
+            qkey = (float) q;
+        }
+        // one atomic per wavefront and utterance (max is order-independent: deterministic)
+        qkey = wave_allmax(qkey);
+        if (r == 0) atomicMax(&S.mu[((n + 1) % 3) * B + b], fkey(qkey));
         if (i == 0) {
             S.off[b] += (double) muprev + (double) emw;
             S.mu[((n + 2) % 3) * B + b] = fkey(-__builtin_inff());
         }
     }
+}
+
+// blockIdx.z selects the direction, so the alpha and beta frames of one step share a launch (they are
+// independent chains): twice the workgroups in flight, half the launches.
+template <typename R>
+__global__ void __launch_bounds__(256) fwd_step_kernel(Problem P, StepBuf<R> Sa, StepBuf<R> Sb, int n, int dir_base) {
+    if ((int) blockIdx.z + dir_base == 0) fwd_step_body<R, false>(P, Sa, n);
+    else fwd_step_body<R, true>(P, Sb, n);
 }
 
 // scores: grid = B, block = 256.  alpha: A + LSE_i(ah[len-1]);  beta: C_0 + LSE_i(q_0), q_0 = I2[0]-emax[0]+bh[0]
@@ -702,6 +731,7 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
         hipLaunchKernelGGL((emax_kernel<R>), dim3(P.T, P.B), dim3(256), 0, stream, P, emax);
         // the p vectors are npad wide: their pad columns must be (and stay) zero
         hipMemsetAsync(wk, 0, 2 * (au(2 * (size_t) P.B * W.npad * e) + au(3 * (size_t) P.B * 4) + au((size_t) P.B * 8)), stream);
+        StepBuf<R> Sd[2];
         for (int dir = 0; dir < 2; ++dir) {
             StepBuf<R> S{};
             S.pbuf = (R *) wk; wk += au(2 * (size_t) P.B * W.npad * e);
@@ -710,25 +740,22 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
             S.emax = emax;
             S.npad = W.npad;
             const bool beta = dir == 1;
-            if (!(full_mask & (beta ? kFullBeta : kFullAlpha))) continue;
             S.state = (R *) (beta ? W.bh : W.ah);
             S.ehat = (const R *) (beta ? W.fhat : W.ehat);
             S.hmax = (const R *) (beta ? W.cmax : W.rmax);
-            dim3 sgrid((P.N + 63) / 64, (P.B + 15) / 16);
-            if (beta) {
-                hipLaunchKernelGGL((fwd_init_kernel<R, true>), dim3(P.B), dim3(256), 0, stream, P, S);
-                for (int n = 0; n + 1 < P.T; ++n)
-                    hipLaunchKernelGGL((fwd_step_kernel<R, true>), sgrid, dim3(256), 0, stream, P, S, n);
-                hipLaunchKernelGGL((fwd_score_kernel<R, true>), dim3(P.B), dim3(256), 0, stream, P, S, (R *) O.full_scores);
-            } else {
-                hipLaunchKernelGGL((fwd_init_kernel<R, false>), dim3(P.B), dim3(256), 0, stream, P, S);
-                for (int n = 0; n + 1 < P.T; ++n)
-                    hipLaunchKernelGGL((fwd_step_kernel<R, false>), sgrid, dim3(256), 0, stream, P, S, n);
-                if (O.full_scores_alpha)
-                    hipLaunchKernelGGL((fwd_score_kernel<R, false>), dim3(P.B), dim3(256), 0, stream, P, S,
-                                       (R *) O.full_scores_alpha);
-            }
+            Sd[dir] = S;
         }
+        const bool do_a = full_mask & kFullAlpha, do_b = full_mask & kFullBeta;
+        if (do_a) hipLaunchKernelGGL((fwd_init_kernel<R, false>), dim3(P.B), dim3(256), 0, stream, P, Sd[0]);
+        if (do_b) hipLaunchKernelGGL((fwd_init_kernel<R, true>), dim3(P.B), dim3(256), 0, stream, P, Sd[1]);
+        dim3 sgrid((P.N + 63) / 64, (P.B + 31) / 32, (do_a && do_b) ? 2 : 1);
+        for (int n = 0; n + 1 < P.T; ++n)
+            hipLaunchKernelGGL((fwd_step_kernel<R>), sgrid, dim3(256), 0, stream, P, Sd[0], Sd[1], n, do_a ? 0 : 1);
+        if (do_b)
+            hipLaunchKernelGGL((fwd_score_kernel<R, true>), dim3(P.B), dim3(256), 0, stream, P, Sd[1], (R *) O.full_scores);
+        if (do_a && O.full_scores_alpha)
+            hipLaunchKernelGGL((fwd_score_kernel<R, false>), dim3(P.B), dim3(256), 0, stream, P, Sd[0],
+                               (R *) O.full_scores_alpha);
     }
     (void) store;
     return hipGetLastError();
