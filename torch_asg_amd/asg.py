@@ -20,11 +20,33 @@ import torch.nn as nn
 from . import _lib
 
 
+class _NullGuard:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+_NULL_GUARD = _NullGuard()
+
+
 class HipBackend:
     """Thin tensor <-> C-ABI adapter.  Every method launches HIP kernels on the current stream."""
 
     def __init__(self):
         self._ctx = {}
+        self._sizes = {}
+
+    def _bytes(self, p):
+        """(state_bytes, scratch_bytes) of a problem shape, cached per (dtype, T, B, N, S)."""
+        key = (p.dtype, p.T, p.B, p.N, p.S)
+        v = self._sizes.get(key)
+        if v is None:
+            L = _lib.lib()
+            v = (L.asg_state_bytes(ctypes.byref(p)), L.asg_scratch_bytes(ctypes.byref(p)))
+            self._sizes[key] = v
+        return v
 
     # -- helpers ---------------------------------------------------------------------------
     @staticmethod
@@ -57,7 +79,8 @@ class HipBackend:
         p.transition_strides[:] = list(transition.stride())
         keep = [inputs, transition]
         if targets is not None:
-            targets = targets.to(dev, non_blocking=True)
+            if targets.device != dev:
+                targets = targets.to(dev, non_blocking=True)
             p.targets = targets.data_ptr()
             p.targets_strides[:] = list(targets.stride())
             p.S = targets.shape[1]
@@ -67,7 +90,10 @@ class HipBackend:
             p.S = 1
         for name, t in (("input_lengths", input_lengths), ("target_lengths", target_lengths)):
             if t is not None:
-                t = t.to(dev, non_blocking=True).contiguous()
+                if t.device != dev:
+                    t = t.to(dev, non_blocking=True)
+                if not t.is_contiguous():
+                    t = t.contiguous()
                 if t.shape != (B,):
                     raise RuntimeError("torch_asg_amd: %s must have shape [%d]" % (name, B))
                 keep.append(t)
@@ -89,6 +115,14 @@ class HipBackend:
         return h
 
     @staticmethod
+    def _guard(device):
+        """Device guard that costs nothing when the tensor's device is already current."""
+        idx = device.index
+        if idx is None or idx == torch.cuda.current_device():
+            return _NULL_GUARD
+        return torch.cuda.device(idx)
+
+    @staticmethod
     def _stream(device):
         return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
@@ -100,9 +134,9 @@ class HipBackend:
     def full_forward(self, inputs, transition, input_lengths, flags=0):
         self._check(inputs, transition, None, input_lengths, None)
         L = _lib.lib()
-        with torch.cuda.device(inputs.device):
+        with self._guard(inputs.device):
             p, keep = self._problem(inputs, transition, None, input_lengths, None)
-            state = self._buf(L.asg_state_bytes(ctypes.byref(p)), inputs.device)
+            state = self._buf(self._bytes(p)[0], inputs.device)
             scores = torch.empty(inputs.shape[1], dtype=inputs.dtype, device=inputs.device)
             _lib.check(L.asg_full_forward(ctypes.byref(p), state.data_ptr(), state.numel(), scores.data_ptr(),
                                           flags, self._stream(inputs.device)), "asg_full_forward")
@@ -111,10 +145,10 @@ class HipBackend:
     def full_backward(self, state, grad_out, inputs, transition, input_lengths):
         L = _lib.lib()
         T, B, N = inputs.shape
-        with torch.cuda.device(inputs.device):
+        with self._guard(inputs.device):
             p, keep = self._problem(inputs, transition, None, input_lengths, None)
             g = grad_out.to(inputs.dtype).contiguous()
-            scratch = self._buf(L.asg_scratch_bytes(ctypes.byref(p)), inputs.device)
+            scratch = self._buf(self._bytes(p)[1], inputs.device)
             gtr = torch.empty(N, N, dtype=inputs.dtype, device=inputs.device)
             gin = torch.empty(T, B, N, dtype=inputs.dtype, device=inputs.device)
             _lib.check(L.asg_full_backward(ctypes.byref(p), state.data_ptr(), state.numel(), g.data_ptr(),
@@ -125,9 +159,9 @@ class HipBackend:
     def aligned_forward(self, inputs, targets, transition, input_lengths, target_lengths, flags=0):
         self._check(inputs, transition, targets, input_lengths, target_lengths)
         L = _lib.lib()
-        with torch.cuda.device(inputs.device):
+        with self._guard(inputs.device):
             p, keep = self._problem(inputs, transition, targets, input_lengths, target_lengths)
-            state = self._buf(L.asg_state_bytes(ctypes.byref(p)), inputs.device)
+            state = self._buf(self._bytes(p)[0], inputs.device)
             scores = torch.empty(inputs.shape[1], dtype=inputs.dtype, device=inputs.device)
             _lib.check(L.asg_aligned_forward(ctypes.byref(p), state.data_ptr(), state.numel(), scores.data_ptr(),
                                              flags, self._stream(inputs.device)), "asg_aligned_forward")
@@ -136,10 +170,10 @@ class HipBackend:
     def aligned_backward(self, state, grad_out, inputs, targets, transition, input_lengths, target_lengths):
         L = _lib.lib()
         T, B, N = inputs.shape
-        with torch.cuda.device(inputs.device):
+        with self._guard(inputs.device):
             p, keep = self._problem(inputs, transition, targets, input_lengths, target_lengths)
             g = grad_out.to(inputs.dtype).contiguous()
-            scratch = self._buf(L.asg_scratch_bytes(ctypes.byref(p)), inputs.device)
+            scratch = self._buf(self._bytes(p)[1], inputs.device)
             gtr = torch.empty(N, N, dtype=inputs.dtype, device=inputs.device)
             gin = torch.empty(T, B, N, dtype=inputs.dtype, device=inputs.device)
             _lib.check(L.asg_aligned_backward(ctypes.byref(p), state.data_ptr(), state.numel(), g.data_ptr(),
@@ -153,9 +187,9 @@ class HipBackend:
         L = _lib.lib()
         B = inputs.shape[1]
         k = 2 if flags & _lib.FLAG_ALPHA_SCORES else 1
-        with torch.cuda.device(inputs.device):
+        with self._guard(inputs.device):
             p, keep = self._problem(inputs, transition, targets, input_lengths, target_lengths)
-            state = self._buf(L.asg_state_bytes(ctypes.byref(p)), inputs.device)
+            state = self._buf(self._bytes(p)[0], inputs.device)
             scores = torch.empty(2, k * B, dtype=inputs.dtype, device=inputs.device)
             _lib.check(L.asg_forward(self._context(inputs.device), ctypes.byref(p), state.data_ptr(), state.numel(),
                                      scores[0].data_ptr(), scores[1].data_ptr(), flags,
@@ -166,11 +200,11 @@ class HipBackend:
         self._check(inputs, transition, targets, input_lengths, target_lengths)
         L = _lib.lib()
         T, B, N = inputs.shape
-        with torch.cuda.device(inputs.device):
+        with self._guard(inputs.device):
             p, keep = self._problem(inputs, transition, targets, input_lengths, target_lengths)
             state = None
             if N > 64 or p.S > 64:
-                state = self._buf(L.asg_state_bytes(ctypes.byref(p)), inputs.device)
+                state = self._buf(self._bytes(p)[0], inputs.device)
             scores = torch.empty(2, B, dtype=inputs.dtype, device=inputs.device)
             _lib.check(L.asg_forward_only(self._context(inputs.device), ctypes.byref(p),
                                           state.data_ptr() if state is not None else None,
@@ -183,10 +217,10 @@ class HipBackend:
                  flags=0):
         L = _lib.lib()
         T, B, N = inputs.shape
-        with torch.cuda.device(inputs.device):
+        with self._guard(inputs.device):
             p, keep = self._problem(inputs, transition, targets, input_lengths, target_lengths)
             g = torch.stack([grad_full.to(inputs.dtype), grad_aligned.to(inputs.dtype)]).contiguous()
-            scratch = self._buf(L.asg_scratch_bytes(ctypes.byref(p)), inputs.device)
+            scratch = self._buf(self._bytes(p)[1], inputs.device)
             gtr = torch.empty(N, N, dtype=inputs.dtype, device=inputs.device)
             gin = torch.empty(T, B, N, dtype=inputs.dtype, device=inputs.device)
             _lib.check(L.asg_backward(self._context(inputs.device), ctypes.byref(p), state.data_ptr(), state.numel(),
@@ -205,25 +239,33 @@ class HipBackend:
         L = _lib.lib()
         B = inputs.shape[1]
         red = self._RED[reduction]
-        with torch.cuda.device(inputs.device):
+        with self._guard(inputs.device):
             p, keep = self._problem(inputs, transition, targets, input_lengths, target_lengths)
-            state = self._buf(L.asg_state_bytes(ctypes.byref(p)), inputs.device)
+            state = self._buf(self._bytes(p)[0], inputs.device)
             scores = torch.empty(2, B, dtype=inputs.dtype, device=inputs.device)
             loss = torch.empty((B,) if red == 0 else (), dtype=inputs.dtype, device=inputs.device)
             _lib.check(L.asg_loss_forward(self._context(inputs.device), ctypes.byref(p), state.data_ptr(),
                                           state.numel(), red, loss.data_ptr(), scores.data_ptr(),
                                           flags & ~_lib.FLAG_ALPHA_SCORES, self._stream(inputs.device)),
                        "asg_loss_forward")
+        self._last_problem = (p, keep)        # picked up by ASGLossFunction: same tensors are saved for backward
         return loss, state
 
     def loss_backward(self, state, grad_loss, inputs, targets, transition, input_lengths, target_lengths,
-                      reduction, flags=0):
+                      reduction, flags=0, problem=None):
         L = _lib.lib()
         T, B, N = inputs.shape
-        with torch.cuda.device(inputs.device):
-            p, keep = self._problem(inputs, transition, targets, input_lengths, target_lengths)
-            g = grad_loss.to(inputs.dtype).contiguous()
-            scratch = self._buf(L.asg_scratch_bytes(ctypes.byref(p)), inputs.device)
+        with self._guard(inputs.device):
+            if problem is not None:
+                p, keep = problem             # built in forward from the very tensors autograd saved
+            else:
+                p, keep = self._problem(inputs, transition, targets, input_lengths, target_lengths)
+            g = grad_loss
+            if g.dtype != inputs.dtype:
+                g = g.to(inputs.dtype)
+            if not g.is_contiguous():
+                g = g.contiguous()
+            scratch = self._buf(self._bytes(p)[1], inputs.device)
             gtr = torch.empty(N, N, dtype=inputs.dtype, device=inputs.device)
             gin = torch.empty(T, B, N, dtype=inputs.dtype, device=inputs.device)
             _lib.check(L.asg_loss_backward(self._context(inputs.device), ctypes.byref(p), state.data_ptr(),
@@ -316,17 +358,20 @@ class ASGLossFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, inputs, transition, outputs, input_lengths, output_lengths, reduction, flags):
-        loss, state = native().loss_forward(inputs, outputs, transition, input_lengths, output_lengths, reduction,
-                                            flags)
+        be = native()
+        loss, state = be.loss_forward(inputs, outputs, transition, input_lengths, output_lengths, reduction, flags)
         ctx.save_for_backward(state, inputs, outputs, input_lengths, output_lengths, transition)
         ctx.reduction = reduction
+        ctx.problem = getattr(be, "_last_problem", None)
         return loss
 
     @staticmethod
     def backward(ctx, grad_loss):
         state, inputs, outputs, input_lengths, output_lengths, transition = ctx.saved_tensors
-        grad_transition, grad_inputs = native().loss_backward(state, grad_loss, inputs, outputs, transition,
-                                                              input_lengths, output_lengths, ctx.reduction)
+        be = native()
+        kw = {"problem": ctx.problem} if ctx.problem is not None else {}
+        grad_transition, grad_inputs = be.loss_backward(state, grad_loss, inputs, outputs, transition,
+                                                        input_lengths, output_lengths, ctx.reduction, **kw)
         return grad_inputs, grad_transition, None, None, None, None, None
 
 

@@ -61,6 +61,13 @@ int check_problem(const asg_problem *p, bool need_targets) {
     if (!p->inputs || !p->transition) return ASG_ERR_INVALID;
     if (need_targets && (p->S < 1 || !p->targets)) return ASG_ERR_INVALID;
     if (p->T > (1 << 30) || p->B > (1 << 30) || p->N > (1 << 30) || p->S > (1 << 30)) return ASG_ERR_UNSUPPORTED;
+    if (p->S > 1024) return ASG_ERR_UNSUPPORTED;              // aligned kernels: one thread per target position
+    {
+        // the kernels address state and gradient rows through 32-bit buffer offsets
+        const double e = p->dtype == ASG_DTYPE_F64 ? 8.0 : 4.0;
+        const double w = (double) (p->N > p->S ? p->N : p->S);
+        if ((double) p->T * (double) p->B * w * e >= 4294967296.0 && small_full(p->N)) return ASG_ERR_UNSUPPORTED;
+    }
     return ASG_OK;
 }
 
