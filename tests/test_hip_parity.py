@@ -227,6 +227,28 @@ def test_golden_cfg5_reduced_large_alphabet():
     util.assert_close(r["grad_inputs"].sum(0), g["f64_grad_inputs_sum_t"], 1e-4, "gin sum")
 
 
+@pytest.mark.parametrize("T,B,N,L,il,tl", [(1, 2, 70, 1, [1, 1], [1, 1]), (5, 2, 80, 1, [5, 3], [1, 1]),
+                                             (6, 3, 90, 4, [6, 2, 5], [3, 4, 4]), (4, 2, 12, 70, [4, 4], [70, 3])])
+def test_generic_edge_cases(T, B, N, L, il, tl):
+    # T=1, S=1, infeasible (tl > il -> +inf loss, NaN-free grads), S > T truncation on the wide-target path
+    tr, x, tg, _, _ = util.synth(T, B, N, L, 77)
+    il, tl = np.array(il), np.array(tl)
+    o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il, tl, "none")
+    r = run_hip(x, tg, tr, il, tl, "none")
+    for k in ("loss", "grad_inputs", "grad_transition"):
+        util.assert_close(r[k], o[k], 1e-4, "generic edge %s" % k)
+    assert not np.isnan(r["grad_inputs"]).any() and not np.isnan(r["grad_transition"]).any()
+
+
+def test_unsupported_shapes_fail_loudly():
+    A = _asg()
+    m = A.ASGLoss(5).to(DEV)
+    x = torch.randn(1100, 1, 5, device=DEV)
+    tg = torch.zeros(1, 1025, dtype=torch.long, device=DEV)
+    with pytest.raises(RuntimeError, match="unsupported"):
+        m(x, tg)
+
+
 def test_generic_forward_only_and_determinism():
     A = _asg()
     tr, x, tg, il, tl = util.synth(30, 3, 90, 70, 4, True)
