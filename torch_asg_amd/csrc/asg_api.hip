@@ -13,6 +13,7 @@ using namespace asg;
 struct asg_ctx {
     hipStream_t side;
     hipEvent_t fork, join;
+    unsigned *counter;      // 256 B of device memory owned by the context: arrival ticket of the in-kernel loss reduce
     int device;
 };
 
@@ -103,12 +104,18 @@ State to_state(const asg_problem *p, const void *state) {
 
 template <typename R>
 int run_forward(asg_ctx *ctx, const asg_problem *p, void *state, void *full_scores, void *aligned_scores,
-                int mask, bool store, int flags, hipStream_t stream) {
+                int mask, bool store, int flags, hipStream_t stream, void *loss = nullptr, int reduction = 0) {
     Problem P = to_problem(p);
     State W = to_state(p, state);
     FwdOut O{};
     O.full_scores = full_scores;
     O.aligned_scores = aligned_scores;
+    if (loss && ctx && small_full(p->N) && small_aligned(p->S)) {
+        O.loss = loss;
+        O.counter = ctx->counter;
+        O.reduction = reduction;
+        O.expected = 2 * (int) p->B;
+    }
     if ((flags & ASG_FLAG_ALPHA_SCORES) && store) {
         if (full_scores) O.full_scores_alpha = (R *) full_scores + p->B;
         if (aligned_scores) O.aligned_scores_alpha = (R *) aligned_scores + p->B;
@@ -224,6 +231,8 @@ int asg_ctx_create(asg_ctx **out) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->join, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipMalloc((void **) &c->counter, 256);
+    if (e == hipSuccess) e = hipMemset(c->counter, 0, 256);
     if (e != hipSuccess) { delete c; return hip_status(e); }
     *out = c;
     return ASG_OK;
@@ -234,6 +243,7 @@ int asg_ctx_destroy(asg_ctx *c) {
     hipEventDestroy(c->fork);
     hipEventDestroy(c->join);
     hipStreamDestroy(c->side);
+    hipFree(c->counter);
     delete c;
     return ASG_OK;
 }
@@ -351,13 +361,22 @@ int asg_backward(asg_ctx *ctx, const asg_problem *p, const void *state, size_t s
 int asg_loss_forward(asg_ctx *ctx, const asg_problem *p, void *state, size_t state_bytes, int reduction,
                      void *loss, void *scores, int flags, void *stream) {
     if (reduction < 0 || reduction > 2 || !loss || !scores) return ASG_ERR_INVALID;
-    const size_t e = p && p->dtype == ASG_DTYPE_F64 ? 8 : 4;
-    char *sc = (char *) scores;
-    int rc = asg_forward(ctx, p, state, state_bytes, sc, sc + (size_t) (p ? p->B : 0) * e, flags & ~ASG_FLAG_ALPHA_SCORES, stream);
+    int rc = check_problem(p, true);
     if (rc) return rc;
+    if (!state) return ASG_ERR_INVALID;
+    if (state_bytes < asg_state_bytes(p)) return ASG_ERR_WORKSPACE;
+    const size_t e = p->dtype == ASG_DTYPE_F64 ? 8 : 4;
+    char *sc = (char *) scores;
+    void *full = sc, *ali = sc + (size_t) p->B * e;
+    flags &= ~ASG_FLAG_ALPHA_SCORES;
+    const bool in_kernel = ctx && small_full(p->N) && small_aligned(p->S);
+    rc = ASG_DISPATCH(p,
+        run_forward<float>(ctx, p, state, full, ali, 15, true, flags, (hipStream_t) stream, loss, reduction),
+        run_forward<double>(ctx, p, state, full, ali, 15, true, flags, (hipStream_t) stream, loss, reduction));
+    if (rc || in_kernel) return rc;
     return hip_status(ASG_DISPATCH(p,
-        launch_loss_reduce<float>(sc, sc + (size_t) p->B * e, (int) p->B, reduction, loss, (hipStream_t) stream),
-        launch_loss_reduce<double>(sc, sc + (size_t) p->B * e, (int) p->B, reduction, loss, (hipStream_t) stream)));
+        launch_loss_reduce<float>(full, ali, (int) p->B, reduction, loss, (hipStream_t) stream),
+        launch_loss_reduce<double>(full, ali, (int) p->B, reduction, loss, (hipStream_t) stream)));
 }
 
 int asg_loss_backward(asg_ctx *ctx, const asg_problem *p, const void *state, size_t state_bytes, int reduction,

@@ -43,6 +43,11 @@ struct FwdOut {
     void *aligned_scores;        // [B]  from the beta pass (force_aligned_lattice.cpp:316)
     void *full_scores_alpha;     // [B] or nullptr: same score from the alpha pass (cross-check)
     void *aligned_scores_alpha;  // [B] or nullptr
+    // optional in-kernel loss reduction (small path): the LAST of the `expected` beta passes to finish reduces
+    // loss[b] = full[b] - aligned[b] (reduction: 0 none, 1 sum, 2 mean) -- no separate reduce launch
+    void *loss;
+    unsigned *counter;           // persistent, zero between calls (self-resetting)
+    int reduction, expected;
 };
 
 struct BwdArgs {

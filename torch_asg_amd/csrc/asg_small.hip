@@ -120,6 +120,41 @@ template <typename R> __device__ __forceinline__ R score_out(double s2) {
     return (s2 < -1e29) ? Num<R>::ninf() : (R) (s2 * kLn2);
 }
 
+// Publish one pass's score; when the in-kernel loss reduction is on, the last of O.expected arriving passes
+// reduces loss = full - aligned over the batch.  Hand-off without fences (MI355X guide, G16 "sc1 both sides"):
+// scores are written with agent-scope (write-through) stores, drained with vmcnt(0), then a relaxed agent-scope
+// ticket is drawn; the last arriver reads every score with agent-scope loads.  Placement-independent.
+template <typename R>
+__device__ __forceinline__ void publish_score(const FwdOut &O, R *slot, int b, int B, R score, int lane) {
+    if (!O.loss) {
+        if (lane == 0) slot[b] = score;
+        return;
+    }
+    unsigned ticket = 0;
+    if (lane == 0) {
+        __hip_atomic_store(slot + b, score, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ticket = __hip_atomic_fetch_add(O.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    ticket = __builtin_amdgcn_readfirstlane(ticket);
+    if (ticket != (unsigned) (O.expected - 1)) return;
+    const R *full = (const R *) O.full_scores, *ali = (const R *) O.aligned_scores;
+    R *loss = (R *) O.loss;
+    double s = 0;
+    for (int q = lane; q < B; q += 64) {
+        R f = __hip_atomic_load(full + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        R a = __hip_atomic_load(ali + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        R l = f - a;
+        if (O.reduction == 0) loss[q] = l;
+        s += (double) l;
+    }
+    if (O.reduction != 0) {
+        s = wave_allsum(s);                      // fixed butterfly order: deterministic
+        if (lane == 0) loss[0] = (R) (O.reduction == 2 ? s / B : s);
+    }
+    if (lane == 0) __hip_atomic_store(O.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ------------------------------------------------------------------ full lattice, alpha
 // State per lane i: ah = alpha_t[i] in log2 units relative to the running offset C (double).
 // Every kRenorm-th step the frame max is folded into C so that p = exp2(ah) stays in range; in between
@@ -346,7 +381,7 @@ __device__ void full_beta_chain(const Problem &P, const State &W, const FwdOut &
     const unsigned voff = act ? (unsigned) lane * sizeof(R) : kOobOffset;
 
     if (len < 1) {
-        if (lane == 0) ((R *) O.full_scores)[b] = NINF;
+        publish_score<R>(O, (R *) O.full_scores, b, P.B, NINF, lane);
         return;
     }
     double C = 0.0;
@@ -402,7 +437,7 @@ __device__ void full_beta_chain(const Problem &P, const State &W, const FwdOut &
     R y = fma(last_raw, L2E, bh);
     R my = fmax(wave_allmax(y), Num<R>::logzero());
     R sm = wave_allsum(Num<R>::exp2(y - my));
-    if (lane == 0) ((R *) O.full_scores)[b] = score_out<R>(C + (double) my + (double) Num<R>::log2(sm));
+    publish_score<R>(O, (R *) O.full_scores, b, P.B, score_out<R>(C + (double) my + (double) Num<R>::log2(sm)), lane);
 }
 
 // ------------------------------------------------------------------ aligned lattice
@@ -542,7 +577,7 @@ __device__ void aligned_beta_chain(const Problem &P, const State &W, const FwdOu
     __amdgpu_buffer_rsrc_t rs = make_rsrc((R *) W.bb + (int64_t) b * T * S, STORE ? (unsigned) T * row_bytes : 0u);
     const unsigned voff = lane < S ? (unsigned) lane * sizeof(R) : kOobOffset;
     if (len < 1 || A.ol < 1) {
-        if (lane == 0) ((R *) O.aligned_scores)[b] = NINF;
+        publish_score<R>(O, (R *) O.aligned_scores, b, P.B, NINF, lane);
         return;
     }
     double C = 0.0;
@@ -573,7 +608,7 @@ __device__ void aligned_beta_chain(const Problem &P, const State &W, const FwdOu
     // S_aligned = beta_0[0] + I~_0[0]   (force_aligned_lattice.cpp:316)
     R y = fma(last_raw, L2E, A.ebias) + bb;
     R y0 = readlane(y, 0);
-    if (lane == 0) ((R *) O.aligned_scores)[b] = score_out<R>(C + (double) y0);
+    publish_score<R>(O, (R *) O.aligned_scores, b, P.B, score_out<R>(C + (double) y0), lane);
 }
 
 // ------------------------------------------------------------------ forward kernel
