@@ -135,13 +135,14 @@ __global__ void __launch_bounds__(256) fwd_init_kernel(Problem P, StepBuf<R> S) 
 // step n: alpha consumes q_{t-1} (t = n+1) and writes ah[t]; beta consumes q_t (t = len-1-n) and writes bh[t-1].
 template <typename R, bool BETA>
 __device__ __forceinline__ void fwd_step_body(const Problem &P, const StepBuf<R> &S, int n) {
-    constexpr int KT = 32, NU = 8;
+    constexpr int KT = 32, NU = 4;
     __shared__ __attribute__((aligned(16))) R Es[KT][64 + 4];
     __shared__ __attribute__((aligned(16))) R Ps[KT][32];
     const int N = P.N, T = P.T, B = P.B, npad = S.npad;
-    const int r = threadIdx.x & 63, ug = threadIdx.x >> 6;
+    // thread (rp = tid & 31, ug = tid >> 5) owns rows i0+2rp, i0+2rp+1 and utterances b0+4ug .. +3:
+    // per k one ds_read_b64 (two rows) + one ds_read_b128 (four utterances) feed 8 FMAs
+    const int rp = threadIdx.x & 31, ug = threadIdx.x >> 5;
     const int i0 = blockIdx.x * 64, b0 = blockIdx.y * 32;
-    const int i = i0 + r;
     const R *pcur = S.pbuf + (int64_t) (n & 1) * B * npad;
     R *pnext = S.pbuf + (int64_t) ((n + 1) & 1) * B * npad;
 
@@ -157,45 +158,65 @@ __device__ __forceinline__ void fwd_step_body(const Problem &P, const StepBuf<R>
         int bb = b0 + pu, jj = k0 + 4 * pc;
         return (bb < B && jj < npad) ? *reinterpret_cast<const V4<R> *>(pcur + (int64_t) bb * npad + jj) : zero4;
     };
-    V4<R> e_a = ldE(0, er0), e_b = ldE(0, er0 + 32), p_a = ldP(0);
-
-    R acc[NU];
+    struct Stage { V4<R> ea, eb, pa; };
+    auto fetch = [&](int k0) -> Stage {
+        Stage st;
+        st.ea = ldE(k0, er0); st.eb = ldE(k0, er0 + 32); st.pa = ldP(k0);
+        return st;
+    };
+    R acc0[NU], acc1[NU];
 #pragma unroll
-    for (int u = 0; u < NU; ++u) acc[u] = 0;
-    for (int k0 = 0; k0 < npad; k0 += KT) {
+    for (int u = 0; u < NU; ++u) { acc0[u] = 0; acc1[u] = 0; }
+    auto consume = [&](const Stage &st) {
         __syncthreads();
-        Es[4 * ec + 0][er0] = e_a.x; Es[4 * ec + 1][er0] = e_a.y; Es[4 * ec + 2][er0] = e_a.z; Es[4 * ec + 3][er0] = e_a.w;
-        Es[4 * ec + 0][er0 + 32] = e_b.x; Es[4 * ec + 1][er0 + 32] = e_b.y; Es[4 * ec + 2][er0 + 32] = e_b.z; Es[4 * ec + 3][er0 + 32] = e_b.w;
-        Ps[4 * pc + 0][pu] = p_a.x; Ps[4 * pc + 1][pu] = p_a.y; Ps[4 * pc + 2][pu] = p_a.z; Ps[4 * pc + 3][pu] = p_a.w;
+        Es[4 * ec + 0][er0] = st.ea.x; Es[4 * ec + 1][er0] = st.ea.y; Es[4 * ec + 2][er0] = st.ea.z; Es[4 * ec + 3][er0] = st.ea.w;
+        Es[4 * ec + 0][er0 + 32] = st.eb.x; Es[4 * ec + 1][er0 + 32] = st.eb.y; Es[4 * ec + 2][er0 + 32] = st.eb.z; Es[4 * ec + 3][er0 + 32] = st.eb.w;
+        Ps[4 * pc + 0][pu] = st.pa.x; Ps[4 * pc + 1][pu] = st.pa.y; Ps[4 * pc + 2][pu] = st.pa.z; Ps[4 * pc + 3][pu] = st.pa.w;
         __syncthreads();
-        if (k0 + KT < npad) { e_a = ldE(k0 + KT, er0); e_b = ldE(k0 + KT, er0 + 32); p_a = ldP(k0 + KT); }
+    };
+    auto compute = [&]() {
 #pragma unroll 8
         for (int kk = 0; kk < KT; ++kk) {
-            const R ev = Es[kk][r];
-            const V4<R> q0 = *reinterpret_cast<const V4<R> *>(&Ps[kk][NU * ug]);
-            const V4<R> q1 = *reinterpret_cast<const V4<R> *>(&Ps[kk][NU * ug + 4]);
-            acc[0] = fma(ev, q0.x, acc[0]); acc[1] = fma(ev, q0.y, acc[1]);
-            acc[2] = fma(ev, q0.z, acc[2]); acc[3] = fma(ev, q0.w, acc[3]);
-            acc[4] = fma(ev, q1.x, acc[4]); acc[5] = fma(ev, q1.y, acc[5]);
-            acc[6] = fma(ev, q1.z, acc[6]); acc[7] = fma(ev, q1.w, acc[7]);
+            const V2<R> ev = *reinterpret_cast<const V2<R> *>(&Es[kk][2 * rp]);
+            const V4<R> q = *reinterpret_cast<const V4<R> *>(&Ps[kk][NU * ug]);
+            acc0[0] = fma(ev.x, q.x, acc0[0]); acc0[1] = fma(ev.x, q.y, acc0[1]);
+            acc0[2] = fma(ev.x, q.z, acc0[2]); acc0[3] = fma(ev.x, q.w, acc0[3]);
+            acc1[0] = fma(ev.y, q.x, acc1[0]); acc1[1] = fma(ev.y, q.y, acc1[1]);
+            acc1[2] = fma(ev.y, q.z, acc1[2]); acc1[3] = fma(ev.y, q.w, acc1[3]);
+        }
+    };
+    // two tiles in flight ahead of the one being consumed
+    Stage sa = fetch(0), sb = fetch(KT);
+    for (int k0 = 0; k0 < npad; k0 += 2 * KT) {
+        consume(sa);
+        sa = fetch(k0 + 2 * KT);
+        compute();
+        if (k0 + KT < npad) {
+            consume(sb);
+            sb = fetch(k0 + 3 * KT);
+            compute();
         }
     }
     // ---- epilogue
     const R L2E = Num<R>::log2e(), LZ = Num<R>::logzero();
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
-        const int b = b0 + NU * ug + u;            // wave-uniform: all 64 lanes of a wave share ug
-        if (b >= B) continue;
-        const int len = P.in_len ? gclampi(P.in_len[b], 0, T) : T;
+        const int b = b0 + NU * ug + u;            // uniform per half-wave (lanes 0-31 / 32-63 differ in ug)
+        const bool bvalid = b < B;
+        const int bc = bvalid ? b : 0;
+        const int len = P.in_len ? gclampi(P.in_len[bc], 0, T) : T;
         const int t = BETA ? len - 1 - n : n + 1;          // frame whose q is consumed (beta) / produced (alpha)
-        const bool active = BETA ? (t >= 1) : (t < len);
-        if (!active) continue;                             // wave-uniform
-        const R muprev = fmax((R) funkey(S.mu[(n % 3) * B + b]), LZ);
-        const int tw = BETA ? t - 1 : t;                   // frame written
-        const R emw = S.emax[(int64_t) tw * B + b];
+        const bool active = bvalid && (BETA ? (t >= 1) : (t < len));
+        const R muprev = fmax((R) funkey(S.mu[(n % 3) * B + bc]), LZ);
+        const int tw = active ? (BETA ? t - 1 : t) : 0;    // frame written
+        const R emw = S.emax[(int64_t) tw * B + bc];
         float qkey = -__builtin_inff();
-        if (i < N) {
-            R lg = Num<R>::log2(acc[u]);
+#pragma unroll
+        for (int rr2 = 0; rr2 < 2; ++rr2) {
+            const int i = i0 + 2 * rp + rr2;
+            if (!active || i >= N) continue;
+            const R a = rr2 == 0 ? acc0[u] : acc1[u];
+            R lg = Num<R>::log2(a);
             R rr = S.hmax[i] + lg;
             if (!(fabs(lg) < Num<R>::lg_limit())) {
                 // exact rare path: log2-sum-exp2 over j of (Tr2[.][.] + q_j) from the log-domain state
@@ -226,15 +247,21 @@ __device__ __forceinline__ void fwd_step_body(const Problem &P, const StepBuf<R>
             else { stv = emis + rr - muprev; q = stv; }
             S.state[((int64_t) b * T + tw) * N + i] = stv;
             pnext[(int64_t) b * npad + i] = Num<R>::exp2(q);
-            qkey = (float) q;
+            qkey = fmaxf(qkey, (float) q);
+            if (i == 0) {
+                S.off[b] += (double) muprev + (double) emw;
+                S.mu[((n + 2) % 3) * B + b] = fkey(-__builtin_inff());
+            }
         }
-        // one atomic per wavefront and utterance (max is order-independent: deterministic)
-        qkey = wave_allmax(qkey);
-        if (r == 0) atomicMax(&S.mu[((n + 1) % 3) * B + b], fkey(qkey));
-        if (i == 0) {
-            S.off[b] += (double) muprev + (double) emw;
-            S.mu[((n + 2) % 3) * B + b] = fkey(-__builtin_inff());
-        }
+        // one atomic per half-wave and utterance (max is order-independent: deterministic).  The two halves of a
+        // wave hold different utterances, so reduce inside 32-lane halves: four DPP row steps + row_bcast:15.
+        qkey = fmaxf(qkey, dpp_mov<kDppXor1>(qkey, qkey));
+        qkey = fmaxf(qkey, dpp_mov<kDppXor2>(qkey, qkey));
+        qkey = fmaxf(qkey, dpp_mov<kDppHalfMirror>(qkey, qkey));
+        qkey = fmaxf(qkey, dpp_mov<kDppMirror>(qkey, qkey));
+        const float other = __shfl_xor(qkey, 16);
+        qkey = fmaxf(qkey, other);
+        if (active && (rp == 0)) atomicMax(&S.mu[((n + 1) % 3) * B + b], fkey(qkey));
     }
 }
 
