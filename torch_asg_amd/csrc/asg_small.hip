@@ -18,6 +18,7 @@
 // per-frame dynamic range unbounded for tight alignments.
 #include "asg_common.h"
 #include "asg_kernels.h"
+#include <cstdlib>
 
 namespace asg {
 
@@ -976,8 +977,10 @@ hipError_t launch_bwd_small(const Problem &P, const State &W, const BwdArgs &A, 
 }
 
 size_t bwd_scratch_bytes_small(int elem, int T, int B, int N, int S, int *chunk, int *nchunks) {
-    // aim for ~768 workgroups (3 per CU, 12 waves per CU) but at least 16 frames per workgroup
-    int nch = (768 + B - 1) / B;
+    // aim for ~512 workgroups (2 per CU; flat between 512 and 768 on MI355X) but at least 16 frames per workgroup
+    int target = 512;
+    if (const char *ev = getenv("ASG_BWD_WGS")) target = atoi(ev) > 0 ? atoi(ev) : target;   // developer probe
+    int nch = (target + B - 1) / B;
     if (nch < 1) nch = 1;
     int ch = (T + nch - 1) / nch;
     if (ch < 16) ch = 16;
