@@ -16,7 +16,7 @@ from oracle import asg_oracle as orc
 pytestmark = pytest.mark.gpu
 
 DEV = "cuda:0"
-MODES = [dict(launch_mode="streams"), dict(launch_mode="single"), dict(launch_mode="serial"),
+MODES = [dict(launch_mode="single"), dict(launch_mode="streams"), dict(launch_mode="serial"),
          dict(gpu_no_stream_impl=True)]
 
 

@@ -379,14 +379,16 @@ class ASGLoss(nn.Module):
     """Auto Segmentation Criterion loss; constructor and forward signature as asg.py:100-142.
 
     launch_mode (extra, optional): how the fused route issues the four recursions --
-      'streams' (default)  full-lattice and force-aligned passes overlapped on two HIP streams
-      'single'             one kernel launch, blockIdx.y = pass
+      'single' (default)   ONE kernel launch, blockIdx.y = pass: all four recursions are co-resident, which is the
+                           overlap the reference builds from 4 CUDA streams (streamlined_fast_gpu.cpp:121-129);
+                           measured fastest on MI355X
+      'streams'            full-lattice and force-aligned passes on two HIP streams with event fork/join
       'serial'             two launches on the caller's stream
     gpu_no_stream_impl=True selects the reference's "serial" route: separate FAC and FCC Functions.
     """
 
     def __init__(self, num_labels, reduction='mean', forward_only=False, gpu_no_stream_impl=False,
-                 launch_mode='streams'):
+                 launch_mode='single'):
         super().__init__()
         self.num_labels = num_labels
         self.reduction = reduction  # mean, sum, none

@@ -11,11 +11,18 @@
 //
 // Design: the full-lattice step  alpha_t[i] = I_t[i] + LSE_j(Tr[i][j] + alpha_{t-1}[j])
 // is evaluated as a row-normalised exp-domain mat-vec: lane i keeps row i of exp2(Tr2 - rowmax) in
-// registers, the previous frame's p_j = exp2(alpha_hat_j) (max == 1) is broadcast through LDS (or
-// v_readlane), N FMAs, one v_log_f32.  If a row sum falls below 1e-30 the lane recomputes that node with
-// an exact max-shifted log-sum-exp, so the result is a true LSE for any input range.
+// registers, the previous frame's p_j = exp2(alpha_hat_j) is broadcast through LDS (or v_readlane), N FMAs,
+// one v_log_f32; the frame max is folded into a double offset every 4th step.  A sticky per-lane flag records
+// any row sum whose |log2| leaves the safe range (underflow, overflow, zero, NaN); it is tested ONCE per
+// 16-step block, and a flagged block is redone from its entry state with exact max-shifted log-sum-exps, so the
+// result is a true LSE for any input range without a branch on the per-step critical path.
 // The aligned lattice stays in the log domain (2-term LSE per node) because its band structure makes
 // per-frame dynamic range unbounded for tight alignments.
+//
+// Things that mattered on gfx950 (each measured): unconditional clamped loads (a select
+// around a load becomes a branch + vmcnt(0)); all LDS broadcast reads issued before the FMAs (sched_barrier);
+// explicit vmcnt hints so the store queue is never drained at a loop head; DPP-fused reductions in inline asm;
+// raw buffer stores whose bounds check replaces EXEC masking; no out-of-line calls in the hot kernel.
 #include "asg_common.h"
 #include "asg_kernels.h"
 #include <cstdlib>
