@@ -198,6 +198,18 @@ __device__ __forceinline__ void buf_store(double v, __amdgpu_buffer_rsrc_t rs, u
     __builtin_amdgcn_raw_buffer_store_b64(w, rs, voff, soff, 0);
 }
 
+// raw buffer loads: per-lane byte offset in a VGPR, per-frame byte offset in an SGPR (one s_mul / s_add per load
+// instead of a 64-bit address computation per lane)
+template <typename R> __device__ __forceinline__ R buf_load(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff);
+template <> __device__ __forceinline__ float buf_load<float>(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+}
+template <> __device__ __forceinline__ double buf_load<double>(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    u2 w = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+    return __hiloint2double((int) w.y, (int) w.x);
+}
+
 // fixed-point helpers for deterministic LDS scatter-adds (integer adds commute)
 template <typename R> __device__ __forceinline__ unsigned long long to_fix(R x) {
     return (unsigned long long) __double2ll_rn((double) x * Num<R>::kFix);

@@ -175,39 +175,142 @@ __device__ __forceinline__ void publish_score(const FwdOut &O, R *slot, int b, i
 // stores simply overwrite the fast attempt's.
 template <typename R> struct ChainState { R v; double C; };
 
-template <typename R> __device__ __forceinline__ unsigned abs_bits(float x) { return __float_as_uint(x) & 0x7fffffffu; }
-template <typename R> __device__ __forceinline__ unsigned abs_bits(double x) {
-    // order-preserving 32-bit summary of |x|: clamp to float range first
-    float f = (float) fmin(fabs(x), 3.0e38);
-    return (x != x) ? 0x7fc00000u : __float_as_uint(f);
+// Order-preserving 32-bit summary of a non-negative row sum (NaN and negative values sort above every finite one),
+// the window [2^-lg_limit, 2^lg_limit] in the same encoding, and the binary exponent used for rescaling.
+template <typename R> struct Rng;
+template <> struct Rng<float> {
+    static __device__ __forceinline__ unsigned bits(float s) { return __float_as_uint(s); }
+    static constexpr unsigned lo = (127u - 100u) << 23, hi = (127u + 100u) << 23;
+    static __device__ __forceinline__ int expo(float s) { return __builtin_amdgcn_frexp_expf(s); }
+};
+template <> struct Rng<double> {
+    static __device__ __forceinline__ unsigned bits(double s) { return (unsigned) __double2hiint(s); }
+    static constexpr unsigned lo = (1023u - 900u) << 20, hi = (1023u + 900u) << 20;
+    static __device__ __forceinline__ int expo(double s) { return __builtin_amdgcn_frexp_exp(s); }
+};
+
+// The LDS broadcast of `matvec`, split in two so that independent work can be placed in the LDS latency window:
+// bcast_issue writes the vector and issues every broadcast read; bcast_dot consumes them.
+template <typename R, int NP>
+__device__ __forceinline__ void bcast_issue(R v, R *lds, int lane, V4<R> (&pv)[NP / 4]) {
+    lds[lane] = v;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < NP / 4; ++j) pv[j] = *reinterpret_cast<const V4<R> *>(lds + 4 * j);
+}
+// A lone wavefront issues one instruction per 4 cycles whatever its kind, so an s_waitcnt per read costs as much as
+// a v_pk_fma.  The reads are therefore awaited in groups of kWaitGroup (fp32: one ds_read_b128 per V4); the waits
+// are explicit because s_waitcnt wants an immediate (hence the compile-time recursion).
+#ifndef ASG_WAIT_GROUP
+#define ASG_WAIT_GROUP 3
+#endif
+constexpr int kWaitGroup = ASG_WAIT_GROUP;
+template <typename R, int NP, int J>
+__device__ __forceinline__ void bcast_dot_step(const V2<R> (&e2)[NP / 2], const V4<R> (&pv)[NP / 4], V2<R> &a0, V2<R> &a1) {
+    constexpr int NR = NP / 4;
+    if constexpr (J < NR) {
+        if constexpr (sizeof(R) == 4 && J % kWaitGroup == 0) {
+            constexpr int last = (J + kWaitGroup - 1 < NR - 1) ? J + kWaitGroup - 1 : NR - 1;
+            __builtin_amdgcn_sched_barrier(0);      // keep the FMAs of later groups behind their wait
+            __builtin_amdgcn_s_waitcnt(0xC07F | ((NR - 1 - last) << 8));      // lgkmcnt only
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        a0 = fma2<R>(e2[2 * J], pv[J].xy, a0);
+        a1 = fma2<R>(e2[2 * J + 1], pv[J].zw, a1);
+        bcast_dot_step<R, NP, J + 1>(e2, pv, a0, a1);
+    }
+}
+template <typename R, int NP>
+__device__ __forceinline__ R bcast_dot(const V2<R> (&e2)[NP / 2], const V4<R> (&pv)[NP / 4]) {
+    V2<R> a0 = {0, 0}, a1 = {0, 0};
+    bcast_dot_step<R, NP, 0>(e2, pv, a0, a1);
+    __builtin_amdgcn_wave_barrier();
+    V2<R> a = a0 + a1;
+    return a.x + a.y;
+}
+
+// Binary exponent of the L1 norm of the vector that went into the last mat-vec.  For N < 64 lane N carries a row
+// of ones, so its row sum IS that norm (one v_frexp + one v_readlane); a full 64-label alphabet pays a reduction.
+template <typename R, int NP>
+__device__ __forceinline__ int scale_exponent(R s_prev, R vec, int N) {
+    if (NP == 64 && N == 64) return Rng<R>::expo(wave_allsum(vec));
+    return __builtin_amdgcn_readlane(Rng<R>::expo(s_prev), N);
 }
 
 template <typename R, int NP, int MV, bool STORE, bool GUARD>
 __device__ __forceinline__ bool full_alpha_block(const R (&cur)[kPF], int nsteps, unsigned soff0, unsigned row_bytes,
-                                                 const V2<R> (&e2)[NP / 2], R RiX, unsigned long long actmask,
+                                                 const V2<R> (&e2)[NP / 2], R RiX, unsigned long long actmask, int N,
                                                  R *lds, int lane, __amdgpu_buffer_rsrc_t rs, unsigned voff,
-                                                 R &ah, double &C) {
+                                                 R &p, R &ah, double &C
+#ifdef ASG_PROBE
+                                                 , long long (&prb)[4]
+#endif
+                                                 ) {
     const R L2E = Num<R>::log2e();
-    unsigned worst = 0;                                  // max over the block of bits(|log2 s|)
+#ifdef ASG_PROBE
+    const long long pc0 = clock64();
+#endif
+    // common scale of the block's emission factors: max over its frames and labels of I2 + rowmax
+    R zl = cur[0];
+#pragma unroll
+    for (int k = 1; k < kPF; ++k)
+        if (!GUARD || k < nsteps) zl = fmax(zl, cur[k]);
+    const R zb = fmax(wave_allmax(fma(zl, L2E, RiX)), Num<R>::logzero());
+    const R RiXz = RiX - zb;                             // -inf on lanes >= N
+    R arg = fma(cur[0], L2E, RiXz), ee = Num<R>::exp2(arg);
+#ifdef ASG_PROBE
+    const long long pc1 = clock64();
+#endif
+    R s_prev = 1, arg_prev = 0;
+    unsigned wlo = 0xffffffffu, whi = 0;
+    int csum = 0;
 #pragma unroll
     for (int k = 0; k < kPF; ++k) {
         if (!GUARD || k < nsteps) {
-            R p = Num<R>::exp2(ah);                      // lanes >= N hold -inf -> 0
-            R s = matvec<R, NP, MV>(e2, p, lds, lane);
-            R lg = Num<R>::log2(s);
-            R x = fma(cur[k], L2E, RiX) + lg;            // RiX = -inf on lanes >= N
-            worst = max(worst, abs_bits<R>(lg));
-            if ((k % kRenorm) == kRenorm - 1) {
-                R m = fmax(wave_allmax(x), Num<R>::logzero());
-                ah = x - m;
-                C += (double) m;
-            } else {
-                ah = x;
+            V4<R> pv[NP / 4];
+            if (MV == 0) bcast_issue<R, NP>(p, lds, lane, pv);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- LDS latency window: nothing here depends on the broadcast
+            R arg_n = arg, ee_n = ee;
+            if (k >= 1) {
+                const unsigned sb = Rng<R>::bits(s_prev);
+                wlo = min(wlo, sb);
+                whi = max(whi, sb);
+                if (STORE) buf_store(Num<R>::log2(s_prev) + arg_prev, rs, voff, soff0 + (unsigned) (k - 1) * row_bytes);
             }
-            if (STORE) buf_store(ah, rs, voff, soff0 + (unsigned) k * row_bytes);
+            if (k + 1 < kPF) {
+                arg_n = fma(cur[k + 1], L2E, RiXz);
+                if ((k % kRenorm) == kRenorm - 2 && (!GUARD || k + 1 < nsteps)) {
+                    const int ex = scale_exponent<R, NP>(s_prev, p, N);
+                    arg_n -= (R) ex;
+                    csum += ex;
+                }
+                ee_n = Num<R>::exp2(arg_n);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- critical path: mat-vec, one multiply
+            const R s = (MV == 0) ? bcast_dot<R, NP>(e2, pv) : matvec<R, NP, 1>(e2, p, lds, lane);
+            p = s * ee;
+            s_prev = s;
+            arg_prev = arg;
+            arg = arg_n;
+            ee = ee_n;
         }
     }
-    return (__ballot(worst >= __float_as_uint((float) Num<R>::lg_limit())) & actmask) != 0;
+#ifdef ASG_PROBE
+    const long long pc2 = clock64();
+    prb[0] += pc1 - pc0;
+    prb[1] += pc2 - pc1;
+#endif
+    {
+        const unsigned sb = Rng<R>::bits(s_prev);
+        wlo = min(wlo, sb);
+        whi = max(whi, sb);
+        ah = Num<R>::log2(s_prev) + arg_prev;
+        if (STORE) buf_store(ah, rs, voff, soff0 + (unsigned) ((GUARD ? nsteps : kPF) - 1) * row_bytes);
+    }
+    C += (double) zb * (double) (GUARD ? nsteps : kPF) + (double) csum;
+    return (__ballot(wlo < Rng<R>::lo || whi > Rng<R>::hi) & actmask) != 0;
 }
 
 // Exact (slow, rare) recursion for `nsteps` frames starting at frame t_first: alpha or beta direction.
@@ -267,8 +370,17 @@ __device__ void full_alpha_chain(const Problem &P, const State &W, const FwdOut 
         for (int j = 0; j < NP / 2; ++j) erow[j] = e2[j];
         ((R *) W.rmax)[lane] = Ri;
     }
+    if (lane == N) {                 // N < 64: lane N sums the broadcast vector (see scale_exponent)
+#pragma unroll
+        for (int j = 0; j < NP / 2; ++j) e2[j] = V2<R>{1, 1};
+    }
 
     const R *in = (const R *) P.inputs + (int64_t) b * P.is1 + (int64_t) lc * P.is2;
+    // emission frames through buffer loads: lane offset in a VGPR, frame offset in an SGPR (launch_fwd_small checks
+    // that both fit 32 bits); indices are clamped, so the resource needs no bound
+    __amdgpu_buffer_rsrc_t rin = make_rsrc((R *) P.inputs + (int64_t) b * P.is1, 0xffffffffu);
+    const unsigned vin = (unsigned) (lc * (int) P.is2) * (unsigned) sizeof(R);
+    const unsigned fstride = (unsigned) P.is0 * (unsigned) sizeof(R);
     const unsigned row_bytes = (unsigned) N * sizeof(R);
     __amdgpu_buffer_rsrc_t rs = make_rsrc((R *) W.ah + (int64_t) b * T * N, STORE ? (unsigned) T * row_bytes : 0u);
     const unsigned voff = act ? (unsigned) lane * sizeof(R) : kOobOffset;
@@ -288,20 +400,29 @@ __device__ void full_alpha_chain(const Problem &P, const State &W, const FwdOut 
         const int nst = len - 1;
         R cur[kPF], nxt[kPF];
 #pragma unroll
-        for (int k = 0; k < kPF; ++k) cur[k] = in[(int64_t) min(1 + k, len - 1) * P.is0];
+        for (int k = 0; k < kPF; ++k) cur[k] = buf_load<R>(rin, vin, (unsigned) min(1 + k, len - 1) * fstride);
         // enter the block loop with no load in flight, so the loop-head wait state is the steady-state one
         // (otherwise hipcc sizes the head-of-loop vmcnt for this first entry and drains the store queue every block)
         __builtin_amdgcn_s_waitcnt(0x0F70);
         int done = 0;
+        R p = Num<R>::exp2(ah);          // exp-domain state carried between blocks; `ah` is its exact log2 twin
+#ifdef ASG_PROBE
+        long long prb[4] = {0, 0, 0, 0};
+        const long long pl0 = clock64();
+#define ASG_PRB , prb
+#else
+#define ASG_PRB
+#endif
         for (; done + kPF <= nst; done += kPF) {
 #pragma unroll
-            for (int k = 0; k < kPF; ++k) nxt[k] = in[(int64_t) min(1 + done + kPF + k, len - 1) * P.is0];
+            for (int k = 0; k < kPF; ++k)
+                nxt[k] = buf_load<R>(rin, vin, (unsigned) min(1 + done + kPF + k, len - 1) * fstride);
             {
                 const R ah0 = ah;
                 const double C0 = C;
                 const bool redo = full_alpha_block<R, NP, MV, STORE, false>(cur, kPF, (unsigned) (1 + done) * row_bytes,
-                                                                            row_bytes, e2, RiX, actmask, lds, lane, rs,
-                                                                            voff, ah, C);
+                                                                            row_bytes, e2, RiX, actmask, N, lds, lane, rs,
+                                                                            voff, p, ah, C ASG_PRB);
                 // consume the prefetched frames BEFORE the (rare) branch: the load-completion wait is then an
                 // exact vmcnt(#stores) here, instead of a conservative drain of the store queue after the merge
                 // The 16 prefetch loads were issued before this block's 16 stores: "at most 16 VMEM ops outstanding"
@@ -315,14 +436,21 @@ __device__ void full_alpha_chain(const Problem &P, const State &W, const FwdOut 
                                                                 (R *) W.ah + (int64_t) b * T * N + lc, N, STORE);
                     ah = r.v;
                     C = r.C;
+                    p = Num<R>::exp2(ah);
                 }
             }
         }
+#ifdef ASG_PROBE
+        if (b == 0 && lane == 0) {
+            long long *d = (long long *) W.dbg;
+            d[0] = 0x1234567890abcdefLL; d[1] = clock64() - pl0; d[2] = prb[0]; d[3] = prb[1]; d[4] = done / kPF;
+        }
+#endif
         if (done < nst) {
             const R ah0 = ah;
             const double C0 = C;
             if (full_alpha_block<R, NP, MV, STORE, true>(cur, nst - done, (unsigned) (1 + done) * row_bytes, row_bytes, e2,
-                                                         RiX, actmask, lds, lane, rs, voff, ah, C)) {
+                                                         RiX, actmask, N, lds, lane, rs, voff, p, ah, C ASG_PRB)) {
                 ChainState<R> r = slow_full_steps<R, false>(in, P.is0, trow, P.ts1, N, lane, 1 + done, nst - done, ah0,
                                                             C0, (R *) W.ah + (int64_t) b * T * N + lc, N, STORE);
                 ah = r.v;
@@ -342,29 +470,59 @@ __device__ void full_alpha_chain(const Problem &P, const State &W, const FwdOut 
 // Iteration n handles frame t = len-1-n: y = I2[t] + bh[t]; it produces bh[t-1] = LSE_j(Tr[j][.] + y_j).
 template <typename R, int NP, int MV, bool STORE, bool GUARD>
 __device__ __forceinline__ bool full_beta_block(const R (&cur)[kPF], int nsteps, unsigned soff0, unsigned row_bytes,
-                                                const V2<R> (&f2)[NP / 2], R CiX, unsigned long long actmask,
+                                                const V2<R> (&f2)[NP / 2], R CiX, unsigned long long actmask, int N,
                                                 R *lds, int lane, __amdgpu_buffer_rsrc_t rs, unsigned voff,
-                                                R &bh, double &C) {
+                                                R &q, R &bh, double &C) {
     const R L2E = Num<R>::log2e();
-    unsigned worst = 0;
+    R zl = cur[0];
+#pragma unroll
+    for (int k = 1; k < kPF; ++k)
+        if (!GUARD || k < nsteps) zl = fmax(zl, cur[k]);
+    const R zb = fmax(wave_allmax(fma(zl, L2E, CiX)), Num<R>::logzero());
+    const R CiXz = CiX - zb;
+    R ee = Num<R>::exp2(fma(cur[0], L2E, CiXz));
+    R s_prev = 1, y = 0;
+    unsigned wlo = 0xffffffffu, whi = 0;
+    int csum = 0;
 #pragma unroll
     for (int k = 0; k < kPF; ++k) {
         if (!GUARD || k < nsteps) {
-            R y = fma(cur[k], L2E, bh);                  // lanes >= N: bh = -inf
-            if ((k % kRenorm) == 0) {
-                R m = fmax(wave_allmax(y), Num<R>::logzero());
-                C += (double) m;
-                y -= m;
+            y = q * ee;
+            V4<R> pv[NP / 4];
+            if (MV == 0) bcast_issue<R, NP>(y, lds, lane, pv);
+            __builtin_amdgcn_sched_barrier(0);
+            R ee_n = ee;
+            if (k >= 1) {
+                const unsigned sb = Rng<R>::bits(s_prev);
+                wlo = min(wlo, sb);
+                whi = max(whi, sb);
+                if (STORE) buf_store(CiX + Num<R>::log2(s_prev), rs, voff, soff0 - (unsigned) (k - 1) * row_bytes);
             }
-            R p = Num<R>::exp2(y);
-            R s = matvec<R, NP, MV>(f2, p, lds, lane);
-            R lg = Num<R>::log2(s);
-            bh = CiX + lg;
-            worst = max(worst, abs_bits<R>(lg));
-            if (STORE) buf_store(bh, rs, voff, soff0 - (unsigned) k * row_bytes);
+            if (k + 1 < kPF) {
+                R arg_n = fma(cur[k + 1], L2E, CiXz);
+                if ((k % kRenorm) == kRenorm - 2 && (!GUARD || k + 1 < nsteps)) {
+                    const int ex = scale_exponent<R, NP>(s_prev, y, N);
+                    arg_n -= (R) ex;
+                    csum += ex;
+                }
+                ee_n = Num<R>::exp2(arg_n);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const R s = (MV == 0) ? bcast_dot<R, NP>(f2, pv) : matvec<R, NP, 1>(f2, y, lds, lane);
+            q = s;
+            s_prev = s;
+            ee = ee_n;
         }
     }
-    return (__ballot(worst >= __float_as_uint((float) Num<R>::lg_limit())) & actmask) != 0;
+    {
+        const unsigned sb = Rng<R>::bits(s_prev);
+        wlo = min(wlo, sb);
+        whi = max(whi, sb);
+        bh = CiX + Num<R>::log2(s_prev);
+        if (STORE) buf_store(bh, rs, voff, soff0 - (unsigned) ((GUARD ? nsteps : kPF) - 1) * row_bytes);
+    }
+    C += (double) zb * (double) (GUARD ? nsteps : kPF) + (double) csum;
+    return (__ballot(wlo < Rng<R>::lo || whi > Rng<R>::hi) & actmask) != 0;
 }
 
 template <typename R, int NP, int MV, bool STORE>
@@ -382,8 +540,15 @@ __device__ void full_beta_chain(const Problem &P, const State &W, const FwdOut &
     R Ci;
     load_norm_row<R, NP>(tcol, P.ts0, N, act, f2, Ci);
     const R CiX = act ? Ci : NINF;
+    if (lane == N) {                 // see full_alpha_chain
+#pragma unroll
+        for (int j = 0; j < NP / 2; ++j) f2[j] = V2<R>{1, 1};
+    }
 
     const R *in = (const R *) P.inputs + (int64_t) b * P.is1 + (int64_t) lc * P.is2;
+    __amdgpu_buffer_rsrc_t rin = make_rsrc((R *) P.inputs + (int64_t) b * P.is1, 0xffffffffu);     // see full_alpha_chain
+    const unsigned vin = (unsigned) (lc * (int) P.is2) * (unsigned) sizeof(R);
+    const unsigned fstride = (unsigned) P.is0 * (unsigned) sizeof(R);
     const unsigned row_bytes = (unsigned) N * sizeof(R);
     __amdgpu_buffer_rsrc_t rs = make_rsrc((R *) W.bh + (int64_t) b * T * N, STORE ? (unsigned) T * row_bytes : 0u);
     const unsigned voff = act ? (unsigned) lane * sizeof(R) : kOobOffset;
@@ -399,18 +564,21 @@ __device__ void full_beta_chain(const Problem &P, const State &W, const FwdOut &
     const int nst = len - 1;
     R cur[kPF], nxt[kPF];
 #pragma unroll
-    for (int k = 0; k < kPF; ++k) cur[k] = in[(int64_t) max(len - 1 - k, 0) * P.is0];
+    for (int k = 0; k < kPF; ++k) cur[k] = buf_load<R>(rin, vin, (unsigned) max(len - 1 - k, 0) * fstride);
     __builtin_amdgcn_s_waitcnt(0x0F70);      // see full_alpha_chain
     int done = 0;
+    // exp-domain state between blocks: beta = Ci + log2 q (relative to C); `bh` is its exact log2 twin
+    R q = act ? Num<R>::exp2(bh - Ci) : R(0);
     for (; done + kPF <= nst; done += kPF) {
 #pragma unroll
-        for (int k = 0; k < kPF; ++k) nxt[k] = in[(int64_t) max(len - 1 - (done + kPF + k), 0) * P.is0];
+        for (int k = 0; k < kPF; ++k)
+            nxt[k] = buf_load<R>(rin, vin, (unsigned) max(len - 1 - (done + kPF + k), 0) * fstride);
         {
             const R bh0 = bh;
             const double C0 = C;
             const bool redo = full_beta_block<R, NP, MV, STORE, false>(cur, kPF, (unsigned) (len - 2 - done) * row_bytes,
-                                                                       row_bytes, f2, CiX, actmask, lds, lane, rs, voff,
-                                                                       bh, C);
+                                                                       row_bytes, f2, CiX, actmask, N, lds, lane, rs, voff,
+                                                                       q, bh, C);
             __builtin_amdgcn_s_waitcnt(STORE ? 0x4F70 : 0x0F70);    // see full_alpha_chain
 #pragma unroll
             for (int k = 0; k < kPF; ++k) cur[k] = nxt[k];
@@ -419,6 +587,7 @@ __device__ void full_beta_chain(const Problem &P, const State &W, const FwdOut &
                                                            (R *) W.bh + (int64_t) b * T * N + lc, N, STORE);
                 bh = r.v;
                 C = r.C;
+                q = act ? Num<R>::exp2(bh - Ci) : R(0);
             }
         }
     }
@@ -428,7 +597,7 @@ __device__ void full_beta_chain(const Problem &P, const State &W, const FwdOut &
             const R bh0 = bh;
             const double C0 = C;
             if (full_beta_block<R, NP, MV, STORE, true>(cur, nst - done, (unsigned) (len - 2 - done) * row_bytes, row_bytes,
-                                                        f2, CiX, actmask, lds, lane, rs, voff, bh, C)) {
+                                                        f2, CiX, actmask, N, lds, lane, rs, voff, q, bh, C)) {
                 ChainState<R> r = slow_full_steps<R, true>(in, P.is0, tcol, P.ts0, N, lane, len - 1 - done, nst - done, bh0,
                                                            C0, (R *) W.bh + (int64_t) b * T * N + lc, N, STORE);
                 bh = r.v;
@@ -966,6 +1135,11 @@ template <typename R>
 hipError_t launch_fwd_small(const Problem &P, const State &W, const FwdOut &O, int chain_mask, bool store,
                             int matvec_variant, hipStream_t stream) {
     if (chain_mask == 0) return hipSuccess;
+    if (chain_mask & (kFullAlpha | kFullBeta)) {
+        // the full-lattice chains address emission frames with 32-bit buffer offsets
+        const double fr = (double) (P.T - 1) * (double) P.is0 * sizeof(R), ln = 63.0 * (double) P.is2 * sizeof(R);
+        if (P.is0 < 0 || P.is2 < 0 || fr >= 4294967296.0 || ln >= 2147483648.0) return hipErrorInvalidValue;
+    }
     if (matvec_variant == 1) return launch_fwd_mv<R, 1>(P, W, O, chain_mask, store, stream);
     return launch_fwd_mv<R, 0>(P, W, O, chain_mask, store, stream);
 }
