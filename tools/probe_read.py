@@ -14,4 +14,6 @@ idx = (v == 0x1234567890abcdef).nonzero().flatten()
 for i in idx.tolist():
     d = v[i:i + 5].tolist()
     nb = d[4]
-    print("loop cycles %d over %d blocks = %.0f/block (%.1f/step); head %.0f/block; steps %.0f/block (%.1f/step)" % (d[1], nb, d[1] / nb, d[1] / nb / 16, d[2] / nb, d[3] / nb, d[3] / nb / 16))
+    h = v[i + 8:i + 11].tolist()
+    print("helper: loop %d cycles, waiting for main %d, refill %d (%.0f/block)" % (h[0], h[1], h[2], h[2] / max(nb, 1)))
+    print("loop cycles %d over %d blocks = %.0f/block (%.1f/step); poll %.0f/block; steps %.0f/block (%.1f/step)" % (d[1], nb, d[1] / nb, d[1] / nb / 16, d[2] / nb, d[3] / nb, d[3] / nb / 16))

@@ -202,7 +202,7 @@ __device__ __forceinline__ void bcast_issue(R v, R *lds, int lane, V4<R> (&pv)[N
 // a v_pk_fma.  The reads are therefore awaited in groups of kWaitGroup (fp32: one ds_read_b128 per V4); the waits
 // are explicit because s_waitcnt wants an immediate (hence the compile-time recursion).
 #ifndef ASG_WAIT_GROUP
-#define ASG_WAIT_GROUP 3
+#define ASG_WAIT_GROUP 5
 #endif
 constexpr int kWaitGroup = ASG_WAIT_GROUP;
 template <typename R, int NP, int J>
@@ -788,6 +788,427 @@ __device__ void aligned_beta_chain(const Problem &P, const State &W, const FwdOu
     publish_score<R>(O, (R *) O.aligned_scores, b, P.B, score_out<R>(C + (double) y0), lane);
 }
 
+// ------------------------------------------------------------------ full lattice, two wavefronts per chain (fp32)
+// A lone wavefront issues one instruction every 4 cycles, whatever its kind: the recursion is bound by its
+// instruction COUNT.  The duo path therefore leaves on the recursion wavefront ("main") only what is on the
+// critical path -- scale, LDS broadcast, N FMAs -- and gives everything else to a second wavefront of the same
+// workgroup ("helper", own SIMD, own issue slots): emission loads, the block scale and its wave reduction, the
+// exp2 of the emission factors, the log2 + store of every frame's state, the range guard and the final score.
+//
+// Both directions run the same loop (X = row max Ri for alpha / column max Ci for beta, f_n = n or len-1-n):
+//   v_n = s_{n-1} * e_n,   e_n = 2^(I2[f_n] + X - zb) [* 2^-ex],   s_n = M v_n,   s_{-1} = 2^-X
+//   alpha: log2 alpha[f_n] = log2 s_{n-1} + arg_n      beta: log2 beta[f_n] = X + log2 s_{n-1}      (up to C)
+//   score = sum(zb) + sum(ex) + log2 sum_i v_{len-1}[i]
+// LDS rings (32 frames): helper -> main  e_n (and arg_n for the helper itself);  main -> helper  s_n.
+// The s ring needs no counter: the helper resets a consumed slot to a NaN sentinel and polls the next one.
+// The helper publishes how many frames of e it has produced; main checks that once per 16-frame block, which by
+// construction also proves that the s slots it is about to overwrite have been consumed.
+// A row sum outside the safe range (or a poll that never completes) makes the helper raise `verdict = 2`:
+// main then redoes the whole chain with the single-wavefront code above, which has the exact fallback.
+constexpr int kRing = 32;
+constexpr unsigned kSentinel = 0x7fc0deadu;
+constexpr int kSpinCap = 1 << 22;
+
+struct DuoLds {
+    __attribute__((aligned(16))) float p[64];
+    float s[kRing][64];
+    float e[kRing][64];
+    float a[kRing][64];
+    int e_prod;        // helper -> main: frames of e produced
+    int verdict;       // helper -> main: 0 running, 1 done, 2 abort (redo with the exact single-wavefront chain)
+    int csum;          // main -> helper: sum of the rescaling exponents
+    int main_done;     // main -> helper
+    int kill;          // main -> helpers: stop (spin cap hit)
+    int c_done;        // consumer -> producer: last frame n whose s_{n-1} has been taken out of the ring
+    int prod_done;     // producer -> consumer: zsum is final
+    double zsum;       // producer -> consumer: sum of the block scales
+    float x[64];       // producer -> consumer: row / column maxima
+};
+
+__device__ __forceinline__ int lds_load_acq(int *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ int lds_load_rlx(int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_store_rel(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_store_rlx(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ float lds_ldf(float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_stf(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// mat-vec consumer with `EXTRA` younger LDS operations in flight behind the broadcast reads
+template <int NP, int EXTRA, int J>
+__device__ __forceinline__ void duo_dot_step(const V2<float> (&e2)[NP / 2], const V4<float> (&pv)[NP / 4], V2<float> &a0,
+                                             V2<float> &a1) {
+    constexpr int NR = NP / 4;
+    if constexpr (J < NR) {
+        if constexpr (J % kWaitGroup == 0) {
+            constexpr int last = (J + kWaitGroup - 1 < NR - 1) ? J + kWaitGroup - 1 : NR - 1;
+            constexpr int cnt = (NR - 1 - last) + (last == NR - 1 ? 0 : EXTRA);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xC07F | ((cnt > 15 ? 15 : cnt) << 8));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        a0 = fma2<float>(e2[2 * J], pv[J].xy, a0);
+        a1 = fma2<float>(e2[2 * J + 1], pv[J].zw, a1);
+        duo_dot_step<NP, EXTRA, J + 1>(e2, pv, a0, a1);
+    }
+}
+
+// 16 steps of the main wavefront: n = n0 .. n0+15 (GUARD: only the first `nsteps`).  Returns nothing: range
+// checking is the helper's job.  s_prev enters as s_{n0-1} and leaves as the last row sums.
+template <int NP, bool GUARD>
+__device__ __forceinline__ void duo_main_block(DuoLds &L, int n0, int nsteps, const V2<float> (&e2)[NP / 2], int N, int lane,
+                                               float e_cur, float &s_prev, int &csum, int need_next, bool &next_ready,
+                                               float &e_next_first) {
+    const int half = (n0 & 16);                    // ring half of this block (n0 is a multiple of 16)
+    int ex = 0;
+    int ep_early = 0;
+    next_ready = false;
+#pragma unroll
+    for (int j = 0; j < kPF; ++j) {
+        if (!GUARD || j < nsteps) {
+            float v = s_prev * e_cur;
+            if ((j % kRenorm) == kRenorm - 1) v = ldexpf(v, -ex);
+            V4<float> pv[NP / 4];
+            bcast_issue<float, NP>(v, L.p, lane, pv);
+            // hand s_{n-1} to the helper (slot (n-1) & 31; nothing to hand over before the first step)
+            if (j > 0) lds_stf(&L.s[(half + j - 1) & (kRing - 1)][lane], s_prev);
+            else if (n0 > 0) lds_stf(&L.s[(half + kRing - 1) & (kRing - 1)][lane], s_prev);
+            float e_nxt = e_cur;
+            if (j + 1 < kPF) e_nxt = lds_ldf(&L.e[half + j + 1][lane]);     // within this block's produced half
+            // look ahead: is the NEXT block's e already there?  Asked at step 12, known at step 14, and then step 15
+            // fetches that block's first e like any other -- the block boundary costs no LDS round trip
+            if (!GUARD && j == kPF - 4) ep_early = lds_load_rlx(&L.e_prod);
+            if (!GUARD && j == kPF - 2) next_ready = __builtin_amdgcn_readfirstlane(ep_early) >= need_next;
+            if (!GUARD && j == kPF - 1) e_next_first = lds_ldf(&L.e[half ^ 16][lane]);
+            __builtin_amdgcn_sched_barrier(0);
+            if ((j % kRenorm) == kRenorm - 2 && (!GUARD || j + 1 < nsteps)) {
+                ex = __builtin_amdgcn_readlane(Rng<float>::expo(s_prev), N);
+                csum += ex;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            V2<float> a0 = {0, 0}, a1 = {0, 0};
+            duo_dot_step<NP, 2, 0>(e2, pv, a0, a1);
+            __builtin_amdgcn_wave_barrier();
+            V2<float> a = a0 + a1;
+            s_prev = a.x + a.y;
+            e_cur = e_nxt;
+        }
+    }
+}
+
+template <int NP, bool STORE, bool BETA>
+__device__ __forceinline__ void duo_main(const Problem &P, const State &W, const FwdOut &O, int b, DuoLds &L) {
+    typedef float R;
+    const int lane = threadIdx.x & 63;
+    const int N = P.N, T = P.T;
+    const int len = __builtin_amdgcn_readfirstlane(P.in_len ? clampi(P.in_len[b], 0, T) : T);
+    const bool act = lane < N;
+    const int lc = act ? lane : 0;
+    const R *tline = (const R *) P.transition + (int64_t) lc * (BETA ? P.ts1 : P.ts0);
+    V2<R> e2[NP / 2];
+    R X;
+    load_norm_row<R, NP>(tline, BETA ? P.ts0 : P.ts1, N, act, e2, X);
+    if (!BETA && STORE && b == 0 && act) {
+        V2<R> *erow = reinterpret_cast<V2<R> *>((R *) W.ehat + (int64_t) lane * W.npad);
+#pragma unroll
+        for (int j = 0; j < NP / 2; ++j) erow[j] = e2[j];
+        ((R *) W.rmax)[lane] = X;
+    }
+    if (lane == N) {
+#pragma unroll
+        for (int j = 0; j < NP / 2; ++j) e2[j] = V2<R>{1, 1};
+    }
+    bool redo = false;
+    if (len >= 2) {
+        const int nst = len - 1;                   // mat-vecs n = 0 .. len-2
+        R s_prev = act ? Num<R>::exp2(-X) : R(0);
+        int csum = 0;
+        bool next_ready = false;
+        R e_next_first = 0;
+#ifdef ASG_PROBE
+        long long pr_poll = 0, pr_blk = 0; const long long pr0 = clock64();
+#endif
+        for (int n0 = 0; n0 < nst && !redo; n0 += kPF) {
+            const int nsteps = min(kPF, nst - n0);
+#ifdef ASG_PROBE
+            const long long pa = clock64();
+#endif
+            // e for frames n0 .. n0+nsteps (one beyond the last step is only needed by the helper itself)
+            const int need = min(n0 + kPF, len);
+            int spins = 0;
+            R e_first = e_next_first;
+            while (!next_ready) {
+                // the counter, the verdict and the block's first e in ONE round trip: LDS executes a wavefront's
+                // reads in order, so an e read issued behind a counter read that says "ready" sees produced data
+                const int ep = lds_load_rlx(&L.e_prod);
+                const int vd = lds_load_rlx(&L.verdict);
+                e_first = lds_ldf(&L.e[n0 & 16][lane]);
+                asm volatile("" ::: "memory");
+                if (vd == 2) { redo = true; break; }
+                if (ep >= need) break;
+                if (++spins > kSpinCap) { lds_store_rlx(&L.kill, 1); redo = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (redo) break;
+#ifdef ASG_PROBE
+            const long long pb = clock64();
+#endif
+            const int need_next = min(n0 + 2 * kPF, len);
+            if (nsteps == kPF)
+                duo_main_block<NP, false>(L, n0, kPF, e2, N, lane, e_first, s_prev, csum, need_next, next_ready, e_next_first);
+            else
+                duo_main_block<NP, true>(L, n0, nsteps, e2, N, lane, e_first, s_prev, csum, need_next, next_ready, e_next_first);
+#ifdef ASG_PROBE
+            const long long pc = clock64();
+            pr_poll += pb - pa; pr_blk += pc - pb;
+#endif
+        }
+#ifdef ASG_PROBE
+        if (!BETA && b == 0 && lane == 0) {
+            long long *d = (long long *) W.dbg;
+            d[0] = 0x1234567890abcdefLL; d[1] = clock64() - pr0; d[2] = pr_poll; d[3] = pr_blk; d[4] = (nst + kPF - 1) / kPF;
+        }
+#endif
+        if (!redo) {
+            lds_stf(&L.s[(nst - 1) & (kRing - 1)][lane], s_prev);
+            lds_store_rlx(&L.csum, csum);
+            lds_store_rel(&L.main_done, 1);
+        }
+    } else {
+        lds_store_rlx(&L.csum, 0);
+        lds_store_rel(&L.main_done, 1);
+    }
+    // wait for the helper's verdict
+    if (!redo) {
+        int spins = 0;
+        while (true) {
+            const int vd = lds_load_acq(&L.verdict);
+            if (vd == 1) break;
+            if (vd == 2) { redo = true; break; }
+            if (++spins > kSpinCap) { lds_store_rlx(&L.kill, 1); redo = true; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+    if (redo) {
+        // the helper has stopped (its stores are drained before it raises the verdict; after a kill it exits at
+        // its next poll); wait for that, then redo the chain with the exact-fallback single-wavefront code
+        int spins = 0;
+        while (lds_load_acq(&L.verdict) != 2 && ++spins < kSpinCap) __builtin_amdgcn_s_sleep(2);
+        if (BETA) full_beta_chain<R, NP, 0, STORE>(P, W, O, b, L.p);
+        else full_alpha_chain<R, NP, 0, STORE>(P, W, O, b, L.p);
+    }
+}
+
+// Producer wavefront: emission loads, block scale, e_n (and arg_n) into the rings.  Only loads on its VMEM queue.
+template <int NP, bool BETA>
+__device__ __forceinline__ void duo_producer(const Problem &P, int b, DuoLds &L) {
+    typedef float R;
+    const int lane = threadIdx.x & 63;
+    const int N = P.N, T = P.T;
+    const int len = __builtin_amdgcn_readfirstlane(P.in_len ? clampi(P.in_len[b], 0, T) : T);
+    const R NINF = Num<R>::ninf(), L2E = Num<R>::log2e(), LZ = Num<R>::logzero();
+    const bool act = lane < N;
+    const int lc = act ? lane : 0;
+    if (len < 1) return;
+    __amdgpu_buffer_rsrc_t rin = make_rsrc((R *) P.inputs + (int64_t) b * P.is1, 0xffffffffu);
+    const unsigned vin = (unsigned) (lc * (int) P.is2) * (unsigned) sizeof(R);
+    const unsigned fstride = (unsigned) P.is0 * (unsigned) sizeof(R);
+    const int nblk = (len + kPF - 1) / kPF;
+    auto frame = [&](int n) { int nn = min(n, len - 1); return BETA ? len - 1 - nn : nn; };
+    R blk0[kPF], nxt[kPF];
+#pragma unroll
+    for (int j = 0; j < kPF; ++j) blk0[j] = buf_load<R>(rin, vin, (unsigned) frame(j) * fstride);
+#pragma unroll
+    for (int j = 0; j < kPF; ++j) nxt[j] = buf_load<R>(rin, vin, (unsigned) frame(kPF + j) * fstride);
+    // X = max over the row (alpha) / column (beta) of the transition matrix, log2 units
+    R X = NINF;
+    {
+        const R *tline = (const R *) P.transition + (int64_t) lc * (BETA ? P.ts1 : P.ts0);
+        const int64_t ts = BETA ? P.ts0 : P.ts1;
+        R raw[NP];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) raw[j] = tline[(int64_t) (j < N ? j : 0) * ts];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) X = fmax(X, (act && j < N) ? raw[j] * L2E : NINF);
+        if (X == NINF) X = 0;
+    }
+    const R XX = act ? X : NINF;
+    L.x[lane] = XX;
+    double zsum = 0.0;
+    auto produce = [&](int K, const R (&em)[kPF]) {          // e (and arg) for frames n = 16K .. 16K+15, n < len
+        const int nv = min(kPF, len - K * kPF);
+        R zl = em[0];
+#pragma unroll
+        for (int j = 1; j < kPF; ++j) zl = (j < nv) ? fmax(zl, em[j]) : zl;
+        const R zb = fmax(wave_allmax(fma(zl, L2E, XX)), LZ);
+        const R Xz = XX - zb;
+        const int half = (K & 1) * kPF;
+#pragma unroll
+        for (int j = 0; j < kPF; ++j) {
+            const R arg = fma(em[j], L2E, Xz);
+            if (!BETA) lds_stf(&L.a[half + j][lane], arg);
+            lds_stf(&L.e[half + j][lane], Num<R>::exp2(arg));
+        }
+        zsum += (double) zb * (double) nv;
+        // one wavefront's LDS operations execute in order: the counter lands after the values, no wait needed
+        asm volatile("" ::: "memory");
+        lds_store_rlx(&L.e_prod, min((K + 1) * kPF, len));
+    };
+    produce(0, blk0);
+    if (nblk > 1) produce(1, nxt);
+    for (int K = 2; K < nblk; ++K) {
+#pragma unroll
+        for (int j = 0; j < kPF; ++j) nxt[j] = buf_load<R>(rin, vin, (unsigned) frame(K * kPF + j) * fstride);
+        // block K reuses the ring half of block K-2: wait until the consumer has seen s_{16(K-1)-1}, i.e. main has
+        // finished block K-2
+        int spins = 0;
+        while (lds_load_rlx(&L.c_done) < (K - 1) * kPF) {
+            if (lds_load_rlx(&L.verdict) == 2 || lds_load_rlx(&L.kill) || ++spins > kSpinCap) return;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        produce(K, nxt);
+    }
+    L.zsum = zsum;
+    asm volatile("" ::: "memory");
+    lds_store_rlx(&L.prod_done, 1);
+}
+
+// Consumer wavefront: range guard, log2 + store of every frame's state, final score.  Only stores on its VMEM queue.
+template <int NP, bool STORE, bool BETA>
+__device__ __forceinline__ void duo_consumer(const Problem &P, const State &W, const FwdOut &O, int b, DuoLds &L) {
+    typedef float R;
+    const int lane = threadIdx.x & 63;
+    const int N = P.N, T = P.T;
+    const int len = __builtin_amdgcn_readfirstlane(P.in_len ? clampi(P.in_len[b], 0, T) : T);
+    const R NINF = Num<R>::ninf();
+    const bool act = lane < N;
+    const unsigned long long actmask = __ballot(act);
+    if (len < 1) {
+        if (BETA) publish_score<R>(O, (R *) O.full_scores, b, P.B, NINF, lane);
+        else if (O.full_scores_alpha && lane == 0) ((R *) O.full_scores_alpha)[b] = NINF;
+        lds_store_rel(&L.verdict, 1);
+        return;
+    }
+    const unsigned row_bytes = (unsigned) N * sizeof(R);
+    __amdgpu_buffer_rsrc_t rs = make_rsrc((R *) (BETA ? W.bh : W.ah) + (int64_t) b * T * N, STORE ? (unsigned) T * row_bytes : 0u);
+    const unsigned voff = act ? (unsigned) lane * sizeof(R) : kOobOffset;
+    auto frame = [&](int n) { return BETA ? len - 1 - n : n; };
+    bool bad = false;
+    // X (and block 0 of the rings) are there once the producer has published its first block
+    {
+        int spins = 0;
+        while (lds_load_acq(&L.e_prod) < 1) {
+            if (++spins > kSpinCap || lds_load_rlx(&L.kill)) { bad = true; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+    const R XX = bad ? NINF : lds_ldf(&L.x[lane]);
+    R sv = act ? Num<R>::exp2(-XX) : R(0);
+    auto wait_slot = [&](int m) {            // until main has written s_m (main writes in order)
+        float *slot = &L.s[m & (kRing - 1)][lane];
+        int spins = 0;
+        while (true) {
+            const R v = lds_ldf(slot);
+            if (__ballot(__float_as_uint(v) != kSentinel) == ~0ull) return true;
+            if (++spins > kSpinCap || lds_load_rlx(&L.kill)) return false;
+            __builtin_amdgcn_s_sleep(1);
+        }
+    };
+    if (STORE && !bad) buf_store((BETA ? XX : lds_ldf(&L.a[0][lane])) + Num<R>::log2(sv), rs, voff, (unsigned) frame(0) * row_bytes);
+    int n = 1;
+    constexpr int GS = 8;                     // frames per poll: amortises the LDS round trips
+    while (n < len && !bad) {
+        // frames n .. n+g-1; a short last group re-processes its last frame in the unused positions (same values,
+        // same addresses), which keeps the code free of predicates
+        const int g = min(GS, len - n);
+        if (!wait_slot(n + g - 2)) { bad = true; break; }
+        R sg[GS], ag[GS];
+#pragma unroll
+        for (int q = 0; q < GS; ++q) {
+            const int m = n + min(q, g - 1);
+            sg[q] = lds_ldf(&L.s[(m - 1) & (kRing - 1)][lane]);
+            ag[q] = BETA ? XX : lds_ldf(&L.a[m & (kRing - 1)][lane]);
+        }
+        unsigned lo = 0xffffffffu, hi = 0;
+#pragma unroll
+        for (int q = 0; q < GS; ++q) {
+            const int m = n + min(q, g - 1);
+            lds_stf(&L.s[(m - 1) & (kRing - 1)][lane], __uint_as_float(kSentinel));
+            const unsigned sb = Rng<R>::bits(sg[q]);
+            lo = min(lo, sb);
+            hi = max(hi, sb);
+        }
+        // the values (incl. arg) are in registers: the producer may now refill (it waits for c_done)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        lds_store_rlx(&L.c_done, n + g - 1);
+        if ((__ballot(lo < Rng<R>::lo || hi > Rng<R>::hi) & actmask) != 0) { bad = true; break; }
+        if (STORE) {
+#pragma unroll
+            for (int q = 0; q < GS; ++q)
+                buf_store(ag[q] + Num<R>::log2(sg[q]), rs, voff, (unsigned) frame(n + min(q, g - 1)) * row_bytes);
+        }
+        sv = sg[GS - 1];
+        n += g;
+    }
+    if (!bad) {
+        int spins = 0;
+        while (!(lds_load_acq(&L.main_done) && lds_load_acq(&L.prod_done))) {
+            if (++spins > kSpinCap || lds_load_rlx(&L.kill)) { bad = true; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    if (bad) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // our stores land before main overwrites them
+        lds_store_rel(&L.verdict, 2);
+        return;
+    }
+    const int csum = lds_load_rlx(&L.csum);
+    const double zsum = L.zsum;
+    const R vlast = sv * lds_ldf(&L.e[(len - 1) & (kRing - 1)][lane]);
+    const R sm = wave_allsum(act ? vlast : R(0));
+    const double sc = zsum + (double) csum + (double) Num<R>::log2(sm);
+    const bool finite_ok = (sm == sm) && sm > R(0) && sm < R(3.0e38f);
+    if (!finite_ok) {                                  // let the exact path decide (all -inf, overflow, NaN)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_store_rel(&L.verdict, 2);
+        return;
+    }
+    lds_store_rlx(&L.verdict, 1);                      // main may leave: nothing to redo
+    if (BETA) publish_score<R>(O, (R *) O.full_scores, b, P.B, score_out<R>(sc), lane);
+    else if (O.full_scores_alpha && lane == 0) ((R *) O.full_scores_alpha)[b] = score_out<R>(sc);
+}
+
+template <int NP, bool STORE>
+__global__ void __launch_bounds__(192, 1) fwd_duo_kernel(Problem P, State W, FwdOut O, int chain_mask) {
+    __shared__ DuoLds L;
+    int which = 0, seen = 0;
+    for (int c = 0; c < 4; ++c) {
+        if (chain_mask & (1 << c)) {
+            if (seen == (int) blockIdx.y) which = 1 << c;
+            ++seen;
+        }
+    }
+    const int b = blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (which == kFullAlpha || which == kFullBeta) {
+        if (threadIdx.x == 0) {
+            L.e_prod = 0; L.verdict = 0; L.csum = 0; L.main_done = 0; L.kill = 0; L.c_done = 0; L.prod_done = 0;
+        }
+        for (int q = threadIdx.x; q < kRing * 64; q += 192) (&L.s[0][0])[q] = __uint_as_float(kSentinel);   // empty s ring
+        __syncthreads();
+        if (which == kFullAlpha) {
+            if (wave == 0) duo_main<NP, STORE, false>(P, W, O, b, L);
+            else if (wave == 1) duo_producer<NP, false>(P, b, L);
+            else duo_consumer<NP, STORE, false>(P, W, O, b, L);
+        } else {
+            if (wave == 0) duo_main<NP, STORE, true>(P, W, O, b, L);
+            else if (wave == 1) duo_producer<NP, true>(P, b, L);
+            else duo_consumer<NP, STORE, true>(P, W, O, b, L);
+        }
+    } else if (wave == 0) {
+        if (which == kAlignedAlpha) aligned_alpha_chain<float, STORE>(P, W, O, b);
+        else if (which == kAlignedBeta) aligned_beta_chain<float, STORE>(P, W, O, b);
+    }
+}
+
 // ------------------------------------------------------------------ forward kernel
 // grid = (B, popcount(chain_mask)), block = 64.  blockIdx.y walks the set bits of chain_mask
 // low to high, so the long full-lattice chains are dispatched first.
@@ -1096,8 +1517,21 @@ __global__ void __launch_bounds__(256) loss_reduce_kernel(const R *full, const R
     if (threadIdx.x == 0) out[0] = (R) (reduction == 2 ? part[0] / B : part[0]);
 }
 
+inline bool duo_enabled() {
+    static const bool on = !(getenv("ASG_NO_DUO") && atoi(getenv("ASG_NO_DUO")) != 0);    // developer A/B switch
+    return on;
+}
+
 template <typename R, int NP, int MV>
 hipError_t launch_fwd_np(const Problem &P, const State &W, const FwdOut &O, int mask, bool store, hipStream_t st) {
+    if constexpr (sizeof(R) == 4 && MV == 0) {
+        if ((mask & (kFullAlpha | kFullBeta)) && P.N < 64 && duo_enabled()) {
+            dim3 grid(P.B, __builtin_popcount(mask)), block(192);
+            if (store) hipLaunchKernelGGL((fwd_duo_kernel<NP, true>), grid, block, 0, st, P, W, O, mask);
+            else hipLaunchKernelGGL((fwd_duo_kernel<NP, false>), grid, block, 0, st, P, W, O, mask);
+            return hipGetLastError();
+        }
+    }
     dim3 grid(P.B, __builtin_popcount(mask)), block(64);
     if (store) hipLaunchKernelGGL((fwd_small_kernel<R, NP, MV, true>), grid, block, 0, st, P, W, O, mask);
     else hipLaunchKernelGGL((fwd_small_kernel<R, NP, MV, false>), grid, block, 0, st, P, W, O, mask);
