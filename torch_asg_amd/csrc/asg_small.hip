@@ -833,13 +833,19 @@ __device__ __forceinline__ float lds_ldf(float *p) { return __hip_atomic_load(p,
 __device__ __forceinline__ void lds_stf(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 // mat-vec consumer with `EXTRA` younger LDS operations in flight behind the broadcast reads
+// The main wavefront of the duo path is not issue-bound (about 40 instructions per 240-cycle step), so it waits for
+// the broadcast reads in pairs: the FMAs then track the arrival of the data instead of starting after half of it.
+#ifndef ASG_DUO_WAIT_GROUP
+#define ASG_DUO_WAIT_GROUP 2
+#endif
+constexpr int kDuoWaitGroup = ASG_DUO_WAIT_GROUP;
 template <int NP, int EXTRA, int J>
 __device__ __forceinline__ void duo_dot_step(const V2<float> (&e2)[NP / 2], const V4<float> (&pv)[NP / 4], V2<float> &a0,
                                              V2<float> &a1) {
     constexpr int NR = NP / 4;
     if constexpr (J < NR) {
-        if constexpr (J % kWaitGroup == 0) {
-            constexpr int last = (J + kWaitGroup - 1 < NR - 1) ? J + kWaitGroup - 1 : NR - 1;
+        if constexpr (J % kDuoWaitGroup == 0) {
+            constexpr int last = (J + kDuoWaitGroup - 1 < NR - 1) ? J + kDuoWaitGroup - 1 : NR - 1;
             constexpr int cnt = (NR - 1 - last) + (last == NR - 1 ? 0 : EXTRA);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_waitcnt(0xC07F | ((cnt > 15 ? 15 : cnt) << 8));
@@ -883,8 +889,8 @@ __device__ __forceinline__ void duo_main_block(DuoLds &L, int n0, int nsteps, co
                 ex = __builtin_amdgcn_readlane(Rng<float>::expo(s_prev), N);
                 csum += ex;
             }
-            __builtin_amdgcn_sched_barrier(0);
             V2<float> a0 = {0, 0}, a1 = {0, 0};
+            __builtin_amdgcn_sched_barrier(0);
             duo_dot_step<NP, 2, 0>(e2, pv, a0, a1);
             __builtin_amdgcn_wave_barrier();
             V2<float> a = a0 + a1;
