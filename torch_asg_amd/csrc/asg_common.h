@@ -26,6 +26,7 @@ template <> struct Num<float> {
     static __device__ __forceinline__ float ninf() { return -__builtin_inff(); }
     static __device__ __forceinline__ float exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32
     static __device__ __forceinline__ float log2(float x) { return __builtin_amdgcn_logf(x); }    // v_log_f32
+    static __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }      // v_rcp_f32
     static __device__ __forceinline__ float log2e() { return 1.4426950408889634f; }
     static __device__ __forceinline__ float logzero() { return -1e30f; }
     static __device__ __forceinline__ float lg_limit() { return 100.0f; }   // |log2(row sum)| beyond this -> exact path
@@ -36,6 +37,7 @@ template <> struct Num<double> {
     static __device__ __forceinline__ double ninf() { return -__builtin_inf(); }
     static __device__ __forceinline__ double exp2(double x) { return ::exp2(x); }
     static __device__ __forceinline__ double log2(double x) { return ::log2(x); }
+    static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
     static __device__ __forceinline__ double log2e() { return 1.4426950408889634; }
     static __device__ __forceinline__ double logzero() { return -1e300; }
     static __device__ __forceinline__ double lg_limit() { return 900.0; }

@@ -1311,8 +1311,13 @@ __global__ void __launch_bounds__(256) bwd_small_kernel(Problem P, State W, BwdA
 
     const R *ahp = (const R *) W.ah + (int64_t) b * T * N + lc;
     const R *bhp = (const R *) W.bh + (int64_t) b * T * N + lc;
-    const R *abp = (const R *) W.ab + (int64_t) b * T * S + ls_;
-    const R *bbp = (const R *) W.bb + (int64_t) b * T * S + ls_;
+    // state rows through buffer loads: lane offset in a VGPR, frame offset in an SGPR (no per-lane 64-bit address math)
+    __amdgpu_buffer_rsrc_t r_ah = make_rsrc((R *) W.ah + (int64_t) b * T * N, (unsigned) T * (unsigned) N * (unsigned) sizeof(R));
+    __amdgpu_buffer_rsrc_t r_bh = make_rsrc((R *) W.bh + (int64_t) b * T * N, (unsigned) T * (unsigned) N * (unsigned) sizeof(R));
+    __amdgpu_buffer_rsrc_t r_ab = make_rsrc((R *) W.ab + (int64_t) b * T * S, (unsigned) T * (unsigned) S * (unsigned) sizeof(R));
+    __amdgpu_buffer_rsrc_t r_bb = make_rsrc((R *) W.bb + (int64_t) b * T * S, (unsigned) T * (unsigned) S * (unsigned) sizeof(R));
+    const unsigned vN = (unsigned) lc * (unsigned) sizeof(R), vS = (unsigned) ls_ * (unsigned) sizeof(R);
+    const unsigned rbN = (unsigned) N * (unsigned) sizeof(R), rbS = (unsigned) S * (unsigned) sizeof(R);
     __amdgpu_buffer_rsrc_t rs_g = make_rsrc((R *) A.grad_inputs + (int64_t) b * N,
                                             (unsigned) ((int64_t) (T - 1) * P.B * N + N) * (unsigned) sizeof(R));
     const unsigned voff = act ? (unsigned) lane * sizeof(R) : kOobOffset;
@@ -1325,16 +1330,20 @@ __global__ void __launch_bounds__(256) bwd_small_kernel(Problem P, State W, BwdA
     R n_ah, n_bh, n_ahp, n_ab, n_bb, n_abp;
     {
         const int tq = min(t0 + wave, T - 1), tqp = tq >= 1 ? tq - 1 : 0;
-        n_ah = ahp[(int64_t) tq * N]; n_bh = bhp[(int64_t) tq * N]; n_ahp = ahp[(int64_t) tqp * N];
-        n_ab = abp[(int64_t) tq * S]; n_bb = bbp[(int64_t) tq * S]; n_abp = abp[(int64_t) tqp * S];
+        n_ah = buf_load<R>(r_ah, vN, (unsigned) tq * rbN); n_bh = buf_load<R>(r_bh, vN, (unsigned) tq * rbN);
+        n_ahp = buf_load<R>(r_ah, vN, (unsigned) tqp * rbN);
+        n_ab = buf_load<R>(r_ab, vS, (unsigned) tq * rbS); n_bb = buf_load<R>(r_bb, vS, (unsigned) tq * rbS);
+        n_abp = buf_load<R>(r_ab, vS, (unsigned) tqp * rbS);
     }
     for (int t = t0 + wave; t < t1; t += 4) {
         R gi = 0;
         const R c_ah = n_ah, c_bh = n_bh, c_ahp = n_ahp, c_ab = n_ab, c_bb = n_bb, c_abp = n_abp;
         {
             const int tq = min(t + 4, T - 1), tqp = tq >= 1 ? tq - 1 : 0;
-            n_ah = ahp[(int64_t) tq * N]; n_bh = bhp[(int64_t) tq * N]; n_ahp = ahp[(int64_t) tqp * N];
-            n_ab = abp[(int64_t) tq * S]; n_bb = bbp[(int64_t) tq * S]; n_abp = abp[(int64_t) tqp * S];
+            n_ah = buf_load<R>(r_ah, vN, (unsigned) tq * rbN); n_bh = buf_load<R>(r_bh, vN, (unsigned) tq * rbN);
+            n_ahp = buf_load<R>(r_ah, vN, (unsigned) tqp * rbN);
+            n_ab = buf_load<R>(r_ab, vS, (unsigned) tq * rbS); n_bb = buf_load<R>(r_bb, vS, (unsigned) tq * rbS);
+            n_abp = buf_load<R>(r_ab, vS, (unsigned) tqp * rbS);
         }
         if (t < len) {
             // the three maxima (full gamma, previous alpha, aligned gamma) in one interleaved reduction pass
@@ -1342,14 +1351,15 @@ __global__ void __launch_bounds__(256) bwd_small_kernel(Problem P, State W, BwdA
             R ahprev = act ? c_ahp : NINF;
             R gam2 = sl ? c_ab + c_bb : LZ;
             R abprev = sl ? c_abp : LZ;
-            R mg = gam, mp = ahprev;
-            wave_allmax2(mg, mp);
-            R mg2 = wave_allmax(gam2);
+            R mg = gam, mg2 = gam2;
+            wave_allmax2(mg, mg2);
             mg = fmax(mg, LZ);
-            mp = fmax(mp, LZ);
             R w = do_full ? Num<R>::exp2(gam - mg) : R(0);
             R w2 = (do_ali && mg2 > R(-1e29)) ? Num<R>::exp2(gam2 - mg2) : R(0);   // infeasible alignment -> no posterior
-            R p = Num<R>::exp2(ahprev - mp);
+            // the forward pass stores alpha_hat relative to an offset that keeps the frame's L1 norm near 1, so it is
+            // exponentiated as is (no third reduction); a frame that underflows anyway fails the `ok` test below and
+            // goes through the exact pass
+            R p = Num<R>::exp2(ahprev);
             R *lds = pbuf[wave];
             if (do_full && t >= 1) {
                 lds[lane] = p;
@@ -1357,8 +1367,9 @@ __global__ void __launch_bounds__(256) bwd_small_kernel(Problem P, State W, BwdA
             }
             R Z = w, Z2 = w2;
             wave_allsum2(Z, Z2);
-            R post2 = (Z2 > 0) ? w2 / Z2 : R(0);            // unscaled aligned state posterior, 0 for s >= ol
-            gi = (Z > 0) ? gf * (w / Z) : R(0);
+            // v_rcp (1 ulp) instead of the ~10-instruction IEEE division: far inside the 1e-4 budget
+            R post2 = (Z2 > 0) ? w2 * Num<R>::rcp(Z2) : R(0);   // unscaled aligned state posterior, 0 for s >= ol
+            gi = (Z > 0) ? gf * (w * Num<R>::rcp(Z)) : R(0);
             if (do_full && t >= 1) {
                 V4<R> pv[NP / 4];
 #pragma unroll
@@ -1374,7 +1385,7 @@ __global__ void __launch_bounds__(256) bwd_small_kernel(Problem P, State W, BwdA
                 R sden = a.x + a.y;                    // row sum of the forward mat-vec (up to the common scale of p)
                 bool ok = fabs(Num<R>::log2(sden)) < Num<R>::lg_limit();
                 any_bad |= (gi != R(0)) && !ok;
-                R u = ok ? gi / sden : R(0);
+                R u = ok ? gi * Num<R>::rcp(sden) : R(0);
                 const V2<R> u2 = {u, u};
 #pragma unroll
                 for (int j = 0; j < NP / 4; ++j) {
@@ -1523,15 +1534,25 @@ __global__ void __launch_bounds__(256) loss_reduce_kernel(const R *full, const R
     if (threadIdx.x == 0) out[0] = (R) (reduction == 2 ? part[0] / B : part[0]);
 }
 
-inline bool duo_enabled() {
+// The three-wavefront chain buys latency with issue slots: it wins while every chain has a compute unit to itself
+// (cfg 3: 128 full-lattice chains on 256 CUs; measured 80 vs 85 us/step at B=64, 95 vs 101 at B=128) and loses once
+// chains have to share (159 vs 134 us/step at B=256), where the single-wavefront chain is the denser packing.
+inline bool duo_enabled(int nchains) {
     static const bool on = !(getenv("ASG_NO_DUO") && atoi(getenv("ASG_NO_DUO")) != 0);    // developer A/B switch
-    return on;
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            n = 256;
+        return n > 0 ? n : 256;
+    }();
+    return on && nchains <= cus;
 }
 
 template <typename R, int NP, int MV>
 hipError_t launch_fwd_np(const Problem &P, const State &W, const FwdOut &O, int mask, bool store, hipStream_t st) {
     if constexpr (sizeof(R) == 4 && MV == 0) {
-        if ((mask & (kFullAlpha | kFullBeta)) && P.N < 64 && duo_enabled()) {
+        if ((mask & (kFullAlpha | kFullBeta)) && P.N < 64 &&
+            duo_enabled(P.B * __builtin_popcount(mask & (kFullAlpha | kFullBeta)))) {
             dim3 grid(P.B, __builtin_popcount(mask)), block(192);
             if (store) hipLaunchKernelGGL((fwd_duo_kernel<NP, true>), grid, block, 0, st, P, W, O, mask);
             else hipLaunchKernelGGL((fwd_duo_kernel<NP, false>), grid, block, 0, st, P, W, O, mask);
