@@ -270,7 +270,8 @@ def main():
                        "parallelism": "batch-sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "fwd_small_kernel (alpha/beta recursions, all four passes in one launch)"
+                         "kernel": "fwd_duo_kernel (alpha/beta recursions, all four passes in one launch; "
+                                   "three wavefronts per full-lattice chain)"
                                    if args.launch == "single" else "asg_forward launches (recursion kernels)",
                          "kernel_ms": kern_ms_med, "kernel_ms_avg": kern_ms_avg,
                          "algorithmic_bytes_per_launch": a_alg,

@@ -66,7 +66,10 @@ def main():
                   "MI355X_MICROARCH.md section HBM says), WRITE_SIZE reads %s KB (exact)." % (cal_f, cal_w), "",
                   "| kernel | FETCH_SIZE raw KB | fetch bytes (x2 x1024) | WRITE_SIZE KB | write bytes | HBM bytes / launch |", "|---|---|---|---|---|---|"]
         summary = {}
-        for key, label in (("fwd_small_kernel", "recursion_kernel"), ("bwd_small_kernel", "assembly_kernel"), ("reduce_tiles_kernel", "reduce_kernel")):
+        for key, label in (("fwd_duo_kernel", "recursion_kernel"), ("fwd_small_kernel", "recursion_kernel"),
+                           ("bwd_small_kernel", "assembly_kernel"), ("reduce_tiles_kernel", "reduce_kernel")):
+            if label + "_hbm_bytes_per_launch" in summary:
+                continue
             f_, _ = avg("FETCH_SIZE", key)
             w_, _ = avg("WRITE_SIZE", key)
             if f_ is None or w_ is None:

@@ -1,5 +1,5 @@
 // torch_asg_amd/csrc/asg_small.hip -- gfx950 kernels for the small-alphabet ASG path
-// (N <= 64 labels, S <= 64 target positions): ONE 64-lane wavefront per recursion chain.
+// (N <= 64 labels, S <= 64 target positions): one recursion chain per workgroup (1 or 3 wavefronts).
 //
 // What each kernel replaces in the reference (paths under /root/reference/torch_asg/native/):
 //   full_alpha_chain    fully_connected_lattice.cpp:9-29   (alpha recursion; no path_contrib tensor)
@@ -9,13 +9,17 @@
 //   bwd_small_kernel    fully_connected_lattice.cpp:49-63,93-105 + force_aligned_lattice.cpp:156-264,321-356
 //                       (+ the atomicAdd scatter kernels force_aligned_lattice_kernel.cu:253-470)
 //
-// Design: the full-lattice step  alpha_t[i] = I_t[i] + LSE_j(Tr[i][j] + alpha_{t-1}[j])
-// is evaluated as a row-normalised exp-domain mat-vec: lane i keeps row i of exp2(Tr2 - rowmax) in
-// registers, the previous frame's p_j = exp2(alpha_hat_j) is broadcast through LDS (or v_readlane), N FMAs,
-// one v_log_f32; the frame max is folded into a double offset every 4th step.  A sticky per-lane flag records
-// any row sum whose |log2| leaves the safe range (underflow, overflow, zero, NaN); it is tested ONCE per
-// 16-step block, and a flagged block is redone from its entry state with exact max-shifted log-sum-exps, so the
-// result is a true LSE for any input range without a branch on the per-step critical path.
+// Design: the full-lattice recursion runs in the exp domain.  Lane i keeps row i of
+// E = exp2(Tr2 - rowmax) in registers; the vector v_t (alpha_t = C_t + log2 v_t) is broadcast through LDS;
+// s_i = sum_j E[i][j] v[j] (N FMAs); v_{t+1}[i] = s_i * e_{t+1}[i] with the emission factor
+// e = exp2(I2 + rowmax - blockmax) prepared off the critical path.  Range control is a lagged power-of-two
+// rescaling driven by lane N's row of ones (its row sum is the L1 norm of v): no reduction, exp or log on the
+// dependent chain.  A sticky min/max of the row sums' bit patterns records any excursion outside 2^+-100; it is
+// tested once per 16-step block and the block (or, on the three-wavefront path, the chain) is redone with exact
+// max-shifted log-sum-exps, so the result is a true LSE for any input range.
+// fp32 chains that have a compute unit to themselves run as THREE wavefronts (fwd_duo_kernel): the recursion
+// wavefront keeps only the critical path, a producer prepares e_t, a consumer turns the row sums into the stored
+// log-domain state and the score; they talk through LDS rings.  Everything else uses one wavefront per chain.
 // The aligned lattice stays in the log domain (2-term LSE per node) because its band structure makes
 // per-frame dynamic range unbounded for tight alignments.
 //
