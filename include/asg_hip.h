@@ -116,6 +116,17 @@ int asg_backward(asg_ctx *ctx, const asg_problem *p, const void *state, size_t s
                  const void *grad_full, const void *grad_aligned, void *scratch, size_t scratch_bytes,
                  void *grad_transition, void *grad_inputs, int flags, void *stream);
 
+/* ---- best-path (Viterbi) force alignment -- SURVEY.md 8(f)3.  No counterpart in the reference (README.md:33 lists
+ * it as TODO; the lattice is force_aligned_lattice.cpp:84-111 with max instead of logsumexp,
+ * doc/tech_report.tex:84-88).  scores[B] (dtype of inputs) = score of the best alignment, path[B][T] int64 = the
+ * target POSITION occupied at each frame (-1 for frames >= input_lengths[b], and everywhere when the utterance has
+ * no finite alignment: score -inf).  Tied comparisons keep "stay" (so among tied paths the one that advances
+ * earliest is returned).  S <= 64 in this build.
+ * `work` holds B*T 64-bit back-pointer masks (asg_viterbi_work_bytes). */
+size_t asg_viterbi_work_bytes(const asg_problem *p);
+int asg_viterbi(asg_ctx *ctx, const asg_problem *p, void *work, size_t work_bytes, void *scores, int64_t *path,
+                int flags, void *stream);
+
 /* ---- whole-loss entry points (no counterpart in the reference's native layer: they fold the Python-side
  * `full - aligned` and reduction of asg.py:128,136-142 and their autograd into the kernels, so one ASGLoss
  * step is 2 + 2 kernel launches with no PyTorch glue kernels in between) ------------------------------------ */

@@ -130,6 +130,52 @@ def aligned_backward(grad_out, alpha, beta, targets, transition, input_lengths, 
     return gtr, gin
 
 
+def viterbi(inputs, targets, transition, input_lengths=None, target_lengths=None):
+    """Best-path force alignment (max-plus version of force_aligned_lattice.cpp:84-111; not in the reference).
+    -> scores[B], path[B,T] int64 (target position per frame, -1 outside the utterance / infeasible)"""
+    inputs = np.asarray(inputs)
+    T, B, N = inputs.shape
+    tg = np.ascontiguousarray(targets, dtype=np.int64)
+    S = tg.shape[1]
+    sfx = _sfx(inputs.dtype)
+    tr = np.ascontiguousarray(transition, dtype=inputs.dtype)
+    il, tl = _lens(input_lengths, B), _lens(target_lengths, B)
+    scores = np.empty(B, inputs.dtype)
+    path = np.empty((B, T), np.int64)
+    rc = getattr(lib(), "asg_oracle_viterbi_" + sfx)(
+        _p(inputs), _istr(inputs), _p(tg), _p(tr), _p(il), _p(tl),
+        ctypes.c_int64(T), ctypes.c_int64(B), ctypes.c_int64(N), ctypes.c_int64(S), _p(scores), _p(path))
+    assert rc == 0, rc
+    return scores, path
+
+
+def brute_force_viterbi(inputs, targets, transition, input_length, target_length):
+    """Exhaustive best alignment for ONE tiny utterance (pure Python). inputs [T,N] float64.
+    Returns (best_score, best_position_path) with ties resolved like the recursion (prefer staying,
+    i.e. the lexicographically LARGEST sequence of advance frames... see tests: only scores are compared
+    when several paths tie)."""
+    import itertools
+    T = int(input_length)
+    tgt = [int(x) for x in targets[:int(target_length)]]
+    L = len(tgt)
+    if L < 1 or L > T:
+        return -np.inf, None
+    best, bestp = -np.inf, None
+    for cuts in itertools.combinations(range(1, T), L - 1):
+        seg, k = [0] * T, 0
+        for t in range(T):
+            if k < L - 1 and t == cuts[k]:
+                k += 1
+            seg[t] = k
+        lab = [tgt[k] for k in seg]
+        sc = inputs[0, lab[0]]
+        for t in range(1, T):
+            sc += transition[lab[t], lab[t - 1]] + inputs[t, lab[t]]
+        if sc > best:
+            best, bestp = sc, seg
+    return best, bestp
+
+
 def asg_loss(inputs, targets, transition, input_lengths=None, target_lengths=None,
              reduction="mean", grad_out=None, need_grad=True):
     """Whole ASGLoss forward+backward on the CPU oracle.

@@ -454,3 +454,65 @@ def test_cfg4_shard_equals_whole():
         assert np.array_equal(part["grad_inputs"], whole["grad_inputs"][:, lo:hi])
     util.assert_close(acc, whole["grad_transition"], 1e-5, "sharded gtr")
     assert abs(loss - float(whole["loss"])) < 1e-4 * abs(float(whole["loss"]))
+
+
+# ------------------------------------------------------------------ best-path (Viterbi) force alignment, SURVEY 8(f)3
+def _path_score(x, tr, tg, pos):
+    """Score of one alignment (float64 numpy): sum of emissions and of the transitions between consecutive frames."""
+    lab = tg[pos]
+    s = x[0, lab[0]]
+    for t in range(1, len(pos)):
+        s += tr[lab[t], lab[t - 1]] + x[t, lab[t]]
+    return s
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("T,B,N,L,variable", [(6, 2, 7, 5, True), (23, 5, 9, 7, True), (150, 16, 30, 20, True),
+                                              (400, 64, 40, 30, False), (70, 3, 64, 64, True), (1, 2, 4, 1, False)])
+def test_viterbi_vs_oracle(T, B, N, L, variable, dtype):
+    A = _asg()
+    tr, x, tg, il, tl = util.synth(T, B, N, L, 7, variable, dtype)
+    tl = torch.minimum(tl, il)
+    sc_o, path_o = orc.viterbi(x.numpy(), tg.numpy(), tr.numpy(), il.numpy(), tl.numpy())
+    sc, pos, lab = A.viterbi_align(x.to(DEV), tg.to(DEV), tr.to(DEV), il.to(DEV), tl.to(DEV))
+    sc, pos, lab = sc.cpu().numpy(), pos.cpu().numpy(), lab.cpu().numpy()
+    # adds and compares only, same order as the oracle: bit-exact in both precisions
+    assert np.array_equal(sc, sc_o)
+    assert np.array_equal(pos, path_o)
+    for b in range(B):
+        n, o = int(il[b]), int(tl[b])
+        p = pos[b, :n]
+        assert p[0] == 0 and p[-1] == o - 1 and np.all(np.diff(p) >= 0) and np.all(np.diff(p) <= 1)
+        assert np.array_equal(lab[b, :n], tg[b].numpy()[p]) and np.all(lab[b, n:] == -1)
+        ref = _path_score(x[:, b].double().numpy(), tr.double().numpy(), tg[b].numpy(), p)
+        assert abs(sc[b] - ref) <= (1e-4 if dtype == torch.float32 else 1e-10) * max(1.0, abs(ref))
+
+
+def test_viterbi_edge_cases_and_module_method():
+    A = _asg()
+    tr, x, tg, il, tl = util.synth(12, 6, 5, 4, 3, False, torch.float64)
+    il = torch.tensor([12, 3, 4, 12, 1, 12])
+    tl = torch.tensor([4, 4, 4, 1, 1, 4])                    # utterance 1: more labels than frames -> no alignment
+    x = x.clone()
+    x[:, 5, :] = -np.inf                                     # utterance 5: nothing emits -> no finite path
+    m = A.ASGLoss(5).to(DEV).double()
+    with torch.no_grad():
+        m.transition.copy_(tr)
+    sc, pos, lab = m.viterbi_align(x.to(DEV), tg.to(DEV), il.to(DEV), tl.to(DEV))
+    sc_o, path_o = orc.viterbi(x.numpy(), tg.numpy(), tr.numpy(), il.numpy(), tl.numpy())
+    assert np.array_equal(sc.cpu().numpy(), sc_o) and np.array_equal(pos.cpu().numpy(), path_o)
+    assert sc[1] == -np.inf and bool((pos[1] == -1).all()) and sc[5] == -np.inf and bool((pos[5] == -1).all())
+    assert pos[2, :4].tolist() == [0, 1, 2, 3] and pos[4, 0] == 0 and not sc.requires_grad
+    # best path <= sum over paths (aligned score of the loss), equality when only one alignment exists
+    fac = A.FAC.apply(m.transition, x.to(DEV), tg.to(DEV), il.to(DEV), tl.to(DEV)).detach()
+    ok = torch.isfinite(sc)
+    assert bool((sc[ok] <= fac[ok] + 1e-9).all()) and abs(float(sc[2] - fac[2])) < 1e-9
+    # defaults (lengths None), S > T truncation like ASGLoss.forward, repeated labels, non-contiguous emissions
+    xt = torch.randn(4, 3, 6, dtype=torch.float64).transpose(0, 2)      # [T=6,B=3,N=4], label-major strides
+    tg2 = torch.tensor([[1, 1, 1, 2, 0, 3, 1, 2]] * 3)
+    sc2, pos2, _ = A.viterbi_align(xt.to(DEV), tg2.to(DEV), torch.zeros(4, 4, dtype=torch.float64, device=DEV))
+    so, po = orc.viterbi(xt.numpy(), tg2[:, :6].numpy(), np.zeros((4, 4)), None, np.array([6, 6, 6]))
+    assert np.array_equal(sc2.cpu().numpy(), so) and np.array_equal(pos2.cpu().numpy(), po)
+    with pytest.raises(RuntimeError):
+        A.viterbi_align(torch.randn(80, 1, 4, device=DEV), torch.zeros(1, 70, dtype=torch.long, device=DEV),
+                        torch.zeros(4, 4, device=DEV))        # S > 64: not in this build, fails loudly

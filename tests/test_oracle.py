@@ -178,3 +178,34 @@ def test_brute_force_enumeration(seed):
     a, _, _ = orc.aligned_forward(x, tg, tr, [il], [tl])
     bf, ba = orc.brute_force_scores(x[:, 0, :], tg[0], tr, il, tl)
     assert abs(f[0] - bf) < 1e-10 and abs(a[0] - ba) < 1e-10
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_viterbi_oracle_against_exhaustive_enumeration(seed):
+    """The reference has no best-path alignment (README.md:33 TODO): the oracle's max-plus restatement of
+    force_aligned_lattice.cpp:84-111 is pinned by enumerating every alignment of tiny utterances."""
+    rng = np.random.default_rng(100 + seed)
+    for _ in range(40):
+        T, N, L = int(rng.integers(1, 7)), int(rng.integers(1, 4)), int(rng.integers(1, 5))
+        x = rng.normal(size=(T, 1, N))
+        tr = rng.normal(size=(N, N))
+        tg = rng.integers(0, N, size=(1, L))
+        il, tl = np.array([rng.integers(1, T + 1)]), np.array([rng.integers(1, L + 1)])
+        sc, path = orc.viterbi(x, tg, tr, il, tl)
+        best, bp = orc.brute_force_viterbi(x[:, 0], tg[0], tr, il[0], tl[0])
+        if bp is None:
+            assert sc[0] == -np.inf and (path == -1).all()
+        else:
+            assert abs(sc[0] - best) < 1e-12
+            assert list(path[0, :il[0]]) == bp and (path[0, il[0]:] == -1).all()
+            # the best path can never beat the sum over all alignments, and is within log(#paths) of it
+            ali = orc.aligned_forward(x, tg, tr, il, tl)[0][0]
+            assert sc[0] <= ali + 1e-12
+
+
+def test_viterbi_oracle_f32_and_ties():
+    # all-zero scores: every alignment ties; "stay" wins every tied comparison, so walking the back-pointers from the
+    # end stays on a position for as long as it was reachable: the best path advances as EARLY as possible
+    x = np.zeros((6, 1, 3), np.float32)
+    sc, path = orc.viterbi(x, np.array([[0, 1, 2]]), np.zeros((3, 3), np.float32), None, None)
+    assert sc[0] == 0 and list(path[0]) == [0, 1, 2, 2, 2, 2]

@@ -16,7 +16,7 @@ FLAG_STREAMS, FLAG_SINGLE_LAUNCH, FLAG_MATVEC_READLANE, FLAG_ALPHA_SCORES = 1, 2
 SYMBOLS = ["asg_hip_version", "asg_hip_strerror", "asg_ctx_create", "asg_ctx_destroy", "asg_state_bytes",
            "asg_scratch_bytes", "asg_full_forward", "asg_full_backward", "asg_aligned_forward",
            "asg_aligned_backward", "asg_forward", "asg_forward_only", "asg_backward", "asg_loss_forward",
-           "asg_loss_backward"]
+           "asg_loss_backward", "asg_viterbi_work_bytes", "asg_viterbi"]
 
 
 class AsgProblem(ctypes.Structure):
@@ -61,6 +61,9 @@ def lib():
     L.asg_backward.argtypes = [vp, pp, vp, sz, vp, vp, vp, sz, vp, vp, ci, vp]
     L.asg_loss_forward.argtypes = [vp, pp, vp, sz, ci, vp, vp, ci, vp]
     L.asg_loss_backward.argtypes = [vp, pp, vp, sz, ci, vp, vp, sz, vp, vp, ci, vp]
+    L.asg_viterbi_work_bytes.restype = sz
+    L.asg_viterbi_work_bytes.argtypes = [pp]
+    L.asg_viterbi.argtypes = [vp, pp, vp, sz, vp, vp, ci, vp]
     for name in SYMBOLS:
         getattr(L, name)
     _LIB = L

@@ -213,6 +213,21 @@ class HipBackend:
                                           self._stream(inputs.device)), "asg_forward_only")
         return scores[0], scores[1]
 
+    def viterbi(self, inputs, targets, transition, input_lengths, target_lengths):
+        """Best-path force alignment -> (scores[B], positions[B,T] int64); see include/asg_hip.h::asg_viterbi."""
+        self._check(inputs, transition, targets, input_lengths, target_lengths)
+        L = _lib.lib()
+        T, B, N = inputs.shape
+        with self._guard(inputs.device):
+            p, keep = self._problem(inputs, transition, targets, input_lengths, target_lengths)
+            work = self._buf(int(L.asg_viterbi_work_bytes(ctypes.byref(p))), inputs.device)
+            scores = torch.empty(B, dtype=inputs.dtype, device=inputs.device)
+            path = torch.empty(B, T, dtype=torch.int64, device=inputs.device)
+            _lib.check(L.asg_viterbi(self._context(inputs.device), ctypes.byref(p), work.data_ptr(), work.numel(),
+                                     scores.data_ptr(), path.data_ptr(), 0, self._stream(inputs.device)),
+                       "asg_viterbi")
+        return scores, path
+
     def backward(self, state, grad_full, grad_aligned, inputs, targets, transition, input_lengths, target_lengths,
                  flags=0):
         L = _lib.lib()
@@ -285,6 +300,31 @@ def native():
         _lib.lib()            # fail loudly here if libasg_hip.so is missing
         _backend = HipBackend()
     return _backend
+
+
+def viterbi_align(inputs, targets, transition, input_lengths=None, target_lengths=None):
+    """Best-path (Viterbi) force alignment of `targets` to `inputs` under the ASG transition model -- the
+    force-aligned lattice of the loss (force_aligned_lattice.cpp:84-111) with max instead of logsumexp
+    (doc/tech_report.tex:84-88; a TODO in the reference, README.md:33).  No gradient.
+
+    inputs [T,B,N] (time-major emissions), targets [B,S] int64, transition [N,N], lengths int64 [B] or None.
+    Returns (scores [B], positions [B,T] int64, labels [B,T] int64): the score of the best alignment, the target
+    position occupied at every frame and the label emitted there; -1 for frames >= input_lengths[b] and for
+    utterances that have no finite alignment (score -inf).  Same defaults and S > T truncation as ASGLoss.forward.
+    """
+    T, B, N = inputs.shape
+    S = targets.shape[1]
+    if target_lengths is None:
+        target_lengths = targets.new_full((B,), S)
+    if input_lengths is None:
+        input_lengths = target_lengths.new_full((B,), T)
+    if S > T:
+        targets = targets[:, :T]
+        target_lengths = torch.clamp(target_lengths, max=T)
+    with torch.no_grad():
+        scores, pos = native().viterbi(inputs.detach(), targets, transition.detach(), input_lengths, target_lengths)
+        labels = torch.where(pos >= 0, torch.gather(targets.to(pos.device), 1, pos.clamp(min=0)), pos)
+    return scores, pos, labels
 
 
 class FAC(torch.autograd.Function):
@@ -399,6 +439,10 @@ class ASGLoss(nn.Module):
 
     def _flags(self):
         return {'streams': _lib.FLAG_STREAMS, 'single': _lib.FLAG_SINGLE_LAUNCH, 'serial': 0}[self.launch_mode]
+
+    def viterbi_align(self, inputs, targets, input_lengths=None, target_lengths=None):
+        """Best-path force alignment under this module's transition matrix: see `torch_asg_amd.viterbi_align`."""
+        return viterbi_align(inputs, targets, self.transition, input_lengths, target_lengths)
 
     def forward(self, inputs, targets, input_lengths=None, target_lengths=None):
         batch_input_len, num_batches, num_labels = inputs.shape

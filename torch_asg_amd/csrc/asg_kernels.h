@@ -86,6 +86,10 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
 template <typename R>
 hipError_t launch_bwd_generic(const Problem &P, const State &W, const BwdArgs &A, int parts, hipStream_t stream);
 
+// ---- best-path force alignment (S <= 64): work = [B][T] 64-bit back-pointer masks
+template <typename R>
+hipError_t launch_viterbi_small(const Problem &P, void *work, void *scores, void *path, hipStream_t stream);
+
 size_t bwd_scratch_bytes_small(int elem, int T, int B, int N, int S, int *chunk, int *nchunks);
 size_t bwd_scratch_bytes_generic(int elem, int T, int B, int N, int S);
 size_t fwd_work_bytes_generic(int elem, int T, int B, int N);

@@ -1,0 +1,114 @@
+// torch_asg_amd/csrc/asg_viterbi.hip -- best-path (Viterbi) force alignment on gfx950, S <= 64 target positions.
+//
+// The force-aligned lattice of /root/reference/torch_asg/native/force_aligned_lattice.cpp:84-111 in the tropical
+// semiring (max instead of log-sum-exp: doc/tech_report.tex:84-88; a TODO in the reference's README.md:33 -- the
+// reference has no implementation; the test suite pins the semantics by exhaustive path enumeration):
+//   v[0][s] = I[0][O_0] for s == 0 else -inf;  v[t][s] = I[t][O_s] + max(v[t-1][s] + Tr[O_s][O_s], v[t-1][s-1] + Tr[O_s][O_{s-1}])
+// One wavefront per utterance, lane s = target position.  Arithmetic is in the caller's natural-log units and in the
+// same order as the plain-C restatement used by the tests (adds and compares only), so scores and paths are
+// bit-identical to it.
+// Forward: the neighbour value arrives through a wave_shr:1 DPP move; the 64 back-pointer bits of a frame are one
+// v_cmp (ballot) and go to the workspace as one 8-byte store.  Backtrace: 64 frames at a time -- every lane loads one
+// frame's mask, then the wave walks the 64 frames with v_readlane + scalar bit tests and writes the positions back
+// with one coalesced store.
+#include "asg_common.h"
+#include "asg_kernels.h"
+
+namespace asg {
+
+namespace {
+
+constexpr int kVPF = 16;      // emission prefetch depth (frames)
+
+template <typename R>
+__global__ void __launch_bounds__(64) viterbi_small_kernel(Problem P, unsigned long long *masks, R *scores, long long *path) {
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x;
+    const int T = P.T, S = P.S;
+    const R NINF = Num<R>::ninf();
+    int len = P.in_len ? (int) (P.in_len[b] < 0 ? 0 : (P.in_len[b] > T ? T : P.in_len[b])) : T;
+    int ol = P.tg_len ? (int) (P.tg_len[b] < 0 ? 0 : (P.tg_len[b] > S ? S : P.tg_len[b])) : S;
+    len = __builtin_amdgcn_readfirstlane(len);
+    ol = __builtin_amdgcn_readfirstlane(ol);
+    long long *pb = path + (long long) b * T;
+    unsigned long long *mb = masks + (long long) b * T;
+    // frames outside the utterance (and everything, if there is no alignment) read -1
+    for (int t = lane; t < T; t += 64) pb[t] = -1;
+    const bool feasible = len >= 1 && ol >= 1 && ol <= len;
+    if (!feasible) {
+        if (lane == 0) scores[b] = NINF;
+        return;
+    }
+    const bool act = lane < ol;
+    const int sc = act ? lane : 0, sp = (act && lane >= 1) ? lane - 1 : 0;
+    const int64_t *tg = P.targets + (int64_t) b * P.gs0;
+    const int64_t cur64 = tg[(int64_t) sc * P.gs1], prv64 = tg[(int64_t) sp * P.gs1];
+    const int cur = (int) (cur64 < 0 ? 0 : (cur64 > P.N - 1 ? P.N - 1 : cur64));
+    const int prv = (int) (prv64 < 0 ? 0 : (prv64 > P.N - 1 ? P.N - 1 : prv64));
+    const R *tr = (const R *) P.transition;
+    const R H = tr[(long long) cur * P.ts0 + (long long) cur * P.ts1];
+    const R Dp = (act && lane >= 1) ? tr[(long long) cur * P.ts0 + (long long) prv * P.ts1] : NINF;
+    const R *in = (const R *) P.inputs + (long long) b * P.is1 + (long long) cur * P.is2;
+
+    R v = (lane == 0) ? in[0] : NINF;
+    R ring[kVPF];
+#pragma unroll
+    for (int k = 0; k < kVPF; ++k) ring[k] = in[(long long) min(1 + k, len - 1) * P.is0];
+    for (int t0 = 1; t0 < len; t0 += kVPF) {
+        R nxt[kVPF];
+#pragma unroll
+        for (int k = 0; k < kVPF; ++k) nxt[k] = in[(long long) min(t0 + kVPF + k, len - 1) * P.is0];
+#pragma unroll
+        for (int k = 0; k < kVPF; ++k) {
+            const int t = t0 + k;
+            if (t < len) {
+                const R stay = v + H;
+                const R left = dpp_mov<kDppWaveShr1, true>(R(0), v);        // lane 0 reads 0; its Dp is -inf
+                const R come = left + Dp;
+                const bool take = come > stay;                               // ties keep "stay"
+                const unsigned long long m = __ballot(take);
+                const R em = act ? ring[k] : NINF;
+                v = em + (take ? come : stay);
+                if (lane == 0) mb[t] = m;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kVPF; ++k) ring[k] = nxt[k];
+    }
+    const R best = readlane(v, ol - 1);
+    if (!(best > NINF) || best != best) {          // no finite path (e.g. -inf emissions on every alignment)
+        if (lane == 0) scores[b] = NINF;
+        return;
+    }
+    if (lane == 0) scores[b] = best;
+    // ---- backtrace: the masks were written by lane 0 of this wavefront; make them visible to all lanes
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int s = ol - 1;
+    for (int c0 = ((len - 1) / 64) * 64; c0 >= 0; c0 -= 64) {
+        const int t_mine = c0 + lane;
+        unsigned long long mv = (t_mine >= 1 && t_mine < len) ? __builtin_nontemporal_load(mb + t_mine) : 0ull;
+        const unsigned mlo = (unsigned) mv, mhi = (unsigned) (mv >> 32);
+        int mine = -1;
+        const int top = min(63, len - 1 - c0);
+        for (int k = top; k >= 0; --k) {
+            mine = (lane == k) ? s : mine;
+            const unsigned lo = __builtin_amdgcn_readlane(mlo, k), hi = __builtin_amdgcn_readlane(mhi, k);
+            const unsigned long long m = ((unsigned long long) hi << 32) | lo;
+            s -= (int) ((m >> s) & 1ull);           // frame 0 has mask 0: s stays (it is 0 for a valid path)
+        }
+        if (t_mine < len) pb[t_mine] = mine;
+    }
+}
+
+}  // namespace
+
+template <typename R>
+hipError_t launch_viterbi_small(const Problem &P, void *work, void *scores, void *path, hipStream_t stream) {
+    hipLaunchKernelGGL((viterbi_small_kernel<R>), dim3(P.B), dim3(64), 0, stream, P, (unsigned long long *) work,
+                       (R *) scores, (long long *) path);
+    return hipGetLastError();
+}
+template hipError_t launch_viterbi_small<float>(const Problem &, void *, void *, void *, hipStream_t);
+template hipError_t launch_viterbi_small<double>(const Problem &, void *, void *, void *, hipStream_t);
+
+}  // namespace asg

@@ -11,7 +11,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["asg_small.hip", "asg_generic.hip", "asg_api.hip"]
+SOURCES = ["asg_small.hip", "asg_generic.hip", "asg_viterbi.hip", "asg_api.hip"]
 HEADERS = ["asg_common.h", "asg_kernels.h", os.path.join("..", "..", "include", "asg_hip.h")]
 OUT = os.path.join(HERE, "libasg_hip.so")
 ARCH = os.environ.get("ASG_HIP_ARCH", "gfx950")
