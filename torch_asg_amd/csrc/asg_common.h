@@ -212,6 +212,21 @@ template <> __device__ __forceinline__ double buf_load<double>(__amdgpu_buffer_r
     return __hiloint2double((int) w.y, (int) w.x);
 }
 
+// Per-frame scatter of the aligned posteriors (values in [0,1], at most 64 of them, sum <= 1 per label): the integer
+// type of the deterministic LDS adds.  fp32 uses 32-bit words with a 2^-30 quantum (v_cvt_u32_f32 / ds_add_u32; the
+// 64-bit route costs ~15 double-precision instructions per frame), fp64 keeps 64-bit words with a 2^-44 quantum.
+template <typename R> struct FrameFix;
+template <> struct FrameFix<float> {
+    typedef unsigned T;
+    static __device__ __forceinline__ T to(float x) { return (T) __builtin_rintf(x * 1073741824.0f); }
+    static __device__ __forceinline__ float from(T v) { return (float) v * (1.0f / 1073741824.0f); }
+};
+template <> struct FrameFix<double> {
+    typedef unsigned long long T;
+    static __device__ __forceinline__ T to(double x) { return (T) __double2ll_rn(x * Num<double>::kFix); }
+    static __device__ __forceinline__ double from(T v) { return (double) (long long) v * (1.0 / Num<double>::kFix); }
+};
+
 // fixed-point helpers for deterministic LDS scatter-adds (integer adds commute)
 template <typename R> __device__ __forceinline__ unsigned long long to_fix(R x) {
     return (unsigned long long) __double2ll_rn((double) x * Num<R>::kFix);

@@ -1257,7 +1257,7 @@ __global__ void __launch_bounds__(64, 1) fwd_small_kernel(Problem P, State W, Fw
 template <typename R, int NP>
 __global__ void __launch_bounds__(256) bwd_small_kernel(Problem P, State W, BwdArgs A, int parts) {
     __shared__ __attribute__((aligned(16))) R pbuf[4][64];
-    __shared__ unsigned long long fxI[4][64];
+    __shared__ typename FrameFix<R>::T fxI[4][64];
     __shared__ unsigned long long fxT[NP * NP];      // aligned edge posteriors (unscaled)
     __shared__ unsigned long long fxX[NP * NP];      // exact-path full-lattice edge posteriors (unscaled)
     __shared__ __attribute__((aligned(16))) R tileF[64 * NP];
@@ -1399,7 +1399,8 @@ __global__ void __launch_bounds__(256) bwd_small_kernel(Problem P, State W, BwdA
                 __builtin_amdgcn_wave_barrier();
             }
             if (do_ali) {
-                if (sact && post2 != R(0)) atomicAdd(&fxI[wave][tgt], to_fix<R>(post2));
+                // unconditional (post2 is 0 on lanes >= ol, and adding 0 is harmless): no EXEC juggling per frame
+                atomicAdd(&fxI[wave][tgt], FrameFix<R>::to(post2));
                 __builtin_amdgcn_wave_barrier();
                 if (t >= 1) {
                     R pc0 = abprev + H2;
@@ -1408,11 +1409,9 @@ __global__ void __launch_bounds__(256) bwd_small_kernel(Problem P, State W, BwdA
                     accH += post2 * Num<R>::exp2(pc0 - l);
                     accD += post2 * Num<R>::exp2(pc1 - l);
                 }
-                unsigned long long fv = fxI[wave][lane];
-                if (fv != 0) {
-                    gi += ga * from_fix<R>(fv);
-                    fxI[wave][lane] = 0;
-                }
+                const typename FrameFix<R>::T fv = fxI[wave][lane];
+                gi += ga * FrameFix<R>::from(fv);
+                fxI[wave][lane] = 0;
                 __builtin_amdgcn_wave_barrier();
             }
         }
