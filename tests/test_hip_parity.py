@@ -516,3 +516,14 @@ def test_viterbi_edge_cases_and_module_method():
     with pytest.raises(RuntimeError):
         A.viterbi_align(torch.randn(80, 1, 4, device=DEV), torch.zeros(1, 70, dtype=torch.long, device=DEV),
                         torch.zeros(4, 4, device=DEV))        # S > 64: not in this build, fails loudly
+
+
+def test_random_shapes_value_ranges_and_determinism_stress():
+    """Many random (T, B, N, L, lengths, value ranges incl. 40-nat transitions and +-60 emission offsets) against the
+    oracle; exercises the three-wavefront chain, its abort-and-redo route, the exact passes, and run-to-run bit equality."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("stress_duo", os.path.join(os.path.dirname(__file__), "..", "tools", "stress_duo.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for seed in (2, 4, 11):
+        mod.run(seed, 60)

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Developer stress test (GPU): the three-wavefront recursion path against the CPU oracle over many random shapes,
+lengths and value ranges; repeated launches must be bit-identical.  Exits non-zero on the first mismatch."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import torch_asg_amd
+from oracle import asg_oracle as orc
+dev = "cuda:0"
+
+
+def run(seed=0, ncase=150):
+    rng = np.random.default_rng(seed)
+    t0 = time.time(); worst = 0.0
+    for case in range(ncase):
+        T = int(rng.choice([1, 2, 3, 15, 16, 17, 18, 31, 32, 33, 34, 47, 48, 49, 64, 65, 100, 257, 600, 1500]))
+        B = int(rng.integers(1, 13)); N = int(rng.integers(1, 64)); L = int(rng.integers(1, min(T, 40) + 1))
+        scale = float(rng.choice([0.1, 1.0, 5.0, 30.0]))
+        g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+        tr = (torch.rand(N, N, generator=g) - 0.5) * float(rng.choice([1.0, 8.0, 40.0]))
+        x = torch.randn(T, B, N, generator=g) * scale + float(rng.choice([0.0, -40.0, 60.0]))
+        if rng.random() < 0.3:
+            x = torch.log_softmax(x, dim=2)
+        tg = torch.randint(0, N, (B, L), generator=g)
+        il = torch.randint(max(1, T // 2), T + 1, (B,), generator=g)
+        tl = torch.minimum(torch.randint(1, L + 1, (B,), generator=g), il)
+        o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il.numpy(), tl.numpy(), "none")
+        m = torch_asg_amd.ASGLoss(N, reduction="none").to(dev)
+        with torch.no_grad(): m.transition.copy_(tr)
+        outs = []
+        for rep in range(2):
+            xd = x.to(dev).requires_grad_(True); m.transition.grad = None
+            loss = m(xd, tg.to(dev), il.to(dev), tl.to(dev)); loss.sum().backward(); torch.cuda.synchronize()
+            outs.append((loss.detach().cpu().numpy(), xd.grad.cpu().numpy(), m.transition.grad.cpu().numpy()))
+        for a, b_ in zip(outs[0], outs[1]):
+            assert np.array_equal(a, b_, equal_nan=True), ("non-deterministic", case, T, B, N, L)
+        for k, a in zip(("loss", "grad_inputs", "grad_transition"), outs[0]):
+            ref = o[k]; fin = np.isfinite(ref)
+            assert np.array_equal(np.isfinite(a), fin), ("finiteness", k, case, T, B, N, L)
+            den = max(1.0, float(np.abs(ref[fin]).max())) if fin.any() else 1.0
+            err = float(np.abs(a[fin] - ref[fin]).max()) / den if fin.any() else 0.0
+            worst = max(worst, err)
+            # emissions with a 30-nat spread put fp32 itself at ~1e-3 (the reference's fp32 path is off by > 1e-2 there)
+            # and at T >= 1000 the aligned lattice's log-domain alpha + beta (|values| ~ 1e3) costs ~1e-4 by cancellation
+            tol = 2e-3 if scale > 5.0 else (1e-3 if T >= 1000 else 1e-4)
+            assert err <= tol, ("mismatch", k, err, case, T, B, N, L, scale)
+    return ncase, worst, time.time() - t0
+
+
+
+if __name__ == "__main__":
+    n, w, dt = run(int(sys.argv[1]) if len(sys.argv) > 1 else 0, int(sys.argv[2]) if len(sys.argv) > 2 else 150)
+    print("stress ok: %d cases, worst scaled error %.2e, %.0f s" % (n, w, dt))

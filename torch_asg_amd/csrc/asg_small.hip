@@ -666,15 +666,27 @@ __device__ __forceinline__ AlignedSetup<R> aligned_setup(const Problem &P, int b
     return A;
 }
 
+// Common offset of a block's emissions (log2 units): taken out of the recursion and into the double offset C, so the
+// log-domain state stays O(block spread) instead of growing by the emissions' absolute level every frame (fp32
+// resolution at |x| ~ 1000 is 1e-4: emissions with a large common offset used to cost exactly that).
+template <typename R>
+__device__ __forceinline__ R aligned_block_scale(const R (&cur)[kPF], int nsteps, bool act) {
+    R zl = Num<R>::ninf();
+#pragma unroll
+    for (int k = 0; k < kPF; ++k) zl = (k < nsteps && act) ? fmax(zl, cur[k]) : zl;
+    const R z = wave_allmax(zl) * Num<R>::log2e();
+    return (z > R(-1e29) && z < R(1e29)) ? z : R(0);
+}
+
 template <typename R, bool STORE, bool GUARD>
 __device__ __forceinline__ void aligned_alpha_block(const R (&cur)[kPF], int nsteps, unsigned soff0, unsigned row_bytes,
-                                                    const AlignedSetup<R> &A, __amdgpu_buffer_rsrc_t rs, unsigned voff,
-                                                    R &ab) {
+                                                    const AlignedSetup<R> &A, R ebias, __amdgpu_buffer_rsrc_t rs,
+                                                    unsigned voff, R &ab) {
     const R L2E = Num<R>::log2e(), LZ = Num<R>::logzero();
 #pragma unroll
     for (int k = 0; k < kPF; ++k) {
         if (!GUARD || k < nsteps) {
-            R em = fma(cur[k], L2E, A.ebias);
+            R em = fma(cur[k], L2E, ebias);
             R stay = ab + A.H2;
             R come = prev_lane_or_zero<R>(ab) + A.Dprev;      // v_add_f32_dpp wave_shr:1; lane 0: 0 + logzero
             ab = fmax(em + lse2<R>(stay, come), LZ);
@@ -716,13 +728,19 @@ __device__ void aligned_alpha_chain(const Problem &P, const State &W, const FwdO
             // renormalise once per block: the log domain is offset-free, this only bounds magnitudes
             R m = wave_allmax(ab);
             if (m > R(-1e29)) { ab = fmax(ab - m, LZ); C += (double) m; }
-            aligned_alpha_block<R, STORE, false>(cur, kPF, (unsigned) (1 + done) * row_bytes, row_bytes, A, rs, voff, ab);
+            const R z = aligned_block_scale<R>(cur, kPF, A.act);
+            C += (double) z * kPF;
+            aligned_alpha_block<R, STORE, false>(cur, kPF, (unsigned) (1 + done) * row_bytes, row_bytes, A, A.ebias - z, rs,
+                                                 voff, ab);
 #pragma unroll
             for (int k = 0; k < kPF; ++k) cur[k] = nxt[k];
         }
-        if (done < nst)
-            aligned_alpha_block<R, STORE, true>(cur, nst - done, (unsigned) (1 + done) * row_bytes, row_bytes, A, rs,
-                                                voff, ab);
+        if (done < nst) {
+            const R z = aligned_block_scale<R>(cur, nst - done, A.act);
+            C += (double) z * (nst - done);
+            aligned_alpha_block<R, STORE, true>(cur, nst - done, (unsigned) (1 + done) * row_bytes, row_bytes, A,
+                                                A.ebias - z, rs, voff, ab);
+        }
     }
     if (O.aligned_scores_alpha) {
         R last = (A.ol >= 1 && len >= 1) ? readlane(ab, A.ol - 1) : LZ;
@@ -732,13 +750,13 @@ __device__ void aligned_alpha_chain(const Problem &P, const State &W, const FwdO
 
 template <typename R, bool STORE, bool GUARD>
 __device__ __forceinline__ void aligned_beta_block(const R (&cur)[kPF], int nsteps, unsigned soff0, unsigned row_bytes,
-                                                   const AlignedSetup<R> &A, __amdgpu_buffer_rsrc_t rs, unsigned voff,
-                                                   R &bb) {
+                                                   const AlignedSetup<R> &A, R ebias, __amdgpu_buffer_rsrc_t rs,
+                                                   unsigned voff, R &bb) {
     const R L2E = Num<R>::log2e(), LZ = Num<R>::logzero();
 #pragma unroll
     for (int k = 0; k < kPF; ++k) {
         if (!GUARD || k < nsteps) {
-            R y = fmax(fma(cur[k], L2E, A.ebias) + bb, LZ);
+            R y = fmax(fma(cur[k], L2E, ebias) + bb, LZ);
             R stay = y + A.H2;
             R go = next_lane_or_zero<R>(y) + A.Dnext;          // v_add_f32_dpp wave_shl:1
             bb = fmax(lse2<R>(stay, go), LZ);
@@ -774,14 +792,19 @@ __device__ void aligned_beta_chain(const Problem &P, const State &W, const FwdOu
         for (int k = 0; k < kPF; ++k) nxt[k] = A.in[(int64_t) max(len - 1 - (done + kPF + k), 0) * P.is0];
         R m = wave_allmax(bb);
         if (m > R(-1e29)) { bb = fmax(bb - m, LZ); C += (double) m; }
-        aligned_beta_block<R, STORE, false>(cur, kPF, (unsigned) (len - 2 - done) * row_bytes, row_bytes, A, rs, voff, bb);
+        const R z = aligned_block_scale<R>(cur, kPF, A.act);
+        C += (double) z * kPF;
+        aligned_beta_block<R, STORE, false>(cur, kPF, (unsigned) (len - 2 - done) * row_bytes, row_bytes, A, A.ebias - z, rs,
+                                            voff, bb);
 #pragma unroll
         for (int k = 0; k < kPF; ++k) cur[k] = nxt[k];
     }
     R last_raw = cur[0];
     if (done < nst) {
-        aligned_beta_block<R, STORE, true>(cur, nst - done, (unsigned) (len - 2 - done) * row_bytes, row_bytes, A, rs,
-                                           voff, bb);
+        const R z = aligned_block_scale<R>(cur, nst - done, A.act);
+        C += (double) z * (nst - done);
+        aligned_beta_block<R, STORE, true>(cur, nst - done, (unsigned) (len - 2 - done) * row_bytes, row_bytes, A,
+                                           A.ebias - z, rs, voff, bb);
         const int r = nst - done;
 #pragma unroll
         for (int k = 1; k < kPF; ++k) last_raw = (k == r) ? cur[k] : last_raw;
@@ -997,6 +1020,9 @@ __device__ __forceinline__ void duo_main(const Problem &P, const State &W, const
             __builtin_amdgcn_s_sleep(2);
         }
     }
+#ifdef ASG_PROBE
+    if (lane == 0) ((long long *) W.dbg)[20 + (BETA ? 1 : 0)] = redo ? 7 : 5;
+#endif
     if (redo) {
         // the helper has stopped (its stores are drained before it raises the verdict; after a kill it exits at
         // its next poll); wait for that, then redo the chain with the exact-fallback single-wavefront code
@@ -1166,6 +1192,9 @@ __device__ __forceinline__ void duo_consumer(const Problem &P, const State &W, c
         }
     }
     if (bad) {
+#ifdef ASG_PROBE
+        if (lane == 0) ((long long *) W.dbg)[16 + (BETA ? 1 : 0)] = 2;
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // our stores land before main overwrites them
         lds_store_rel(&L.verdict, 2);
         return;
@@ -1175,8 +1204,14 @@ __device__ __forceinline__ void duo_consumer(const Problem &P, const State &W, c
     const R vlast = sv * lds_ldf(&L.e[(len - 1) & (kRing - 1)][lane]);
     const R sm = wave_allsum(act ? vlast : R(0));
     const double sc = zsum + (double) csum + (double) Num<R>::log2(sm);
-    const bool finite_ok = (sm == sm) && sm > R(0) && sm < R(3.0e38f);
-    if (!finite_ok) {                                  // let the exact path decide (all -inf, overflow, NaN)
+    // same window as the row sums: a last emission factor far below its block's scale leaves a denormal sum, whose
+    // v_log_f32 is -inf; the exact path then decides (as it does for all -inf, overflow, NaN)
+    const unsigned smb = Rng<R>::bits(sm);
+    const bool finite_ok = smb >= Rng<R>::lo && smb <= Rng<R>::hi;
+#ifdef ASG_PROBE
+    if (lane == 0) { ((long long *) W.dbg)[16 + (BETA ? 1 : 0)] = finite_ok ? 1 : 4; ((double *) W.dbg)[18 + (BETA ? 1 : 0)] = sc; ((double *) W.dbg)[22 + (BETA ? 1 : 0)] = zsum; ((long long *) W.dbg)[24 + (BETA ? 1 : 0)] = csum; }
+#endif
+    if (!finite_ok) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         lds_store_rel(&L.verdict, 2);
         return;
@@ -1421,24 +1456,34 @@ __global__ void __launch_bounds__(256) bwd_small_kernel(Problem P, State W, BwdA
     // ---- rare exact pass: rows whose recomputed sum was unusable (forward took its exact path there too)
     if (do_full && __any(any_bad)) {
         const R *trow = (const R *) P.transition + (int64_t) lc * P.ts0;
-        for (int t = max(t0 + wave, 1); t < min(t1, len); t += 4) {
+        // same frame ownership as the fast loop (t = t0 + wave + 4k); frame 0 has no incoming transition
+        for (int t = (t0 + wave == 0) ? 4 : t0 + wave; t < min(t1, len); t += 4) {
             R ahv = act ? ahp[(int64_t) t * N] : NINF, bhv = act ? bhp[(int64_t) t * N] : NINF;
             R ahprev = act ? ahp[(int64_t) (t - 1) * N] : NINF;
             R gam = ahv + bhv;
             R mg = fmax(wave_allmax(gam), LZ);
             R w = Num<R>::exp2(gam - mg);
             R Z = wave_allsum(w);
-            R post = (Z > 0) ? w / Z : R(0);
-            R mp = fmax(wave_allmax(ahprev), LZ);
-            R p = Num<R>::exp2(ahprev - mp);
-            R sden = 0;
-            for (int j = 0; j < N; ++j) {
-                R ej = R(0);
+            R post = (Z > 0) ? w * Num<R>::rcp(Z) : R(0);
+            // the SAME row sums, bit for bit, as the fast path computed (same operands, same order), so that "bad"
+            // here is exactly the set of rows the fast path skipped
+            R p = Num<R>::exp2(ahprev);
+            R *lds = pbuf[wave];
+            lds[lane] = p;
+            __builtin_amdgcn_wave_barrier();
+            V2<R> a0 = {0, 0}, a1 = {0, 0};
 #pragma unroll
-                for (int q = 0; q < NP / 2; ++q) { ej = (2 * q == j) ? e2[q].x : ej; ej = (2 * q + 1 == j) ? e2[q].y : ej; }
-                sden = fma(ej, readlane(p, j), sden);
+            for (int j = 0; j < NP / 4; ++j) {
+                const V4<R> pvj = *reinterpret_cast<const V4<R> *>(lds + 4 * j);
+                a0 = fma2<R>(e2[2 * j], pvj.xy, a0);
+                a1 = fma2<R>(e2[2 * j + 1], pvj.zw, a1);
             }
-            bool bad = act && post != R(0) && !(fabs(Num<R>::log2(sden)) < Num<R>::lg_limit());
+            __builtin_amdgcn_wave_barrier();
+            const V2<R> a = a0 + a1;
+            const R sden = a.x + a.y;
+            const R gi_f = (Z > 0) ? gf * (w * Num<R>::rcp(Z)) : R(0);
+            const bool ok = fabs(Num<R>::log2(sden)) < Num<R>::lg_limit();
+            bool bad = act && gi_f != R(0) && !ok;
             if (__any(bad)) {
                 R lse = exact_lse_row<R>(trow, P.ts1, ahprev, N, act);
                 for (int j = 0; j < N; ++j) {
