@@ -527,3 +527,28 @@ def test_random_shapes_value_ranges_and_determinism_stress():
     spec.loader.exec_module(mod)
     for seed in (2, 4, 11):
         mod.run(seed, 60)
+
+
+@pytest.mark.parametrize("mode", ["input_size", "input_size_sqrt", "target_size", "target_size_sqrt"])
+def test_scale_modes(mode):
+    """wav2letter-style per-utterance scaling: loss_b * 1/len or 1/sqrt(len); checked against the oracle's
+    unreduced loss and the gradients obtained by feeding the same weights as upstream gradients."""
+    A = _asg()
+    tr, x, tg, il, tl = util.synth(40, 6, 11, 8, 5, True, torch.float64)
+    lens = (il if mode.startswith("input") else tl).double()
+    w = 1.0 / (lens.sqrt() if mode.endswith("sqrt") else lens)
+    o = orc.asg_loss(x.numpy(), tg.numpy(), tr.numpy(), il.numpy(), tl.numpy(), "none", grad_out=w.numpy())
+    for red in ("mean", "sum", "none"):
+        m = A.ASGLoss(11, reduction=red, scale_mode=mode).to(DEV).double()
+        with torch.no_grad():
+            m.transition.copy_(tr)
+        xd = x.to(DEV).requires_grad_(True)
+        loss = m(xd, tg.to(DEV), il.to(DEV), tl.to(DEV))
+        ref = o["loss"] * w.numpy()
+        k = 1.0 / 6 if red == "mean" else 1.0
+        util.assert_close(loss.detach().cpu().numpy(), ref.mean() if red == "mean" else (ref.sum() if red == "sum" else ref), 1e-9, mode)
+        loss.sum().backward()
+        util.assert_close(xd.grad.cpu().numpy(), o["grad_inputs"] * k, 1e-9, mode + "/gi")
+        util.assert_close(m.transition.grad.cpu().numpy(), o["grad_transition"] * k, 1e-9, mode + "/gt")
+    with pytest.raises(ValueError):
+        A.ASGLoss(4, scale_mode="bogus")

@@ -425,11 +425,21 @@ class ASGLoss(nn.Module):
       'streams'            full-lattice and force-aligned passes on two HIP streams with event fork/join
       'serial'             two launches on the caller's stream
     gpu_no_stream_impl=True selects the reference's "serial" route: separate FAC and FCC Functions.
+    scale_mode (extra, optional): the wav2letter criterion scaling that the reference dropped
+      (README.md:93-94, vestiges at test_asg.py:169-173): each utterance's loss is multiplied by 1/len or 1/sqrt(len)
+      of its input or target before the reduction -- 'none' (default, = the reference), 'input_size',
+      'input_size_sqrt', 'target_size', 'target_size_sqrt'.
+    Batch-major activations need no copy: pass `acts.transpose(0, 1)` ([B,T,N] -> a [T,B,N] view); the kernels take
+    arbitrary strides.
     """
+    SCALE_MODES = ('none', 'input_size', 'input_size_sqrt', 'target_size', 'target_size_sqrt')
 
     def __init__(self, num_labels, reduction='mean', forward_only=False, gpu_no_stream_impl=False,
-                 launch_mode='single'):
+                 launch_mode='single', scale_mode='none'):
         super().__init__()
+        if scale_mode not in self.SCALE_MODES:
+            raise ValueError("scale_mode must be one of %s" % (self.SCALE_MODES,))
+        self.scale_mode = scale_mode
         self.num_labels = num_labels
         self.reduction = reduction  # mean, sum, none
         self.transition = nn.Parameter(torch.zeros(num_labels, num_labels))
@@ -458,6 +468,11 @@ class ASGLoss(nn.Module):
             targets = targets[:, :batch_output_len]
             target_lengths = torch.clamp(target_lengths, max=batch_output_len)
 
+        scaled = self.scale_mode != 'none'
+        if scaled:
+            lens = (input_lengths if self.scale_mode.startswith('input') else target_lengths)
+            lens = lens.to(device=inputs.device, dtype=inputs.dtype).clamp(min=1)
+            weights = 1.0 / (lens.sqrt() if self.scale_mode.endswith('sqrt') else lens)
         if self.gpu_no_stream_impl:
             # the reference's "serial" route (asg.py:124-128)
             fac_result = FAC.apply(self.transition, inputs, targets, input_lengths, target_lengths)
@@ -468,12 +483,17 @@ class ASGLoss(nn.Module):
                                                  self._flags())
         elif self.reduction in ('sum', 'mean', 'none'):
             # fused training route: the reference's ASGGPUFast + (full - aligned) + reduction (asg.py:133-142)
-            return ASGLossFunction.apply(inputs, self.transition, targets, input_lengths, target_lengths,
-                                         self.reduction, self._flags())
+            if not scaled:
+                return ASGLossFunction.apply(inputs, self.transition, targets, input_lengths, target_lengths,
+                                             self.reduction, self._flags())
+            result = ASGLossFunction.apply(inputs, self.transition, targets, input_lengths, target_lengths,
+                                           'none', self._flags())
         else:
             full_scores, aligned_scores = ASGGPUFast.apply(inputs, self.transition, targets, input_lengths,
                                                            target_lengths, self._flags())
             result = full_scores - aligned_scores
+        if scaled:
+            result = result * weights
         if self.reduction == 'sum':
             return result.sum()
         elif self.reduction == 'mean':
