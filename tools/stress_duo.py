@@ -9,12 +9,16 @@ from oracle import asg_oracle as orc
 dev = "cuda:0"
 
 
-def run(seed=0, ncase=150, dtype=torch.float32):
+def run(seed=0, ncase=150, dtype=torch.float32, generic=False):
     rng = np.random.default_rng(seed)
     t0 = time.time(); worst = 0.0
     for case in range(ncase):
         T = int(rng.choice([1, 2, 3, 15, 16, 17, 18, 31, 32, 33, 34, 47, 48, 49, 64, 65, 100, 257, 600, 1500]))
         B = int(rng.integers(1, 13)); N = int(rng.integers(1, 64)); L = int(rng.integers(1, min(T, 40) + 1))
+        if generic:       # large-alphabet / long-target kernels (N > 64 and/or S > 64)
+            T = min(T, 257); B = min(B, 4)
+            N = int(rng.integers(65, 260)) if rng.random() < 0.7 else N
+            L = int(rng.integers(1, min(T, 100) + 1))
         scale = float(rng.choice([0.1, 1.0, 5.0, 30.0]))
         g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
         tr = (torch.rand(N, N, generator=g) - 0.5) * float(rng.choice([1.0, 8.0, 40.0]))
@@ -51,5 +55,6 @@ def run(seed=0, ncase=150, dtype=torch.float32):
 
 if __name__ == "__main__":
     n, w, dt = run(int(sys.argv[1]) if len(sys.argv) > 1 else 0, int(sys.argv[2]) if len(sys.argv) > 2 else 150,
-                   torch.float64 if (len(sys.argv) > 3 and sys.argv[3] == "f64") else torch.float32)
+                   torch.float64 if (len(sys.argv) > 3 and "f64" in sys.argv[3]) else torch.float32,
+                   generic=(len(sys.argv) > 3 and "generic" in sys.argv[3]))
     print("stress ok: %d cases, worst scaled error %.2e, %.0f s" % (n, w, dt))
