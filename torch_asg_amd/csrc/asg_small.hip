@@ -1526,25 +1526,26 @@ __global__ void __launch_bounds__(256) bwd_small_kernel(Problem P, State W, BwdA
 }
 
 // Sum G partial tiles in a fixed order -> deterministic grad_transition.
-// block = 256 threads = 32 elements x 8 tile-groups; thread (e, grp) sums tiles grp, grp+8, ... with 16
-// independent accumulators (16 loads in flight: the kernel is pure L2 latency), then a fixed-order LDS
-// combine over the 8 groups.
+// block = 1024 threads = 32 elements x 32 tile-groups; thread (e, grp) sums tiles grp, grp+32, ... with 16
+// independent accumulators (16 loads in flight: the kernel is pure L2 latency, so the 512 tiles of cfg 3 take ONE
+// round of loads per thread), then a fixed-order LDS combine over the 32 groups.
+constexpr int kRedGroups = 32;
 template <typename R>
-__global__ void __launch_bounds__(256) reduce_tiles_kernel(const R *tiles, int G, int n, R *out) {
-    __shared__ R part[8][32];
+__global__ void __launch_bounds__(1024) reduce_tiles_kernel(const R *tiles, int G, int n, R *out) {
+    __shared__ R part[kRedGroups][32];
     const int e = threadIdx.x & 31, grp = threadIdx.x >> 5;
     const int k = min(blockIdx.x * 32 + e, n - 1);
     R acc[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0;
     int g = grp;
-    for (; g + 8 * 15 < G; g += 8 * 16) {
+    for (; g + kRedGroups * 15 < G; g += kRedGroups * 16) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) acc[q] += tiles[(int64_t) (g + 8 * q) * n + k];
+        for (int q = 0; q < 16; ++q) acc[q] += tiles[(int64_t) (g + kRedGroups * q) * n + k];
     }
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-        int gg = g + 8 * q;
+        int gg = g + kRedGroups * q;
         R v = tiles[(int64_t) min(gg, G - 1) * n + k];        // unconditional load, masked add
         acc[q] += (gg < G) ? v : R(0);
     }
@@ -1556,7 +1557,7 @@ __global__ void __launch_bounds__(256) reduce_tiles_kernel(const R *tiles, int G
     if (grp == 0 && blockIdx.x * 32 + e < n) {
         R t = part[0][e];
 #pragma unroll
-        for (int q = 1; q < 8; ++q) t += part[q][e];
+        for (int q = 1; q < kRedGroups; ++q) t += part[q][e];
         out[k] = t;
     }
 }
@@ -1633,7 +1634,7 @@ hipError_t launch_bwd_np(const Problem &P, const State &W, const BwdArgs &A, int
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int n = P.N * P.N, G = P.B * A.nchunks;
-    hipLaunchKernelGGL((reduce_tiles_kernel<R>), dim3((n + 31) / 32), dim3(256), 0, st,
+    hipLaunchKernelGGL((reduce_tiles_kernel<R>), dim3((n + 31) / 32), dim3(1024), 0, st,
                        (const R *) A.scratch, G, n, (R *) A.grad_transition);
     return hipGetLastError();
 }
