@@ -468,7 +468,8 @@ def _path_score(x, tr, tg, pos):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 @pytest.mark.parametrize("T,B,N,L,variable", [(6, 2, 7, 5, True), (23, 5, 9, 7, True), (150, 16, 30, 20, True),
-                                              (400, 64, 40, 30, False), (70, 3, 64, 64, True), (1, 2, 4, 1, False)])
+                                              (400, 64, 40, 30, False), (70, 3, 64, 64, True), (1, 2, 4, 1, False),
+                                              (150, 3, 30, 100, True), (300, 2, 12, 300, False), (1030, 1, 5, 1000, True)])
 def test_viterbi_vs_oracle(T, B, N, L, variable, dtype):
     A = _asg()
     tr, x, tg, il, tl = util.synth(T, B, N, L, 7, variable, dtype)
@@ -514,8 +515,8 @@ def test_viterbi_edge_cases_and_module_method():
     so, po = orc.viterbi(xt.numpy(), tg2[:, :6].numpy(), np.zeros((4, 4)), None, np.array([6, 6, 6]))
     assert np.array_equal(sc2.cpu().numpy(), so) and np.array_equal(pos2.cpu().numpy(), po)
     with pytest.raises(RuntimeError):
-        A.viterbi_align(torch.randn(80, 1, 4, device=DEV), torch.zeros(1, 70, dtype=torch.long, device=DEV),
-                        torch.zeros(4, 4, device=DEV))        # S > 64: not in this build, fails loudly
+        A.viterbi_align(torch.randn(1100, 1, 4, device=DEV), torch.zeros(1, 1025, dtype=torch.long, device=DEV),
+                        torch.zeros(4, 4, device=DEV))        # S > 1024: not supported, fails loudly
 
 
 def test_random_shapes_value_ranges_and_determinism_stress():

@@ -347,7 +347,7 @@ int asg_forward_only(asg_ctx *ctx, const asg_problem *p, void *state, size_t sta
 
 size_t asg_viterbi_work_bytes(const asg_problem *p) {
     if (check_problem(p, true) != ASG_OK) return 0;
-    return (size_t) p->B * (size_t) p->T * sizeof(unsigned long long);
+    return (size_t) p->B * (size_t) p->T * (size_t) ((p->S + 63) / 64) * sizeof(unsigned long long);
 }
 
 int asg_viterbi(asg_ctx *ctx, const asg_problem *p, void *work, size_t work_bytes, void *scores, int64_t *path,
@@ -356,7 +356,6 @@ int asg_viterbi(asg_ctx *ctx, const asg_problem *p, void *work, size_t work_byte
     int rc = check_problem(p, true);
     if (rc) return rc;
     if (!work || !scores || !path) return ASG_ERR_INVALID;
-    if (!small_aligned(p->S)) return ASG_ERR_UNSUPPORTED;          // one wavefront per utterance: S <= 64
     if (work_bytes < asg_viterbi_work_bytes(p)) return ASG_ERR_WORKSPACE;
     const Problem P = to_problem(p);
     return hip_status(ASG_DISPATCH(p, launch_viterbi_small<float>(P, work, scores, path, (hipStream_t) stream),

@@ -1,4 +1,5 @@
-// torch_asg_amd/csrc/asg_viterbi.hip -- best-path (Viterbi) force alignment on gfx950, S <= 64 target positions.
+// torch_asg_amd/csrc/asg_viterbi.hip -- best-path (Viterbi) force alignment on gfx950 (S <= 64: one wavefront per
+// utterance; S <= 1024: one workgroup per utterance).
 //
 // The force-aligned lattice of /root/reference/torch_asg/native/force_aligned_lattice.cpp:84-111 in the tropical
 // semiring (max instead of log-sum-exp: doc/tech_report.tex:84-88; a TODO in the reference's README.md:33 -- the
@@ -100,12 +101,114 @@ __global__ void __launch_bounds__(64) viterbi_small_kernel(Problem P, unsigned l
     }
 }
 
+// S up to 1024: one workgroup per utterance, thread s = target position, 64 positions per wavefront.  The left
+// neighbour crosses wavefront boundaries through a double-buffered LDS line (one __syncthreads per frame); every
+// wavefront stores its own 64 back-pointer bits per frame (masks[b][t][wave]).  The backtrace runs in wavefront 0, 64
+// frames at a time: within 64 frames the position moves by at most 64, so the two mask words a frame can need are
+// loaded up front by its lane and the walk itself touches no memory.
+template <typename R>
+__global__ void __launch_bounds__(1024) viterbi_wide_kernel(Problem P, unsigned long long *masks, R *scores, long long *path) {
+    __shared__ R line[2][1024 + 1];
+    __shared__ R best_sh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    const int T = P.T, S = P.S;
+    const int nw = (S + 63) / 64;
+    const R NINF = Num<R>::ninf();
+    int len = P.in_len ? (int) (P.in_len[b] < 0 ? 0 : (P.in_len[b] > T ? T : P.in_len[b])) : T;
+    int ol = P.tg_len ? (int) (P.tg_len[b] < 0 ? 0 : (P.tg_len[b] > S ? S : P.tg_len[b])) : S;
+    long long *pb = path + (long long) b * T;
+    unsigned long long *mb = masks + (long long) b * T * nw;
+    for (int t = tid; t < T; t += blockDim.x) pb[t] = -1;
+    const bool feasible = len >= 1 && ol >= 1 && ol <= len;
+    if (!feasible) {
+        if (tid == 0) scores[b] = NINF;
+        return;
+    }
+    const bool act = tid < ol;
+    const int sc = act ? tid : 0, sp = (act && tid >= 1) ? tid - 1 : 0;
+    const int64_t *tg = P.targets + (int64_t) b * P.gs0;
+    const int64_t cur64 = tg[(int64_t) sc * P.gs1], prv64 = tg[(int64_t) sp * P.gs1];
+    const int cur = (int) (cur64 < 0 ? 0 : (cur64 > P.N - 1 ? P.N - 1 : cur64));
+    const int prv = (int) (prv64 < 0 ? 0 : (prv64 > P.N - 1 ? P.N - 1 : prv64));
+    const R *tr = (const R *) P.transition;
+    const R H = tr[(long long) cur * P.ts0 + (long long) cur * P.ts1];
+    const R Dp = (act && tid >= 1) ? tr[(long long) cur * P.ts0 + (long long) prv * P.ts1] : NINF;
+    const R *in = (const R *) P.inputs + (long long) b * P.is1 + (long long) cur * P.is2;
+
+    R v = (tid == 0) ? in[0] : NINF;
+    if (tid == 0) { line[0][0] = NINF; line[1][0] = NINF; }     // the neighbour of position 0
+    constexpr int PF = 8;
+    R ring[PF];
+#pragma unroll
+    for (int k = 0; k < PF; ++k) ring[k] = in[(long long) min(1 + k, len - 1) * P.is0];
+    for (int t0 = 1; t0 < len; t0 += PF) {
+        R nxt[PF];
+#pragma unroll
+        for (int k = 0; k < PF; ++k) nxt[k] = in[(long long) min(t0 + PF + k, len - 1) * P.is0];
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            const int t = t0 + k;
+            if (t < len) {                                       // uniform
+                R *ln = line[t & 1];
+                ln[tid + 1] = v;
+                __syncthreads();
+                const R stay = v + H;
+                const R come = ln[tid] + Dp;
+                const bool take = come > stay;
+                const unsigned long long m = __ballot(take);
+                const R em = act ? ring[k] : NINF;
+                v = em + (take ? come : stay);
+                if (lane == 0) mb[(long long) t * nw + wave] = m;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PF; ++k) ring[k] = nxt[k];
+    }
+    if (tid == ol - 1) best_sh = v;
+    __threadfence_block();
+    __syncthreads();                      // also orders the mask stores of all wavefronts before the loads below
+    const R best = best_sh;
+    if (!(best > NINF) || best != best) {
+        if (tid == 0) scores[b] = NINF;
+        return;
+    }
+    if (tid == 0) scores[b] = best;
+    if (wave != 0) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int s = ol - 1;
+    for (int c0 = ((len - 1) / 64) * 64; c0 >= 0; c0 -= 64) {
+        const int t_mine = c0 + lane;
+        const int w_hi = s >> 6, w_lo = max(w_hi - 1, 0);
+        unsigned long long mh = 0, ml = 0;
+        if (t_mine >= 1 && t_mine < len) {
+            mh = __builtin_nontemporal_load(mb + (long long) t_mine * nw + w_hi);
+            ml = __builtin_nontemporal_load(mb + (long long) t_mine * nw + w_lo);
+        }
+        int mine = -1;
+        const int top = min(63, len - 1 - c0);
+        for (int k = top; k >= 0; --k) {
+            mine = (lane == k) ? s : mine;
+            const bool hi = (s >> 6) == w_hi;
+            const unsigned lo32 = __builtin_amdgcn_readlane(hi ? (unsigned) mh : (unsigned) ml, k);
+            const unsigned hi32 = __builtin_amdgcn_readlane(hi ? (unsigned) (mh >> 32) : (unsigned) (ml >> 32), k);
+            const unsigned long long m = ((unsigned long long) hi32 << 32) | lo32;
+            s -= (int) ((m >> (s & 63)) & 1ull);
+        }
+        if (t_mine < len) pb[t_mine] = mine;
+    }
+}
+
 }  // namespace
 
 template <typename R>
 hipError_t launch_viterbi_small(const Problem &P, void *work, void *scores, void *path, hipStream_t stream) {
-    hipLaunchKernelGGL((viterbi_small_kernel<R>), dim3(P.B), dim3(64), 0, stream, P, (unsigned long long *) work,
-                       (R *) scores, (long long *) path);
+    if (P.S <= 64)
+        hipLaunchKernelGGL((viterbi_small_kernel<R>), dim3(P.B), dim3(64), 0, stream, P, (unsigned long long *) work,
+                           (R *) scores, (long long *) path);
+    else
+        hipLaunchKernelGGL((viterbi_wide_kernel<R>), dim3(P.B), dim3((P.S + 63) / 64 * 64), 0, stream, P,
+                           (unsigned long long *) work, (R *) scores, (long long *) path);
     return hipGetLastError();
 }
 template hipError_t launch_viterbi_small<float>(const Problem &, void *, void *, void *, hipStream_t);
