@@ -1310,6 +1310,27 @@ __global__ void __launch_bounds__(256) bwd_small_kernel(Problem P, State W, BwdA
     const bool act = lane < N, sl = lane < S, sact = lane < ol;
     const int lc = act ? lane : 0, ls_ = sl ? lane : 0;
 
+    const R *ahp = (const R *) W.ah + (int64_t) b * T * N + lc;
+    const R *bhp = (const R *) W.bh + (int64_t) b * T * N + lc;
+    // state rows through buffer loads: lane offset in a VGPR, frame offset in an SGPR (no per-lane 64-bit address math)
+    __amdgpu_buffer_rsrc_t r_ah = make_rsrc((R *) W.ah + (int64_t) b * T * N, (unsigned) T * (unsigned) N * (unsigned) sizeof(R));
+    __amdgpu_buffer_rsrc_t r_bh = make_rsrc((R *) W.bh + (int64_t) b * T * N, (unsigned) T * (unsigned) N * (unsigned) sizeof(R));
+    __amdgpu_buffer_rsrc_t r_ab = make_rsrc((R *) W.ab + (int64_t) b * T * S, (unsigned) T * (unsigned) S * (unsigned) sizeof(R));
+    __amdgpu_buffer_rsrc_t r_bb = make_rsrc((R *) W.bb + (int64_t) b * T * S, (unsigned) T * (unsigned) S * (unsigned) sizeof(R));
+    const unsigned vN = (unsigned) lc * (unsigned) sizeof(R), vS = (unsigned) ls_ * (unsigned) sizeof(R);
+    const unsigned rbN = (unsigned) N * (unsigned) sizeof(R), rbS = (unsigned) S * (unsigned) sizeof(R);
+    const int t0 = chunk * A.chunk;
+    const int t1 = min(T, t0 + A.chunk);
+    // software prefetch: the six state values of the NEXT frame are loaded before the current one is processed; the
+    // first frame's are issued before anything else so that their latency hides under the rest of the prologue
+    R n_ah, n_bh, n_ahp, n_ab, n_bb, n_abp;
+    {
+        const int tq = min(t0 + wave, T - 1), tqp = tq >= 1 ? tq - 1 : 0;
+        n_ah = buf_load<R>(r_ah, vN, (unsigned) tq * rbN); n_bh = buf_load<R>(r_bh, vN, (unsigned) tq * rbN);
+        n_ahp = buf_load<R>(r_ah, vN, (unsigned) tqp * rbN);
+        n_ab = buf_load<R>(r_ab, vS, (unsigned) tq * rbS); n_bb = buf_load<R>(r_bb, vS, (unsigned) tq * rbS);
+        n_abp = buf_load<R>(r_ab, vS, (unsigned) tqp * rbS);
+    }
     // ---- prologue: everything below is ONE round of independent loads
     const R g0 = A.grad_full ? (R) ((double) ((const R *) A.grad_full)[(int64_t) b * A.gstride] * A.gscale) : R(0);
     const R gf = do_full ? g0 : R(0);
@@ -1348,32 +1369,12 @@ __global__ void __launch_bounds__(256) bwd_small_kernel(Problem P, State W, BwdA
     R accH = 0, accD = 0;    // unscaled edge posteriors: stay on s ; arrive at s from s-1
     bool any_bad = false;
 
-    const R *ahp = (const R *) W.ah + (int64_t) b * T * N + lc;
-    const R *bhp = (const R *) W.bh + (int64_t) b * T * N + lc;
-    // state rows through buffer loads: lane offset in a VGPR, frame offset in an SGPR (no per-lane 64-bit address math)
-    __amdgpu_buffer_rsrc_t r_ah = make_rsrc((R *) W.ah + (int64_t) b * T * N, (unsigned) T * (unsigned) N * (unsigned) sizeof(R));
-    __amdgpu_buffer_rsrc_t r_bh = make_rsrc((R *) W.bh + (int64_t) b * T * N, (unsigned) T * (unsigned) N * (unsigned) sizeof(R));
-    __amdgpu_buffer_rsrc_t r_ab = make_rsrc((R *) W.ab + (int64_t) b * T * S, (unsigned) T * (unsigned) S * (unsigned) sizeof(R));
-    __amdgpu_buffer_rsrc_t r_bb = make_rsrc((R *) W.bb + (int64_t) b * T * S, (unsigned) T * (unsigned) S * (unsigned) sizeof(R));
-    const unsigned vN = (unsigned) lc * (unsigned) sizeof(R), vS = (unsigned) ls_ * (unsigned) sizeof(R);
-    const unsigned rbN = (unsigned) N * (unsigned) sizeof(R), rbS = (unsigned) S * (unsigned) sizeof(R);
     __amdgpu_buffer_rsrc_t rs_g = make_rsrc((R *) A.grad_inputs + (int64_t) b * N,
                                             (unsigned) ((int64_t) (T - 1) * P.B * N + N) * (unsigned) sizeof(R));
     const unsigned voff = act ? (unsigned) lane * sizeof(R) : kOobOffset;
     const unsigned grow_bytes = (unsigned) P.B * N * sizeof(R);
     __syncthreads();
 
-    const int t0 = chunk * A.chunk;
-    const int t1 = min(T, t0 + A.chunk);
-    // software prefetch: the six state values of the NEXT frame are loaded before the current one is processed
-    R n_ah, n_bh, n_ahp, n_ab, n_bb, n_abp;
-    {
-        const int tq = min(t0 + wave, T - 1), tqp = tq >= 1 ? tq - 1 : 0;
-        n_ah = buf_load<R>(r_ah, vN, (unsigned) tq * rbN); n_bh = buf_load<R>(r_bh, vN, (unsigned) tq * rbN);
-        n_ahp = buf_load<R>(r_ah, vN, (unsigned) tqp * rbN);
-        n_ab = buf_load<R>(r_ab, vS, (unsigned) tq * rbS); n_bb = buf_load<R>(r_bb, vS, (unsigned) tq * rbS);
-        n_abp = buf_load<R>(r_ab, vS, (unsigned) tqp * rbS);
-    }
     for (int t = t0 + wave; t < t1; t += 4) {
         R gi = 0;
         const R c_ah = n_ah, c_bh = n_bh, c_ahp = n_ahp, c_ab = n_ab, c_bb = n_bb, c_abp = n_abp;
