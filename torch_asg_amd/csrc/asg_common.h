@@ -216,11 +216,19 @@ template <> __device__ __forceinline__ double buf_load<double>(__amdgpu_buffer_r
 // type of the deterministic LDS adds.  fp32 uses 32-bit words with a 2^-30 quantum (v_cvt_u32_f32 / ds_add_u32; the
 // 64-bit route costs ~15 double-precision instructions per frame), fp64 keeps 64-bit words with a 2^-44 quantum.
 template <typename R> struct FrameFix;
+#ifdef ASG_OLD_FIX
+template <> struct FrameFix<float> {
+    typedef unsigned long long T;
+    static __device__ __forceinline__ T to(float x) { return (T) __double2ll_rn((double) x * 1099511627776.0); }
+    static __device__ __forceinline__ float from(T v) { return (float) ((double) (long long) v * (1.0 / 1099511627776.0)); }
+};
+#else
 template <> struct FrameFix<float> {
     typedef unsigned T;
     static __device__ __forceinline__ T to(float x) { return (T) __builtin_rintf(x * 1073741824.0f); }
     static __device__ __forceinline__ float from(T v) { return (float) v * (1.0f / 1073741824.0f); }
 };
+#endif
 template <> struct FrameFix<double> {
     typedef unsigned long long T;
     static __device__ __forceinline__ T to(double x) { return (T) __double2ll_rn(x * Num<double>::kFix); }

@@ -36,6 +36,8 @@ namespace asg {
 namespace {
 
 constexpr int kPF = 16;     // emission prefetch depth (frames), register ring; also the unroll of one block
+constexpr int kAliRenorm = 16;  // aligned lattice (log domain): frame max folded into the offset once per block (a
+                                // finer grain was measured: no accuracy gain, the error sits in off-peak positions)
 constexpr int kRenorm = 4;  // full lattice: subtract the frame max every kRenorm steps (must divide kPF)
 
 
@@ -668,24 +670,36 @@ __device__ __forceinline__ AlignedSetup<R> aligned_setup(const Problem &P, int b
 
 // Common offset of a block's emissions (log2 units): taken out of the recursion and into the double offset C, so the
 // log-domain state stays O(block spread) instead of growing by the emissions' absolute level every frame (fp32
-// resolution at |x| ~ 1000 is 1e-4: emissions with a large common offset used to cost exactly that).
+// resolution at |x| ~ 1000 is 1e-4: emissions with a large common offset used to cost exactly that).  The offset is
+// the MEAN over the block's frames and the utterance's target positions -- centring on the maximum would push
+// zero-mean emissions down by ~3 per frame and cost precision there; the maximum is only the fallback when the mean
+// is not finite (-inf emissions).
 template <typename R>
-__device__ __forceinline__ R aligned_block_scale(const R (&cur)[kPF], int nsteps, bool act) {
-    R zl = Num<R>::ninf();
+__device__ __forceinline__ R aligned_block_scale(const R (&cur)[kPF], int nsteps, bool act, int ol) {
+    R zs = 0, zl = Num<R>::ninf();
 #pragma unroll
-    for (int k = 0; k < kPF; ++k) zl = (k < nsteps && act) ? fmax(zl, cur[k]) : zl;
-    const R z = wave_allmax(zl) * Num<R>::log2e();
-    return (z > R(-1e29) && z < R(1e29)) ? z : R(0);
+    for (int k = 0; k < kPF; ++k) {
+        zs += (k < nsteps && act) ? cur[k] : R(0);
+        zl = (k < nsteps && act) ? fmax(zl, cur[k]) : zl;
+    }
+    const R zmean = wave_allsum(zs) / (R) (nsteps * (ol > 0 ? ol : 1)) * Num<R>::log2e();
+    if (zmean > R(-1e29) && zmean < R(1e29)) return zmean;
+    const R zmax = wave_allmax(zl) * Num<R>::log2e();
+    return (zmax > R(-1e29) && zmax < R(1e29)) ? zmax : R(0);
 }
 
 template <typename R, bool STORE, bool GUARD>
 __device__ __forceinline__ void aligned_alpha_block(const R (&cur)[kPF], int nsteps, unsigned soff0, unsigned row_bytes,
                                                     const AlignedSetup<R> &A, R ebias, __amdgpu_buffer_rsrc_t rs,
-                                                    unsigned voff, R &ab) {
+                                                    unsigned voff, R &ab, double &C) {
     const R L2E = Num<R>::log2e(), LZ = Num<R>::logzero();
 #pragma unroll
     for (int k = 0; k < kPF; ++k) {
         if (!GUARD || k < nsteps) {
+            if (k > 0 && (k % kAliRenorm) == 0) {       // keep |state| small: fp32 rounding scales with it
+                const R m = wave_allmax(ab);
+                if (m > R(-1e29)) { ab = fmax(ab - m, LZ); C += (double) m; }
+            }
             R em = fma(cur[k], L2E, ebias);
             R stay = ab + A.H2;
             R come = prev_lane_or_zero<R>(ab) + A.Dprev;      // v_add_f32_dpp wave_shr:1; lane 0: 0 + logzero
@@ -728,18 +742,18 @@ __device__ void aligned_alpha_chain(const Problem &P, const State &W, const FwdO
             // renormalise once per block: the log domain is offset-free, this only bounds magnitudes
             R m = wave_allmax(ab);
             if (m > R(-1e29)) { ab = fmax(ab - m, LZ); C += (double) m; }
-            const R z = aligned_block_scale<R>(cur, kPF, A.act);
+            const R z = aligned_block_scale<R>(cur, kPF, A.act, A.ol);
             C += (double) z * kPF;
             aligned_alpha_block<R, STORE, false>(cur, kPF, (unsigned) (1 + done) * row_bytes, row_bytes, A, A.ebias - z, rs,
-                                                 voff, ab);
+                                                 voff, ab, C);
 #pragma unroll
             for (int k = 0; k < kPF; ++k) cur[k] = nxt[k];
         }
         if (done < nst) {
-            const R z = aligned_block_scale<R>(cur, nst - done, A.act);
+            const R z = aligned_block_scale<R>(cur, nst - done, A.act, A.ol);
             C += (double) z * (nst - done);
             aligned_alpha_block<R, STORE, true>(cur, nst - done, (unsigned) (1 + done) * row_bytes, row_bytes, A,
-                                                A.ebias - z, rs, voff, ab);
+                                                A.ebias - z, rs, voff, ab, C);
         }
     }
     if (O.aligned_scores_alpha) {
@@ -751,11 +765,15 @@ __device__ void aligned_alpha_chain(const Problem &P, const State &W, const FwdO
 template <typename R, bool STORE, bool GUARD>
 __device__ __forceinline__ void aligned_beta_block(const R (&cur)[kPF], int nsteps, unsigned soff0, unsigned row_bytes,
                                                    const AlignedSetup<R> &A, R ebias, __amdgpu_buffer_rsrc_t rs,
-                                                   unsigned voff, R &bb) {
+                                                   unsigned voff, R &bb, double &C) {
     const R L2E = Num<R>::log2e(), LZ = Num<R>::logzero();
 #pragma unroll
     for (int k = 0; k < kPF; ++k) {
         if (!GUARD || k < nsteps) {
+            if (k > 0 && (k % kAliRenorm) == 0) {
+                const R m = wave_allmax(bb);
+                if (m > R(-1e29)) { bb = fmax(bb - m, LZ); C += (double) m; }
+            }
             R y = fmax(fma(cur[k], L2E, ebias) + bb, LZ);
             R stay = y + A.H2;
             R go = next_lane_or_zero<R>(y) + A.Dnext;          // v_add_f32_dpp wave_shl:1
@@ -792,19 +810,19 @@ __device__ void aligned_beta_chain(const Problem &P, const State &W, const FwdOu
         for (int k = 0; k < kPF; ++k) nxt[k] = A.in[(int64_t) max(len - 1 - (done + kPF + k), 0) * P.is0];
         R m = wave_allmax(bb);
         if (m > R(-1e29)) { bb = fmax(bb - m, LZ); C += (double) m; }
-        const R z = aligned_block_scale<R>(cur, kPF, A.act);
+        const R z = aligned_block_scale<R>(cur, kPF, A.act, A.ol);
         C += (double) z * kPF;
         aligned_beta_block<R, STORE, false>(cur, kPF, (unsigned) (len - 2 - done) * row_bytes, row_bytes, A, A.ebias - z, rs,
-                                            voff, bb);
+                                            voff, bb, C);
 #pragma unroll
         for (int k = 0; k < kPF; ++k) cur[k] = nxt[k];
     }
     R last_raw = cur[0];
     if (done < nst) {
-        const R z = aligned_block_scale<R>(cur, nst - done, A.act);
+        const R z = aligned_block_scale<R>(cur, nst - done, A.act, A.ol);
         C += (double) z * (nst - done);
         aligned_beta_block<R, STORE, true>(cur, nst - done, (unsigned) (len - 2 - done) * row_bytes, row_bytes, A,
-                                           A.ebias - z, rs, voff, bb);
+                                           A.ebias - z, rs, voff, bb, C);
         const int r = nst - done;
 #pragma unroll
         for (int k = 1; k < kPF; ++k) last_raw = (k == r) ? cur[k] : last_raw;
