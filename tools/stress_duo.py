@@ -42,11 +42,15 @@ def run(seed=0, ncase=150, dtype=torch.float32, generic=False):
             ref = o[k]; fin = np.isfinite(ref)
             assert np.array_equal(np.isfinite(a), fin), ("finiteness", k, case, T, B, N, L)
             den = max(1.0, float(np.abs(ref[fin]).max())) if fin.any() else 1.0
+            if k == "loss":                 # full - aligned, both rounded to fp32 at the API: scale by the scores
+                fs = np.abs(o["full_scores"]); fs = fs[np.isfinite(fs)]
+                den = max(den, 1e-3 * float(fs.max())) if fs.size else den
+            if k == "grad_transition":      # a difference of two O(sum of lengths) lattice sums: scale by the components
+                den = max(den, 0.01 * float(il.sum()))
             err = float(np.abs(a[fin] - ref[fin]).max()) / den if fin.any() else 0.0
             worst = max(worst, err)
-            # emissions with a 30-nat spread put fp32 itself at ~1e-3 (the reference's fp32 path is off by > 1e-2 there)
-            # and at T >= 1000 the aligned lattice's log-domain alpha + beta (|values| ~ 1e3) costs ~1e-4 by cancellation
-            tol = 2e-3 if scale > 5.0 else (1e-3 if T >= 1000 else 1e-4)
+            # emissions with a 30-nat spread put fp32 itself near 1e-4 (the reference's fp32 path is off by > 1e-2 there)
+            tol = 1e-4 if scale <= 5.0 else 1e-3
             if dtype == torch.float64: tol = 1e-9
             assert err <= tol, ("mismatch", k, err, case, T, B, N, L, scale)
     return ncase, worst, time.time() - t0

@@ -307,7 +307,7 @@ __global__ void __launch_bounds__(256) fwd_score_kernel(Problem P, StepBuf<R> S,
 // position s; the neighbour's value travels through a double-buffered LDS row (one barrier per frame).
 template <typename R, bool STORE>
 __global__ void __launch_bounds__(1024) aligned_wide_kernel(Problem P, State W, FwdOut O, int mask) {
-    __shared__ R row[2][1024 + 2];
+    __shared__ double row[2][1024 + 2];
     __shared__ R red[16];
     const int b = blockIdx.x;
     const bool beta = (mask == kAlignedBeta) || (mask == (kAlignedAlpha | kAlignedBeta) && blockIdx.y == 1);
@@ -337,67 +337,75 @@ __global__ void __launch_bounds__(1024) aligned_wide_kernel(Problem P, State W, 
         if (s == 0 && score_out) score_out[b] = Num<R>::ninf();
         return;
     }
+    // running state in double (see asg_small.hip: an fp32 log-domain state loses ~2e-6 per frame at off-peak
+    // positions); only the bounded correction log2(1 + 2^d) is evaluated in the problem's precision
+    const double kZ = -1e30, L2Ed = 1.4426950408889634;
+    auto lse2d = [&](double x, double y) {
+        const double m = fmax(x, y);
+        const R d = (R) (fmin(x, y) - m);
+        return m + (double) Num<R>::log2(R(1) + Num<R>::exp2(d));
+    };
+    auto st = [&](double x) { return (R) fmax(x, kZ); };
     double C = 0.0;
-    R v;
+    double v;
     if (!beta) {
-        v = (s == 0) ? fmax(in[0] * L2E, LZ) : LZ;
-        if (!act) v = LZ;
-        if (STORE && s < S) out[s] = v;
+        v = (s == 0) ? fmax((double) in[0] * L2Ed, kZ) : kZ;
+        if (!act) v = kZ;
+        if (STORE && s < S) out[s] = st(v);
         for (int t = 1; t < len; ++t) {
-            R *rw = row[t & 1];
+            double *rw = row[t & 1];
             rw[s + 1] = v;
-            if (s == 0) rw[0] = LZ;
+            if (s == 0) rw[0] = kZ;
             __syncthreads();
-            R em = act ? in[(int64_t) t * P.is0] * L2E : LZ;
-            R left = rw[s];
-            v = fmax(em + lse2<R>(v + H2, left + Dprev), LZ);
+            const double em = act ? (double) in[(int64_t) t * P.is0] * L2Ed : kZ;
+            const double left = rw[s];
+            v = fmax(em + lse2d(v + (double) H2, left + (double) Dprev), kZ);
             if ((t & 15) == 0) {            // renormalise now and then: log domain is offset free
-                R m = v;
-                m = wave_allmax(m);
+                R m = wave_allmax((R) v);
                 if ((s & 63) == 0) red[s >> 6] = m;
                 __syncthreads();
                 R mm = red[0];
                 for (int w = 1; w < (int) (blockDim.x >> 6); ++w) mm = fmax(mm, red[w]);
-                if (mm > R(-1e29)) { v = fmax(v - mm, LZ); C += (double) mm; }
+                if (mm > R(-1e29)) { v = fmax(v - (double) mm, kZ); C += (double) mm; }
                 __syncthreads();
             }
-            if (STORE && s < S) out[(int64_t) t * S + s] = v;
+            if (STORE && s < S) out[(int64_t) t * S + s] = st(v);
         }
         if (score_out) {
             row[0][s] = v;
             __syncthreads();
             if (s == 0) {
-                double sc = C + (double) row[0][ol - 1];
+                double sc = C + row[0][ol - 1];
                 score_out[b] = (sc < -1e29) ? Num<R>::ninf() : (R) (sc * kLn2);
             }
         }
     } else {
-        v = (s == ol - 1) ? R(0) : LZ;
-        if (STORE && s < S) out[(int64_t) (len - 1) * S + s] = v;
+        v = (s == ol - 1) ? 0.0 : kZ;
+        if (STORE && s < S) out[(int64_t) (len - 1) * S + s] = st(v);
         for (int t = len - 1; t >= 1; --t) {
-            R em = act ? in[(int64_t) t * P.is0] * L2E : LZ;
-            R y = fmax(em + v, LZ);
-            R *rw = row[t & 1];
+            const double em = act ? (double) in[(int64_t) t * P.is0] * L2Ed : kZ;
+            const double y = fmax(em + v, kZ);
+            double *rw = row[t & 1];
             rw[s] = y;
-            if (s == (int) blockDim.x - 1) rw[blockDim.x] = LZ;
+            if (s == (int) blockDim.x - 1) rw[blockDim.x] = kZ;
             __syncthreads();
-            R right = rw[s + 1];
-            v = fmax(lse2<R>(y + H2, right + Dnext), LZ);
+            const double right = rw[s + 1];
+            v = fmax(lse2d(y + (double) H2, right + (double) Dnext), kZ);
             if ((t & 15) == 0) {
-                R m = wave_allmax(v);
+                R m = wave_allmax((R) v);
                 if ((s & 63) == 0) red[s >> 6] = m;
                 __syncthreads();
                 R mm = red[0];
                 for (int w = 1; w < (int) (blockDim.x >> 6); ++w) mm = fmax(mm, red[w]);
-                if (mm > R(-1e29)) { v = fmax(v - mm, LZ); C += (double) mm; }
+                if (mm > R(-1e29)) { v = fmax(v - (double) mm, kZ); C += (double) mm; }
                 __syncthreads();
             }
-            if (STORE && s < S) out[(int64_t) (t - 1) * S + s] = v;
+            if (STORE && s < S) out[(int64_t) (t - 1) * S + s] = st(v);
         }
         if (score_out) {
-            R em = act ? in[0] * L2E : LZ;
+            const double em = act ? (double) in[0] * L2Ed : kZ;
             if (s == 0) {
-                double sc = C + (double) (em + v);
+                double sc = C + (em + v);
                 score_out[b] = (sc < -1e29) ? Num<R>::ninf() : (R) (sc * kLn2);
             }
         }

@@ -36,8 +36,6 @@ namespace asg {
 namespace {
 
 constexpr int kPF = 16;     // emission prefetch depth (frames), register ring; also the unroll of one block
-constexpr int kAliRenorm = 16;  // aligned lattice (log domain): frame max folded into the offset once per block (a
-                                // finer grain was measured: no accuracy gain, the error sits in off-peak positions)
 constexpr int kRenorm = 4;  // full lattice: subtract the frame max every kRenorm steps (must divide kPF)
 
 
@@ -688,23 +686,31 @@ __device__ __forceinline__ R aligned_block_scale(const R (&cur)[kPF], int nsteps
     return (zmax > R(-1e29) && zmax < R(1e29)) ? zmax : R(0);
 }
 
+// The running state of the aligned chains is kept in DOUBLE even for fp32 problems: in the log domain every step adds
+// numbers of magnitude ~30 (off-peak positions), so an fp32 state loses ~2e-6 per step and ~3e-5 over 400 frames --
+// the whole error budget of the aligned gradient.  Only the bounded correction log2(1 + 2^d), d <= 0, is evaluated in
+// the problem's precision (v_exp_f32 / v_log_f32); the sums are double adds.  Stores round to R once.
+constexpr double kLZd = -1e30;
+template <typename R> __device__ __forceinline__ double lse2_acc(double a, double b) {
+    const double m = fmax(a, b);
+    const R d = (R) (fmin(a, b) - m);
+    return m + (double) Num<R>::log2(R(1) + Num<R>::exp2(d));
+}
+template <typename R> __device__ __forceinline__ R to_state(double v) { return (R) fmax(v, kLZd); }
+
 template <typename R, bool STORE, bool GUARD>
 __device__ __forceinline__ void aligned_alpha_block(const R (&cur)[kPF], int nsteps, unsigned soff0, unsigned row_bytes,
-                                                    const AlignedSetup<R> &A, R ebias, __amdgpu_buffer_rsrc_t rs,
-                                                    unsigned voff, R &ab, double &C) {
-    const R L2E = Num<R>::log2e(), LZ = Num<R>::logzero();
+                                                    const AlignedSetup<R> &A, double ebias, __amdgpu_buffer_rsrc_t rs,
+                                                    unsigned voff, double &ab) {
+    const double L2Ed = 1.4426950408889634, H2 = (double) A.H2, Dprev = (double) A.Dprev;
 #pragma unroll
     for (int k = 0; k < kPF; ++k) {
         if (!GUARD || k < nsteps) {
-            if (k > 0 && (k % kAliRenorm) == 0) {       // keep |state| small: fp32 rounding scales with it
-                const R m = wave_allmax(ab);
-                if (m > R(-1e29)) { ab = fmax(ab - m, LZ); C += (double) m; }
-            }
-            R em = fma(cur[k], L2E, ebias);
-            R stay = ab + A.H2;
-            R come = prev_lane_or_zero<R>(ab) + A.Dprev;      // v_add_f32_dpp wave_shr:1; lane 0: 0 + logzero
-            ab = fmax(em + lse2<R>(stay, come), LZ);
-            if (STORE) buf_store(ab, rs, voff, soff0 + (unsigned) k * row_bytes);
+            const double em = fma((double) cur[k], L2Ed, ebias);
+            const double stay = ab + H2;
+            const double come = prev_lane_or_zero<double>(ab) + Dprev;      // lane 0: 0 + logzero
+            ab = fmax(em + lse2_acc<R>(stay, come), kLZd);
+            if (STORE) buf_store(to_state<R>(ab), rs, voff, soff0 + (unsigned) k * row_bytes);
         }
     }
 }
@@ -713,7 +719,6 @@ template <typename R, bool STORE>
 __device__ void aligned_alpha_chain(const Problem &P, const State &W, const FwdOut &O, int b) {
     const int lane = threadIdx.x & 63;
     const int T = P.T, S = P.S;
-    const R L2E = Num<R>::log2e(), LZ = Num<R>::logzero();
     const AlignedSetup<R> A = aligned_setup<R>(P, b, lane);
     const int len = A.len;
     const unsigned row_bytes = (unsigned) S * sizeof(R);
@@ -727,10 +732,10 @@ __device__ void aligned_alpha_chain(const Problem &P, const State &W, const FwdO
         reinterpret_cast<int2 *>(W.asi)[(int64_t) b * S + lane] = ii;
     }
     double C = 0.0;
-    R ab = LZ;
+    double ab = kLZd;
     if (len >= 1) {
-        ab = (lane == 0) ? fmax(fma(A.in[0], L2E, A.ebias), LZ) : LZ;
-        if (STORE) buf_store(ab, rs, voff, 0u);
+        ab = (lane == 0) ? fmax(fma((double) A.in[0], 1.4426950408889634, (double) A.ebias), kLZd) : kLZd;
+        if (STORE) buf_store(to_state<R>(ab), rs, voff, 0u);
         const int nst = len - 1;
         R cur[kPF], nxt[kPF];
 #pragma unroll
@@ -740,12 +745,12 @@ __device__ void aligned_alpha_chain(const Problem &P, const State &W, const FwdO
 #pragma unroll
             for (int k = 0; k < kPF; ++k) nxt[k] = A.in[(int64_t) min(1 + done + kPF + k, len - 1) * P.is0];
             // renormalise once per block: the log domain is offset-free, this only bounds magnitudes
-            R m = wave_allmax(ab);
-            if (m > R(-1e29)) { ab = fmax(ab - m, LZ); C += (double) m; }
+            R m = wave_allmax((R) ab);
+            if (m > R(-1e29)) { ab = fmax(ab - (double) m, kLZd); C += (double) m; }
             const R z = aligned_block_scale<R>(cur, kPF, A.act, A.ol);
             C += (double) z * kPF;
-            aligned_alpha_block<R, STORE, false>(cur, kPF, (unsigned) (1 + done) * row_bytes, row_bytes, A, A.ebias - z, rs,
-                                                 voff, ab, C);
+            aligned_alpha_block<R, STORE, false>(cur, kPF, (unsigned) (1 + done) * row_bytes, row_bytes, A,
+                                                 (double) A.ebias - (double) z, rs, voff, ab);
 #pragma unroll
             for (int k = 0; k < kPF; ++k) cur[k] = nxt[k];
         }
@@ -753,32 +758,28 @@ __device__ void aligned_alpha_chain(const Problem &P, const State &W, const FwdO
             const R z = aligned_block_scale<R>(cur, nst - done, A.act, A.ol);
             C += (double) z * (nst - done);
             aligned_alpha_block<R, STORE, true>(cur, nst - done, (unsigned) (1 + done) * row_bytes, row_bytes, A,
-                                                A.ebias - z, rs, voff, ab, C);
+                                                (double) A.ebias - (double) z, rs, voff, ab);
         }
     }
     if (O.aligned_scores_alpha) {
-        R last = (A.ol >= 1 && len >= 1) ? readlane(ab, A.ol - 1) : LZ;
-        if (lane == 0) ((R *) O.aligned_scores_alpha)[b] = score_out<R>(C + (double) last);
+        const double last = (A.ol >= 1 && len >= 1) ? readlane(ab, A.ol - 1) : kLZd;
+        if (lane == 0) ((R *) O.aligned_scores_alpha)[b] = score_out<R>(C + last);
     }
 }
 
 template <typename R, bool STORE, bool GUARD>
 __device__ __forceinline__ void aligned_beta_block(const R (&cur)[kPF], int nsteps, unsigned soff0, unsigned row_bytes,
-                                                   const AlignedSetup<R> &A, R ebias, __amdgpu_buffer_rsrc_t rs,
-                                                   unsigned voff, R &bb, double &C) {
-    const R L2E = Num<R>::log2e(), LZ = Num<R>::logzero();
+                                                   const AlignedSetup<R> &A, double ebias, __amdgpu_buffer_rsrc_t rs,
+                                                   unsigned voff, double &bb) {
+    const double L2Ed = 1.4426950408889634, H2 = (double) A.H2, Dnext = (double) A.Dnext;
 #pragma unroll
     for (int k = 0; k < kPF; ++k) {
         if (!GUARD || k < nsteps) {
-            if (k > 0 && (k % kAliRenorm) == 0) {
-                const R m = wave_allmax(bb);
-                if (m > R(-1e29)) { bb = fmax(bb - m, LZ); C += (double) m; }
-            }
-            R y = fmax(fma(cur[k], L2E, ebias) + bb, LZ);
-            R stay = y + A.H2;
-            R go = next_lane_or_zero<R>(y) + A.Dnext;          // v_add_f32_dpp wave_shl:1
-            bb = fmax(lse2<R>(stay, go), LZ);
-            if (STORE) buf_store(bb, rs, voff, soff0 - (unsigned) k * row_bytes);
+            const double y = fmax(fma((double) cur[k], L2Ed, ebias) + bb, kLZd);
+            const double stay = y + H2;
+            const double go = next_lane_or_zero<double>(y) + Dnext;
+            bb = fmax(lse2_acc<R>(stay, go), kLZd);
+            if (STORE) buf_store(to_state<R>(bb), rs, voff, soff0 - (unsigned) k * row_bytes);
         }
     }
 }
@@ -787,7 +788,7 @@ template <typename R, bool STORE>
 __device__ void aligned_beta_chain(const Problem &P, const State &W, const FwdOut &O, int b) {
     const int lane = threadIdx.x & 63;
     const int T = P.T, S = P.S;
-    const R NINF = Num<R>::ninf(), L2E = Num<R>::log2e(), LZ = Num<R>::logzero();
+    const R NINF = Num<R>::ninf();
     const AlignedSetup<R> A = aligned_setup<R>(P, b, lane);
     const int len = A.len;
     const unsigned row_bytes = (unsigned) S * sizeof(R);
@@ -798,8 +799,8 @@ __device__ void aligned_beta_chain(const Problem &P, const State &W, const FwdOu
         return;
     }
     double C = 0.0;
-    R bb = (lane == A.ol - 1) ? R(0) : LZ;
-    if (STORE) buf_store(bb, rs, voff, (unsigned) (len - 1) * row_bytes);
+    double bb = (lane == A.ol - 1) ? 0.0 : kLZd;
+    if (STORE) buf_store(to_state<R>(bb), rs, voff, (unsigned) (len - 1) * row_bytes);
     const int nst = len - 1;
     R cur[kPF], nxt[kPF];
 #pragma unroll
@@ -808,12 +809,12 @@ __device__ void aligned_beta_chain(const Problem &P, const State &W, const FwdOu
     for (; done + kPF <= nst; done += kPF) {
 #pragma unroll
         for (int k = 0; k < kPF; ++k) nxt[k] = A.in[(int64_t) max(len - 1 - (done + kPF + k), 0) * P.is0];
-        R m = wave_allmax(bb);
-        if (m > R(-1e29)) { bb = fmax(bb - m, LZ); C += (double) m; }
+        R m = wave_allmax((R) bb);
+        if (m > R(-1e29)) { bb = fmax(bb - (double) m, kLZd); C += (double) m; }
         const R z = aligned_block_scale<R>(cur, kPF, A.act, A.ol);
         C += (double) z * kPF;
-        aligned_beta_block<R, STORE, false>(cur, kPF, (unsigned) (len - 2 - done) * row_bytes, row_bytes, A, A.ebias - z, rs,
-                                            voff, bb, C);
+        aligned_beta_block<R, STORE, false>(cur, kPF, (unsigned) (len - 2 - done) * row_bytes, row_bytes, A,
+                                            (double) A.ebias - (double) z, rs, voff, bb);
 #pragma unroll
         for (int k = 0; k < kPF; ++k) cur[k] = nxt[k];
     }
@@ -822,15 +823,15 @@ __device__ void aligned_beta_chain(const Problem &P, const State &W, const FwdOu
         const R z = aligned_block_scale<R>(cur, nst - done, A.act, A.ol);
         C += (double) z * (nst - done);
         aligned_beta_block<R, STORE, true>(cur, nst - done, (unsigned) (len - 2 - done) * row_bytes, row_bytes, A,
-                                           A.ebias - z, rs, voff, bb, C);
+                                           (double) A.ebias - (double) z, rs, voff, bb);
         const int r = nst - done;
 #pragma unroll
         for (int k = 1; k < kPF; ++k) last_raw = (k == r) ? cur[k] : last_raw;
     }
     // S_aligned = beta_0[0] + I~_0[0]   (force_aligned_lattice.cpp:316)
-    R y = fma(last_raw, L2E, A.ebias) + bb;
-    R y0 = readlane(y, 0);
-    publish_score<R>(O, (R *) O.aligned_scores, b, P.B, score_out<R>(C + (double) y0), lane);
+    const double y = fma((double) last_raw, 1.4426950408889634, (double) A.ebias) + bb;
+    const double y0 = readlane(y, 0);
+    publish_score<R>(O, (R *) O.aligned_scores, b, P.B, score_out<R>(C + y0), lane);
 }
 
 // ------------------------------------------------------------------ full lattice, two wavefronts per chain (fp32)
