@@ -234,6 +234,40 @@ def main():
     kern_ms = sorted(e0.elapsed_time(e1) for e0, e1 in ev_pairs)
     kern_ms_avg = sum(kern_ms) / len(kern_ms)
     kern_ms_med = kern_ms[len(kern_ms) // 2]
+    kern_method = "HIP events around single eager launches (includes ~3 us of dispatch)"
+    # Tighter: a hipGraph holding ONLY that kernel launch, replayed back to back between one pair of HIP events
+    # (launch gaps inside a graph are ~1 us); this is the number that tracks rocprofv3's kernel time.
+    try:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        kg = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            be.forward(xd, tg, trd, il, tl, lflags)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        per_graph = 25
+        with torch.cuda.graph(kg):
+            for _ in range(per_graph):
+                be.forward(xd, tg, trd, il, tl, lflags)
+        for _ in range(3):
+            kg.replay()
+        torch.cuda.synchronize()
+        reps = []
+        for _ in range(max(nk // per_graph, 4)):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            kg.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            reps.append(e0.elapsed_time(e1) / per_graph)
+        reps.sort()
+        kern_ms_eager = kern_ms_med
+        kern_ms_med = reps[len(reps) // 2]
+        kern_ms_avg = sum(reps) / len(reps)
+        kern_method = ("HIP events around a hipGraph of %d consecutive launches of this kernel only, per launch "
+                       "(single eager launches: %.4f ms incl. ~3 us dispatch)" % (per_graph, kern_ms_eager))
+    except Exception as e:
+        sys.stderr.write("[bench] single-kernel graph timing failed (%s); keeping eager event pairs\n" % (e,))
 
     if rank == 0:
         a_alg = algorithmic_bytes(T, B, N, L)
@@ -273,7 +307,7 @@ def main():
                          "kernel": "fwd_duo_kernel (alpha/beta recursions, all four passes in one launch; "
                                    "three wavefronts per full-lattice chain)"
                                    if args.launch == "single" else "asg_forward launches (recursion kernels)",
-                         "kernel_ms": kern_ms_med, "kernel_ms_avg": kern_ms_avg,
+                         "kernel_ms": kern_ms_med, "kernel_ms_avg": kern_ms_avg, "kernel_timing": kern_method,
                          "algorithmic_bytes_per_launch": a_alg,
                          "step_achieved": a_alg / (ms_per_step * 1e-3) / 1e9,
                          "note": "serial-latency-bound scan: 400 dependent steps x 64 utterances; see DESIGN.md"},
