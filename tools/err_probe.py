@@ -1,3 +1,4 @@
+"""Developer probe (GPU): per-lattice gradient / score errors of the HIP path against the fp64 oracle at cfg sizes."""
 import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, torch_asg_amd
 from oracle import asg_oracle as orc
