@@ -63,10 +63,10 @@ class OracleBackend:
         fs, as_, state = self.forward(inputs, targets, transition, input_lengths, target_lengths)
         per = fs - as_
         loss = per if reduction == "none" else (per.sum() if reduction == "sum" else per.mean())
-        return loss, state
+        return loss, state, None
 
     def loss_backward(self, state, grad_loss, inputs, targets, transition, input_lengths, target_lengths,
-                      reduction, flags=0):
+                      reduction, flags=0, problem=None):
         B = inputs.shape[1]
         g = grad_loss.reshape(-1).to(inputs.dtype)
         if reduction != "none":

@@ -105,6 +105,23 @@ def test_golden_configs_f32(name, mode):
         util.assert_close(val, g["f32_" + key], 1e-4 + noise, "%s/%s vs ref f32" % (name, what))
 
 
+@pytest.mark.parametrize("name", ["cfg2", "cfg2_var", "cfg3", "cfg3_var"])
+def test_configs_every_gradient_element_vs_fp64_oracle(name):
+    """The fixtures hold samples of grad_inputs (they must stay small); here EVERY element of both gradients at the
+    BASELINE sizes is compared with the fp64 oracle (itself pinned to the same fixtures in tests/test_oracle.py)."""
+    g = util.load(name)
+    tr, x, tg, il, tl = util.synth(int(g["T"]), int(g["B"]), int(g["N"]), int(g["L"]), int(g["seed"]),
+                                   bool(g["variable"]))
+    red = str(g["reduction"])
+    o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il.numpy(), tl.numpy(), red)
+    util.assert_close(o["loss"], g["f64_loss"], 1e-9, "oracle vs fixture")
+    util.assert_close(o["grad_inputs"][::7, ::3, :], g["f64_grad_inputs_sample"], 1e-9, "oracle vs fixture")
+    for kw in (MODES[0], MODES[1]):
+        r = run_hip(x, tg, tr, il, tl, red, torch.float32, **kw)
+        for k in ("loss", "grad_inputs", "grad_transition"):
+            util.assert_close(r[k], o[k], 1e-4, "%s/%s full tensor vs fp64 oracle" % (name, k))
+
+
 @pytest.mark.parametrize("name", ["cfg2_var", "cfg3_var"])
 def test_golden_configs_f64(name):
     g = util.load(name)
@@ -261,22 +278,42 @@ def test_generic_forward_only_and_determinism():
     with torch.no_grad():
         m.transition.copy_(tr)
     out = m(x.to(DEV), tg.to(DEV), il.to(DEV), tl.to(DEV))
-    util.assert_close(out.cpu().numpy(), ref["loss"], 1e-5, "generic forward-only")
+    o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il.numpy(), tl.numpy(), "none", need_grad=False)
+    util.assert_close(out.cpu().numpy(), o["loss"], 1e-4, "generic forward-only vs oracle")
 
 
 # ------------------------------------------------------------------ routes
-def test_forward_only_and_eval_routes():
+@pytest.mark.parametrize("mode", ["single", "streams", "serial"])
+def test_forward_only_and_eval_routes(mode):
+    """The beta-only evaluation route (streamlined_fast_gpu.cpp:24-94, routing asg.py:129-131) against the reference's
+    fp64 fixtures (cfg2_var / cfg3_var) and against the oracle on a small and on a generic (N > 64, S > 64) shape."""
     A = _asg()
-    tr, x, tg, il, tl = util.synth(60, 5, 21, 9, 3, True)
-    ref = run_hip(x, tg, tr, il, tl, "none")["loss"]
-    for kw, train in ((dict(forward_only=True), True), (dict(), False)):
-        m = A.ASGLoss(21, reduction="none", **kw).to(DEV)
-        with torch.no_grad():
-            m.transition.copy_(tr)
-        m.train(train)
-        out = m(x.to(DEV).requires_grad_(True), tg.to(DEV), il.to(DEV), tl.to(DEV))
-        assert not out.requires_grad            # no backward support on this route (asg.py:66-68)
-        util.assert_close(out.cpu().numpy(), ref, 1e-6, "forward-only")
+
+    def route(tr, x, tg, il, tl, N, red, **kw):
+        outs = []
+        for ctor, train in ((dict(forward_only=True), True), (dict(), False)):
+            m = A.ASGLoss(N, reduction=red, launch_mode=mode, **ctor).to(DEV)
+            with torch.no_grad():
+                m.transition.copy_(tr)
+            m.train(train)
+            out = m(x.to(DEV).requires_grad_(True), tg.to(DEV), il.to(DEV), tl.to(DEV))
+            assert not out.requires_grad            # no backward support on this route (asg.py:66-68)
+            outs.append(out.cpu().numpy())
+        assert np.array_equal(outs[0], outs[1])     # forward_only=True and .eval() are the same route
+        return outs[0]
+
+    for name in ("cfg2_var", "cfg3_var"):
+        g = util.load(name)
+        tr, x, tg, il, tl = util.synth(int(g["T"]), int(g["B"]), int(g["N"]), int(g["L"]), int(g["seed"]), True)
+        out = route(tr, x, tg, il, tl, int(g["N"]), str(g["reduction"]))
+        util.assert_close(out, g["f64_loss"], 1e-4, name + " forward-only vs ref f64")
+    for T, B, N, L, seed in ((60, 5, 21, 9, 3), (40, 3, 90, 70, 4)):
+        tr, x, tg, il, tl = util.synth(T, B, N, L, seed, True)
+        tl = torch.minimum(tl, il)
+        o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il.numpy(), tl.numpy(), "none",
+                         need_grad=False)
+        out = route(tr, x, tg, il, tl, N, "none")
+        util.assert_close(out, o["loss"], 1e-4, "forward-only vs oracle T%d N%d L%d" % (T, N, L))
 
 
 def test_fcc_fac_functions_direct():
@@ -350,6 +387,51 @@ def test_transition_grad_accumulates_like_a_parameter():
     m(x.to(DEV), tg.to(DEV), il.to(DEV), tl.to(DEV)).backward()
     assert torch.allclose(m.transition.grad, 2 * g1, rtol=1e-6, atol=1e-7)
     assert "transition" in m.state_dict()
+
+
+def test_concurrent_calls_on_two_streams_from_two_threads():
+    """Re-entrancy of the C ABI (SURVEY.md 8b "Threading"): two ASGLoss forward+backward pairs in flight at the same
+    time, on two HIP streams, driven by two host threads, in every launch mode -- bit-identical to the same two
+    calls run one after the other.  Everything a call mutates on the device lives in that call's own buffers."""
+    import threading
+    A = _asg()
+    shapes = [(400, 64, 40, 30, 0), (350, 48, 33, 25, 1)]
+    probs = [util.synth(T, B, N, L, seed, True) for T, B, N, L, seed in shapes]
+
+    def one(k, mode, stream, out, reps):
+        tr, x, tg, il, tl = probs[k]
+        N = tr.shape[0]
+        with torch.cuda.stream(stream):
+            m = A.ASGLoss(N, reduction="mean", launch_mode=mode).to(DEV)
+            with torch.no_grad():
+                m.transition.copy_(tr)
+            xd = x.to(DEV)
+            tgd, ild, tld = tg.to(DEV), il.to(DEV), tl.to(DEV)
+            res = []
+            for _ in range(reps):
+                xr = xd.clone().requires_grad_(True)
+                m.transition.grad = None
+                loss = m(xr, tgd, ild, tld)
+                loss.backward()
+                res.append((loss.detach().clone(), xr.grad.clone(), m.transition.grad.clone()))
+            stream.synchronize()
+            out[k] = [tuple(t.cpu().numpy() for t in r) for r in res]
+
+    for mode in ("single", "streams", "serial"):
+        seq = {}
+        for k in (0, 1):
+            one(k, mode, torch.cuda.current_stream(), seq, 1)
+        par = {}
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        th = [threading.Thread(target=one, args=(k, mode, streams[k], par, 20)) for k in (0, 1)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        for k in (0, 1):
+            for r in par[k]:
+                for a, b_ in zip(seq[k][0], r):
+                    assert np.array_equal(a, b_), "concurrent call differs from sequential (mode %s)" % mode
 
 
 # ------------------------------------------------------------------ reference's own tests, re-typed
@@ -438,22 +520,75 @@ def test_cfg3_properties():
 
 
 def test_cfg4_shard_equals_whole():
-    # cfg 4: B=512 = 8 shards of 64; sharded sum of grads == unsharded
+    """BASELINE cfg 4 at its stated size on one GPU: T=400 B=512 N=40 L=30 as ONE batch vs 8 `shard_batch` shards of 64
+    (SURVEY.md 8e): grad_inputs bit-equal, grad_transition and loss equal to summation order, and every shard within
+    1e-4 of an fp64 oracle run of that shard."""
     A = _asg()
-    T, B, N, L = 400, 128, 40, 30
+    T, B, N, L, W = 400, 512, 40, 30, 8
     tr, x, tg, il, tl = util.synth(T, B, N, L, 2, True)
     whole = run_hip(x, tg, tr, il, tl, "sum")
     acc = np.zeros((N, N), np.float64)
     loss = 0.0
-    for r in range(4):
-        xs, tgs, ils, tls = A.shard_batch(x, tg, il, tl, r, 4)
+    for r in range(W):
+        xs, tgs, ils, tls = A.shard_batch(x, tg, il, tl, r, W)
+        assert xs.shape[1] == B // W
         part = run_hip(xs, tgs, tr, ils, tls, "sum")
         acc += part["grad_transition"]
         loss += float(part["loss"])
-        lo, hi = r * 32, (r + 1) * 32
+        lo, hi = r * (B // W), (r + 1) * (B // W)
         assert np.array_equal(part["grad_inputs"], whole["grad_inputs"][:, lo:hi])
+        o = orc.asg_loss(xs.double().numpy(), tgs.numpy(), tr.double().numpy(), ils.numpy(), tls.numpy(), "sum")
+        for k in ("loss", "grad_inputs", "grad_transition"):
+            util.assert_close(part[k], o[k], 1e-4, "cfg4 shard %d/%s vs fp64 oracle" % (r, k))
     util.assert_close(acc, whole["grad_transition"], 1e-5, "sharded gtr")
-    assert abs(loss - float(whole["loss"])) < 1e-4 * abs(float(whole["loss"]))
+    assert abs(loss - float(whole["loss"])) < 1e-5 * abs(float(whole["loss"]))
+
+
+def test_cfg5_full_size_properties():
+    """BASELINE cfg 5 at FULL size (T=2000 B=32 N=10000 L=60, variable lengths).  The reference cannot run it
+    (path_contrib would be 25.6 TB, fully_connected_lattice.cpp:77) and the fp64 oracle would take hours, so parity at
+    this size is asserted through size-independent properties of the lattice (value parity of the same kernels is
+    checked at the reduced size the reference can run, test_golden_cfg5_reduced_large_alphabet):
+      * the score from the alpha pass equals the score from the beta pass (two independent recursions);
+      * per valid frame the full-lattice posterior and the aligned posterior both sum to g: their difference sums to 0;
+      * frames t >= input_lengths[b] get exactly-zero gradients;
+      * every path leaves by as many transitions as the aligned path: sum(grad_transition) == 0 to rounding;
+      * the loss is positive (S_full >= S_aligned) and finite."""
+    A = _asg()
+    from torch_asg_amd import _lib
+    T, B, N, L = 2000, 32, 10000, 60
+    g = torch.Generator(device=DEV).manual_seed(0)
+    tr = torch.rand(N, N, generator=g, device=DEV)
+    x = torch.randn(T, B, N, generator=g, device=DEV)
+    tg = torch.randint(0, N, (B, L), generator=g, device=DEV)
+    il = torch.randint(T // 2, T + 1, (B,), generator=g, device=DEV)
+    tl = torch.randint(L // 2, L + 1, (B,), generator=g, device=DEV)
+    be = A.asg.native()
+    full, ali, st = be.forward(x, tg, tr, il, tl, _lib.FLAG_ALPHA_SCORES)
+    fb, fa, ab_, aa = full[:B].double(), full[B:].double(), ali[:B].double(), ali[B:].double()
+    assert bool(torch.isfinite(full).all()) and bool(torch.isfinite(ali).all())
+    assert float(((fa - fb).abs() / fb.abs()).max()) < 2e-6, "full lattice: alpha score != beta score"
+    assert float(((aa - ab_).abs() / ab_.abs()).max()) < 2e-6, "aligned lattice: alpha score != beta score"
+    assert bool((fb > ab_).all()), "S_full must exceed S_aligned"
+    gf = torch.full((B,), 1.0 / B, device=DEV)
+    gtr, gin = be.backward(st, gf, -gf, x, tg, tr, il, tl)
+    del st
+    assert bool(torch.isfinite(gtr).all()) and bool(torch.isfinite(gin).all())
+    valid = torch.arange(T, device=DEV)[:, None] < il[None, :]
+    rows = gin.sum(-1)
+    assert float(rows[valid].abs().max()) < 1e-4 / B, "posteriors of the two lattices must cancel per frame"
+    assert float(gin[~valid].abs().max()) == 0.0, "padded frames must have exactly-zero gradients"
+    # |grad_inputs| <= g per element, and the full posterior alone sums to g per frame: spot-check magnitudes
+    assert float(gin.abs().max()) <= 1.0 / B * (1 + 1e-5)
+    tot, mag = float(gtr.double().sum()), float(gtr.double().abs().sum())
+    assert abs(tot) < 1e-5 * mag, (tot, mag)
+    # the whole criterion through the module (fused loss route) agrees with the scores above
+    m = A.ASGLoss(N, reduction="none").to(DEV)
+    with torch.no_grad():
+        m.transition.copy_(tr)
+    m.eval()
+    loss = m(x, tg, il, tl).double()
+    assert float(((loss - (fb - ab_)).abs() / (fb - ab_).abs()).max()) < 1e-5
 
 
 # ------------------------------------------------------------------ best-path (Viterbi) force alignment, SURVEY 8(f)3
@@ -519,15 +654,32 @@ def test_viterbi_edge_cases_and_module_method():
                         torch.zeros(4, 4, device=DEV))        # S > 1024: not supported, fails loudly
 
 
-def test_random_shapes_value_ranges_and_determinism_stress():
-    """Many random (T, B, N, L, lengths, value ranges incl. 40-nat transitions and +-60 emission offsets) against the
-    oracle; exercises the three-wavefront chain, its abort-and-redo route, the exact passes, and run-to-run bit equality."""
+def _stress():
     import importlib.util, os
     spec = importlib.util.spec_from_file_location("stress_duo", os.path.join(os.path.dirname(__file__), "..", "tools", "stress_duo.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    for seed in (2, 4, 11):
-        mod.run(seed, 60)
+    return mod
+
+
+@pytest.mark.parametrize("seed", [2, 4, 11])
+def test_random_shapes_plain_gate_and_determinism(seed):
+    """Random (T, B, N, L, lengths) with emissions of ordinary scale (spread <= 5 nats, no common offset; log-probs in
+    30% of the cases) and transitions spanning up to 40 nats, against the fp64 oracle under the PLAIN parity rule
+    max|x - ref| <= 1e-4 * max(1, max|ref|) per tensor; repeated launches bit-identical.  Exercises the three-wavefront
+    chain, its abort-and-redo route and the exact passes."""
+    n, worst, _ = _stress().run(seed, 60, regime="plain")
+    print("plain-gate battery: %d cases, worst scaled error %.2e" % (n, worst))
+
+
+@pytest.mark.parametrize("seed", [2, 4, 11])
+def test_random_shapes_extended_range_report(seed):
+    """REPORTED SEPARATELY from the 1e-4 gate: emissions offset by -40 / +60 and/or spread over 30 nats, where absolute
+    scores reach 1e5 and fp32 itself resolves the loss (a difference of two such scores) to ~1e-2.  Gate here:
+    determinism, finiteness pattern, and errors within 1e-4 of the magnitude of the quantities the result is a
+    difference OF (scores for the loss, sum of lengths for grad_transition), 1e-3 when the spread is 30 nats."""
+    n, worst, _ = _stress().run(seed, 60, regime="extended")
+    print("extended-range battery: %d cases, worst error (extended rule) %.2e" % (n, worst))
 
 
 @pytest.mark.parametrize("mode", ["input_size", "input_size_sqrt", "target_size", "target_size_sqrt"])

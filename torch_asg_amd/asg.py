@@ -12,6 +12,7 @@ All numerical work happens in hand-written HIP kernels behind the C ABI of inclu
 CPU tensors are rejected: this package has no CPU fallback by design.
 """
 import ctypes
+import threading
 
 import torch
 import torch.autograd
@@ -37,6 +38,7 @@ class HipBackend:
     def __init__(self):
         self._ctx = {}
         self._sizes = {}
+        self._lock = threading.Lock()
 
     def _bytes(self, p):
         """(state_bytes, scratch_bytes) of a problem shape, cached per (dtype, T, B, N, S)."""
@@ -67,6 +69,10 @@ class HipBackend:
             if t is not None and t.dtype != torch.int64:
                 # the reference asserts kLong (utils.cpp:28,46) and uses accessor<int64_t>
                 raise RuntimeError("torch_asg_amd: expected scalar type Long but found %s for %s" % (t.dtype, name))
+        B = inputs.shape[1]
+        if targets is not None and (targets.dim() != 2 or targets.shape[0] != B or targets.shape[1] < 1):
+            # the kernels index targets[b][s] for every b < B: a short or mis-shaped tensor would be read out of bounds
+            raise RuntimeError("torch_asg_amd: targets must be [B=%d, S>=1] but got %s" % (B, tuple(targets.shape)))
 
     @staticmethod
     def _problem(inputs, transition, targets, input_lengths, target_lengths):
@@ -105,13 +111,19 @@ class HipBackend:
         return p, keep
 
     def _context(self, device):
+        """Side stream + fork/join events of the 'streams' launch mode, ONE SET PER CALLING STREAM: calls issued on
+        different streams (other threads, other modules, a capture in progress) never share an event pair."""
         idx = device.index if device.index is not None else torch.cuda.current_device()
-        h = self._ctx.get(idx)
+        key = (idx, torch.cuda.current_stream(idx).cuda_stream)
+        h = self._ctx.get(key)
         if h is None:
-            h = ctypes.c_void_p()
-            with torch.cuda.device(idx):
-                _lib.check(_lib.lib().asg_ctx_create(ctypes.byref(h)), "asg_ctx_create")
-            self._ctx[idx] = h
+            with self._lock:
+                h = self._ctx.get(key)
+                if h is None:
+                    h = ctypes.c_void_p()
+                    with torch.cuda.device(idx):
+                        _lib.check(_lib.lib().asg_ctx_create(ctypes.byref(h)), "asg_ctx_create")
+                    self._ctx[key] = h
         return h
 
     @staticmethod
@@ -263,8 +275,7 @@ class HipBackend:
                                           state.numel(), red, loss.data_ptr(), scores.data_ptr(),
                                           flags & ~_lib.FLAG_ALPHA_SCORES, self._stream(inputs.device)),
                        "asg_loss_forward")
-        self._last_problem = (p, keep)        # picked up by ASGLossFunction: same tensors are saved for backward
-        return loss, state
+        return loss, state, (p, keep)         # the problem block is reused by backward: same tensors are saved there
 
     def loss_backward(self, state, grad_loss, inputs, targets, transition, input_lengths, target_lengths,
                       reduction, flags=0, problem=None):
@@ -399,10 +410,11 @@ class ASGLossFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, inputs, transition, outputs, input_lengths, output_lengths, reduction, flags):
         be = native()
-        loss, state = be.loss_forward(inputs, outputs, transition, input_lengths, output_lengths, reduction, flags)
+        loss, state, problem = be.loss_forward(inputs, outputs, transition, input_lengths, output_lengths, reduction,
+                                               flags)
         ctx.save_for_backward(state, inputs, outputs, input_lengths, output_lengths, transition)
         ctx.reduction = reduction
-        ctx.problem = getattr(be, "_last_problem", None)
+        ctx.problem = problem
         return loss
 
     @staticmethod
@@ -416,87 +428,98 @@ class ASGLossFunction(torch.autograd.Function):
 
 
 class ASGLoss(nn.Module):
-    """Auto Segmentation Criterion loss; constructor and forward signature as asg.py:100-142.
+    """Auto Segmentation Criterion.  Constructor arguments, `forward` signature, the `transition` parameter and the
+    routing between the serial / evaluation / training implementations follow the reference module
+    (/root/reference/torch_asg/asg.py:100-142) so that checkpoints and call sites carry over unchanged.
 
-    launch_mode (extra, optional): how the fused route issues the four recursions --
-      'single' (default)   ONE kernel launch, blockIdx.y = pass: all four recursions are co-resident, which is the
-                           overlap the reference builds from 4 CUDA streams (streamlined_fast_gpu.cpp:121-129);
-                           measured fastest on MI355X
-      'streams'            full-lattice and force-aligned passes on two HIP streams with event fork/join
-      'serial'             two launches on the caller's stream
-    gpu_no_stream_impl=True selects the reference's "serial" route: separate FAC and FCC Functions.
-    scale_mode (extra, optional): the wav2letter criterion scaling that the reference dropped
-      (README.md:93-94, vestiges at test_asg.py:169-173): each utterance's loss is multiplied by 1/len or 1/sqrt(len)
-      of its input or target before the reduction -- 'none' (default, = the reference), 'input_size',
-      'input_size_sqrt', 'target_size', 'target_size_sqrt'.
+    Extra, optional keyword arguments (not in the reference):
+      launch_mode  how the fused route issues the four recursions --
+        'single' (default)   ONE kernel launch: all four recursions are co-resident, which is the overlap the reference
+                             builds from 4 CUDA streams (streamlined_fast_gpu.cpp:121-129); measured fastest on MI355X
+        'streams'            full-lattice and force-aligned passes on two HIP streams with event fork/join
+        'serial'             two launches on the caller's stream
+      scale_mode   the wav2letter criterion scaling that the reference dropped (README.md:93-94, vestiges at
+                   test_asg.py:169-173): every utterance's loss is multiplied by 1/len or 1/sqrt(len) of its input or
+                   target before the reduction -- 'none' (default, = the reference), 'input_size', 'input_size_sqrt',
+                   'target_size', 'target_size_sqrt' (SURVEY.md 8(f)4).
+    `gpu_no_stream_impl=True` selects the reference's "serial" route (separate FAC and FCC Functions).
     Batch-major activations need no copy: pass `acts.transpose(0, 1)` ([B,T,N] -> a [T,B,N] view); the kernels take
     arbitrary strides.
     """
     SCALE_MODES = ('none', 'input_size', 'input_size_sqrt', 'target_size', 'target_size_sqrt')
+    _LAUNCH_FLAGS = {'streams': _lib.FLAG_STREAMS, 'single': _lib.FLAG_SINGLE_LAUNCH, 'serial': 0}
 
     def __init__(self, num_labels, reduction='mean', forward_only=False, gpu_no_stream_impl=False,
                  launch_mode='single', scale_mode='none'):
         super().__init__()
         if scale_mode not in self.SCALE_MODES:
             raise ValueError("scale_mode must be one of %s" % (self.SCALE_MODES,))
-        self.scale_mode = scale_mode
+        if launch_mode not in self._LAUNCH_FLAGS:
+            raise ValueError("launch_mode must be one of %s" % (tuple(self._LAUNCH_FLAGS),))
         self.num_labels = num_labels
-        self.reduction = reduction  # mean, sum, none
-        self.transition = nn.Parameter(torch.zeros(num_labels, num_labels))
+        self.reduction = reduction
         self.forward_only = forward_only
         self.gpu_no_stream_impl = gpu_no_stream_impl
         self.launch_mode = launch_mode
+        self.scale_mode = scale_mode
+        # transition[i, j] scores the move from label j to label i; starts at zero like the reference's (asg.py:105)
+        self.transition = nn.Parameter(torch.zeros(num_labels, num_labels))
 
     def _flags(self):
-        return {'streams': _lib.FLAG_STREAMS, 'single': _lib.FLAG_SINGLE_LAUNCH, 'serial': 0}[self.launch_mode]
+        return self._LAUNCH_FLAGS[self.launch_mode]
 
     def viterbi_align(self, inputs, targets, input_lengths=None, target_lengths=None):
         """Best-path force alignment under this module's transition matrix: see `torch_asg_amd.viterbi_align`."""
         return viterbi_align(inputs, targets, self.transition, input_lengths, target_lengths)
 
+    @staticmethod
+    def _canonical(inputs, targets, input_lengths, target_lengths):
+        """Missing lengths mean "the whole axis" (asg.py:113-117); a target axis longer than the time axis is cut to T
+        frames and the lengths clipped with it (asg.py:119-122)."""
+        T, B = inputs.shape[0], inputs.shape[1]
+        S = targets.shape[1]
+        if target_lengths is None:
+            target_lengths = targets.new_full((B,), S)
+        if input_lengths is None:
+            input_lengths = target_lengths.new_full((B,), T)
+        if S > T:
+            targets = targets[:, :T]
+            target_lengths = target_lengths.clamp(max=T)
+        return targets, input_lengths, target_lengths
+
+    def _utterance_weights(self, inputs, input_lengths, target_lengths):
+        if self.scale_mode == 'none':
+            return None
+        n = input_lengths if self.scale_mode.startswith('input') else target_lengths
+        n = n.to(device=inputs.device, dtype=inputs.dtype).clamp(min=1)
+        return (n.rsqrt() if self.scale_mode.endswith('sqrt') else n.reciprocal())
+
     def forward(self, inputs, targets, input_lengths=None, target_lengths=None):
-        batch_input_len, num_batches, num_labels = inputs.shape
-        _, batch_output_len = targets.shape
+        targets, input_lengths, target_lengths = self._canonical(inputs, targets, input_lengths, target_lengths)
+        weights = self._utterance_weights(inputs, input_lengths, target_lengths)
+        args = (targets, input_lengths, target_lengths)
 
-        if target_lengths is None:                                   # asg.py:113-114
-            target_lengths = targets.new_full((num_batches,), batch_output_len)
-        if input_lengths is None:                                    # asg.py:116-117
-            input_lengths = target_lengths.new_full((num_batches,), batch_input_len)
-
-        if batch_output_len > batch_input_len:                       # asg.py:119-122
-            batch_output_len = batch_input_len
-            targets = targets[:, :batch_output_len]
-            target_lengths = torch.clamp(target_lengths, max=batch_output_len)
-
-        scaled = self.scale_mode != 'none'
-        if scaled:
-            lens = (input_lengths if self.scale_mode.startswith('input') else target_lengths)
-            lens = lens.to(device=inputs.device, dtype=inputs.dtype).clamp(min=1)
-            weights = 1.0 / (lens.sqrt() if self.scale_mode.endswith('sqrt') else lens)
         if self.gpu_no_stream_impl:
-            # the reference's "serial" route (asg.py:124-128)
-            fac_result = FAC.apply(self.transition, inputs, targets, input_lengths, target_lengths)
-            fcc_result = FCC.apply(self.transition, inputs, targets, input_lengths, target_lengths)
-            result = fcc_result - fac_result
+            # "serial" route: two independent Functions, difference taken by autograd (asg.py:124-128)
+            per_utt = (FCC.apply(self.transition, inputs, *args) - FAC.apply(self.transition, inputs, *args))
         elif self.forward_only or not self.training:
-            result = ASGGPUFastForwardOnly.apply(inputs, targets, self.transition, input_lengths, target_lengths,
-                                                 self._flags())
-        elif self.reduction in ('sum', 'mean', 'none'):
-            # fused training route: the reference's ASGGPUFast + (full - aligned) + reduction (asg.py:133-142)
-            if not scaled:
-                return ASGLossFunction.apply(inputs, self.transition, targets, input_lengths, target_lengths,
-                                             self.reduction, self._flags())
-            result = ASGLossFunction.apply(inputs, self.transition, targets, input_lengths, target_lengths,
-                                           'none', self._flags())
+            # evaluation route: beta recursions only, nothing saved, no gradient (asg.py:129-131)
+            per_utt = ASGGPUFastForwardOnly.apply(inputs, targets, self.transition, input_lengths, target_lengths,
+                                                  self._flags())
+        elif self.reduction not in ('mean', 'sum', 'none'):
+            # an unknown reduction string behaves like the reference: the unreduced loss falls through (asg.py:141-142)
+            full, aligned = ASGGPUFast.apply(inputs, self.transition, *args, self._flags())
+            per_utt = full - aligned
+        elif weights is None:
+            # training route: subtraction, reduction and their gradients are inside the kernels
+            return ASGLossFunction.apply(inputs, self.transition, *args, self.reduction, self._flags())
         else:
-            full_scores, aligned_scores = ASGGPUFast.apply(inputs, self.transition, targets, input_lengths,
-                                                           target_lengths, self._flags())
-            result = full_scores - aligned_scores
-        if scaled:
-            result = result * weights
+            per_utt = ASGLossFunction.apply(inputs, self.transition, *args, 'none', self._flags())
+
+        if weights is not None:
+            per_utt = per_utt * weights
+        if self.reduction == 'mean':
+            return per_utt.mean()
         if self.reduction == 'sum':
-            return result.sum()
-        elif self.reduction == 'mean':
-            return result.mean()
-        else:
-            return result
+            return per_utt.sum()
+        return per_utt

@@ -10,10 +10,31 @@
 
 using namespace asg;
 
+namespace asg {
+size_t bwd_scratch_bytes_small(int elem, int T, int B, int N, int S, int *chunk, int *nchunks) {
+    // aim for ~512 workgroups (2 per CU; flat between 512 and 768 on MI355X) but at least 16 frames per workgroup
+    int target = 512;
+#ifdef ASG_DEV_PROBES
+    if (const char *ev = getenv("ASG_BWD_WGS")) target = atoi(ev) > 0 ? atoi(ev) : target;   // developer probe
+#endif
+    int nch = (target + B - 1) / B;
+    if (nch < 1) nch = 1;
+    int ch = (T + nch - 1) / nch;
+    if (ch < 16) ch = 16;
+    ch = (ch + 3) / 4 * 4;
+    nch = (T + ch - 1) / ch;
+    if (nch < 1) nch = 1;
+    if (chunk) *chunk = ch;
+    if (nchunks) *nchunks = nch;
+    return (size_t) B * nch * N * N * elem;
+}
+}  // namespace asg
+
+// Host-side handles only (side stream + fork/join events of ASG_FLAG_STREAMS); no device memory, no per-call state:
+// everything a call mutates on the device lives in the caller-owned `state` buffer of that call.
 struct asg_ctx {
     hipStream_t side;
     hipEvent_t fork, join;
-    unsigned *counter;      // 256 B of device memory owned by the context: arrival ticket of the in-kernel loss reduce
     int device;
 };
 
@@ -24,7 +45,7 @@ inline int hip_status(hipError_t e) { return e == hipSuccess ? ASG_OK : ASG_ERR_
 inline size_t align_up(size_t x) { return (x + 255) & ~(size_t) 255; }
 
 struct Layout {
-    size_t ah, bh, ab, bb, ehat, fhat, rmax, cmax, asu, asi, dbg, work, total;
+    size_t ah, bh, ab, bb, ehat, fhat, rmax, cmax, asu, asi, dbg, ticket, work, total;
     int npad;
 };
 
@@ -49,7 +70,8 @@ Layout make_layout(const asg_problem *p) {
     }
     L.asu = off; off = align_up(off + B * S * 2 * e);
     L.asi = off; off = align_up(off + B * S * 2 * sizeof(int));
-    L.dbg = off; off = align_up(off + 512);      // developer timing stamps (ASG_TIMING builds only)
+    L.dbg = off; off = align_up(off + 512);      // developer timing stamps (ASG_PROBE builds only)
+    L.ticket = off; off = align_up(off + 256);   // arrival ticket of the in-kernel loss reduction (zeroed per call)
     if (!small_full(p->N)) { L.work = off; off = align_up(off + fwd_work_bytes_generic((int) e, (int) T, (int) B, (int) N)); }
     L.total = off;
     return L;
@@ -96,6 +118,7 @@ State to_state(const asg_problem *p, const void *state) {
         if (!small_full(p->N)) { W.fhat = base + L.fhat; W.cmax = base + L.cmax; }
         W.asu = base + L.asu; W.asi = (int *) (base + L.asi);
         W.dbg = base + L.dbg;
+        W.ticket = (unsigned *) (base + L.ticket);
         if (!small_full(p->N)) W.work = base + L.work;
     }
     W.npad = L.npad;
@@ -110,18 +133,24 @@ int run_forward(asg_ctx *ctx, const asg_problem *p, void *state, void *full_scor
     FwdOut O{};
     O.full_scores = full_scores;
     O.aligned_scores = aligned_scores;
-    if (loss && ctx && small_full(p->N) && small_aligned(p->S)) {
+    if (loss && small_full(p->N) && small_aligned(p->S)) {
+        // the last beta pass to finish reduces the loss; its arrival ticket is part of THIS call's state buffer
+        // and is zeroed on the launch stream ahead of the kernels (a memset node under graph capture)
         O.loss = loss;
-        O.counter = ctx->counter;
+        O.counter = W.ticket;
         O.reduction = reduction;
         O.expected = 2 * (int) p->B;
+        hipError_t me = hipMemsetAsync(W.ticket, 0, 256, stream);
+        if (me != hipSuccess) return hip_status(me);
     }
     if ((flags & ASG_FLAG_ALPHA_SCORES) && store) {
         if (full_scores) O.full_scores_alpha = (R *) full_scores + p->B;
         if (aligned_scores) O.aligned_scores_alpha = (R *) aligned_scores + p->B;
     }
     const int mv = (flags & ASG_FLAG_MATVEC_READLANE) ? 1 : 0;
+#ifdef ASG_DEV_PROBES
     if (const char *dm = getenv("ASG_DEBUG_MASK")) mask &= atoi(dm);      // developer probe: time single passes
+#endif
     const int full_mask = mask & (kFullAlpha | kFullBeta);
     const int ali_mask = mask & (kAlignedAlpha | kAlignedBeta);
     const bool sf = small_full(p->N), sa = small_aligned(p->S);
@@ -231,8 +260,6 @@ int asg_ctx_create(asg_ctx **out) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->join, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipMalloc((void **) &c->counter, 256);
-    if (e == hipSuccess) e = hipMemset(c->counter, 0, 256);
     if (e != hipSuccess) { delete c; return hip_status(e); }
     *out = c;
     return ASG_OK;
@@ -243,7 +270,6 @@ int asg_ctx_destroy(asg_ctx *c) {
     hipEventDestroy(c->fork);
     hipEventDestroy(c->join);
     hipStreamDestroy(c->side);
-    hipFree(c->counter);
     delete c;
     return ASG_OK;
 }
@@ -386,7 +412,7 @@ int asg_loss_forward(asg_ctx *ctx, const asg_problem *p, void *state, size_t sta
     char *sc = (char *) scores;
     void *full = sc, *ali = sc + (size_t) p->B * e;
     flags &= ~ASG_FLAG_ALPHA_SCORES;
-    const bool in_kernel = ctx && small_full(p->N) && small_aligned(p->S);
+    const bool in_kernel = small_full(p->N) && small_aligned(p->S);
     rc = ASG_DISPATCH(p,
         run_forward<float>(ctx, p, state, full, ali, 15, true, flags, (hipStream_t) stream, loss, reduction),
         run_forward<double>(ctx, p, state, full, ali, 15, true, flags, (hipStream_t) stream, loss, reduction));

@@ -1,4 +1,4 @@
-// torch_asg_amd/csrc/asg_small.hip -- gfx950 kernels for the small-alphabet ASG path
+// torch_asg_amd/csrc/asg_chains.h -- gfx950 device code of the small-alphabet ASG recursions
 // (N <= 64 labels, S <= 64 target positions): one recursion chain per workgroup (1 or 3 wavefronts).
 //
 // What each kernel replaces in the reference (paths under /root/reference/torch_asg/native/):
@@ -27,6 +27,11 @@
 // around a load becomes a branch + vmcnt(0)); all LDS broadcast reads issued before the FMAs (sched_barrier);
 // explicit vmcnt hints so the store queue is never drained at a loop head; DPP-fused reductions in inline asm;
 // raw buffer stores whose bounds check replaces EXEC masking; no out-of-line calls in the hot kernel.
+//
+// This header holds the DEVICE code (recursion chains, the three-wavefront chain and its kernel); it is included by
+// the translation units that instantiate kernels from it: asg_small_f32/f64.hip (recursion kernels),
+// asg_fused.hip (recursions + gradient assembly in one launch).  Everything lives in an anonymous namespace.
+#pragma once
 #include "asg_common.h"
 #include "asg_kernels.h"
 #include <cstdlib>
@@ -1272,449 +1277,5 @@ __global__ void __launch_bounds__(192, 1) fwd_duo_kernel(Problem P, State W, Fwd
         else if (which == kAlignedBeta) aligned_beta_chain<float, STORE>(P, W, O, b);
     }
 }
-
-// ------------------------------------------------------------------ forward kernel
-// grid = (B, popcount(chain_mask)), block = 64.  blockIdx.y walks the set bits of chain_mask
-// low to high, so the long full-lattice chains are dispatched first.
-// launch_bounds(64, 1): one wave per SIMD is all this latency-bound kernel ever has (one chain per CU at cfg 3);
-// without the explicit 1 hipcc schedules for 4 waves/SIMD (<=128 VGPRs) and serialises the LDS broadcast reads
-// of the mat-vec into 3-4 dependent groups per step (+45% step latency) as soon as a few more values are live.
-template <typename R, int NP, int MV, bool STORE>
-__global__ void __launch_bounds__(64, 1) fwd_small_kernel(Problem P, State W, FwdOut O, int chain_mask) {
-    __shared__ __attribute__((aligned(16))) R lds[64];
-    int which = 0, seen = 0;
-    for (int c = 0; c < 4; ++c) {
-        if (chain_mask & (1 << c)) {
-            if (seen == (int) blockIdx.y) which = 1 << c;
-            ++seen;
-        }
-    }
-    const int b = blockIdx.x;
-    if (which == kFullAlpha) full_alpha_chain<R, NP, MV, STORE>(P, W, O, b, lds);
-    else if (which == kFullBeta) full_beta_chain<R, NP, MV, STORE>(P, W, O, b, lds);
-    else if (which == kAlignedAlpha) aligned_alpha_chain<R, STORE>(P, W, O, b);
-    else if (which == kAlignedBeta) aligned_beta_chain<R, STORE>(P, W, O, b);
-}
-
-// ------------------------------------------------------------------ backward (gradient assembly)
-// grid = (B, nchunks), block = 256 (4 waves).  Wave w of chunk c owns frames t = c*chunk + w, +4, ...
-// Per frame (non-recursive, every frame independent):
-//   full:    posterior_i = softmax_i(alpha_hat + beta_hat)                    -> grad_inputs row
-//            p_j = exp2(alpha_hat_{t-1}[j] - max), s_i = sum_j E[i][j] p_j    (row sums recomputed here, so the
-//            forward pass has nothing to save but alpha_hat / beta_hat), u_i = g * posterior_i / s_i,
-//            acc[i][j] += u_i * p_j   (lane i keeps row i in registers; scaled by E[i][j] once at the end)
-//   aligned: posterior_s = softmax_s(alpha_bar + beta_bar), scattered back to labels with fixed-point
-//            LDS adds (integer adds commute -> deterministic), stay/advance edge posteriors per lane.
-// Rows whose recomputed sum is outside the safe range are skipped on the fast path (sticky flag) and handled
-// by an exact second pass over the wave's frames into a fixed-point LDS tile -- rare, off the fast path.
-// Output: grad_inputs rows for its frames, one partial [N][N] tile per workgroup.
-template <typename R, int NP>
-__global__ void __launch_bounds__(256) bwd_small_kernel(Problem P, State W, BwdArgs A, int parts) {
-    __shared__ __attribute__((aligned(16))) R pbuf[4][64];
-    __shared__ typename FrameFix<R>::T fxI[4][64];
-    __shared__ unsigned long long fxT[NP * NP];      // aligned edge posteriors (unscaled)
-    __shared__ unsigned long long fxX[NP * NP];      // exact-path full-lattice edge posteriors (unscaled)
-    __shared__ __attribute__((aligned(16))) R tileF[64 * NP];
-
-    const int lane = threadIdx.x & 63;
-    // wave index made provably uniform: otherwise every frame index, pointer and store offset derived from it is
-    // treated as divergent (EXEC-masked loop control, waterfall loop around the buffer store)
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int b = blockIdx.x, chunk = blockIdx.y;
-    const int N = P.N, T = P.T, S = P.S;
-    const R NINF = Num<R>::ninf(), L2E = Num<R>::log2e(), LZ = Num<R>::logzero();
-    const bool do_full = parts & 1, do_ali = parts & 2;
-    const int len = P.in_len ? clampi(P.in_len[b], 0, T) : T;
-    const int ol = (do_ali && P.targets) ? (P.tg_len ? clampi(P.tg_len[b], 0, S) : S) : 0;
-    const bool act = lane < N, sl = lane < S, sact = lane < ol;
-    const int lc = act ? lane : 0, ls_ = sl ? lane : 0;
-
-    const R *ahp = (const R *) W.ah + (int64_t) b * T * N + lc;
-    const R *bhp = (const R *) W.bh + (int64_t) b * T * N + lc;
-    // state rows through buffer loads: lane offset in a VGPR, frame offset in an SGPR (no per-lane 64-bit address math)
-    __amdgpu_buffer_rsrc_t r_ah = make_rsrc((R *) W.ah + (int64_t) b * T * N, (unsigned) T * (unsigned) N * (unsigned) sizeof(R));
-    __amdgpu_buffer_rsrc_t r_bh = make_rsrc((R *) W.bh + (int64_t) b * T * N, (unsigned) T * (unsigned) N * (unsigned) sizeof(R));
-    __amdgpu_buffer_rsrc_t r_ab = make_rsrc((R *) W.ab + (int64_t) b * T * S, (unsigned) T * (unsigned) S * (unsigned) sizeof(R));
-    __amdgpu_buffer_rsrc_t r_bb = make_rsrc((R *) W.bb + (int64_t) b * T * S, (unsigned) T * (unsigned) S * (unsigned) sizeof(R));
-    const unsigned vN = (unsigned) lc * (unsigned) sizeof(R), vS = (unsigned) ls_ * (unsigned) sizeof(R);
-    const unsigned rbN = (unsigned) N * (unsigned) sizeof(R), rbS = (unsigned) S * (unsigned) sizeof(R);
-    const int t0 = chunk * A.chunk;
-    const int t1 = min(T, t0 + A.chunk);
-    // software prefetch: the six state values of the NEXT frame are loaded before the current one is processed; the
-    // first frame's are issued before anything else so that their latency hides under the rest of the prologue
-    R n_ah, n_bh, n_ahp, n_ab, n_bb, n_abp;
-    {
-        const int tq = min(t0 + wave, T - 1), tqp = tq >= 1 ? tq - 1 : 0;
-        n_ah = buf_load<R>(r_ah, vN, (unsigned) tq * rbN); n_bh = buf_load<R>(r_bh, vN, (unsigned) tq * rbN);
-        n_ahp = buf_load<R>(r_ah, vN, (unsigned) tqp * rbN);
-        n_ab = buf_load<R>(r_ab, vS, (unsigned) tq * rbS); n_bb = buf_load<R>(r_bb, vS, (unsigned) tq * rbS);
-        n_abp = buf_load<R>(r_ab, vS, (unsigned) tqp * rbS);
-    }
-    // ---- prologue: everything below is ONE round of independent loads
-    const R g0 = A.grad_full ? (R) ((double) ((const R *) A.grad_full)[(int64_t) b * A.gstride] * A.gscale) : R(0);
-    const R gf = do_full ? g0 : R(0);
-    const R ga = do_ali ? (A.neg_aligned ? -g0
-                                         : (R) ((double) ((const R *) A.grad_aligned)[(int64_t) b * A.gstride] * A.gscale))
-                        : R(0);
-    V2<R> e2[NP / 2];
-    if (do_full) {
-        const V4<R> *erow = reinterpret_cast<const V4<R> *>((const R *) W.ehat + (int64_t) lc * W.npad);
-#pragma unroll
-        for (int j = 0; j < NP / 4; ++j) {
-            V4<R> v = erow[j];
-            e2[2 * j] = v.xy;
-            e2[2 * j + 1] = v.zw;
-        }
-        if (!act) {
-#pragma unroll
-            for (int j = 0; j < NP / 2; ++j) e2[j] = V2<R>{0, 0};
-        }
-    }
-    V2<R> hd = {0, 0};
-    int2 tp = {0, 0};
-    if (do_ali) {
-        hd = reinterpret_cast<const V2<R> *>(W.asu)[(int64_t) b * S + ls_];
-        tp = reinterpret_cast<const int2 *>(W.asi)[(int64_t) b * S + ls_];
-    }
-    const R H2 = hd.x, Dprev = hd.y;
-    const int tgt = tp.x, prv = tp.y;
-
-    for (int k = threadIdx.x; k < N * N; k += 256) { fxT[k] = 0; fxX[k] = 0; }
-    fxI[wave][lane] = 0;
-
-    V2<R> acc[NP / 2];
-#pragma unroll
-    for (int j = 0; j < NP / 2; ++j) acc[j] = V2<R>{0, 0};
-    R accH = 0, accD = 0;    // unscaled edge posteriors: stay on s ; arrive at s from s-1
-    bool any_bad = false;
-
-    __amdgpu_buffer_rsrc_t rs_g = make_rsrc((R *) A.grad_inputs + (int64_t) b * N,
-                                            (unsigned) ((int64_t) (T - 1) * P.B * N + N) * (unsigned) sizeof(R));
-    const unsigned voff = act ? (unsigned) lane * sizeof(R) : kOobOffset;
-    const unsigned grow_bytes = (unsigned) P.B * N * sizeof(R);
-    __syncthreads();
-
-    for (int t = t0 + wave; t < t1; t += 4) {
-        R gi = 0;
-        const R c_ah = n_ah, c_bh = n_bh, c_ahp = n_ahp, c_ab = n_ab, c_bb = n_bb, c_abp = n_abp;
-        {
-            const int tq = min(t + 4, T - 1), tqp = tq >= 1 ? tq - 1 : 0;
-            n_ah = buf_load<R>(r_ah, vN, (unsigned) tq * rbN); n_bh = buf_load<R>(r_bh, vN, (unsigned) tq * rbN);
-            n_ahp = buf_load<R>(r_ah, vN, (unsigned) tqp * rbN);
-            n_ab = buf_load<R>(r_ab, vS, (unsigned) tq * rbS); n_bb = buf_load<R>(r_bb, vS, (unsigned) tq * rbS);
-            n_abp = buf_load<R>(r_ab, vS, (unsigned) tqp * rbS);
-        }
-        if (t < len) {
-            // the three maxima (full gamma, previous alpha, aligned gamma) in one interleaved reduction pass
-            R gam = act ? c_ah + c_bh : NINF;
-            R ahprev = act ? c_ahp : NINF;
-            R gam2 = sl ? c_ab + c_bb : LZ;
-            R abprev = sl ? c_abp : LZ;
-            R mg = gam, mg2 = gam2;
-            wave_allmax2(mg, mg2);
-            mg = fmax(mg, LZ);
-            R w = do_full ? Num<R>::exp2(gam - mg) : R(0);
-            R w2 = (do_ali && mg2 > R(-1e29)) ? Num<R>::exp2(gam2 - mg2) : R(0);   // infeasible alignment -> no posterior
-            // the forward pass stores alpha_hat relative to an offset that keeps the frame's L1 norm near 1, so it is
-            // exponentiated as is (no third reduction); a frame that underflows anyway fails the `ok` test below and
-            // goes through the exact pass
-            R p = Num<R>::exp2(ahprev);
-            R *lds = pbuf[wave];
-            if (do_full && t >= 1) {
-                lds[lane] = p;
-                __builtin_amdgcn_wave_barrier();
-            }
-            R Z = w, Z2 = w2;
-            wave_allsum2(Z, Z2);
-            // v_rcp (1 ulp) instead of the ~10-instruction IEEE division: far inside the 1e-4 budget
-            R post2 = (Z2 > 0) ? w2 * Num<R>::rcp(Z2) : R(0);   // unscaled aligned state posterior, 0 for s >= ol
-            gi = (Z > 0) ? gf * (w * Num<R>::rcp(Z)) : R(0);
-            if (do_full && t >= 1) {
-                V4<R> pv[NP / 4];
-#pragma unroll
-                for (int j = 0; j < NP / 4; ++j) pv[j] = *reinterpret_cast<const V4<R> *>(lds + 4 * j);
-                __builtin_amdgcn_sched_barrier(0);
-                V2<R> a0 = {0, 0}, a1 = {0, 0};
-#pragma unroll
-                for (int j = 0; j < NP / 4; ++j) {
-                    a0 = fma2<R>(e2[2 * j], pv[j].xy, a0);
-                    a1 = fma2<R>(e2[2 * j + 1], pv[j].zw, a1);
-                }
-                V2<R> a = a0 + a1;
-                R sden = a.x + a.y;                    // row sum of the forward mat-vec (up to the common scale of p)
-                bool ok = fabs(Num<R>::log2(sden)) < Num<R>::lg_limit();
-                any_bad |= (gi != R(0)) && !ok;
-                R u = ok ? gi * Num<R>::rcp(sden) : R(0);
-                const V2<R> u2 = {u, u};
-#pragma unroll
-                for (int j = 0; j < NP / 4; ++j) {
-                    acc[2 * j] = fma2<R>(u2, pv[j].xy, acc[2 * j]);
-                    acc[2 * j + 1] = fma2<R>(u2, pv[j].zw, acc[2 * j + 1]);
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-            if (do_ali) {
-                // unconditional (post2 is 0 on lanes >= ol, and adding 0 is harmless): no EXEC juggling per frame
-                atomicAdd(&fxI[wave][tgt], FrameFix<R>::to(post2));
-                __builtin_amdgcn_wave_barrier();
-                if (t >= 1) {
-                    R pc0 = abprev + H2;
-                    R pc1 = prev_lane_or_zero<R>(abprev) + Dprev;
-                    R l = lse2<R>(pc0, pc1);
-                    accH += post2 * Num<R>::exp2(pc0 - l);
-                    accD += post2 * Num<R>::exp2(pc1 - l);
-                }
-                const typename FrameFix<R>::T fv = fxI[wave][lane];
-                gi += ga * FrameFix<R>::from(fv);
-                fxI[wave][lane] = 0;
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-        buf_store(gi, rs_g, voff, (unsigned) t * grow_bytes);
-    }
-
-    // ---- rare exact pass: rows whose recomputed sum was unusable (forward took its exact path there too)
-    if (do_full && __any(any_bad)) {
-        const R *trow = (const R *) P.transition + (int64_t) lc * P.ts0;
-        // same frame ownership as the fast loop (t = t0 + wave + 4k); frame 0 has no incoming transition
-        for (int t = (t0 + wave == 0) ? 4 : t0 + wave; t < min(t1, len); t += 4) {
-            R ahv = act ? ahp[(int64_t) t * N] : NINF, bhv = act ? bhp[(int64_t) t * N] : NINF;
-            R ahprev = act ? ahp[(int64_t) (t - 1) * N] : NINF;
-            R gam = ahv + bhv;
-            R mg = fmax(wave_allmax(gam), LZ);
-            R w = Num<R>::exp2(gam - mg);
-            R Z = wave_allsum(w);
-            R post = (Z > 0) ? w * Num<R>::rcp(Z) : R(0);
-            // the SAME row sums, bit for bit, as the fast path computed (same operands, same order), so that "bad"
-            // here is exactly the set of rows the fast path skipped
-            R p = Num<R>::exp2(ahprev);
-            R *lds = pbuf[wave];
-            lds[lane] = p;
-            __builtin_amdgcn_wave_barrier();
-            V2<R> a0 = {0, 0}, a1 = {0, 0};
-#pragma unroll
-            for (int j = 0; j < NP / 4; ++j) {
-                const V4<R> pvj = *reinterpret_cast<const V4<R> *>(lds + 4 * j);
-                a0 = fma2<R>(e2[2 * j], pvj.xy, a0);
-                a1 = fma2<R>(e2[2 * j + 1], pvj.zw, a1);
-            }
-            __builtin_amdgcn_wave_barrier();
-            const V2<R> a = a0 + a1;
-            const R sden = a.x + a.y;
-            const R gi_f = (Z > 0) ? gf * (w * Num<R>::rcp(Z)) : R(0);
-            const bool ok = fabs(Num<R>::log2(sden)) < Num<R>::lg_limit();
-            bool bad = act && gi_f != R(0) && !ok;
-            if (__any(bad)) {
-                R lse = exact_lse_row<R>(trow, P.ts1, ahprev, N, act);
-                for (int j = 0; j < N; ++j) {
-                    R aj = readlane(ahprev, j);
-                    R x = bad ? post * Num<R>::exp2(trow[(int64_t) j * P.ts1] * L2E + aj - lse) : R(0);
-                    if (x == x && x != R(0)) atomicAdd(&fxX[lane * N + j], to_fix<R>(x));
-                }
-            }
-        }
-    }
-
-    // ---- epilogue: one partial [N][N] tile per workgroup
-#pragma unroll
-    for (int j = 0; j < NP / 2; ++j) acc[j] = acc[j] * e2[j];
-    for (int w = 0; w < 4; ++w) {
-        if (wave == w && act) {
-#pragma unroll
-            for (int j = 0; j < NP / 2; ++j) {
-                V2<R> *dst = reinterpret_cast<V2<R> *>(&tileF[lane * NP + 2 * j]);
-                V2<R> prev = (w == 0) ? V2<R>{0, 0} : *dst;
-                *dst = prev + acc[j];
-            }
-        }
-        __syncthreads();
-    }
-    if (do_ali && sact) {
-        if (accH != R(0)) atomicAdd(&fxT[tgt * N + tgt], to_fix<R>(accH));
-        if (lane >= 1 && accD != R(0)) atomicAdd(&fxT[tgt * N + prv], to_fix<R>(accD));
-    }
-    __syncthreads();
-    R *tile_out = (R *) A.scratch + ((int64_t) b * A.nchunks + chunk) * N * N;
-    for (int k = threadIdx.x; k < N * N; k += 256) {
-        int i = k / N, j = k - i * N;
-        R v = do_full ? tileF[i * NP + j] : R(0);
-        unsigned long long fv = fxT[k], fx = fxX[k];
-        if (fv != 0) v += ga * from_fix<R>(fv);
-        if (fx != 0) v += gf * from_fix<R>(fx);
-        tile_out[k] = v;
-    }
-}
-
-// Sum G partial tiles in a fixed order -> deterministic grad_transition.
-// block = 1024 threads = 32 elements x 32 tile-groups; thread (e, grp) sums tiles grp, grp+32, ... with 16
-// independent accumulators (16 loads in flight: the kernel is pure L2 latency, so the 512 tiles of cfg 3 take ONE
-// round of loads per thread), then a fixed-order LDS combine over the 32 groups.
-constexpr int kRedGroups = 32;
-template <typename R>
-__global__ void __launch_bounds__(1024) reduce_tiles_kernel(const R *tiles, int G, int n, R *out) {
-    __shared__ R part[kRedGroups][32];
-    const int e = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    const int k = min(blockIdx.x * 32 + e, n - 1);
-    R acc[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) acc[q] = 0;
-    int g = grp;
-    for (; g + kRedGroups * 15 < G; g += kRedGroups * 16) {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) acc[q] += tiles[(int64_t) (g + kRedGroups * q) * n + k];
-    }
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        int gg = g + kRedGroups * q;
-        R v = tiles[(int64_t) min(gg, G - 1) * n + k];        // unconditional load, masked add
-        acc[q] += (gg < G) ? v : R(0);
-    }
-    R s = 0;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) s += acc[q];
-    part[grp][e] = s;
-    __syncthreads();
-    if (grp == 0 && blockIdx.x * 32 + e < n) {
-        R t = part[0][e];
-#pragma unroll
-        for (int q = 1; q < kRedGroups; ++q) t += part[q][e];
-        out[k] = t;
-    }
-}
-
-// loss[b] = full[b] - aligned[b]  (asg.py:128,136) and its reduction (asg.py:137-142), one workgroup,
-// fixed-order tree -> deterministic.
-template <typename R>
-__global__ void __launch_bounds__(256) loss_reduce_kernel(const R *full, const R *aligned, int B, int reduction, R *out) {
-    __shared__ double part[256];
-    double s = 0;
-    for (int b = threadIdx.x; b < B; b += 256) {
-        R l = full[b] - aligned[b];
-        if (reduction == 0) out[b] = l;
-        s += (double) l;
-    }
-    if (reduction == 0) return;
-    part[threadIdx.x] = s;
-    __syncthreads();
-    for (int w = 128; w >= 1; w >>= 1) {
-        if ((int) threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) out[0] = (R) (reduction == 2 ? part[0] / B : part[0]);
-}
-
-// The three-wavefront chain buys latency with issue slots: it wins while every chain has a compute unit to itself
-// (cfg 3: 128 full-lattice chains on 256 CUs; measured 80 vs 85 us/step at B=64, 95 vs 101 at B=128) and loses once
-// chains have to share (159 vs 134 us/step at B=256), where the single-wavefront chain is the denser packing.
-inline bool duo_enabled(int nchains) {
-    static const bool on = !(getenv("ASG_NO_DUO") && atoi(getenv("ASG_NO_DUO")) != 0);    // developer A/B switch
-    static const int cus = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-            n = 256;
-        return n > 0 ? n : 256;
-    }();
-    return on && nchains <= cus;
-}
-
-template <typename R, int NP, int MV>
-hipError_t launch_fwd_np(const Problem &P, const State &W, const FwdOut &O, int mask, bool store, hipStream_t st) {
-    if constexpr (sizeof(R) == 4 && MV == 0) {
-        if ((mask & (kFullAlpha | kFullBeta)) && P.N < 64 &&
-            duo_enabled(P.B * __builtin_popcount(mask & (kFullAlpha | kFullBeta)))) {
-            dim3 grid(P.B, __builtin_popcount(mask)), block(192);
-            if (store) hipLaunchKernelGGL((fwd_duo_kernel<NP, true>), grid, block, 0, st, P, W, O, mask);
-            else hipLaunchKernelGGL((fwd_duo_kernel<NP, false>), grid, block, 0, st, P, W, O, mask);
-            return hipGetLastError();
-        }
-    }
-    dim3 grid(P.B, __builtin_popcount(mask)), block(64);
-    if (store) hipLaunchKernelGGL((fwd_small_kernel<R, NP, MV, true>), grid, block, 0, st, P, W, O, mask);
-    else hipLaunchKernelGGL((fwd_small_kernel<R, NP, MV, false>), grid, block, 0, st, P, W, O, mask);
-    return hipGetLastError();
-}
-
-template <typename R, int MV>
-hipError_t launch_fwd_mv(const Problem &P, const State &W, const FwdOut &O, int mask, bool store, hipStream_t st) {
-    const int N = P.N;
-    if (!(mask & (kFullAlpha | kFullBeta)) || N <= 8) return launch_fwd_np<R, 8, MV>(P, W, O, mask, store, st);
-    if (N <= 16) return launch_fwd_np<R, 16, MV>(P, W, O, mask, store, st);
-    if (N <= 24) return launch_fwd_np<R, 24, MV>(P, W, O, mask, store, st);
-    if (N <= 32) return launch_fwd_np<R, 32, MV>(P, W, O, mask, store, st);
-    if (N <= 40) return launch_fwd_np<R, 40, MV>(P, W, O, mask, store, st);
-    if (N <= 48) return launch_fwd_np<R, 48, MV>(P, W, O, mask, store, st);
-    if (N <= 56) return launch_fwd_np<R, 56, MV>(P, W, O, mask, store, st);
-    return launch_fwd_np<R, 64, MV>(P, W, O, mask, store, st);
-}
-
-template <typename R, int NP>
-hipError_t launch_bwd_np(const Problem &P, const State &W, const BwdArgs &A, int parts, hipStream_t st) {
-    dim3 grid(P.B, A.nchunks), block(256);
-    hipLaunchKernelGGL((bwd_small_kernel<R, NP>), grid, block, 0, st, P, W, A, parts);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    const int n = P.N * P.N, G = P.B * A.nchunks;
-    hipLaunchKernelGGL((reduce_tiles_kernel<R>), dim3((n + 31) / 32), dim3(1024), 0, st,
-                       (const R *) A.scratch, G, n, (R *) A.grad_transition);
-    return hipGetLastError();
-}
-
 }  // namespace
-
-template <typename R>
-hipError_t launch_fwd_small(const Problem &P, const State &W, const FwdOut &O, int chain_mask, bool store,
-                            int matvec_variant, hipStream_t stream) {
-    if (chain_mask == 0) return hipSuccess;
-    if (chain_mask & (kFullAlpha | kFullBeta)) {
-        // the full-lattice chains address emission frames with 32-bit buffer offsets
-        const double fr = (double) (P.T - 1) * (double) P.is0 * sizeof(R), ln = 63.0 * (double) P.is2 * sizeof(R);
-        if (P.is0 < 0 || P.is2 < 0 || fr >= 4294967296.0 || ln >= 2147483648.0) return hipErrorInvalidValue;
-    }
-    if (matvec_variant == 1) return launch_fwd_mv<R, 1>(P, W, O, chain_mask, store, stream);
-    return launch_fwd_mv<R, 0>(P, W, O, chain_mask, store, stream);
-}
-
-template <typename R>
-hipError_t launch_bwd_small(const Problem &P, const State &W, const BwdArgs &A, int parts, hipStream_t stream) {
-    const int N = P.N;
-    if (N <= 8) return launch_bwd_np<R, 8>(P, W, A, parts, stream);
-    if (N <= 16) return launch_bwd_np<R, 16>(P, W, A, parts, stream);
-    if (N <= 24) return launch_bwd_np<R, 24>(P, W, A, parts, stream);
-    if (N <= 32) return launch_bwd_np<R, 32>(P, W, A, parts, stream);
-    if (N <= 40) return launch_bwd_np<R, 40>(P, W, A, parts, stream);
-    if (N <= 48) return launch_bwd_np<R, 48>(P, W, A, parts, stream);
-    if (N <= 56) return launch_bwd_np<R, 56>(P, W, A, parts, stream);
-    return launch_bwd_np<R, 64>(P, W, A, parts, stream);
-}
-
-size_t bwd_scratch_bytes_small(int elem, int T, int B, int N, int S, int *chunk, int *nchunks) {
-    // aim for ~512 workgroups (2 per CU; flat between 512 and 768 on MI355X) but at least 16 frames per workgroup
-    int target = 512;
-    if (const char *ev = getenv("ASG_BWD_WGS")) target = atoi(ev) > 0 ? atoi(ev) : target;   // developer probe
-    int nch = (target + B - 1) / B;
-    if (nch < 1) nch = 1;
-    int ch = (T + nch - 1) / nch;
-    if (ch < 16) ch = 16;
-    ch = (ch + 3) / 4 * 4;
-    nch = (T + ch - 1) / ch;
-    if (nch < 1) nch = 1;
-    if (chunk) *chunk = ch;
-    if (nchunks) *nchunks = nch;
-    return (size_t) B * nch * N * N * elem;
-}
-
-template hipError_t launch_fwd_small<float>(const Problem &, const State &, const FwdOut &, int, bool, int, hipStream_t);
-template hipError_t launch_fwd_small<double>(const Problem &, const State &, const FwdOut &, int, bool, int, hipStream_t);
-template <typename R>
-hipError_t launch_loss_reduce(const void *full, const void *aligned, int B, int reduction, void *out, hipStream_t stream) {
-    hipLaunchKernelGGL((loss_reduce_kernel<R>), dim3(1), dim3(256), 0, stream, (const R *) full, (const R *) aligned, B,
-                       reduction, (R *) out);
-    return hipGetLastError();
-}
-template hipError_t launch_loss_reduce<float>(const void *, const void *, int, int, void *, hipStream_t);
-template hipError_t launch_loss_reduce<double>(const void *, const void *, int, int, void *, hipStream_t);
-
-template hipError_t launch_bwd_small<float>(const Problem &, const State &, const BwdArgs &, int, hipStream_t);
-template hipError_t launch_bwd_small<double>(const Problem &, const State &, const BwdArgs &, int, hipStream_t);
-
 }  // namespace asg

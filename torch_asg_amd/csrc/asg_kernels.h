@@ -34,6 +34,7 @@ struct State {
     void *asu;
     int *asi;
     void *dbg;
+    unsigned *ticket;   // 256 B, zeroed per call: arrival counter of the in-kernel loss reduction
     void *work;      // generic path: forward work buffers (emission maxima, p vectors, normalisers, offsets)
     int npad;
 };
@@ -46,7 +47,7 @@ struct FwdOut {
     // optional in-kernel loss reduction (small path): the LAST of the `expected` beta passes to finish reduces
     // loss[b] = full[b] - aligned[b] (reduction: 0 none, 1 sum, 2 mean) -- no separate reduce launch
     void *loss;
-    unsigned *counter;           // persistent, zero between calls (self-resetting)
+    unsigned *counter;           // State::ticket of this call (zeroed on the stream before the launch)
     int reduction, expected;
 };
 
