@@ -194,6 +194,9 @@ int run_forward(asg_ctx *ctx, const asg_problem *p, void *state, void *full_scor
         if ((e = hipStreamWaitEvent(stream, ctx->join, 0)) != hipSuccess) return hip_status(e);
         return ASG_OK;
     }
+    if constexpr (sizeof(R) == 4) {
+        if ((flags & 16) && mask == 15 && p->N < 64) return hip_status(launch_fwd_cohab(P, W, O, store, stream));   // experiment
+    }
     if (flags & ASG_FLAG_SINGLE_LAUNCH) return hip_status(launch_fwd_small<R>(P, W, O, mask, store, mv, stream));
     if (full_mask && (e = launch_fwd_small<R>(P, W, O, full_mask, store, mv, stream)) != hipSuccess) return hip_status(e);
     if (ali_mask && (e = launch_fwd_small<R>(P, W, O, ali_mask, store, mv, stream)) != hipSuccess) return hip_status(e);

@@ -73,6 +73,7 @@ hipError_t launch_fwd_small(const Problem &P, const State &W, const FwdOut &O, i
                             int matvec_variant, hipStream_t stream);
 template <typename R>
 hipError_t launch_bwd_small(const Problem &P, const State &W, const BwdArgs &A, int parts, hipStream_t stream);
+hipError_t launch_fwd_cohab(const Problem &P, const State &W, const FwdOut &O, bool store, hipStream_t stream);
 // loss[b] = full[b] - aligned[b], reduced: 0 = none ([B] out), 1 = sum, 2 = mean ([1] out); fixed-order tree
 template <typename R>
 hipError_t launch_loss_reduce(const void *full, const void *aligned, int B, int reduction, void *out, hipStream_t stream);
