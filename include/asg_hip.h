@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define ASG_HIP_VERSION 100
+#define ASG_HIP_VERSION 200
 
 #define ASG_DTYPE_F32 0
 #define ASG_DTYPE_F64 1
@@ -44,7 +44,7 @@ extern "C" {
                                        without it everything is issued on `stream` in order
                                        (= ASGLoss(gpu_no_stream_impl=True), asg.py:124) */
 #define ASG_FLAG_SINGLE_LAUNCH 2    /* all four recursions in ONE kernel launch (blockIdx.y = pass) */
-#define ASG_FLAG_MATVEC_READLANE 4  /* tuning: broadcast the previous frame with v_readlane instead of LDS */
+#define ASG_FLAG_MATVEC_READLANE 4  /* accepted and ignored (a tuning variant of round 1 that lost every measurement) */
 #define ASG_FLAG_ALPHA_SCORES 8     /* debugging: forward also writes the scores obtained from the alpha passes
                                        into full_scores[B..2B) / aligned_scores[B..2B) */
 
@@ -63,9 +63,11 @@ typedef struct asg_problem {
     int32_t reserved;
 } asg_problem;
 
-/* Opaque per-module context: side stream + events for ASG_FLAG_STREAMS. Not thread-safe: use one
- * per calling thread/module (the reference keeps none: it borrows streams from the CUDA stream pool,
- * streamlined_fast_gpu.cpp:121-129). */
+/* Opaque context: the side stream + fork/join events of ASG_FLAG_STREAMS -- host handles only, no device memory and
+ * no per-call state (the reference keeps none either: it borrows streams from the CUDA stream pool,
+ * streamlined_fast_gpu.cpp:121-129).  Calls that use the SAME context are ordered through its events, so use one
+ * context per calling stream (or thread); everything else in this library is re-entrant: whatever a call mutates on
+ * the device lives in the buffers the caller passed to that call. */
 typedef struct asg_ctx asg_ctx;
 
 int asg_hip_version(void);
@@ -144,6 +146,29 @@ int asg_loss_forward(asg_ctx *ctx, const asg_problem *p, void *state, size_t sta
 int asg_loss_backward(asg_ctx *ctx, const asg_problem *p, const void *state, size_t state_bytes, int reduction,
                       const void *grad_loss, void *scratch, size_t scratch_bytes, void *grad_transition,
                       void *grad_inputs, int flags, void *stream);
+
+/* ---- fused training step: the whole criterion, forward AND gradient assembly, in one launch -----------------
+ * The reference's GPU fast route runs every recursion in forward and none in backward
+ * (fast_asg_gpu_forward / fast_asg_gpu_backward, streamlined_fast_gpu.cpp:104-297); this pair goes one step further:
+ * asg_loss_fused_forward also assembles d(loss)/d(inputs) and the per-utterance transition-gradient tiles for an
+ * upstream gradient of 1, as the alpha and beta recursions cross (nothing but half of the lattice state ever goes
+ * to HBM); asg_loss_fused_backward multiplies by the actual upstream gradient (a no-op when that is 1), reduces the
+ * tiles in a fixed order into grad_transition and redoes, exactly, any utterance the fused path declined
+ * (row sums outside the fp32-safe range, fewer than 4 frames).  Results are bit-deterministic.
+ *   supported: float32, N < 64, S <= 64 (asg_loss_fused_supported returns 1); otherwise use asg_loss_forward/backward.
+ *   state:     asg_state_bytes(p) bytes, as for asg_loss_forward; the SAME buffer must be passed to backward.
+ *   scratch:   asg_loss_fused_scratch_bytes(p) bytes; the SAME buffer must be passed to backward.
+ *   grad_inputs [T,B,N] contiguous: written by forward, rescaled in place by backward.
+ *   ticket:    256 bytes of device memory that are ZERO on entry; the call leaves them zero.  Calls that may run
+ *              concurrently (different streams) need different tickets; calls on one stream may share one.
+ * The library allocates nothing and keeps no state between calls. */
+int asg_loss_fused_supported(const asg_problem *p);
+size_t asg_loss_fused_scratch_bytes(const asg_problem *p);
+int asg_loss_fused_forward(const asg_problem *p, void *state, size_t state_bytes, int reduction, void *loss, void *scores,
+                           void *scratch, size_t scratch_bytes, void *grad_inputs, void *ticket, int flags, void *stream);
+int asg_loss_fused_backward(const asg_problem *p, void *state, size_t state_bytes, int reduction, const void *grad_loss,
+                            void *scratch, size_t scratch_bytes, void *grad_inputs, void *grad_transition, int flags,
+                            void *stream);
 
 #ifdef __cplusplus
 }

@@ -60,13 +60,15 @@ class OracleBackend:
         return g1 + g2, i1 + i2
 
     def loss_forward(self, inputs, targets, transition, input_lengths, target_lengths, reduction, flags=0):
+        from torch_asg_amd.asg import _Saved
         fs, as_, state = self.forward(inputs, targets, transition, input_lengths, target_lengths)
         per = fs - as_
         loss = per if reduction == "none" else (per.sum() if reduction == "sum" else per.mean())
-        return loss, state, None
+        return loss, _Saved("split", (state,), None, None, None)
 
-    def loss_backward(self, state, grad_loss, inputs, targets, transition, input_lengths, target_lengths,
-                      reduction, flags=0, problem=None):
+    def loss_backward(self, saved, tensors, grad_loss, inputs, targets, transition, input_lengths, target_lengths,
+                      reduction):
+        (state,) = tensors
         B = inputs.shape[1]
         g = grad_loss.reshape(-1).to(inputs.dtype)
         if reduction != "none":

@@ -20,6 +20,6 @@ def timed(fn):
     for _ in range(K): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / K * 1e3
-for flags in (2, 2 | 16, 2, 2 | 16):
+for flags in (2, 2 | 16, 2 | 16 | 32, 2 | 16 | 64, 2, 2 | 16, 2 | 16 | 32, 2 | 16 | 64):
     full, ali, st = be.forward(x, tg, tr, il, tl, flags)
     print("flags %2d: %.1f us   scores %.5f %.5f" % (flags, timed(lambda: be.forward(x, tg, tr, il, tl, flags)), float(full.mean()), float(ali.mean())))

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Developer probe (GPU): which utterances the fused forward flagged, and forward / backward kernel times."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import torch_asg_amd, bench
+from torch_asg_amd import _lib
+dev = "cuda:0"
+T, B, N, L = [int(v) for v in (sys.argv[1:5] if len(sys.argv) >= 5 else (400, 64, 40, 30))]
+g = torch.Generator().manual_seed(0)
+tr = torch.rand(N, N, generator=g).to(dev); x = torch.randn(T, B, N, generator=g).to(dev); tg = torch.randint(0, N, (B, L), generator=g).to(dev)
+il = torch.full((B,), T, dtype=torch.int64, device=dev); tl = torch.full((B,), L, dtype=torch.int64, device=dev)
+be = torch_asg_amd.asg.native()
+loss, saved = be.loss_forward(x, tg, tr, il, tl, "mean", _lib.FLAG_SINGLE_LAUNCH)
+torch.cuda.synchronize()
+ws, gin = saved.tensors
+sc, stb, fs = saved.sizes
+tiles = (B * N * N * 4 + 255) // 256 * 256
+flags = ws[sc + stb + tiles: sc + stb + tiles + 4 * B].view(torch.int32).cpu().numpy()
+print("mode", saved.mode, "flagged", int(flags.sum()), "of", B, "loss", float(loss))
+one = torch.ones((), device=dev)
+def timed(fn, K=50):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda._sleep(20_000_000)
+    e0.record()
+    for _ in range(K): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / K * 1e3
+print("forward %.1f us" % timed(lambda: be.loss_forward(x, tg, tr, il, tl, "mean", _lib.FLAG_SINGLE_LAUNCH)))
+def fb():
+    l, sv = be.loss_forward(x, tg, tr, il, tl, "mean", _lib.FLAG_SINGLE_LAUNCH)
+    be.loss_backward(sv, sv.tensors, one, x, tg, tr, il, tl, "mean")
+print("forward+backward %.1f us" % timed(fb))
+if os.environ.get("ASG_DBG"):
+    al = lambda v: (v + 255) // 256 * 256
+    S = L
+    off = 0
+    for sz in (B * T * N * 4, B * T * N * 4, B * T * S * 4, B * T * S * 4, N * ((N + 7) // 8 * 8) * 4, N * 4, B * S * 2 * 4, B * S * 2 * 4):
+        off = al(off + sz)
+    be.loss_forward(x, tg, tr, il, tl, "mean", _lib.FLAG_SINGLE_LAUNCH)
+    l2, sv2 = be.loss_forward(x, tg, tr, il, tl, "mean", _lib.FLAG_SINGLE_LAUNCH)
+    torch.cuda.synchronize()
+    d = sv2.tensors[0][sc + off: sc + off + 512].view(torch.int64).cpu().numpy()
+    names = ["main-a", "main-b", "cons-a", "cons-b", "ali-a", "ali-b", "fin-a", "fin-b"]
+    what = {"main": ["poll e"], "cons": ["slot 1st half", "other side st_done", "slot 2nd half", "row ring space"],
+            "ali": ["ring space"], "fin": ["other ast_done", "row_done", "ar_done"]}
+    for r, nm in enumerate(names):
+        v = d[r * 5: r * 5 + 5]
+        w = what[nm.split("-")[0]]
+        print("%-7s total %8d cyc (%.1f us @2.4GHz)  " % (nm, v[0], v[0] / 2400.0) + "  ".join("%s %d" % (w[k], v[1 + k]) for k in range(len(w))))

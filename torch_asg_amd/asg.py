@@ -39,6 +39,9 @@ class HipBackend:
         self._ctx = {}
         self._sizes = {}
         self._lock = threading.Lock()
+        self._tickets = {}
+        self._pools = {}
+        self._pool_keep = []
 
     def _bytes(self, p):
         """(state_bytes, scratch_bytes) of a problem shape, cached per (dtype, T, B, N, S)."""
@@ -260,45 +263,117 @@ class HipBackend:
     # -- whole loss: full - aligned, reduction and their gradients inside the kernels -----------------------
     _RED = {"none": 0, "sum": 1, "mean": 2}
 
+    def _ticket(self, device):
+        """256 zeroed bytes for the arrival ticket of the in-launch loss reduction (include/asg_hip.h: zero on entry,
+        left zero).  One slot per calling stream for eager calls (calls on one stream are ordered, they may share);
+        a fresh slot for every call made while a hipGraph is being captured, so that graphs replayed concurrently
+        never share one.  Slots come from a pool that is zeroed ONCE, outside the hot path."""
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        capturing = torch.cuda.is_current_stream_capturing()
+        key = (idx, torch.cuda.current_stream(idx).cuda_stream)
+        if not capturing:
+            t = self._tickets.get(key)
+            if t is not None:
+                return t
+        with self._lock:
+            pool = self._pools.get(idx)
+            if pool is None or pool[1] >= pool[0].shape[0]:
+                pool = [torch.zeros(1024, 64, dtype=torch.int32, device=device), 0]
+                self._pools[idx] = pool
+                self._pool_keep.append(pool[0])
+            t = pool[0][pool[1]]
+            pool[1] += 1
+            if not capturing:
+                self._tickets[key] = t
+        return t
+
+    def fused_supported(self, p):
+        return bool(_lib.lib().asg_loss_fused_supported(ctypes.byref(p)))
+
     def loss_forward(self, inputs, targets, transition, input_lengths, target_lengths, reduction,
                      flags=_lib.FLAG_STREAMS):
+        """loss = reduce(full - aligned).  Returns (loss, saved): `saved` is what loss_backward needs --
+        saved.tensors (device buffers, to go through ctx.save_for_backward) and host-side bookkeeping.
+
+        With launch mode 'single' and a supported shape this is the FUSED step: the launch also assembles the
+        gradients (for an upstream gradient of 1) into saved.tensors; otherwise the recursion kernels run alone and
+        the assembly kernels run in loss_backward."""
         self._check(inputs, transition, targets, input_lengths, target_lengths)
         L = _lib.lib()
-        B = inputs.shape[1]
+        T, B, N = inputs.shape
         red = self._RED[reduction]
-        with self._guard(inputs.device):
+        dev = inputs.device
+        with self._guard(dev):
             p, keep = self._problem(inputs, transition, targets, input_lengths, target_lengths)
-            state = self._buf(self._bytes(p)[0], inputs.device)
-            scores = torch.empty(2, B, dtype=inputs.dtype, device=inputs.device)
-            loss = torch.empty((B,) if red == 0 else (), dtype=inputs.dtype, device=inputs.device)
-            _lib.check(L.asg_loss_forward(self._context(inputs.device), ctypes.byref(p), state.data_ptr(),
+            state_bytes = self._bytes(p)[0]
+            loss = torch.empty((B,) if red == 0 else (), dtype=inputs.dtype, device=dev)
+            if (flags & _lib.FLAG_SINGLE_LAUNCH) and self.fused_supported(p):
+                key = ("fs", p.T, p.B, p.N, p.S)
+                fs = self._sizes.get(key)
+                if fs is None:
+                    fs = int(L.asg_loss_fused_scratch_bytes(ctypes.byref(p)))
+                    self._sizes[key] = fs
+                # one workspace: [scores 2B | state | scratch]
+                sc_bytes = (2 * B * 4 + 255) // 256 * 256
+                ws = torch.empty(sc_bytes + state_bytes + fs, dtype=torch.uint8, device=dev)
+                gin = torch.empty(T, B, N, dtype=inputs.dtype, device=dev)
+                base = ws.data_ptr()
+                _lib.check(L.asg_loss_fused_forward(ctypes.byref(p), base + sc_bytes, state_bytes, red, loss.data_ptr(),
+                                                    base, base + sc_bytes + state_bytes, fs, gin.data_ptr(),
+                                                    self._ticket(dev).data_ptr(), 0, self._stream(dev)),
+                           "asg_loss_fused_forward")
+                return loss, _Saved("fused", (ws, gin), p, keep, (sc_bytes, state_bytes, fs))
+            state = self._buf(state_bytes, dev)
+            scores = torch.empty(2, B, dtype=inputs.dtype, device=dev)
+            _lib.check(L.asg_loss_forward(self._context(dev), ctypes.byref(p), state.data_ptr(),
                                           state.numel(), red, loss.data_ptr(), scores.data_ptr(),
-                                          flags & ~_lib.FLAG_ALPHA_SCORES, self._stream(inputs.device)),
+                                          flags & ~_lib.FLAG_ALPHA_SCORES, self._stream(dev)),
                        "asg_loss_forward")
-        return loss, state, (p, keep)         # the problem block is reused by backward: same tensors are saved there
+        return loss, _Saved("split", (state,), p, keep, None)
 
-    def loss_backward(self, state, grad_loss, inputs, targets, transition, input_lengths, target_lengths,
-                      reduction, flags=0, problem=None):
+    def loss_backward(self, saved, tensors, grad_loss, inputs, targets, transition, input_lengths, target_lengths,
+                      reduction):
+        """(grad_transition, grad_inputs) of the reduced loss.  `tensors` are saved.tensors as autograd handed them
+        back (they may have travelled through saved-tensor hooks)."""
         L = _lib.lib()
         T, B, N = inputs.shape
-        with self._guard(inputs.device):
-            if problem is not None:
-                p, keep = problem             # built in forward from the very tensors autograd saved
-            else:
-                p, keep = self._problem(inputs, transition, targets, input_lengths, target_lengths)
+        dev = inputs.device
+        with self._guard(dev):
+            p = saved.problem
+            if p.inputs != inputs.data_ptr() or p.transition != transition.data_ptr() or p.targets != targets.data_ptr():
+                # the saved tensors came back at other addresses (saved-tensor hooks): rebuild the problem block
+                p, _ = self._problem(inputs, transition, targets, input_lengths, target_lengths)
             g = grad_loss
             if g.dtype != inputs.dtype:
                 g = g.to(inputs.dtype)
             if not g.is_contiguous():
                 g = g.contiguous()
-            scratch = self._buf(self._bytes(p)[1], inputs.device)
-            gtr = torch.empty(N, N, dtype=inputs.dtype, device=inputs.device)
-            gin = torch.empty(T, B, N, dtype=inputs.dtype, device=inputs.device)
-            _lib.check(L.asg_loss_backward(self._context(inputs.device), ctypes.byref(p), state.data_ptr(),
+            gtr = torch.empty(N, N, dtype=inputs.dtype, device=dev)
+            if saved.mode == "fused":
+                ws, gin = tensors
+                sc_bytes, state_bytes, fs = saved.sizes
+                base = ws.data_ptr()
+                _lib.check(L.asg_loss_fused_backward(ctypes.byref(p), base + sc_bytes, state_bytes, self._RED[reduction],
+                                                     g.data_ptr(), base + sc_bytes + state_bytes, fs, gin.data_ptr(),
+                                                     gtr.data_ptr(), 0, self._stream(dev)), "asg_loss_fused_backward")
+                return gtr, gin
+            (state,) = tensors
+            scratch = self._buf(self._bytes(p)[1], dev)
+            gin = torch.empty(T, B, N, dtype=inputs.dtype, device=dev)
+            _lib.check(L.asg_loss_backward(self._context(dev), ctypes.byref(p), state.data_ptr(),
                                            state.numel(), self._RED[reduction], g.data_ptr(), scratch.data_ptr(),
-                                           scratch.numel(), gtr.data_ptr(), gin.data_ptr(), flags,
-                                           self._stream(inputs.device)), "asg_loss_backward")
+                                           scratch.numel(), gtr.data_ptr(), gin.data_ptr(), 0,
+                                           self._stream(dev)), "asg_loss_backward")
         return gtr, gin
+
+
+class _Saved:
+    """Host-side record of one loss_forward call: which route ran, the device buffers it filled, the C problem block."""
+    __slots__ = ("mode", "tensors", "problem", "keep", "sizes", "consumed")
+
+    def __init__(self, mode, tensors, problem, keep, sizes):
+        self.mode, self.tensors, self.problem, self.keep, self.sizes = mode, tensors, problem, keep, sizes
+        self.consumed = False
 
 
 _backend = None
@@ -404,26 +479,41 @@ class ASGGPUFast(torch.autograd.Function):
 
 
 class ASGLossFunction(torch.autograd.Function):
-    """The whole criterion in one Function: loss = reduce(full - aligned) (asg.py:128,136-142) with the
-    subtraction, the reduction and their gradients done inside the kernels (no PyTorch glue launches)."""
+    """The whole criterion in one Function: loss = reduce(full - aligned) (asg.py:128,136-142) with the subtraction,
+    the reduction and their gradients done inside the kernels (no PyTorch glue launches).
+
+    On the fused route (launch mode 'single', float32, N < 64, S <= 64) forward ALSO assembles the gradients for an
+    upstream gradient of 1 -- the reference's "no recursion in backward" (README.md:17-20) taken one step further --
+    and backward is one small launch that multiplies by the actual upstream gradient and reduces the per-utterance
+    transition-gradient tiles."""
 
     @staticmethod
     def forward(ctx, inputs, transition, outputs, input_lengths, output_lengths, reduction, flags):
         be = native()
-        loss, state, problem = be.loss_forward(inputs, outputs, transition, input_lengths, output_lengths, reduction,
-                                               flags)
-        ctx.save_for_backward(state, inputs, outputs, input_lengths, output_lengths, transition)
+        loss, saved = be.loss_forward(inputs, outputs, transition, input_lengths, output_lengths, reduction, flags)
+        ctx.save_for_backward(inputs, outputs, input_lengths, output_lengths, transition, *saved.tensors)
+        saved.tensors = None          # autograd owns them now (and frees them after backward)
+        saved.keep = None
         ctx.reduction = reduction
-        ctx.problem = problem
+        ctx.flags = flags
+        ctx.saved = saved
         return loss
 
     @staticmethod
     def backward(ctx, grad_loss):
-        state, inputs, outputs, input_lengths, output_lengths, transition = ctx.saved_tensors
+        inputs, outputs, input_lengths, output_lengths, transition, *tensors = ctx.saved_tensors
         be = native()
-        kw = {"problem": ctx.problem} if ctx.problem is not None else {}
-        grad_transition, grad_inputs = be.loss_backward(state, grad_loss, inputs, outputs, transition,
-                                                        input_lengths, output_lengths, ctx.reduction, **kw)
+        saved = ctx.saved
+        if saved.consumed and saved.mode == "fused":
+            # backward through a retained graph a second time: the gradient buffers of the first pass were handed to
+            # autograd (and rescaled in place), so the step is recomputed
+            with torch.no_grad():
+                _, saved = be.loss_forward(inputs, outputs, transition, input_lengths, output_lengths, ctx.reduction,
+                                           ctx.flags)
+            tensors = saved.tensors
+        grad_transition, grad_inputs = be.loss_backward(saved, tensors, grad_loss, inputs, outputs, transition,
+                                                        input_lengths, output_lengths, ctx.reduction)
+        ctx.saved.consumed = True
         return grad_inputs, grad_transition, None, None, None, None, None
 
 

@@ -194,9 +194,6 @@ int run_forward(asg_ctx *ctx, const asg_problem *p, void *state, void *full_scor
         if ((e = hipStreamWaitEvent(stream, ctx->join, 0)) != hipSuccess) return hip_status(e);
         return ASG_OK;
     }
-    if constexpr (sizeof(R) == 4) {
-        if ((flags & 16) && mask == 15 && p->N < 64) return hip_status(launch_fwd_cohab(P, W, O, store, stream));   // experiment
-    }
     if (flags & ASG_FLAG_SINGLE_LAUNCH) return hip_status(launch_fwd_small<R>(P, W, O, mask, store, mv, stream));
     if (full_mask && (e = launch_fwd_small<R>(P, W, O, full_mask, store, mv, stream)) != hipSuccess) return hip_status(e);
     if (ali_mask && (e = launch_fwd_small<R>(P, W, O, ali_mask, store, mv, stream)) != hipSuccess) return hip_status(e);
@@ -439,6 +436,76 @@ int asg_loss_backward(asg_ctx *ctx, const asg_problem *p, const void *state, siz
     return ASG_DISPATCH(p,
         run_backward<float>(p, state, grad_loss, nullptr, scratch, scratch_bytes, grad_transition, grad_inputs, 3, (hipStream_t) stream, gstride, gscale, 1),
         run_backward<double>(p, state, grad_loss, nullptr, scratch, scratch_bytes, grad_transition, grad_inputs, 3, (hipStream_t) stream, gstride, gscale, 1));
+}
+
+/* ---- fused training step (asg_fused.hip) ------------------------------------------------------------------ */
+
+namespace {
+struct FusedLayout { size_t tiles, flags, dump, ticket2, total; };
+FusedLayout fused_layout(const asg_problem *p) {
+    FusedLayout L{};
+    size_t off = 0;
+    L.tiles = off; off = align_up(off + (size_t) p->B * p->N * p->N * 4);
+    L.flags = off; off = align_up(off + (size_t) p->B * 4);
+    L.dump = off; off = align_up(off + (size_t) p->B * 3 * 4);
+    L.ticket2 = off; off = align_up(off + 256);
+    L.total = off;
+    return L;
+}
+FusedArgs fused_args(const asg_problem *p, void *scratch, int reduction) {
+    const FusedLayout L = fused_layout(p);
+    char *base = (char *) scratch;
+    FusedArgs F{};
+    F.tiles = base + L.tiles;
+    F.flags = (int *) (base + L.flags);
+    F.dump = base + L.dump;
+    F.ticket2 = (unsigned *) (base + L.ticket2);
+    F.reduction = reduction;
+    F.gscale = reduction == 2 ? (float) (1.0 / (double) p->B) : 1.0f;
+    return F;
+}
+}  // namespace
+
+int asg_loss_fused_supported(const asg_problem *p) {
+    if (check_problem(p, true) != ASG_OK) return 0;
+    if (p->dtype != ASG_DTYPE_F32 || p->N >= 64 || p->S > 64) return 0;
+    const double fr = (double) (p->T - 1) * (double) p->inputs_strides[0] * 4.0, ln = 63.0 * (double) p->inputs_strides[2] * 4.0;
+    if (p->inputs_strides[0] < 0 || p->inputs_strides[2] < 0 || fr >= 4294967296.0 || ln >= 2147483648.0) return 0;
+    if ((double) p->T * (double) p->B * (double) p->N * 4.0 >= 4294967296.0) return 0;
+    return 1;
+}
+
+size_t asg_loss_fused_scratch_bytes(const asg_problem *p) {
+    if (!p || p->T < 1 || p->B < 1 || p->N < 1) return 0;
+    return fused_layout(p).total;
+}
+
+int asg_loss_fused_forward(const asg_problem *p, void *state, size_t state_bytes, int reduction, void *loss, void *scores,
+                           void *scratch, size_t scratch_bytes, void *grad_inputs, void *ticket, int flags, void *stream) {
+    (void) flags;
+    if (reduction < 0 || reduction > 2 || !loss || !scores || !scratch || !grad_inputs || !ticket || !state) return ASG_ERR_INVALID;
+    if (!asg_loss_fused_supported(p)) return check_problem(p, true) != ASG_OK ? check_problem(p, true) : ASG_ERR_UNSUPPORTED;
+    if (state_bytes < asg_state_bytes(p) || scratch_bytes < asg_loss_fused_scratch_bytes(p)) return ASG_ERR_WORKSPACE;
+    FusedArgs F = fused_args(p, scratch, reduction);
+    F.loss = loss;
+    F.scores = scores;
+    F.grad_inputs = grad_inputs;
+    F.ticket = (unsigned *) ticket;
+    return hip_status(launch_fused_forward(to_problem(p), to_state(p, state), F, (hipStream_t) stream));
+}
+
+int asg_loss_fused_backward(const asg_problem *p, void *state, size_t state_bytes, int reduction, const void *grad_loss,
+                            void *scratch, size_t scratch_bytes, void *grad_inputs, void *grad_transition, int flags,
+                            void *stream) {
+    (void) flags;
+    if (reduction < 0 || reduction > 2 || !grad_loss || !scratch || !grad_inputs || !grad_transition || !state) return ASG_ERR_INVALID;
+    if (!asg_loss_fused_supported(p)) return check_problem(p, true) != ASG_OK ? check_problem(p, true) : ASG_ERR_UNSUPPORTED;
+    if (state_bytes < asg_state_bytes(p) || scratch_bytes < asg_loss_fused_scratch_bytes(p)) return ASG_ERR_WORKSPACE;
+    FusedArgs F = fused_args(p, scratch, reduction);
+    F.grad_inputs = grad_inputs;
+    F.grad_loss = grad_loss;
+    F.grad_transition = grad_transition;
+    return hip_status(launch_fused_backward(to_problem(p), to_state(p, state), F, (hipStream_t) stream));
 }
 
 }  // extern "C"

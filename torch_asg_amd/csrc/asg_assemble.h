@@ -79,7 +79,8 @@ __device__ __forceinline__ void assemble_frames(const Problem &P, const State &W
         n_abp = buf_load<R>(r_ab, vS, (unsigned) tqp * rbS);
     }
     // ---- prologue: everything below is ONE round of independent loads
-    const R g0 = A.grad_full ? (R) ((double) ((const R *) A.grad_full)[(int64_t) b * A.gstride] * A.gscale) : R(0);
+    const R g0 = A.unit_grad ? (R) A.gscale
+                             : (A.grad_full ? (R) ((double) ((const R *) A.grad_full)[(int64_t) b * A.gstride] * A.gscale) : R(0));
     const R gf = do_full ? g0 : R(0);
     const R ga = do_ali ? (A.neg_aligned ? -g0
                                          : (R) ((double) ((const R *) A.grad_aligned)[(int64_t) b * A.gstride] * A.gscale))

@@ -874,6 +874,12 @@ struct DuoLds {
     int prod_done;     // producer -> consumer: zsum is final
     double zsum;       // producer -> consumer: sum of the block scales
     float x[64];       // producer -> consumer: row / column maxima
+    // the buffer main broadcasts step n's vector through, and the helpers' common "stop" test
+    __device__ __forceinline__ float *pslot(int) { return p; }
+    __device__ __forceinline__ bool stop() {
+        return __hip_atomic_load(&verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 2 ||
+               __hip_atomic_load(&kill, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
+    }
 };
 
 __device__ __forceinline__ int lds_load_acq(int *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -910,8 +916,8 @@ __device__ __forceinline__ void duo_dot_step(const V2<float> (&e2)[NP / 2], cons
 
 // 16 steps of the main wavefront: n = n0 .. n0+15 (GUARD: only the first `nsteps`).  Returns nothing: range
 // checking is the helper's job.  s_prev enters as s_{n0-1} and leaves as the last row sums.
-template <int NP, bool GUARD>
-__device__ __forceinline__ void duo_main_block(DuoLds &L, int n0, int nsteps, const V2<float> (&e2)[NP / 2], int N, int lane,
+template <int NP, bool GUARD, class LdsT>
+__device__ __forceinline__ void duo_main_block(LdsT &L, int n0, int nsteps, const V2<float> (&e2)[NP / 2], int N, int lane,
                                                float e_cur, float &s_prev, int &csum, int need_next, bool &next_ready,
                                                float &e_next_first) {
     const int half = (n0 & 16);                    // ring half of this block (n0 is a multiple of 16)
@@ -924,7 +930,7 @@ __device__ __forceinline__ void duo_main_block(DuoLds &L, int n0, int nsteps, co
             float v = s_prev * e_cur;
             if ((j % kRenorm) == kRenorm - 1) v = ldexpf(v, -ex);
             V4<float> pv[NP / 4];
-            bcast_issue<float, NP>(v, L.p, lane, pv);
+            bcast_issue<float, NP>(v, L.pslot(half + j), lane, pv);
             // hand s_{n-1} to the helper (slot (n-1) & 31; nothing to hand over before the first step)
             if (j > 0) lds_stf(&L.s[(half + j - 1) & (kRing - 1)][lane], s_prev);
             else if (n0 > 0) lds_stf(&L.s[(half + kRing - 1) & (kRing - 1)][lane], s_prev);
@@ -1058,8 +1064,8 @@ __device__ __forceinline__ void duo_main(const Problem &P, const State &W, const
 }
 
 // Producer wavefront: emission loads, block scale, e_n (and arg_n) into the rings.  Only loads on its VMEM queue.
-template <int NP, bool BETA>
-__device__ __forceinline__ void duo_producer(const Problem &P, int b, DuoLds &L) {
+template <int NP, bool BETA, class LdsT>
+__device__ __forceinline__ void duo_producer(const Problem &P, int b, LdsT &L) {
     typedef float R;
     const int lane = threadIdx.x & 63;
     const int N = P.N, T = P.T;
@@ -1121,7 +1127,7 @@ __device__ __forceinline__ void duo_producer(const Problem &P, int b, DuoLds &L)
         // finished block K-2
         int spins = 0;
         while (lds_load_rlx(&L.c_done) < (K - 1) * kPF) {
-            if (lds_load_rlx(&L.verdict) == 2 || lds_load_rlx(&L.kill) || ++spins > kSpinCap) return;
+            if (L.stop() || ++spins > kSpinCap) return;
             __builtin_amdgcn_s_sleep(2);
         }
         produce(K, nxt);

@@ -1,71 +1,885 @@
-// torch_asg_amd/csrc/asg_fused.hip -- ONE workgroup per utterance: all four recursions of the utterance co-resident on
-// one compute unit (stage 1: chains only; the state still goes to HBM and the stand-alone assembly kernels follow).
+// torch_asg_amd/csrc/asg_fused.hip -- the fused training step of the small-alphabet path (fp32, N < 64, S <= 64):
+// ONE launch runs the four recursions of every utterance AND assembles its gradients as the frames become ready.
+//
+// Replaces, for the ASGLoss training route, fast_asg_gpu_forward + fast_asg_gpu_backward
+// (/root/reference/torch_asg/native/streamlined_fast_gpu.cpp:104-297) and everything under them
+// (fully_connected_lattice.cpp:9-105, force_aligned_lattice.cpp:15-356, force_aligned_lattice_kernel.cu): the reference's
+// split "both recursions in forward, no recursion in backward" is kept and taken one step further -- the
+// non-recursive assembly happens inside the forward launch too, and backward only scales by the upstream gradient.
+//
+// One workgroup (12 wavefronts, one compute unit) per utterance.  The alpha chains walk frames 0 -> len-1, the beta chains
+// len-1 -> 0; they cross at mid = len/2.  Before the crossing each chain stores its state for the other side (frames
+// < mid from alpha, >= mid from beta: half of what the stand-alone kernels store); after it, the side that reaches a
+// frame SECOND holds everything the frame's gradient needs:
+//   posterior_t = softmax(alpha_t + beta_t)                      -> grad_inputs row (minus the aligned posterior)
+//   alpha side:  xi_t(i,j)    = posterior_t[i]   / s_i  * E[i][j] * v_{t-1}[j]     s = E v_{t-1}  (this step's row sums)
+//   beta side:   xi_{t+1}(i,j) = posterior_t[j] / s'_j * F[j][i] * y_{t+1}[i]      s' = F y_{t+1}
+// i.e. the recursion's OWN row sums and broadcast vector -- the stand-alone assembly kernel's second mat-vec is gone, and
+// the sum over frames of the outer products (posterior / s) (x) v runs on the matrix cores (asg_outer.h).
+// Wave roles (waves with equal index % 4 share a SIMD):
+//   0/1  recursion wavefronts alpha/beta   (critical path only; as fwd_duo_kernel)
+//   4/5  aligned chains (beside the recursion wavefronts: both are dependent chains that leave most issue slots free)
+//   6/7  producers (emission factors)      2/3  consumers: first half = log-domain state -> HBM; second half = posterior,
+//                                                          row -> LDS ring, outer-product accumulation (MFMA)
+//   10/11 finishers: aligned posterior, deterministic scatter, final grad_inputs row, aligned edge posteriors
+//   8/9  housekeeping (zero rows of padded frames, normalised transition rows for the exact path), then exit
+// Everything is bit-deterministic: no float atomics, fixed accumulation orders.
+// An utterance whose row sums leave the safe range (or shorter than kMinFused frames, or any bounded wait that runs
+// out) is FLAGGED: its scores are recomputed here with exact log-sum-exps, its gradients by the exact stand-alone code
+// in the backward launch (fused_bwd_kernel), so results are true log-sum-exps for any input.
 #include "asg_assemble.h"
+#include "asg_outer.h"
 
 namespace asg {
 namespace {
 
-// Wave roles.  A workgroup's waves are dealt to the CU's four SIMDs cyclically, so waves with equal (index % 4) share a
-// SIMD: the two recursion wavefronts (0, 1) share theirs only with their own light producers (4, 5); the heavy helpers
-// sit on the other two SIMDs.
-template <int NP, bool STORE>
-__global__ void __launch_bounds__(768, 1) fwd_cohab_kernel(Problem P, State W, FwdOut O) {
-    __shared__ DuoLds LA, LB;
-    const int b = blockIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (threadIdx.x == 0) {
-        LA.e_prod = 0; LA.verdict = 0; LA.csum = 0; LA.main_done = 0; LA.kill = 0; LA.c_done = 0; LA.prod_done = 0;
-        LB.e_prod = 0; LB.verdict = 0; LB.csum = 0; LB.main_done = 0; LB.kill = 0; LB.c_done = 0; LB.prod_done = 0;
+constexpr int kRow = 16;        // consumer -> finisher ring of grad_inputs rows (frames)
+constexpr int kAR = 32;         // aligned chain -> finisher ring of aligned states (frames)
+constexpr int kGS = 8;          // frames per poll of the consumers / finishers
+constexpr int kMinFused = 4;
+constexpr int kFusedThreads = 768;
+constexpr unsigned kSc1 = 16;   // buffer load/store aux bit: agent scope (served by / written through to L2)
+
+struct FusedSide {
+    __attribute__((aligned(16))) float p[kRing][64];   // step n's broadcast vector v_n (slot n & 31)
+    float s[kRing][64];                                  // row sums s_n, main -> consumer (self-describing: NaN sentinel)
+    float e[kRing][64];                                  // emission factors, producer -> main
+    float a[kRing][64];                                  // their log2 (alpha side), producer -> consumer
+    float row[kRow][64];                                 // gscale * full posterior of a frame, consumer -> finisher
+    float ar[kAR][64];                                   // aligned states, aligned chain -> finisher
+    float x[64];                                         // row / column maxima of the transition matrix
+    unsigned fx[kGS][64];                                // finisher: fixed-point scatter of the aligned posteriors, one per frame of a group
+    double zsum;
+    int e_prod, csum, main_done, c_done, prod_done, kill;
+    int st_done;      // consumer: state rows of indices [0, st_done) are in HBM/L2 and visible
+    int row_done;     // consumer: rows of indices [h, row_done) are in `row`
+    int ast_done;     // aligned chain: states of indices [0, ast_done) are in HBM/L2 and visible
+    int ar_done;      // aligned chain: states of indices [0, ar_done) have been written to `ar`
+    int fin_done;     // finisher: indices [h, fin_done) are finished (their ring slots are free)
+    __device__ __forceinline__ float *pslot(int n) { return p[n & (kRing - 1)]; }
+    __device__ __forceinline__ bool stop() { return __hip_atomic_load(&kill, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0; }
+};
+
+template <int NP>
+struct TileLds {
+    float tileF[64][NP + 1];
+    unsigned long long fxT[NP * NP];
+};
+
+template <int NP>
+struct FusedShared {
+    union U {
+        struct G { FusedSide A, B; } g;
+        TileLds<NP> t;
+    } u;
+    float xa[64], xb[64];
+    double score_full, score_ali;
+    int flagged;
+};
+
+// developer probes (-DASG_PROBE): per role of utterance 0, total cycles and cycles spent in each kind of wait
+#ifdef ASG_PROBE
+#define PRB_DECL const long long prb_t0 = clock64(); long long prb_w[4] = {0, 0, 0, 0};
+#define PRB_WAIT(i, expr) { const long long prb_a = clock64(); expr; prb_w[i] += clock64() - prb_a; }
+#define PRB_END(dbgp, role) if (b == 0 && (threadIdx.x & 63) == 0) { long long *d = (long long *) (dbgp) + (role) * 5; \
+    d[0] = clock64() - prb_t0; d[1] = prb_w[0]; d[2] = prb_w[1]; d[3] = prb_w[2]; d[4] = prb_w[3]; }
+#else
+#define PRB_DECL
+#define PRB_WAIT(i, expr) { expr; }
+#define PRB_END(dbgp, role)
+#endif
+
+__device__ __forceinline__ void abort_all(FusedSide &L, FusedSide &O) {
+    lds_store_rlx(&L.kill, 1);
+    lds_store_rlx(&O.kill, 1);
+}
+
+// bounded wait until *p >= need; false on abort / time-out (then everything is aborted)
+__device__ __forceinline__ bool wait_ge(int *p, int need, FusedSide &L, FusedSide &O) {
+    int spins = 0;
+    while (lds_load_rlx(p) < need) {
+        if (L.stop()) return false;
+        if (++spins > kSpinCap) { abort_all(L, O); return false; }
+        __builtin_amdgcn_s_sleep(2);
     }
-    for (int q = threadIdx.x; q < kRing * 64; q += 768) {
+    asm volatile("" ::: "memory");
+    return true;
+}
+
+__device__ __forceinline__ float buf_load_sc1(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, kSc1));
+}
+
+// ------------------------------------------------------------------ recursion wavefront
+template <int NP, bool BETA>
+__device__ __forceinline__ void fused_main(const Problem &P, int b, FusedSide &L, FusedSide &O, int len, void *dbg) {
+    typedef float R;
+    PRB_DECL
+    const int lane = threadIdx.x & 63;
+    const int N = P.N;
+    const bool act = lane < N;
+    const int lc = act ? lane : 0;
+    const R *tline = (const R *) P.transition + (int64_t) lc * (BETA ? P.ts1 : P.ts0);
+    V2<R> e2[NP / 2];
+    R X;
+    load_norm_row<R, NP>(tline, BETA ? P.ts0 : P.ts1, N, act, e2, X);
+    if (lane == N) {
+#pragma unroll
+        for (int j = 0; j < NP / 2; ++j) e2[j] = V2<R>{1, 1};
+    }
+    const int nst = len - 1;                   // mat-vecs n = 0 .. len-2
+    R s_prev = act ? Num<R>::exp2(-X) : R(0);
+    int csum = 0;
+    bool next_ready = false;
+    R e_next_first = 0;
+    for (int n0 = 0; n0 < nst; n0 += kPF) {
+        const int nsteps = min(kPF, nst - n0);
+        const int need = min(n0 + kPF, len);
+        int spins = 0;
+        R e_first = e_next_first;
+        PRB_WAIT(0, while (!next_ready) {
+            const int ep = lds_load_rlx(&L.e_prod);
+            const int kl = lds_load_rlx(&L.kill);
+            e_first = lds_ldf(&L.e[n0 & 16][lane]);
+            asm volatile("" ::: "memory");
+            if (kl) return;
+            if (ep >= need) break;
+            if (++spins > kSpinCap) { abort_all(L, O); return; }
+            __builtin_amdgcn_s_sleep(1);
+        })
+        const int need_next = min(n0 + 2 * kPF, len);
+        if (nsteps == kPF)
+            duo_main_block<NP, false>(L, n0, kPF, e2, N, lane, e_first, s_prev, csum, need_next, next_ready, e_next_first);
+        else
+            duo_main_block<NP, true>(L, n0, nsteps, e2, N, lane, e_first, s_prev, csum, need_next, next_ready, e_next_first);
+    }
+    lds_stf(&L.s[(nst - 1) & (kRing - 1)][lane], s_prev);
+    lds_store_rlx(&L.csum, csum);
+    lds_store_rel(&L.main_done, 1);
+    PRB_END(dbg, BETA ? 1 : 0)
+}
+
+// ------------------------------------------------------------------ consumer / full-lattice assembler
+// Index convention of a side: index m = 0 .. len-1 is frame f_m = m (alpha) or len-1-m (beta); s_{m-1} are the row sums
+// that lead to index m, v_{m-1} (= p slot m-1) the vector that produced them.  Indices < h are the side's first half.
+template <int NP, bool BETA>
+__device__ __forceinline__ void fused_consumer(const Problem &P, const State &W, const FusedArgs &F, int b, FusedSide &L,
+                                               FusedSide &O, int len, int h, V4<float> (&acc)[((NP + 15) / 16) * ((NP + 15) / 16)],
+                                               double &score_out2) {
+    typedef float R;
+    constexpr int NT = (NP + 15) / 16;
+    const int lane = threadIdx.x & 63;
+    const int N = P.N, T = P.T;
+    const R NINF = Num<R>::ninf();
+    const bool act = lane < N;
+    const unsigned long long actmask = __ballot(act);
+    const int lc = act ? lane : 0;
+    const unsigned row_bytes = (unsigned) N * sizeof(R);
+    __amdgpu_buffer_rsrc_t rs = make_rsrc((R *) (BETA ? W.bh : W.ah) + (int64_t) b * T * N, (unsigned) T * row_bytes);
+    __amdgpu_buffer_rsrc_t ro = make_rsrc((R *) (BETA ? W.ah : W.bh) + (int64_t) b * T * N, (unsigned) T * row_bytes);
+    const unsigned voff = act ? (unsigned) lane * sizeof(R) : kOobOffset;
+    const unsigned vld = (unsigned) lc * (unsigned) sizeof(R);
+    auto frame = [&](int n) { return BETA ? len - 1 - n : n; };
+    const R gscale = F.gscale;
+    score_out2 = -1e300;
+    PRB_DECL
+    if (!wait_ge(&L.e_prod, 1, L, O)) return;                 // X and block 0 of the rings are there
+    const R XX = lds_ldf(&L.x[lane]);
+    R sv = act ? Num<R>::exp2(-XX) : R(0);
+    auto wait_slot = [&](int m) {                             // until main has written s_m (main writes in order)
+        float *slot = &L.s[m & (kRing - 1)][lane];
+        int spins = 0;
+        while (true) {
+            const R v = lds_ldf(slot);
+            if (__ballot(__float_as_uint(v) != kSentinel) == ~0ull) return true;
+            if (L.stop()) return false;
+            if (++spins > kSpinCap) { abort_all(L, O); return false; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    };
+    buf_store((BETA ? XX : lds_ldf(&L.a[0][lane])) + Num<R>::log2(sv), rs, voff, (unsigned) frame(0) * row_bytes);
+    int n = 1;
+    // ---- first half: log-domain state of indices 1 .. h-1 to HBM for the other side
+    while (n < h) {
+        const int g = min(kGS, h - n);
+        PRB_WAIT(0, if (!wait_slot(n + g - 2)) return;)
+        R sg[kGS], ag[kGS];
+#pragma unroll
+        for (int q = 0; q < kGS; ++q) {
+            const int m = n + min(q, g - 1);
+            sg[q] = lds_ldf(&L.s[(m - 1) & (kRing - 1)][lane]);
+            ag[q] = BETA ? XX : lds_ldf(&L.a[m & (kRing - 1)][lane]);
+        }
+        unsigned lo = 0xffffffffu, hi = 0;
+#pragma unroll
+        for (int q = 0; q < kGS; ++q) {
+            const int m = n + min(q, g - 1);
+            lds_stf(&L.s[(m - 1) & (kRing - 1)][lane], __uint_as_float(kSentinel));
+            const unsigned sb = Rng<R>::bits(sg[q]);
+            lo = min(lo, sb);
+            hi = max(hi, sb);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        lds_store_rlx(&L.c_done, n + g - 1);
+        if ((__ballot(lo < Rng<R>::lo || hi > Rng<R>::hi) & actmask) != 0) { abort_all(L, O); return; }
+#pragma unroll
+        for (int q = 0; q < kGS; ++q)
+            buf_store(ag[q] + Num<R>::log2(sg[q]), rs, voff, (unsigned) frame(n + min(q, g - 1)) * row_bytes);
+        sv = sg[kGS - 1];
+        n += g;
+    }
+    // the first half is complete in L2 before the other side is told so
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_store_rel(&L.st_done, h);
+    PRB_WAIT(1, if (!wait_ge(&O.st_done, len - h, L, O)) return;)
+    // ---- second half: indices h .. len-1; the other side's state of the same frames is prefetched one group ahead
+    R oth[kGS];
+#pragma unroll
+    for (int q = 0; q < kGS; ++q) oth[q] = buf_load_sc1(ro, vld, (unsigned) frame(min(n + q, len - 1)) * row_bytes);
+    while (n < len) {
+        const int g = min(kGS, len - n);
+        PRB_WAIT(2, if (!wait_slot(n + g - 2)) return;)
+        R sg[kGS], ag[kGS], pg[kGS];
+#pragma unroll
+        for (int q = 0; q < kGS; ++q) {
+            const int m = n + min(q, g - 1);
+            sg[q] = lds_ldf(&L.s[(m - 1) & (kRing - 1)][lane]);
+            ag[q] = BETA ? XX : lds_ldf(&L.a[m & (kRing - 1)][lane]);
+            pg[q] = lds_ldf(&L.p[(m - 1) & (kRing - 1)][lane]);
+        }
+        unsigned lo = 0xffffffffu, hi = 0;
+#pragma unroll
+        for (int q = 0; q < kGS; ++q) {
+            const int m = n + min(q, g - 1);
+            lds_stf(&L.s[(m - 1) & (kRing - 1)][lane], __uint_as_float(kSentinel));
+            const unsigned sb = Rng<R>::bits(sg[q]);
+            lo = min(lo, sb);
+            hi = max(hi, sb);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        lds_store_rlx(&L.c_done, n + g - 1);
+        if ((__ballot(lo < Rng<R>::lo || hi > Rng<R>::hi) & actmask) != 0) { abort_all(L, O); return; }
+        // posterior of the frame: softmax of (own state + other side's state); both are stored relative to offsets
+        // that keep each frame's largest term near 1, so no max-shift -- a normaliser outside [2^-100, 2^100] aborts
+        R w[kGS];
+#pragma unroll
+        for (int q = 0; q < kGS; ++q) {
+            const R gam = act ? (ag[q] + Num<R>::log2(sg[q])) + oth[q] : NINF;
+            w[q] = Num<R>::exp2(gam);
+        }
+        // the next group's rows of the other side (its first half is complete: no further checks)
+        R othn[kGS];
+#pragma unroll
+        for (int q = 0; q < kGS; ++q) othn[q] = buf_load_sc1(ro, vld, (unsigned) frame(min(n + g + q, len - 1)) * row_bytes);
+        R Z[kGS];
+#pragma unroll
+        for (int q = 0; q < kGS; q += 2) {
+            Z[q] = w[q];
+            Z[q + 1] = w[q + 1];
+            wave_allsum2(Z[q], Z[q + 1]);
+        }
+        unsigned zlo = 0xffffffffu, zhi = 0;
+#pragma unroll
+        for (int q = 0; q < kGS; ++q) {
+            const unsigned zb = Rng<R>::bits(Z[q]);
+            zlo = min(zlo, zb);
+            zhi = max(zhi, zb);
+        }
+        if (zlo < Rng<R>::lo || zhi > Rng<R>::hi) { abort_all(L, O); return; }
+        // ring space: the finisher has taken index n + g - 1 - kRow
+        PRB_WAIT(3, if (!wait_ge(&L.fin_done, n + g - kRow, L, O)) return;)
+        R u[kGS];
+#pragma unroll
+        for (int q = 0; q < kGS; ++q) {
+            const R post = w[q] * Num<R>::rcp(Z[q]);
+            const int m = n + min(q, g - 1);
+            lds_stf(&L.row[m & (kRow - 1)][lane], post * gscale);
+            // xi: alpha side skips its first assembled index (the beta side's last one covers that transition)
+            const bool take = q < g && (BETA || n + q > h);
+            u[q] = (take && act) ? post * Num<R>::rcp(sg[q]) : R(0);
+            pg[q] = act ? pg[q] : R(0);
+        }
+        asm volatile("" ::: "memory");
+        lds_store_rlx(&L.row_done, n + g);
+        {
+            float ua[4] = {u[0], u[1], u[2], u[3]}, va[4] = {pg[0], pg[1], pg[2], pg[3]};
+            outer4_accumulate<NT>(ua, va, acc);
+            float ub[4] = {u[4], u[5], u[6], u[7]}, vb[4] = {pg[4], pg[5], pg[6], pg[7]};
+            outer4_accumulate<NT>(ub, vb, acc);
+        }
+#pragma unroll
+        for (int q = 0; q < kGS; ++q) oth[q] = othn[q];
+        sv = sg[kGS - 1];
+        n += g;
+    }
+    // ---- end of the chain: score (beta side), exactly as the three-wavefront kernel
+    {
+        int spins = 0;
+        while (!(lds_load_acq(&L.main_done) && lds_load_acq(&L.prod_done))) {
+            if (L.stop()) return;
+            if (++spins > kSpinCap) { abort_all(L, O); return; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    if (BETA) {
+        const int csum = lds_load_rlx(&L.csum);
+        const double zsum = L.zsum;
+        const R vlast = sv * lds_ldf(&L.e[(len - 1) & (kRing - 1)][lane]);
+        const R sm = wave_allsum(act ? vlast : R(0));
+        const unsigned smb = Rng<R>::bits(sm);
+        if (!(smb >= Rng<R>::lo && smb <= Rng<R>::hi)) { abort_all(L, O); return; }
+        score_out2 = zsum + (double) csum + (double) Num<R>::log2(sm);
+    }
+    PRB_END(W.dbg, BETA ? 3 : 2)
+}
+
+// ------------------------------------------------------------------ aligned chain
+// The stand-alone aligned chains (asg_chains.h) with two changes: every state also goes into the `ar` ring for the
+// finisher of this side, and only the first half goes to HBM (for the finisher of the other side).
+template <bool BETA>
+__device__ __forceinline__ void fused_aligned(const Problem &P, const State &W, int b, FusedSide &L, FusedSide &O, int len,
+                                              int h, double &score_out2) {
+    typedef float R;
+    const int lane = threadIdx.x & 63;
+    const int T = P.T, S = P.S;
+    const AlignedSetup<R> A = aligned_setup<R>(P, b, lane);
+    const unsigned row_bytes = (unsigned) S * sizeof(R);
+    __amdgpu_buffer_rsrc_t rs = make_rsrc((R *) (BETA ? W.bb : W.ab) + (int64_t) b * T * S, (unsigned) T * row_bytes);
+    const unsigned voff = lane < S ? (unsigned) lane * sizeof(R) : kOobOffset;
+    const double L2Ed = 1.4426950408889634, H2 = (double) A.H2, Dp = (double) A.Dprev, Dn = (double) A.Dnext;
+    auto frame = [&](int m) { return BETA ? len - 1 - m : m; };
+    score_out2 = -1e300;
+    PRB_DECL
+    double C = 0.0;
+    // index 0
+    double st;
+    if (!BETA) st = (lane == 0) ? fmax(fma((double) A.in[0], L2Ed, (double) A.ebias), kLZd) : kLZd;
+    else st = (lane == A.ol - 1) ? 0.0 : kLZd;
+    {
+        const R v = to_state<R>(st);
+        lds_stf(&L.ar[0][lane], v);
+        buf_store(v, rs, voff, (unsigned) frame(0) * row_bytes);
+    }
+    bool told = false;
+    auto tell_first_half = [&](int upto) {              // indices [0, upto) done
+        if (!told && upto >= h) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lds_store_rel(&L.ast_done, h);
+            told = true;
+        }
+    };
+    lds_store_rlx(&L.ar_done, 1);
+    tell_first_half(1);
+    const int nst = len - 1;
+    R cur[kPF], nxt[kPF];
+    // step k of a block starting at `done` reads emission frame ef = (alpha) 1+done+k / (beta) len-1-done-k and produces
+    // the state of index 1+done+k
+#pragma unroll
+    for (int k = 0; k < kPF; ++k) cur[k] = A.in[(int64_t) (BETA ? max(len - 1 - k, 0) : min(1 + k, len - 1)) * P.is0];
+    R last_raw = cur[0];
+    for (int done = 0; done < nst; done += kPF) {
+        const int nsteps = min(kPF, nst - done);
+#pragma unroll
+        for (int k = 0; k < kPF; ++k)
+            nxt[k] = A.in[(int64_t) (BETA ? max(len - 1 - (done + kPF + k), 0) : min(1 + done + kPF + k, len - 1)) * P.is0];
+        // ring space: the slots this block overwrites held indices m0-32 .. m0-17, last needed (as "previous") by m0-16
+        const int m0 = 1 + done;
+        PRB_WAIT(0, if (!wait_ge(&L.fin_done, m0 - 15, L, O)) return;)
+        {
+            const R m = wave_allmax((R) st);
+            if (m > R(-1e29)) { st = fmax(st - (double) m, kLZd); C += (double) m; }
+        }
+        const R z = aligned_block_scale<R>(cur, nsteps, A.act, A.ol);
+        C += (double) z * nsteps;
+        const double ebias = (double) A.ebias - (double) z;
+#pragma unroll
+        for (int k = 0; k < kPF; ++k) {
+            if (k < nsteps) {
+                if (!BETA) {
+                    const double em = fma((double) cur[k], L2Ed, ebias);
+                    const double stay = st + H2;
+                    const double come = prev_lane_or_zero<double>(st) + Dp;
+                    st = fmax(em + lse2_acc<R>(stay, come), kLZd);
+                } else {
+                    const double y = fmax(fma((double) cur[k], L2Ed, ebias) + st, kLZd);
+                    const double stay = y + H2;
+                    const double go = next_lane_or_zero<double>(y) + Dn;
+                    st = fmax(lse2_acc<R>(stay, go), kLZd);
+                }
+                const int m = m0 + k;
+                const R v = to_state<R>(st);
+                lds_stf(&L.ar[m & (kAR - 1)][lane], v);
+                buf_store(v, rs, (m < h) ? voff : kOobOffset, (unsigned) frame(min(m, len - 1)) * row_bytes);
+            }
+        }
+        asm volatile("" ::: "memory");
+        lds_store_rlx(&L.ar_done, m0 + nsteps);
+        tell_first_half(m0 + nsteps);
+        if (BETA && done + kPF >= nst) {
+            // the frame-0 emission sits right after the last consumed ring slot (or is nxt[0] when the block was full)
+            const int r = nst - done;
+            last_raw = (r == kPF) ? nxt[0] : cur[0];
+#pragma unroll
+            for (int k = 1; k < kPF; ++k) last_raw = (k == r) ? cur[k] : last_raw;
+        }
+#pragma unroll
+        for (int k = 0; k < kPF; ++k) cur[k] = nxt[k];
+    }
+    tell_first_half(len);
+    if (BETA) {
+        // S_aligned = beta_0[0] + I~_0[0]   (force_aligned_lattice.cpp:316)
+        const double y = fma((double) last_raw, L2Ed, (double) A.ebias) + st;
+        const double y0 = readlane(y, 0);
+        score_out2 = (A.ol >= 1) ? C + y0 : -1e300;
+    }
+    PRB_END(W.dbg, BETA ? 5 : 4)
+}
+
+// ------------------------------------------------------------------ finisher
+template <bool BETA>
+__device__ __forceinline__ void fused_finisher(const Problem &P, const State &W, const FusedArgs &F, int b, FusedSide &L,
+                                               FusedSide &O, int len, int h, float &accH, float &accD) {
+    typedef float R;
+    const int lane = threadIdx.x & 63;
+    const int N = P.N, T = P.T, S = P.S;
+    const R LZ = Num<R>::logzero();
+    const AlignedSetup<R> A = aligned_setup<R>(P, b, lane);
+    const bool sl = lane < S;
+    const R H2 = A.H2, Dprev = A.Dprev;
+    const int tgt = A.tgt;
+    const unsigned rbS = (unsigned) S * sizeof(R);
+    __amdgpu_buffer_rsrc_t ro = make_rsrc((R *) (BETA ? W.ab : W.bb) + (int64_t) b * T * S, (unsigned) T * rbS);
+    const unsigned vS = (unsigned) (sl ? lane : 0) * (unsigned) sizeof(R);
+    __amdgpu_buffer_rsrc_t rs_g = make_rsrc((R *) F.grad_inputs + (int64_t) b * N,
+                                            (unsigned) ((int64_t) (T - 1) * P.B * N + N) * (unsigned) sizeof(R));
+    const unsigned voff = lane < N ? (unsigned) lane * sizeof(R) : kOobOffset;
+    const unsigned grow_bytes = (unsigned) P.B * N * sizeof(R);
+    const R gscale = F.gscale;
+    auto frame = [&](int m) { return BETA ? len - 1 - m : m; };
+    accH = 0;
+    accD = 0;
+    PRB_DECL
+#pragma unroll
+    for (int q = 0; q < kGS; ++q) L.fx[q][lane] = 0;
+    PRB_WAIT(0, if (!wait_ge(&O.ast_done, len - h, L, O)) return;)      // the other side's aligned first half is visible
+    int n = h;
+    // other side's aligned state of the group's frames; the beta side (frames descending) also needs ab of the frame
+    // below each frame for the edge posteriors: that is the next frame of the group / the first of the next group
+    R oth[kGS];
+#pragma unroll
+    for (int q = 0; q < kGS; ++q) oth[q] = buf_load_sc1(ro, vS, (unsigned) max(frame(min(n + q, len - 1)), 0) * rbS);
+    while (n < len) {
+        const int g = min(kGS, len - n);
+        PRB_WAIT(1, if (!wait_ge(&L.row_done, n + g, L, O)) return;)
+        PRB_WAIT(2, if (!wait_ge(&L.ar_done, n + g, L, O)) return;)
+        R rowv[kGS], own[kGS], ownp[kGS];
+#pragma unroll
+        for (int q = 0; q < kGS; ++q) {
+            const int m = n + min(q, g - 1);
+            rowv[q] = lds_ldf(&L.row[m & (kRow - 1)][lane]);
+            own[q] = lds_ldf(&L.ar[m & (kAR - 1)][lane]);
+            ownp[q] = lds_ldf(&L.ar[(m - 1) & (kAR - 1)][lane]);     // alpha side: ab of the previous frame (m >= h >= 1)
+        }
+        R othn[kGS];
+#pragma unroll
+        for (int q = 0; q < kGS; ++q) othn[q] = buf_load_sc1(ro, vS, (unsigned) max(frame(min(n + g + q, len - 1)), 0) * rbS);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        lds_store_rlx(&L.fin_done, n + g);
+        // aligned posteriors of the group's frames, two frames per reduction pass
+        R post2[kGS];
+#pragma unroll
+        for (int q = 0; q < kGS; q += 2) {
+            R g0 = sl ? own[q] + oth[q] : LZ, g1 = sl ? own[q + 1] + oth[q + 1] : LZ;
+            R m0 = g0, m1 = g1;
+            wave_allmax2(m0, m1);
+            R w0 = (m0 > R(-1e29)) ? Num<R>::exp2(g0 - m0) : R(0);       // infeasible alignment -> no posterior
+            R w1 = (m1 > R(-1e29)) ? Num<R>::exp2(g1 - m1) : R(0);
+            R z0 = w0, z1 = w1;
+            wave_allsum2(z0, z1);
+            post2[q] = (z0 > 0) ? w0 * Num<R>::rcp(z0) : R(0);
+            post2[q + 1] = (z1 > 0) ? w1 * Num<R>::rcp(z1) : R(0);
+        }
+        // scatter to labels: integer LDS adds commute -> repeated labels give bit-identical sums run to run.  The eight
+        // frames of the group go through eight separate arrays, so the adds, reads and resets of the whole group
+        // are three back-to-back bursts (one wavefront's LDS operations execute in order)
+#pragma unroll
+        for (int q = 0; q < kGS; ++q) atomicAdd(&L.fx[q][tgt], FrameFix<R>::to(q < g ? post2[q] : R(0)));
+        __builtin_amdgcn_wave_barrier();
+        unsigned fv[kGS];
+#pragma unroll
+        for (int q = 0; q < kGS; ++q) fv[q] = L.fx[q][lane];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < kGS; ++q) L.fx[q][lane] = 0;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < kGS; ++q) {
+            if (q < g) {
+                const int f = frame(n + q);
+                buf_store(rowv[q] - gscale * FrameFix<R>::from(fv[q]), rs_g, voff, (unsigned) f * grow_bytes);
+                if (f >= 1) {
+                    // stay / arrive posteriors of the edge into (f, s): needs alpha-bar of frame f-1
+                    const R abprev = BETA ? ((q + 1 < kGS) ? ((q + 1 < g) ? oth[(q + 1) & (kGS - 1)] : othn[0]) : othn[0]) : ownp[q];
+                    const R ap = sl ? abprev : LZ;
+                    const R pc0 = ap + H2;
+                    const R pc1 = prev_lane_or_zero<R>(ap) + Dprev;
+                    const R l = lse2<R>(pc0, pc1);
+                    accH += post2[q] * Num<R>::exp2(pc0 - l);
+                    accD += post2[q] * Num<R>::exp2(pc1 - l);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < kGS; ++q) oth[q] = othn[q];
+        n += g;
+    }
+    PRB_END(W.dbg, BETA ? 7 : 6)
+}
+
+// exact full-lattice score of one utterance by ONE wavefront (log-domain beta recursion, max-shifted log-sum-exps)
+template <int NP>
+__device__ __forceinline__ double slow_full_score(const Problem &P, int b, int len) {
+    typedef float R;
+    const int lane = threadIdx.x & 63;
+    const int N = P.N;
+    const R NINF = Num<R>::ninf(), L2E = Num<R>::log2e();
+    if (len < 1) return -1e300;
+    const bool act = lane < N;
+    const int lc = act ? lane : 0;
+    const R *tcol = (const R *) P.transition + (int64_t) lc * P.ts1;
+    const R *in = (const R *) P.inputs + (int64_t) b * P.is1 + (int64_t) lc * P.is2;
+    ChainState<R> r;
+    r.v = act ? R(0) : NINF;
+    r.C = 0.0;
+    if (len >= 2) r = slow_full_steps<R, true>(in, P.is0, tcol, P.ts0, N, lane, len - 1, len - 1, r.v, r.C, (R *) nullptr, 0, false);
+    const R y = act ? fma(in[0], L2E, r.v) : NINF;
+    const R my = fmax(wave_allmax(y), Num<R>::logzero());
+    const R sm = wave_allsum(Num<R>::exp2(y - my));
+    return r.C + (double) my + (double) Num<R>::log2(sm);
+}
+
+// ------------------------------------------------------------------ the fused forward kernel
+template <int NP>
+__global__ void __launch_bounds__(kFusedThreads, 3) fused_fwd_kernel(Problem P, State W, FusedArgs F) {
+    typedef float R;
+    constexpr int NT = (NP + 15) / 16;
+    __shared__ FusedShared<NP> SH;
+    FusedSide &LA = SH.u.g.A, &LB = SH.u.g.B;
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int N = P.N, T = P.T, S = P.S;
+    const int len = __builtin_amdgcn_readfirstlane(P.in_len ? clampi(P.in_len[b], 0, T) : T);
+    const int mid = len / 2;
+    const bool fused = len >= kMinFused;
+
+    if (threadIdx.x == 0) {
+        FusedSide *sd[2] = {&LA, &LB};
+        for (int k = 0; k < 2; ++k) {
+            FusedSide &L = *sd[k];
+            const int h = k == 0 ? mid : len - mid;
+            L.e_prod = 0; L.csum = 0; L.main_done = 0; L.c_done = 0; L.prod_done = 0; L.kill = 0;
+            L.st_done = 0; L.row_done = h; L.ast_done = 0; L.ar_done = 0; L.fin_done = h;
+        }
+        SH.score_full = -1e300;
+        SH.score_ali = -1e300;
+        SH.flagged = fused ? 0 : 1;
+    }
+    if (b == 0 && threadIdx.x < 64) F.ticket2[threadIdx.x] = 0;        // for the backward launch
+    for (int q = threadIdx.x; q < kRing * 64; q += kFusedThreads) {
         (&LA.s[0][0])[q] = __uint_as_float(kSentinel);
         (&LB.s[0][0])[q] = __uint_as_float(kSentinel);
     }
     __syncthreads();
-#ifdef ASG_PROBE
-    if ((threadIdx.x & 63) == 0 && b == 0) {
-        unsigned hw;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        ((unsigned *) W.dbg)[64 + wave] = hw;
+
+    V4<float> acc[NT * NT];
+#pragma unroll
+    for (int q = 0; q < NT * NT; ++q) acc[q] = V4<float>{0, 0, 0, 0};
+    float accH = 0, accD = 0;
+    double sc2 = -1e300;
+
+    // ---- phase 1: the roles.  Control flow is uniform per wavefront; nothing in here uses a workgroup barrier.
+    if (wave == 8) {
+        // padded frames get exactly-zero gradients (the reference: roll_to_end + masked softmax, utils.cpp:11-66)
+        __amdgpu_buffer_rsrc_t rs_g = make_rsrc((R *) F.grad_inputs + (int64_t) b * N,
+                                                (unsigned) ((int64_t) (T - 1) * P.B * N + N) * (unsigned) sizeof(R));
+        const unsigned voff = lane < N ? (unsigned) lane * sizeof(R) : kOobOffset;
+        const unsigned grow_bytes = (unsigned) P.B * N * sizeof(R);
+        for (int t = len; t < T; ++t) buf_store(R(0), rs_g, voff, (unsigned) t * grow_bytes);
+    } else if (wave == 9) {
+        if (b == 0) {
+            // normalised transition rows for the exact stand-alone code (asg_assemble.h reads them)
+            const bool act = lane < N;
+            const int lc = act ? lane : 0;
+            V2<R> e2[NP / 2];
+            R Ri;
+            load_norm_row<R, NP>((const R *) P.transition + (int64_t) lc * P.ts0, P.ts1, N, act, e2, Ri);
+            if (act) {
+                V2<R> *erow = reinterpret_cast<V2<R> *>((R *) W.ehat + (int64_t) lane * W.npad);
+#pragma unroll
+                for (int j = 0; j < NP / 2; ++j) erow[j] = e2[j];
+                ((R *) W.rmax)[lane] = Ri;
+            }
+        }
+    } else if (fused) {
+        switch (wave) {
+            case 0: fused_main<NP, false>(P, b, LA, LB, len, W.dbg); break;
+            case 1: fused_main<NP, true>(P, b, LB, LA, len, W.dbg); break;
+            case 6: duo_producer<NP, false>(P, b, LA); break;
+            case 7: duo_producer<NP, true>(P, b, LB); break;
+            case 2: fused_consumer<NP, false>(P, W, F, b, LA, LB, len, mid, acc, sc2); break;
+            case 3: fused_consumer<NP, true>(P, W, F, b, LB, LA, len, len - mid, acc, sc2); break;
+            case 4: fused_aligned<false>(P, W, b, LA, LB, len, mid, sc2); break;
+            case 5: fused_aligned<true>(P, W, b, LB, LA, len, len - mid, sc2); break;
+            case 10: fused_finisher<false>(P, W, F, b, LA, LB, len, mid, accH, accD); break;
+            case 11: fused_finisher<true>(P, W, F, b, LB, LA, len, len - mid, accH, accD); break;
+            default: break;
+        }
+        if (wave == 3 && lane == 0) SH.score_full = sc2;
+        if (wave == 5 && lane == 0) SH.score_ali = sc2;
+        if (wave == 6) SH.xa[lane] = LA.x[lane];      // the producers wrote them first thing
+        if (wave == 7) SH.xb[lane] = LB.x[lane];
     }
-#endif
-    switch (wave) {
-        case 0: __builtin_amdgcn_s_setprio(3); duo_main<NP, STORE, false>(P, W, O, b, LA); break;
-        case 1: __builtin_amdgcn_s_setprio(3); duo_main<NP, STORE, true>(P, W, O, b, LB); break;
-        case 4: duo_producer<NP, false>(P, b, LA); break;
-        case 5: duo_producer<NP, true>(P, b, LB); break;
-        case 2: duo_consumer<NP, STORE, false>(P, W, O, b, LA); break;
-        case 3: duo_consumer<NP, STORE, true>(P, W, O, b, LB); break;
-        case 6: aligned_alpha_chain<float, STORE>(P, W, O, b); break;
-        case 7: aligned_beta_chain<float, STORE>(P, W, O, b); break;
-        default: break;
+    __syncthreads();
+    const bool flagged = !fused || LA.stop() || LB.stop();
+    __syncthreads();
+    if (flagged) {
+        // exact scores here (so that the loss of this launch is right), exact gradients in the backward launch
+        if (wave == 0) {
+            const double s = slow_full_score<NP>(P, b, len);
+            if (lane == 0) SH.score_full = s;
+        } else if (wave == 1) {
+            // the stand-alone aligned beta chain, forward-only; its score lands in scores[B + b]
+            FwdOut O{};
+            O.aligned_scores = (R *) F.scores + P.B;
+            aligned_beta_chain<R, false>(P, W, O, b);
+        }
+        __syncthreads();
+    } else {
+        // ---- phase 2: this utterance's [N][N] tile.  The rings are dead: their memory becomes the tile.
+        TileLds<NP> &TL = SH.u.t;
+        for (int k = threadIdx.x; k < 64 * (NP + 1); k += kFusedThreads) (&TL.tileF[0][0])[k] = 0;
+        for (int k = threadIdx.x; k < NP * NP; k += kFusedThreads) TL.fxT[k] = 0;
+        __syncthreads();
+        const R L2E = Num<R>::log2e();
+        const R *tr = (const R *) P.transition;
+        if (wave == 2) {
+            // alpha side: acc[i][j] * E[i][j],  E = exp2(Tr2[i][j] - rowmax_i)
+#pragma unroll
+            for (int r = 0; r < NT; ++r)
+#pragma unroll
+                for (int c = 0; c < NT; ++c)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int i = 16 * r + 4 * (lane >> 4) + q, j = 16 * c + (lane & 15);
+                        if (i < N && j < N) {
+                            const R e = Num<R>::exp2(tr[(int64_t) i * P.ts0 + (int64_t) j * P.ts1] * L2E - SH.xa[i]);
+                            TL.tileF[i][j] = acc[r * NT + c][q] * e;
+                        }
+                    }
+        }
+        __syncthreads();
+        if (wave == 3) {
+            // beta side: acc'[j][i] * F[j][i],  F = exp2(Tr2[i][j] - colmax_j)   (rows of acc' are SOURCE labels j)
+#pragma unroll
+            for (int r = 0; r < NT; ++r)
+#pragma unroll
+                for (int c = 0; c < NT; ++c)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int j = 16 * r + 4 * (lane >> 4) + q, i = 16 * c + (lane & 15);
+                        if (i < N && j < N) {
+                            const R f = Num<R>::exp2(tr[(int64_t) i * P.ts0 + (int64_t) j * P.ts1] * L2E - SH.xb[j]);
+                            TL.tileF[i][j] += acc[r * NT + c][q] * f;
+                        }
+                    }
+        }
+        if (wave == 10 || wave == 11) {
+            const AlignedSetup<R> A = aligned_setup<R>(P, b, lane);
+            if (A.act) {
+                if (accH != R(0)) atomicAdd(&TL.fxT[A.tgt * N + A.tgt], to_fix<R>(accH));
+                if (lane >= 1 && accD != R(0)) atomicAdd(&TL.fxT[A.tgt * N + A.prv], to_fix<R>(accD));
+            }
+        }
+        __syncthreads();
+        R *tile_out = (R *) F.tiles + (int64_t) b * N * N;
+        for (int k = threadIdx.x; k < N * N; k += kFusedThreads) {
+            const int i = k / N, j = k - i * N;
+            R v = TL.tileF[i][j];
+            const unsigned long long fv = TL.fxT[k];
+            if (fv != 0) v -= from_fix<R>(fv);
+            tile_out[k] = v * F.gscale;
+        }
+    }
+    // ---- phase 3: loss of this utterance; the last workgroup to arrive reduces the batch (fixed order)
+    if (wave == 0) {
+        R full = score_out<R>(SH.score_full);
+        R ali = flagged ? __hip_atomic_load((R *) F.scores + P.B + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                        : score_out<R>(SH.score_ali);
+        if (lane == 0) {
+            ((R *) F.scores)[b] = full;
+            if (!flagged) ((R *) F.scores)[P.B + b] = ali;
+            F.flags[b] = flagged ? 1 : 0;
+        }
+        R *lossb = (R *) F.dump;                    // [B] per-utterance losses for the reducing workgroup
+        const R l = full - ali;
+        if (F.reduction == 0) {
+            if (lane == 0) ((R *) F.loss)[b] = l;
+        } else {
+            unsigned ticket = 0;
+            if (lane == 0) {
+                __hip_atomic_store(lossb + b, l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                ticket = __hip_atomic_fetch_add(F.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            ticket = __builtin_amdgcn_readfirstlane(ticket);
+            if (ticket == (unsigned) (P.B - 1)) {
+                double s = 0;
+                for (int q = lane; q < P.B; q += 64)
+                    s += (double) __hip_atomic_load(lossb + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s = wave_allsum(s);
+                if (lane == 0) {
+                    ((R *) F.loss)[0] = (R) (F.reduction == 2 ? s / P.B : s);
+                    __hip_atomic_store(F.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
     }
 }
 
+// ------------------------------------------------------------------ the backward kernel
+// grid = B + R workgroups of 256 threads.
+//   workgroup b < B:   redo utterance b exactly if it is flagged; scale its grad_inputs rows by the upstream gradient
+//                      (nothing when that is 1); arrive.
+//   workgroup B + r:   once all B have arrived, grad_transition[slice r] = sum_b g_b * tile[b][slice r], b ascending.
+constexpr int kBwdSlice = 64;
 template <int NP>
-hipError_t launch_cohab_np(const Problem &P, const State &W, const FwdOut &O, bool store, hipStream_t st) {
-    dim3 grid(P.B), block(768);
-    if (store) hipLaunchKernelGGL((fwd_cohab_kernel<NP, true>), grid, block, 0, st, P, W, O);
-    else hipLaunchKernelGGL((fwd_cohab_kernel<NP, false>), grid, block, 0, st, P, W, O);
+__global__ void __launch_bounds__(256) fused_bwd_kernel(Problem P, State W, FusedArgs F) {
+    typedef float R;
+    __shared__ AssembleLds<R, NP, 4> S;
+    __shared__ __attribute__((aligned(16))) R lds4[4][64];
+    __shared__ R part[4][kBwdSlice];
+    const int N = P.N, T = P.T, B = P.B;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if ((int) blockIdx.x < B) {
+        const int b = blockIdx.x;
+        const R g = ((const R *) F.grad_loss)[F.reduction == 0 ? b : 0];
+        const bool flagged = F.flags[b] != 0;
+        if (flagged) {
+            FwdOut O{};
+            O.full_scores = (R *) F.dump + B;            // scratch: the scores of this launch's forward stay as they are
+            O.aligned_scores = (R *) F.dump + 2 * B;
+            if (wave == 0) full_alpha_chain<R, NP, 0, true>(P, W, O, b, lds4[0]);
+            else if (wave == 1) full_beta_chain<R, NP, 0, true>(P, W, O, b, lds4[1]);
+            else if (wave == 2) aligned_alpha_chain<R, true>(P, W, O, b);
+            else aligned_beta_chain<R, true>(P, W, O, b);
+            // the four chains' state rows are read back by all four wavefronts: make them visible past the L1
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            BwdArgs A{};
+            A.unit_grad = 1;
+            A.neg_aligned = 1;
+            A.gscale = (double) F.gscale;
+            A.grad_inputs = F.grad_inputs;
+            A.chunk = T;
+            A.nchunks = 1;
+            assemble_frames<R, NP, 4>(P, W, A, 3, b, 0, (R *) F.tiles + (int64_t) b * N * N, S);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __syncthreads();
+        }
+        if (g != R(1)) {
+            R *gi = (R *) F.grad_inputs + (int64_t) b * N;
+            const int total = T * N;
+            for (int k = threadIdx.x; k < total; k += 256) {
+                const int t = k / N, i = k - t * N;
+                R *ptr = gi + (int64_t) t * B * N + i;
+                *ptr = *ptr * g;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(F.ticket2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+    // ---- reducers
+    const int r = (int) blockIdx.x - B;
+    {
+        int spins = 0;
+        while (__hip_atomic_load(F.ticket2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned) B) {
+            if (++spins > (1 << 24)) break;               // cannot happen: arrivals never wait on anything
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    const int n2 = N * N;
+    const int k = min(r * kBwdSlice + lane, n2 - 1);
+    const R *tiles = (const R *) F.tiles;
+    const R *gl = (const R *) F.grad_loss;
+    // wave w sums utterances b = w, w+4, ... (16 loads in flight), then a fixed-order combine over the four waves
+    R a[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) a[q] = 0;
+    for (int b0 = wave; b0 < B; b0 += 64) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int bb = b0 + 4 * q;
+            const int bc = min(bb, B - 1);
+            const R v = __hip_atomic_load(tiles + (int64_t) bc * n2 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const R g = gl[F.reduction == 0 ? bc : 0];
+            a[q] += (bb < B) ? v * g : R(0);
+        }
+    }
+    R s = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) s += a[q];
+    part[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && r * kBwdSlice + lane < n2)
+        ((R *) F.grad_transition)[k] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+}
+
+template <int NP>
+hipError_t launch_fused_np(const Problem &P, const State &W, const FusedArgs &F, bool backward, hipStream_t st) {
+    if (!backward) {
+        hipLaunchKernelGGL((fused_fwd_kernel<NP>), dim3(P.B), dim3(kFusedThreads), 0, st, P, W, F);
+    } else {
+        const int R = (P.N * P.N + kBwdSlice - 1) / kBwdSlice;
+        hipLaunchKernelGGL((fused_bwd_kernel<NP>), dim3(P.B + R), dim3(256), 0, st, P, W, F);
+    }
     return hipGetLastError();
+}
+
+hipError_t launch_fused(const Problem &P, const State &W, const FusedArgs &F, bool backward, hipStream_t stream) {
+    const int N = P.N;
+#ifdef ASG_DEV_ONLY_NP
+    (void) N;
+    return launch_fused_np<ASG_DEV_ONLY_NP>(P, W, F, backward, stream);
+#else
+    if (N <= 8) return launch_fused_np<8>(P, W, F, backward, stream);
+    if (N <= 16) return launch_fused_np<16>(P, W, F, backward, stream);
+    if (N <= 24) return launch_fused_np<24>(P, W, F, backward, stream);
+    if (N <= 32) return launch_fused_np<32>(P, W, F, backward, stream);
+    if (N <= 40) return launch_fused_np<40>(P, W, F, backward, stream);
+    if (N <= 48) return launch_fused_np<48>(P, W, F, backward, stream);
+    if (N <= 56) return launch_fused_np<56>(P, W, F, backward, stream);
+    return launch_fused_np<64>(P, W, F, backward, stream);
+#endif
 }
 
 }  // namespace
 
-hipError_t launch_fwd_cohab(const Problem &P, const State &W, const FwdOut &O, bool store, hipStream_t stream) {
-    const int N = P.N;
-#ifdef ASG_DEV_ONLY_NP
-    (void) N;
-    return launch_cohab_np<ASG_DEV_ONLY_NP>(P, W, O, store, stream);
-#else
-    if (N <= 8) return launch_cohab_np<8>(P, W, O, store, stream);
-    if (N <= 16) return launch_cohab_np<16>(P, W, O, store, stream);
-    if (N <= 24) return launch_cohab_np<24>(P, W, O, store, stream);
-    if (N <= 32) return launch_cohab_np<32>(P, W, O, store, stream);
-    if (N <= 40) return launch_cohab_np<40>(P, W, O, store, stream);
-    if (N <= 48) return launch_cohab_np<48>(P, W, O, store, stream);
-    return launch_cohab_np<56>(P, W, O, store, stream);
-#endif
+hipError_t launch_fused_forward(const Problem &P, const State &W, const FusedArgs &F, hipStream_t stream) {
+    // the recursion wavefronts address emission frames with 32-bit buffer offsets (as launch_fwd_small)
+    const double fr = (double) (P.T - 1) * (double) P.is0 * sizeof(float), ln = 63.0 * (double) P.is2 * sizeof(float);
+    if (P.is0 < 0 || P.is2 < 0 || fr >= 4294967296.0 || ln >= 2147483648.0) return hipErrorInvalidValue;
+    return launch_fused(P, W, F, false, stream);
+}
+
+hipError_t launch_fused_backward(const Problem &P, const State &W, const FusedArgs &F, hipStream_t stream) {
+    return launch_fused(P, W, F, true, stream);
 }
 
 }  // namespace asg

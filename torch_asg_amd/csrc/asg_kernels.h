@@ -62,6 +62,25 @@ struct BwdArgs {
     void *scratch;               // partial tiles etc.
     int chunk;                   // frames per workgroup (small path)
     int nchunks;
+    int unit_grad;               // 1: the upstream gradient is 1 for every utterance (grad_full is not read)
+};
+
+// Fused training step of the whole criterion (asg_fused.hip): the forward launch also assembles the gradients for an
+// upstream gradient of 1; the backward launch scales them (nothing to do when the upstream gradient IS 1), reduces
+// the per-utterance transition-gradient tiles in a fixed order and redoes flagged utterances exactly.
+struct FusedArgs {
+    void *loss;                  // [B] (reduction none) or [1]
+    void *scores;                // [2][B]: full, aligned
+    void *grad_inputs;           // [T,B,N] contiguous
+    void *tiles;                 // [B][N][N] per-utterance transition-gradient tiles (times gscale)
+    int *flags;                  // [B]: 1 = the fused path declined this utterance (range guard, very short, time-out)
+    void *dump;                  // [2][B] scratch scores for the exact redo
+    unsigned *ticket;            // 256 B, caller-zeroed, returned zeroed: arrival ticket of the forward loss reduction
+    unsigned *ticket2;           // 256 B, zeroed by the forward launch for the backward launch
+    const void *grad_loss;       // backward: [B] (none) or [1]
+    void *grad_transition;       // backward: [N,N]
+    int reduction;
+    float gscale;                // 1/B for reduction mean, else 1
 };
 
 enum ChainBits { kFullAlpha = 1, kFullBeta = 2, kAlignedAlpha = 4, kAlignedBeta = 8 };
@@ -73,7 +92,8 @@ hipError_t launch_fwd_small(const Problem &P, const State &W, const FwdOut &O, i
                             int matvec_variant, hipStream_t stream);
 template <typename R>
 hipError_t launch_bwd_small(const Problem &P, const State &W, const BwdArgs &A, int parts, hipStream_t stream);
-hipError_t launch_fwd_cohab(const Problem &P, const State &W, const FwdOut &O, bool store, hipStream_t stream);
+hipError_t launch_fused_forward(const Problem &P, const State &W, const FusedArgs &F, hipStream_t stream);
+hipError_t launch_fused_backward(const Problem &P, const State &W, const FusedArgs &F, hipStream_t stream);
 // loss[b] = full[b] - aligned[b], reduced: 0 = none ([B] out), 1 = sum, 2 = mean ([1] out); fixed-order tree
 template <typename R>
 hipError_t launch_loss_reduce(const void *full, const void *aligned, int B, int reduction, void *out, hipStream_t stream);
