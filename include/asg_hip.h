@@ -151,21 +151,23 @@ int asg_loss_backward(asg_ctx *ctx, const asg_problem *p, const void *state, siz
  * The reference's GPU fast route runs every recursion in forward and none in backward
  * (fast_asg_gpu_forward / fast_asg_gpu_backward, streamlined_fast_gpu.cpp:104-297); this pair goes one step further:
  * asg_loss_fused_forward also assembles d(loss)/d(inputs) and the per-utterance transition-gradient tiles for an
- * upstream gradient of 1, as the alpha and beta recursions cross (nothing but half of the lattice state ever goes
- * to HBM); asg_loss_fused_backward multiplies by the actual upstream gradient (a no-op when that is 1), reduces the
+ * upstream gradient of 1, as the alpha and beta recursions cross (only half of the lattice state and the aligned
+ * posteriors ever go to HBM); asg_loss_fused_backward multiplies by the actual upstream gradient (a no-op when that is 1), reduces the
  * tiles in a fixed order into grad_transition and redoes, exactly, any utterance the fused path declined
  * (row sums outside the fp32-safe range, fewer than 4 frames).  Results are bit-deterministic.
  *   supported: float32, N < 64, S <= 64 (asg_loss_fused_supported returns 1); otherwise use asg_loss_forward/backward.
  *   state:     asg_state_bytes(p) bytes, as for asg_loss_forward; the SAME buffer must be passed to backward.
  *   scratch:   asg_loss_fused_scratch_bytes(p) bytes; the SAME buffer must be passed to backward.
  *   grad_inputs [T,B,N] contiguous: written by forward, rescaled in place by backward.
- *   ticket:    256 bytes of device memory that are ZERO on entry; the call leaves them zero.  Calls that may run
- *              concurrently (different streams) need different tickets; calls on one stream may share one.
+ *   sync:      asg_loss_fused_sync_bytes(p) bytes of device memory that are ZERO on entry; the call leaves them
+ *              zero.  They hold the words through which the workgroups of the launch talk to each other.  Calls that
+ *              may run concurrently (different streams) need different regions; calls on one stream may share one.
  * The library allocates nothing and keeps no state between calls. */
 int asg_loss_fused_supported(const asg_problem *p);
 size_t asg_loss_fused_scratch_bytes(const asg_problem *p);
+size_t asg_loss_fused_sync_bytes(const asg_problem *p);
 int asg_loss_fused_forward(const asg_problem *p, void *state, size_t state_bytes, int reduction, void *loss, void *scores,
-                           void *scratch, size_t scratch_bytes, void *grad_inputs, void *ticket, int flags, void *stream);
+                           void *scratch, size_t scratch_bytes, void *grad_inputs, void *sync, int flags, void *stream);
 int asg_loss_fused_backward(const asg_problem *p, void *state, size_t state_bytes, int reduction, const void *grad_loss,
                             void *scratch, size_t scratch_bytes, void *grad_inputs, void *grad_transition, int flags,
                             void *stream);

@@ -17,7 +17,8 @@ SYMBOLS = ["asg_hip_version", "asg_hip_strerror", "asg_ctx_create", "asg_ctx_des
            "asg_scratch_bytes", "asg_full_forward", "asg_full_backward", "asg_aligned_forward",
            "asg_aligned_backward", "asg_forward", "asg_forward_only", "asg_backward", "asg_loss_forward",
            "asg_loss_backward", "asg_viterbi_work_bytes", "asg_viterbi", "asg_loss_fused_supported",
-           "asg_loss_fused_scratch_bytes", "asg_loss_fused_forward", "asg_loss_fused_backward"]
+           "asg_loss_fused_scratch_bytes", "asg_loss_fused_sync_bytes", "asg_loss_fused_forward",
+           "asg_loss_fused_backward"]
 
 
 class AsgProblem(ctypes.Structure):
@@ -68,6 +69,8 @@ def lib():
     L.asg_loss_fused_supported.argtypes = [pp]
     L.asg_loss_fused_scratch_bytes.restype = sz
     L.asg_loss_fused_scratch_bytes.argtypes = [pp]
+    L.asg_loss_fused_sync_bytes.restype = sz
+    L.asg_loss_fused_sync_bytes.argtypes = [pp]
     L.asg_loss_fused_forward.argtypes = [pp, vp, sz, ci, vp, vp, vp, sz, vp, vp, ci, vp]
     L.asg_loss_fused_backward.argtypes = [pp, vp, sz, ci, vp, vp, sz, vp, vp, ci, vp]
     for name in SYMBOLS:

@@ -263,26 +263,27 @@ class HipBackend:
     # -- whole loss: full - aligned, reduction and their gradients inside the kernels -----------------------
     _RED = {"none": 0, "sum": 1, "mean": 2}
 
-    def _ticket(self, device):
-        """256 zeroed bytes for the arrival ticket of the in-launch loss reduction (include/asg_hip.h: zero on entry,
-        left zero).  One slot per calling stream for eager calls (calls on one stream are ordered, they may share);
-        a fresh slot for every call made while a hipGraph is being captured, so that graphs replayed concurrently
-        never share one.  Slots come from a pool that is zeroed ONCE, outside the hot path."""
+    def _sync(self, device, nbytes):
+        """Zeroed device memory for the cross-workgroup words of a fused launch (include/asg_hip.h: zero on entry,
+        left zero).  One region per calling stream for eager calls (calls on one stream are ordered, they may share);
+        a fresh region for every call made while a hipGraph is being captured, so that graphs replayed concurrently
+        never share one.  Regions are carved from pools that are zeroed ONCE, outside the hot path."""
         idx = device.index if device.index is not None else torch.cuda.current_device()
         capturing = torch.cuda.is_current_stream_capturing()
         key = (idx, torch.cuda.current_stream(idx).cuda_stream)
         if not capturing:
             t = self._tickets.get(key)
-            if t is not None:
+            if t is not None and t.numel() >= nbytes:
                 return t
+        nbytes = (int(nbytes) + 255) // 256 * 256
         with self._lock:
             pool = self._pools.get(idx)
-            if pool is None or pool[1] >= pool[0].shape[0]:
-                pool = [torch.zeros(1024, 64, dtype=torch.int32, device=device), 0]
+            if pool is None or pool[1] + nbytes > pool[0].numel():
+                pool = [torch.zeros(max(1 << 20, 4 * nbytes), dtype=torch.uint8, device=device), 0]
                 self._pools[idx] = pool
                 self._pool_keep.append(pool[0])
-            t = pool[0][pool[1]]
-            pool[1] += 1
+            t = pool[0][pool[1]: pool[1] + nbytes]
+            pool[1] += nbytes
             if not capturing:
                 self._tickets[key] = t
         return t
@@ -309,10 +310,11 @@ class HipBackend:
             loss = torch.empty((B,) if red == 0 else (), dtype=inputs.dtype, device=dev)
             if (flags & _lib.FLAG_SINGLE_LAUNCH) and self.fused_supported(p):
                 key = ("fs", p.T, p.B, p.N, p.S)
-                fs = self._sizes.get(key)
-                if fs is None:
-                    fs = int(L.asg_loss_fused_scratch_bytes(ctypes.byref(p)))
-                    self._sizes[key] = fs
+                fsz = self._sizes.get(key)
+                if fsz is None:
+                    fsz = (int(L.asg_loss_fused_scratch_bytes(ctypes.byref(p))), int(L.asg_loss_fused_sync_bytes(ctypes.byref(p))))
+                    self._sizes[key] = fsz
+                fs, sync_bytes = fsz
                 # one workspace: [scores 2B | state | scratch]
                 sc_bytes = (2 * B * 4 + 255) // 256 * 256
                 ws = torch.empty(sc_bytes + state_bytes + fs, dtype=torch.uint8, device=dev)
@@ -320,7 +322,7 @@ class HipBackend:
                 base = ws.data_ptr()
                 _lib.check(L.asg_loss_fused_forward(ctypes.byref(p), base + sc_bytes, state_bytes, red, loss.data_ptr(),
                                                     base, base + sc_bytes + state_bytes, fs, gin.data_ptr(),
-                                                    self._ticket(dev).data_ptr(), 0, self._stream(dev)),
+                                                    self._sync(dev, sync_bytes).data_ptr(), 0, self._stream(dev)),
                            "asg_loss_fused_forward")
                 return loss, _Saved("fused", (ws, gin), p, keep, (sc_bytes, state_bytes, fs))
             state = self._buf(state_bytes, dev)

@@ -441,7 +441,7 @@ int asg_loss_backward(asg_ctx *ctx, const asg_problem *p, const void *state, siz
 /* ---- fused training step (asg_fused.hip) ------------------------------------------------------------------ */
 
 namespace {
-struct FusedLayout { size_t tiles, flags, dump, ticket2, total; };
+struct FusedLayout { size_t tiles, flags, dump, ticket2, p2, edges, ascore, aoff, total; };
 FusedLayout fused_layout(const asg_problem *p) {
     FusedLayout L{};
     size_t off = 0;
@@ -449,6 +449,10 @@ FusedLayout fused_layout(const asg_problem *p) {
     L.flags = off; off = align_up(off + (size_t) p->B * 4);
     L.dump = off; off = align_up(off + (size_t) p->B * 3 * 4);
     L.ticket2 = off; off = align_up(off + 256);
+    L.p2 = off; off = align_up(off + (size_t) p->B * 2 * (p->T + 8) * (p->S < 1 ? 1 : p->S) * 4);
+    L.edges = off; off = align_up(off + (size_t) p->B * 2 * 3 * 128 * 4);
+    L.ascore = off; off = align_up(off + (size_t) p->B * 8);
+    L.aoff = off; off = align_up(off + (size_t) p->B * 2 * ((p->T + 15) / 16 + 1) * 2 * 8);
     L.total = off;
     return L;
 }
@@ -460,6 +464,10 @@ FusedArgs fused_args(const asg_problem *p, void *scratch, int reduction) {
     F.flags = (int *) (base + L.flags);
     F.dump = base + L.dump;
     F.ticket2 = (unsigned *) (base + L.ticket2);
+    F.p2 = base + L.p2;
+    F.edges = base + L.edges;
+    F.ascore = base + L.ascore;
+    F.aoff = base + L.aoff;
     F.reduction = reduction;
     F.gscale = reduction == 2 ? (float) (1.0 / (double) p->B) : 1.0f;
     return F;
@@ -472,6 +480,7 @@ int asg_loss_fused_supported(const asg_problem *p) {
     const double fr = (double) (p->T - 1) * (double) p->inputs_strides[0] * 4.0, ln = 63.0 * (double) p->inputs_strides[2] * 4.0;
     if (p->inputs_strides[0] < 0 || p->inputs_strides[2] < 0 || fr >= 4294967296.0 || ln >= 2147483648.0) return 0;
     if ((double) p->T * (double) p->B * (double) p->N * 4.0 >= 4294967296.0) return 0;
+    if (p->T > 4000) return 0;              // per-block offset tables of the aligned finishers (asg_fused.hip: kMaxBlk)
     return 1;
 }
 
@@ -480,17 +489,22 @@ size_t asg_loss_fused_scratch_bytes(const asg_problem *p) {
     return fused_layout(p).total;
 }
 
+size_t asg_loss_fused_sync_bytes(const asg_problem *p) {
+    if (!p || p->B < 1) return 0;
+    return align_up(256 + (size_t) p->B * 32);
+}
+
 int asg_loss_fused_forward(const asg_problem *p, void *state, size_t state_bytes, int reduction, void *loss, void *scores,
-                           void *scratch, size_t scratch_bytes, void *grad_inputs, void *ticket, int flags, void *stream) {
+                           void *scratch, size_t scratch_bytes, void *grad_inputs, void *sync, int flags, void *stream) {
     (void) flags;
-    if (reduction < 0 || reduction > 2 || !loss || !scores || !scratch || !grad_inputs || !ticket || !state) return ASG_ERR_INVALID;
+    if (reduction < 0 || reduction > 2 || !loss || !scores || !scratch || !grad_inputs || !sync || !state) return ASG_ERR_INVALID;
     if (!asg_loss_fused_supported(p)) return check_problem(p, true) != ASG_OK ? check_problem(p, true) : ASG_ERR_UNSUPPORTED;
     if (state_bytes < asg_state_bytes(p) || scratch_bytes < asg_loss_fused_scratch_bytes(p)) return ASG_ERR_WORKSPACE;
     FusedArgs F = fused_args(p, scratch, reduction);
     F.loss = loss;
     F.scores = scores;
     F.grad_inputs = grad_inputs;
-    F.ticket = (unsigned *) ticket;
+    F.sync = (unsigned *) sync;
     return hip_status(launch_fused_forward(to_problem(p), to_state(p, state), F, (hipStream_t) stream));
 }
 

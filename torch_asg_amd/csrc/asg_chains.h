@@ -876,6 +876,7 @@ struct DuoLds {
     float x[64];       // producer -> consumer: row / column maxima
     // the buffer main broadcasts step n's vector through, and the helpers' common "stop" test
     __device__ __forceinline__ float *pslot(int) { return p; }
+    __device__ __forceinline__ int consumed() { return __hip_atomic_load(&c_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
     __device__ __forceinline__ bool stop() {
         return __hip_atomic_load(&verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 2 ||
                __hip_atomic_load(&kill, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
@@ -1126,7 +1127,7 @@ __device__ __forceinline__ void duo_producer(const Problem &P, int b, LdsT &L) {
         // block K reuses the ring half of block K-2: wait until the consumer has seen s_{16(K-1)-1}, i.e. main has
         // finished block K-2
         int spins = 0;
-        while (lds_load_rlx(&L.c_done) < (K - 1) * kPF) {
+        while (L.consumed() < (K - 1) * kPF) {
             if (L.stop() || ++spins > kSpinCap) return;
             __builtin_amdgcn_s_sleep(2);
         }

@@ -7,22 +7,27 @@
 // split "both recursions in forward, no recursion in backward" is kept and taken one step further -- the
 // non-recursive assembly happens inside the forward launch too, and backward only scales by the upstream gradient.
 //
-// One workgroup (12 wavefronts, one compute unit) per utterance.  The alpha chains walk frames 0 -> len-1, the beta chains
-// len-1 -> 0; they cross at mid = len/2.  Before the crossing each chain stores its state for the other side (frames
-// < mid from alpha, >= mid from beta: half of what the stand-alone kernels store); after it, the side that reaches a
-// frame SECOND holds everything the frame's gradient needs:
-//   posterior_t = softmax(alpha_t + beta_t)                      -> grad_inputs row (minus the aligned posterior)
+// Two workgroups per utterance, on two compute units (grid = 2B, 768 threads):
+//   * the ALIGNED workgroup (block b < B) owns the force-aligned lattice: both chains, their crossing, the aligned
+//     posteriors and the edge posteriors.  It depends on nothing and never waits for another workgroup.
+//   * the FULL workgroup (block B + b) owns the fully-connected lattice and writes the final grad_inputs rows; it reads
+//     the aligned posteriors of a frame from HBM/L2 behind a progress word (one-way dependency on a workgroup with a
+//     LOWER block index, i.e. dispatched earlier -- and every wait is bounded anyway).
+// In both, the alpha chain walks frames 0 -> len-1 and the beta chain len-1 -> 0; they cross at mid = len/2.  Before the
+// crossing each chain stores its state for the other side (frames < mid from alpha, >= mid from beta: half of what the
+// stand-alone kernels store); after it, the side that reaches a frame SECOND holds everything the frame's gradient needs:
+//   posterior_t = softmax(alpha_t + beta_t)                      -> grad_inputs row (minus the scattered aligned posterior)
 //   alpha side:  xi_t(i,j)    = posterior_t[i]   / s_i  * E[i][j] * v_{t-1}[j]     s = E v_{t-1}  (this step's row sums)
 //   beta side:   xi_{t+1}(i,j) = posterior_t[j] / s'_j * F[j][i] * y_{t+1}[i]      s' = F y_{t+1}
 // i.e. the recursion's OWN row sums and broadcast vector -- the stand-alone assembly kernel's second mat-vec is gone, and
 // the sum over frames of the outer products (posterior / s) (x) v runs on the matrix cores (asg_outer.h).
-// Wave roles (waves with equal index % 4 share a SIMD):
-//   0/1  recursion wavefronts alpha/beta   (critical path only; as fwd_duo_kernel)
-//   4/5  aligned chains (beside the recursion wavefronts: both are dependent chains that leave most issue slots free)
-//   6/7  producers (emission factors)      2/3  consumers: first half = log-domain state -> HBM; second half = posterior,
-//                                                          row -> LDS ring, outer-product accumulation (MFMA)
-//   10/11 finishers: aligned posterior, deterministic scatter, final grad_inputs row, aligned edge posteriors
-//   8/9  housekeeping (zero rows of padded frames, normalised transition rows for the exact path), then exit
+// Wave roles of the full workgroup (waves with equal index % 4 share a SIMD):
+//   0/1  recursion wavefronts alpha/beta   (critical path only; as fwd_duo_kernel)       4/5  producers (emission factors)
+//   2,6 / 3,7  consumers alpha / beta: first half = log-domain state -> HBM (one of the pair); second half = posterior ->
+//        LDS row ring, xi accumulation (MFMA), the two of a pair taking alternate groups of 8 frames
+//   8/9  row finishers: aligned posterior of the frame (from the aligned workgroup) scattered to labels with
+//        deterministic fixed-point LDS adds, final grad_inputs row
+// of the aligned workgroup:  0/1 chains alpha/beta   2/3 finishers (aligned posterior -> HBM, edge posteriors)
 // Everything is bit-deterministic: no float atomics, fixed accumulation orders.
 // An utterance whose row sums leave the safe range (or shorter than kMinFused frames, or any bounded wait that runs
 // out) is FLAGGED: its scores are recomputed here with exact log-sum-exps, its gradients by the exact stand-alone code
@@ -33,49 +38,132 @@
 namespace asg {
 namespace {
 
-constexpr int kRow = 16;        // consumer -> finisher ring of grad_inputs rows (frames)
+constexpr int kRow = 64;        // consumer -> row finisher ring of grad_inputs rows (frames)
 constexpr int kAR = 32;         // aligned chain -> finisher ring of aligned states (frames)
 constexpr int kGS = 8;          // frames per poll of the consumers / finishers
 constexpr int kMinFused = 4;
+constexpr int kAF = 3;          // aligned finisher wavefronts per side (round-robin over 8-index groups)
+constexpr int kRF = 2;          // row finisher wavefronts per side
 constexpr int kFusedThreads = 768;
 constexpr unsigned kSc1 = 16;   // buffer load/store aux bit: agent scope (served by / written through to L2)
 
-struct FusedSide {
+struct FusedSide {                                        // one direction (alpha / beta) of the FULL workgroup
     __attribute__((aligned(16))) float p[kRing][64];   // step n's broadcast vector v_n (slot n & 31)
     float s[kRing][64];                                  // row sums s_n, main -> consumer (self-describing: NaN sentinel)
     float e[kRing][64];                                  // emission factors, producer -> main
     float a[kRing][64];                                  // their log2 (alpha side), producer -> consumer
-    float row[kRow][64];                                 // gscale * full posterior of a frame, consumer -> finisher
-    float ar[kAR][64];                                   // aligned states, aligned chain -> finisher
+    float row[kRow][64];                                 // gscale * full posterior of a frame, consumer -> row finisher
     float x[64];                                         // row / column maxima of the transition matrix
-    unsigned fx[kGS][64];                                // finisher: fixed-point scatter of the aligned posteriors, one per frame of a group
+    unsigned fx[2][kGS][64];                             // row finisher k: fixed-point scatter of the aligned posteriors
     double zsum;
-    int e_prod, csum, main_done, c_done, prod_done, kill;
-    int st_done;      // consumer: state rows of indices [0, st_done) are in HBM/L2 and visible
-    int row_done;     // consumer: rows of indices [h, row_done) are in `row`
-    int ast_done;     // aligned chain: states of indices [0, ast_done) are in HBM/L2 and visible
-    int ar_done;      // aligned chain: states of indices [0, ar_done) have been written to `ar`
-    int fin_done;     // finisher: indices [h, fin_done) are finished (their ring slots are free)
+    int e_prod, csum, main_done, prod_done, kill;
+    // TWO consumer wavefronts per side: wave 0 takes the whole first half and the even 8-index groups of the second
+    // half, wave 1 the odd groups.  cd[k] = (last index of wave k's latest group) + 8: everything up to
+    // min(cd[0], cd[1]) has been taken out of the rings (wave 1 counts as "infinitely far" during the first half).
+    int cd[2];
+    int rd[2];        // consumer k: rows of its groups up to index rd[k] - 1 are in `row`
+    int st_done;      // consumer 0: state rows of indices [0, st_done) are in HBM/L2 and visible
+    int fd[kRF];      // row finisher k: (count of indices through its latest group) + 8 * (kRF - 1); the row ring is free
+                      // up to min over k (same prefix rule as cd)
+    __device__ __forceinline__ int finished() {
+        return min(__hip_atomic_load(&fd[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP),
+                   __hip_atomic_load(&fd[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    }
+    __device__ __forceinline__ int consumed() {
+        return min(__hip_atomic_load(&cd[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP),
+                   __hip_atomic_load(&cd[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    }
     __device__ __forceinline__ float *pslot(int n) { return p[n & (kRing - 1)]; }
     __device__ __forceinline__ bool stop() { return __hip_atomic_load(&kill, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0; }
 };
 
+constexpr int kMaxBlk = 128;                              // blocks of 16 indices per half whose offsets the finisher keeps in LDS
+struct AliSide {                                          // one direction of the ALIGNED workgroup
+    float ar[kAR][64];                                   // aligned states, chain -> finisher (slot (index - 1) & 31)
+    double cb[4][2];                                     // per 16-index block (slot j & 3): offset at block entry, per-index step
+    double ob[kMaxBlk][2];                               // finisher: the OTHER side's first-half block offsets (from HBM, once);
+                                                         // entry j + 1 = block j, entry 0 = {0, 0} for index 0
+    int kill;
+    int ast_done;     // chain: states of indices [0, ast_done) are in HBM/L2 and visible
+    int ar_done;      // chain: states of indices [0, ar_done) have been written to `ar`
+    int fd[kAF];      // finisher k: (count of indices through its latest group) + 8 * (kAF - 1); ring slots are free up to
+                      // the minimum over k
+    __device__ __forceinline__ int finished() {
+        return min(min(__hip_atomic_load(&fd[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP),
+                       __hip_atomic_load(&fd[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)),
+                   __hip_atomic_load(&fd[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    }
+    __device__ __forceinline__ bool stop() { return __hip_atomic_load(&kill, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0; }
+};
+
+// Cross-workgroup words of one utterance (FusedArgs::sync, after the 64-word ticket block).  Zero on entry, zero on exit.
+struct UttSync {
+    unsigned prog[2][kAF];  // aligned finisher k of a side: the aligned posteriors of ITS groups up to index prog - 1 are in P2
+    unsigned adone;         // aligned workgroup: 1 = finished (edges + score written), 2 = finished but gave up
+    unsigned pad;
+};
+
 template <int NP>
 struct TileLds {
-    float tileF[64][NP + 1];
-    unsigned long long fxT[NP * NP];
+    float sa[64][NP + 1];               // alpha-side xi sums  [to i][from j]   (before the E[i][j] factor)
+    float sb[64][NP + 1];               // beta-side xi sums   [from j][to i]   (before the F[j][i] factor)
+    unsigned long long fxT[NP * NP];    // aligned edge posteriors, fixed point, [to][from]
 };
 
 template <int NP>
 struct FusedShared {
     union U {
         struct G { FusedSide A, B; } g;
+        struct H { AliSide A, B; } h;
         TileLds<NP> t;
     } u;
     float xa[64], xb[64];
     double score_full, score_ali;
-    int flagged;
+    int adone;
 };
+
+// ---- kernel parameters ------------------------------------------------------------------------------------------
+// The three parameter blocks are ~80 SGPRs.  Left as ordinary by-value kernel parameters they are loaded at kernel
+// entry and kept live through every role (they are needed again in the epilogue), and the recursion loops then run on
+// spilled scalars (v_readlane per use).  Instead every role re-reads what it needs from the kernarg segment through a
+// pointer the compiler cannot see through, so the values live only inside that role.
+struct FusedParams {
+    Problem P;
+    State W;
+    FusedArgs F;
+};
+typedef const FusedParams __attribute__((address_space(4))) *KParams;
+
+__device__ __forceinline__ KParams kernarg_params() {
+    KParams p = (KParams) __builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+__device__ __forceinline__ Problem ld_problem(KParams k) {
+    Problem P;
+    P.inputs = k->P.inputs; P.is0 = k->P.is0; P.is1 = k->P.is1; P.is2 = k->P.is2;
+    P.transition = k->P.transition; P.ts0 = k->P.ts0; P.ts1 = k->P.ts1;
+    P.targets = k->P.targets; P.gs0 = k->P.gs0; P.gs1 = k->P.gs1;
+    P.in_len = k->P.in_len; P.tg_len = k->P.tg_len;
+    P.T = k->P.T; P.B = k->P.B; P.N = k->P.N; P.S = k->P.S;
+    return P;
+}
+__device__ __forceinline__ State ld_state(KParams k) {
+    State W;
+    W.ah = k->W.ah; W.bh = k->W.bh; W.ab = k->W.ab; W.bb = k->W.bb;
+    W.ehat = k->W.ehat; W.fhat = k->W.fhat; W.rmax = k->W.rmax; W.cmax = k->W.cmax;
+    W.asu = k->W.asu; W.asi = k->W.asi; W.dbg = k->W.dbg; W.ticket = k->W.ticket; W.work = k->W.work;
+    W.npad = k->W.npad;
+    return W;
+}
+__device__ __forceinline__ FusedArgs ld_fargs(KParams k) {
+    FusedArgs F;
+    F.loss = k->F.loss; F.scores = k->F.scores; F.grad_inputs = k->F.grad_inputs; F.tiles = k->F.tiles;
+    F.flags = k->F.flags; F.dump = k->F.dump; F.p2 = k->F.p2; F.edges = k->F.edges; F.ascore = k->F.ascore;
+    F.aoff = k->F.aoff; F.sync = k->F.sync; F.ticket2 = k->F.ticket2; F.grad_loss = k->F.grad_loss;
+    F.grad_transition = k->F.grad_transition; F.reduction = k->F.reduction; F.gscale = k->F.gscale;
+    return F;
+}
 
 // developer probes (-DASG_PROBE): per role of utterance 0, total cycles and cycles spent in each kind of wait
 #ifdef ASG_PROBE
@@ -89,13 +177,15 @@ struct FusedShared {
 #define PRB_END(dbgp, role)
 #endif
 
-__device__ __forceinline__ void abort_all(FusedSide &L, FusedSide &O) {
+template <class SideT>
+__device__ __forceinline__ void abort_all(SideT &L, SideT &O) {
     lds_store_rlx(&L.kill, 1);
     lds_store_rlx(&O.kill, 1);
 }
 
 // bounded wait until *p >= need; false on abort / time-out (then everything is aborted)
-__device__ __forceinline__ bool wait_ge(int *p, int need, FusedSide &L, FusedSide &O) {
+template <class SideT>
+__device__ __forceinline__ bool wait_ge(int *p, int need, SideT &L, SideT &O) {
     int spins = 0;
     while (lds_load_rlx(p) < need) {
         if (L.stop()) return false;
@@ -106,8 +196,37 @@ __device__ __forceinline__ bool wait_ge(int *p, int need, FusedSide &L, FusedSid
     return true;
 }
 
+// bounded wait until L.finished() >= need
+template <class SideT>
+__device__ __forceinline__ bool wait_finished(int need, SideT &L, SideT &O) {
+    int spins = 0;
+    while (L.finished() < need) {
+        if (L.stop()) return false;
+        if (++spins > kSpinCap) { abort_all(L, O); return false; }
+        __builtin_amdgcn_s_sleep(2);
+    }
+    asm volatile("" ::: "memory");
+    return true;
+}
+
 __device__ __forceinline__ float buf_load_sc1(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
     return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, kSc1));
+}
+__device__ __forceinline__ void buf_store_sc1(float v, __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, voff, soff, kSc1);
+}
+// global progress word of another workgroup: bounded relaxed agent-scope poll (one lane's value, uniform)
+template <class SideT>
+__device__ __forceinline__ bool wait_global_ge(unsigned *p, unsigned need, unsigned &seen, SideT &L, SideT &O) {
+    int spins = 0;
+    while (seen < need) {
+        seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (seen >= need) break;
+        if (L.stop()) return false;
+        if (++spins > kSpinCap) { abort_all(L, O); return false; }
+        __builtin_amdgcn_s_sleep(4);
+    }
+    return true;
 }
 
 // ------------------------------------------------------------------ recursion wavefront
@@ -165,7 +284,7 @@ __device__ __forceinline__ void fused_main(const Problem &P, int b, FusedSide &L
 template <int NP, bool BETA>
 __device__ __forceinline__ void fused_consumer(const Problem &P, const State &W, const FusedArgs &F, int b, FusedSide &L,
                                                FusedSide &O, int len, int h, V4<float> (&acc)[((NP + 15) / 16) * ((NP + 15) / 16)],
-                                               double &score_out2) {
+                                               double &score_out2, const int cw) {
     typedef float R;
     constexpr int NT = (NP + 15) / 16;
     const int lane = threadIdx.x & 63;
@@ -197,9 +316,10 @@ __device__ __forceinline__ void fused_consumer(const Problem &P, const State &W,
             __builtin_amdgcn_s_sleep(1);
         }
     };
-    buf_store((BETA ? XX : lds_ldf(&L.a[0][lane])) + Num<R>::log2(sv), rs, voff, (unsigned) frame(0) * row_bytes);
     int n = 1;
-    // ---- first half: log-domain state of indices 1 .. h-1 to HBM for the other side
+    if (cw == 0) {
+    buf_store((BETA ? XX : lds_ldf(&L.a[0][lane])) + Num<R>::log2(sv), rs, voff, (unsigned) frame(0) * row_bytes);
+    // ---- first half (consumer 0 only): log-domain state of indices 1 .. h-1 to HBM for the other side
     while (n < h) {
         const int g = min(kGS, h - n);
         PRB_WAIT(0, if (!wait_slot(n + g - 2)) return;)
@@ -220,7 +340,7 @@ __device__ __forceinline__ void fused_consumer(const Problem &P, const State &W,
             hi = max(hi, sb);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        lds_store_rlx(&L.c_done, n + g - 1);
+        lds_store_rlx(&L.cd[0], n + g - 1);
         if ((__ballot(lo < Rng<R>::lo || hi > Rng<R>::hi) & actmask) != 0) { abort_all(L, O); return; }
 #pragma unroll
         for (int q = 0; q < kGS; ++q)
@@ -228,14 +348,20 @@ __device__ __forceinline__ void fused_consumer(const Problem &P, const State &W,
         sv = sg[kGS - 1];
         n += g;
     }
-    // the first half is complete in L2 before the other side is told so
+    // from here on consumer 1 counts: its "previous group" ends at h - 1
+    lds_store_rlx(&L.cd[1], h - 1 + kGS);
+    // the first half is complete in L2 before the other side (and consumer 1) is told so
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_store_rel(&L.st_done, h);
+    } else {
+        PRB_WAIT(0, if (!wait_ge(&L.st_done, h, L, O)) return;)
+    }
+    n = h + cw * kGS;                     // this wavefront's first group of the second half
     PRB_WAIT(1, if (!wait_ge(&O.st_done, len - h, L, O)) return;)
     // ---- second half: indices h .. len-1; the other side's state of the same frames is prefetched one group ahead
     R oth[kGS];
 #pragma unroll
-    for (int q = 0; q < kGS; ++q) oth[q] = buf_load_sc1(ro, vld, (unsigned) frame(min(n + q, len - 1)) * row_bytes);
+    for (int q = 0; q < kGS; ++q) oth[q] = buf_load<R>(ro, vld, (unsigned) frame(min(n + q, len - 1)) * row_bytes);
     while (n < len) {
         const int g = min(kGS, len - n);
         PRB_WAIT(2, if (!wait_slot(n + g - 2)) return;)
@@ -257,7 +383,7 @@ __device__ __forceinline__ void fused_consumer(const Problem &P, const State &W,
             hi = max(hi, sb);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        lds_store_rlx(&L.c_done, n + g - 1);
+        lds_store_rlx(&L.cd[cw], n + g - 1 + kGS);
         if ((__ballot(lo < Rng<R>::lo || hi > Rng<R>::hi) & actmask) != 0) { abort_all(L, O); return; }
         // posterior of the frame: softmax of (own state + other side's state); both are stored relative to offsets
         // that keep each frame's largest term near 1, so no max-shift -- a normaliser outside [2^-100, 2^100] aborts
@@ -267,10 +393,11 @@ __device__ __forceinline__ void fused_consumer(const Problem &P, const State &W,
             const R gam = act ? (ag[q] + Num<R>::log2(sg[q])) + oth[q] : NINF;
             w[q] = Num<R>::exp2(gam);
         }
-        // the next group's rows of the other side (its first half is complete: no further checks)
+        // the next group's rows of the other side: plain loads (its first half was complete in L2 before st_done was
+        // published, and this compute unit has not touched those lines before)
         R othn[kGS];
 #pragma unroll
-        for (int q = 0; q < kGS; ++q) othn[q] = buf_load_sc1(ro, vld, (unsigned) frame(min(n + g + q, len - 1)) * row_bytes);
+        for (int q = 0; q < kGS; ++q) othn[q] = buf_load<R>(ro, vld, (unsigned) frame(min(n + 2 * kGS + q, len - 1)) * row_bytes);
         R Z[kGS];
 #pragma unroll
         for (int q = 0; q < kGS; q += 2) {
@@ -286,8 +413,10 @@ __device__ __forceinline__ void fused_consumer(const Problem &P, const State &W,
             zhi = max(zhi, zb);
         }
         if (zlo < Rng<R>::lo || zhi > Rng<R>::hi) { abort_all(L, O); return; }
-        // ring space: the finisher has taken index n + g - 1 - kRow
-        PRB_WAIT(3, if (!wait_ge(&L.fin_done, n + g - kRow, L, O)) return;)
+        // ring space: the row finisher has taken index n + g - 1 - kRow
+#ifndef ASG_X_NOROWFIN
+        PRB_WAIT(3, if (!wait_finished(n + g - kRow, L, O)) return;)
+#endif
         R u[kGS];
 #pragma unroll
         for (int q = 0; q < kGS; ++q) {
@@ -300,7 +429,7 @@ __device__ __forceinline__ void fused_consumer(const Problem &P, const State &W,
             pg[q] = act ? pg[q] : R(0);
         }
         asm volatile("" ::: "memory");
-        lds_store_rlx(&L.row_done, n + g);
+        lds_store_rlx(&L.rd[cw], n + g);
         {
             float ua[4] = {u[0], u[1], u[2], u[3]}, va[4] = {pg[0], pg[1], pg[2], pg[3]};
             outer4_accumulate<NT>(ua, va, acc);
@@ -310,9 +439,12 @@ __device__ __forceinline__ void fused_consumer(const Problem &P, const State &W,
 #pragma unroll
         for (int q = 0; q < kGS; ++q) oth[q] = othn[q];
         sv = sg[kGS - 1];
-        n += g;
+        n += 2 * kGS;
     }
-    // ---- end of the chain: score (beta side), exactly as the three-wavefront kernel
+    // (a consumer without a last group still has to let the producer's bookkeeping see "everything taken")
+    lds_store_rlx(&L.cd[cw], len + 2 * kGS);
+    // ---- end of the chain: score (beta side), by the consumer that took the last group; as the three-wavefront kernel
+    if (((((len - h + kGS - 1) / kGS) - 1) & 1) != cw) return;
     {
         int spins = 0;
         while (!(lds_load_acq(&L.main_done) && lds_load_acq(&L.prod_done))) {
@@ -333,12 +465,45 @@ __device__ __forceinline__ void fused_consumer(const Problem &P, const State &W,
     PRB_END(W.dbg, BETA ? 3 : 2)
 }
 
+// 16 (GUARD: nsteps) steps of an aligned chain; the state of index m0 + k goes to ring slot (m0 + k - 1) & 31 -- blocks
+// start at m0 = 1 + 16 j, so the 16 slots of a block are consecutive and every ring store is base + constant -- and to HBM
+// (every index, as the stand-alone chains do: a per-step "first half only" test costs more than the bytes).
+// Branch-free inside a full block so that consecutive steps overlap.
+template <bool BETA, bool GUARD>
+__device__ __forceinline__ void aligned_steps(const float (&cur)[kPF], int nsteps, int m0, int len, double H2, double Dx,
+                                              double ebias, float *ringrow, __amdgpu_buffer_rsrc_t rs,
+                                              unsigned voff, unsigned row_bytes, double &st) {
+    typedef float R;
+    const double L2Ed = 1.4426950408889634;
+    const int f0 = BETA ? len - 1 - m0 : m0;             // frame of index m0
+    const unsigned soff0 = (unsigned) f0 * row_bytes;
+#pragma unroll
+    for (int k = 0; k < kPF; ++k) {
+        if (!GUARD || k < nsteps) {
+            if (!BETA) {
+                const double em = fma((double) cur[k], L2Ed, ebias);
+                const double stay = st + H2;
+                const double come = prev_lane_or_zero<double>(st) + Dx;
+                st = fmax(em + lse2_acc<R>(stay, come), kLZd);
+            } else {
+                const double y = fmax(fma((double) cur[k], L2Ed, ebias) + st, kLZd);
+                const double stay = y + H2;
+                const double go = next_lane_or_zero<double>(y) + Dx;
+                st = fmax(lse2_acc<R>(stay, go), kLZd);
+            }
+            const R v = to_state<R>(st);
+            ringrow[k * 64] = v;
+            buf_store(v, rs, voff, BETA ? soff0 - (unsigned) k * row_bytes : soff0 + (unsigned) k * row_bytes);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ aligned chain
 // The stand-alone aligned chains (asg_chains.h) with two changes: every state also goes into the `ar` ring for the
 // finisher of this side, and only the first half goes to HBM (for the finisher of the other side).
 template <bool BETA>
-__device__ __forceinline__ void fused_aligned(const Problem &P, const State &W, int b, FusedSide &L, FusedSide &O, int len,
-                                              int h, double &score_out2) {
+__device__ __forceinline__ void fused_aligned(const Problem &P, const State &W, int b, AliSide &L, AliSide &O, int len,
+                                              int h, double &score_out2, void *aoff) {
     typedef float R;
     const int lane = threadIdx.x & 63;
     const int T = P.T, S = P.S;
@@ -357,7 +522,7 @@ __device__ __forceinline__ void fused_aligned(const Problem &P, const State &W, 
     else st = (lane == A.ol - 1) ? 0.0 : kLZd;
     {
         const R v = to_state<R>(st);
-        lds_stf(&L.ar[0][lane], v);
+        L.ar[kAR - 1][lane] = v;                         // slot (0 - 1) & 31
         buf_store(v, rs, voff, (unsigned) frame(0) * row_bytes);
     }
     bool told = false;
@@ -377,53 +542,64 @@ __device__ __forceinline__ void fused_aligned(const Problem &P, const State &W, 
 #pragma unroll
     for (int k = 0; k < kPF; ++k) cur[k] = A.in[(int64_t) (BETA ? max(len - 1 - k, 0) : min(1 + k, len - 1)) * P.is0];
     R last_raw = cur[0];
-    for (int done = 0; done < nst; done += kPF) {
-        const int nsteps = min(kPF, nst - done);
-#pragma unroll
-        for (int k = 0; k < kPF; ++k)
-            nxt[k] = A.in[(int64_t) (BETA ? max(len - 1 - (done + kPF + k), 0) : min(1 + done + kPF + k, len - 1)) * P.is0];
+    // block prologue: ring space, renormalisation, block scale, per-block offsets; returns the emission bias of the block
+    auto block_begin = [&](int done, int nsteps, bool &ok) -> double {
         // ring space: the slots this block overwrites held indices m0-32 .. m0-17, last needed (as "previous") by m0-16
         const int m0 = 1 + done;
-        PRB_WAIT(0, if (!wait_ge(&L.fin_done, m0 - 15, L, O)) return;)
+        ok = true;
+#ifndef ASG_X_NOFIN
+        PRB_WAIT(0, ok = wait_finished(m0 - 15, L, O);)
+#endif
         {
             const R m = wave_allmax((R) st);
             if (m > R(-1e29)) { st = fmax(st - (double) m, kLZd); C += (double) m; }
         }
         const R z = aligned_block_scale<R>(cur, nsteps, A.act, A.ol);
-        C += (double) z * nsteps;
-        const double ebias = (double) A.ebias - (double) z;
-#pragma unroll
-        for (int k = 0; k < kPF; ++k) {
-            if (k < nsteps) {
-                if (!BETA) {
-                    const double em = fma((double) cur[k], L2Ed, ebias);
-                    const double stay = st + H2;
-                    const double come = prev_lane_or_zero<double>(st) + Dp;
-                    st = fmax(em + lse2_acc<R>(stay, come), kLZd);
-                } else {
-                    const double y = fmax(fma((double) cur[k], L2Ed, ebias) + st, kLZd);
-                    const double stay = y + H2;
-                    const double go = next_lane_or_zero<double>(y) + Dn;
-                    st = fmax(lse2_acc<R>(stay, go), kLZd);
-                }
-                const int m = m0 + k;
-                const R v = to_state<R>(st);
-                lds_stf(&L.ar[m & (kAR - 1)][lane], v);
-                buf_store(v, rs, (m < h) ? voff : kOobOffset, (unsigned) frame(min(m, len - 1)) * row_bytes);
+        // the state of index m0 + k is stored relative to  Cbase + z * (k + 1):  the finishers turn stored states back
+        // into absolute log-scores with these two numbers per block (ring slot here, HBM for the other side)
+        const int j = done / kPF;
+        if (lane == 0) {
+            L.cb[j & 3][0] = C;
+            L.cb[j & 3][1] = (double) z;
+            if (m0 < h) {
+                double *o = (double *) aoff + (int64_t) j * 2;
+                o[0] = C;
+                o[1] = (double) z;
             }
         }
+        C += (double) z * nsteps;
+        return (double) A.ebias - (double) z;
+    };
+    auto block_end = [&](int done, int nsteps) {
         asm volatile("" ::: "memory");
-        lds_store_rlx(&L.ar_done, m0 + nsteps);
-        tell_first_half(m0 + nsteps);
-        if (BETA && done + kPF >= nst) {
-            // the frame-0 emission sits right after the last consumed ring slot (or is nxt[0] when the block was full)
-            const int r = nst - done;
-            last_raw = (r == kPF) ? nxt[0] : cur[0];
+        lds_store_rlx(&L.ar_done, 1 + done + nsteps);
+        tell_first_half(1 + done + nsteps);
+    };
+    int done = 0;
+    // full blocks in their own loop: branch-free bodies whose consecutive steps overlap (a shared body with a runtime
+    // step count gets a branch per step)
+    for (; done + kPF <= nst; done += kPF) {
 #pragma unroll
-            for (int k = 1; k < kPF; ++k) last_raw = (k == r) ? cur[k] : last_raw;
-        }
+        for (int k = 0; k < kPF; ++k)
+            nxt[k] = A.in[(int64_t) (BETA ? max(len - 1 - (done + kPF + k), 0) : min(1 + done + kPF + k, len - 1)) * P.is0];
+        bool ok;
+        const double ebias = block_begin(done, kPF, ok);
+        if (!ok) return;
+        aligned_steps<BETA, false>(cur, kPF, 1 + done, len, H2, BETA ? Dn : Dp, ebias, &L.ar[done & (kAR - 1)][lane], rs, voff, row_bytes, st);
+        block_end(done, kPF);
 #pragma unroll
         for (int k = 0; k < kPF; ++k) cur[k] = nxt[k];
+    }
+    last_raw = cur[0];                       // beta, no remainder: the frame-0 emission is the next one in line
+    if (done < nst) {
+        const int r = nst - done;
+        bool ok;
+        const double ebias = block_begin(done, r, ok);
+        if (!ok) return;
+        aligned_steps<BETA, true>(cur, r, 1 + done, len, H2, BETA ? Dn : Dp, ebias, &L.ar[done & (kAR - 1)][lane], rs, voff, row_bytes, st);
+        block_end(done, r);
+#pragma unroll
+        for (int k = 1; k < kPF; ++k) last_raw = (k == r) ? cur[k] : last_raw;
     }
     tell_first_half(len);
     if (BETA) {
@@ -435,105 +611,242 @@ __device__ __forceinline__ void fused_aligned(const Problem &P, const State &W, 
     PRB_END(W.dbg, BETA ? 5 : 4)
 }
 
-// ------------------------------------------------------------------ finisher
+// ------------------------------------------------------------------ finisher of the aligned workgroup
+// Aligned posterior of every second-half frame of this side -> P2[b][frame][s] (write-through, behind a progress word)
+// and the stay / arrive edge posteriors accumulated per target position.
+//
+// No per-frame normalisation: sum_s alpha_t(s) beta_t(s) is the SAME number for every frame -- the aligned score -- so it
+// is measured once (first frame of this side's half, one max + one sum reduction) and every later posterior is
+//   exp2(alpha_hat + beta_hat + (offset_alpha(t) + offset_beta(t) - score))
+// with the per-frame offsets the two chains publish per block (the stored states are relative to them).  The reference
+// normalises each frame with a softmax (force_aligned_lattice.cpp:164-166); the two agree to fp32 rounding of the states.
 template <bool BETA>
-__device__ __forceinline__ void fused_finisher(const Problem &P, const State &W, const FusedArgs &F, int b, FusedSide &L,
-                                               FusedSide &O, int len, int h, float &accH, float &accD) {
+__device__ __forceinline__ void fused_afin(const Problem &P, const State &W, const FusedArgs &F, int b, AliSide &L,
+                                           AliSide &O, int len, int h, UttSync *us, const int fw) {
     typedef float R;
     const int lane = threadIdx.x & 63;
-    const int N = P.N, T = P.T, S = P.S;
+    const int T = P.T, S = P.S;
     const R LZ = Num<R>::logzero();
     const AlignedSetup<R> A = aligned_setup<R>(P, b, lane);
     const bool sl = lane < S;
     const R H2 = A.H2, Dprev = A.Dprev;
-    const int tgt = A.tgt;
     const unsigned rbS = (unsigned) S * sizeof(R);
     __amdgpu_buffer_rsrc_t ro = make_rsrc((R *) (BETA ? W.ab : W.bb) + (int64_t) b * T * S, (unsigned) T * rbS);
+    // P2 of this side: [quad = (index - h) / 4][position s][4 consecutive indices] -- one 16-byte write-through store per
+    // lane per four frames (4-byte write-through stores cost a fabric write per lane)
+    __amdgpu_buffer_rsrc_t rp = make_rsrc((R *) F.p2 + ((int64_t) b * 2 + (BETA ? 1 : 0)) * (T + 8) * S, (unsigned) (T + 8) * rbS);
     const unsigned vS = (unsigned) (sl ? lane : 0) * (unsigned) sizeof(R);
+    const unsigned vQ = sl ? (unsigned) lane * 16u : kOobOffset;
+    unsigned *prog = &us->prog[BETA ? 1 : 0][fw];
+    const int nblk = (T + kPF - 1) / kPF + 1;
+    const double *ao = (const double *) F.aoff + ((int64_t) b * 2 + (BETA ? 0 : 1)) * nblk * 2;    // the OTHER side's
+    auto frame = [&](int m) { return BETA ? len - 1 - m : m; };
+    // offsets of stored states, branch-free (uniform addresses: broadcast LDS reads, all issued before one wait)
+    auto off_own = [&](int m) -> double {            // this side's index m >= 2 (ring slots of the last 4 blocks)
+        const int j = (m - 1) >> 4, k = (m - 1) & 15;
+        const V2<double> c = *reinterpret_cast<const V2<double> *>(&L.cb[j & 3][0]);
+        return c.x + c.y * (double) (k + 1);
+    };
+    auto off_oth = [&](int mo) -> double {           // the other side's index mo >= 0 (its first half)
+        const int j = (mo - 1) >> 4, k = (mo - 1) & 15;         // mo = 0: entry 0 = {0, 0}
+        const V2<double> c = *reinterpret_cast<const V2<double> *>(&L.ob[j + 1][0]);
+        return c.x + c.y * (double) (k + 1);
+    };
+    R accH = 0, accS = 0;          // sum of stay-edge posteriors; sum of state posteriors of frames >= 1 (arrive = accS - accH)
+    PRB_DECL
+    PRB_WAIT(0, if (!wait_ge(&O.ast_done, len - h, L, O)) return;)      // the other side's aligned first half is visible
+    // its block offsets, once, into LDS (launch_fused_forward admits at most kMaxBlk - 1 blocks per half)
+    {
+        const int oblk = (len - h + kPF - 1) / kPF;
+        for (int j = lane; j < kMaxBlk - 1; j += 64) {
+            const int jc = min(j, max(oblk - 1, 0));
+            const double c0 = __hip_atomic_load(ao + 2 * jc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const double c1 = __hip_atomic_load(ao + 2 * jc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            L.ob[j + 1][0] = c0;
+            L.ob[j + 1][1] = c1;
+        }
+        if (lane == 0) { L.ob[0][0] = 0.0; L.ob[0][1] = 0.0; }
+        __builtin_amdgcn_wave_barrier();
+    }
+    int n = h + fw * kGS;                 // this wavefront's groups: fw, fw + kAF, ...
+    R oth[kGS];
+#pragma unroll
+    for (int q = 0; q < kGS; ++q) oth[q] = buf_load<R>(ro, vS, (unsigned) max(frame(min(n + q, len - 1)), 0) * rbS);
+    double Sd = 0.0;               // the aligned score (log2 units) as measured on this side's first frame
+    bool feasible = false, calibrated = false;
+    while (n < len) {
+        const int g = min(kGS, len - n);
+        PRB_WAIT(1, if (!wait_ge(&L.ar_done, n + g, L, O)) return;)
+        R own[kGS], ownp[kGS];
+        double K[kGS];
+#pragma unroll
+        for (int q = 0; q < kGS; ++q) {
+            const int m = n + min(q, g - 1);
+            own[q] = L.ar[(m - 1) & (kAR - 1)][lane];
+            ownp[q] = L.ar[(m - 2) & (kAR - 1)][lane];        // alpha side: alpha-bar of the previous frame (m >= h >= 2)
+            K[q] = off_own(m) + off_oth(len - 1 - m);
+        }
+        // the other side's state rows of the next group: plain (L1-cacheable) loads -- they were complete in L2 before
+        // that side's ast_done, and this compute unit has not touched those lines before
+        R othn[kGS];
+#pragma unroll
+        for (int q = 0; q < kGS; ++q) othn[q] = buf_load<R>(ro, vS, (unsigned) max(frame(min(n + kAF * kGS + q, len - 1)), 0) * rbS);
+        // beta side: alpha-bar of the frame below the group's last frame (the next consecutive index, another wavefront's group)
+        const R obelow = buf_load<R>(ro, vS, (unsigned) max(frame(min(n + g, len - 1)), 0) * rbS);
+        PRB_WAIT(3, asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");)
+        lds_store_rlx(&L.fd[fw], n + g + (kAF - 1) * kGS);
+        if (!calibrated) {
+            const R g0 = sl ? own[0] + oth[0] : LZ;
+            const R mg = wave_allmax(g0);
+            const R w0 = (mg > R(-1e29)) ? Num<R>::exp2(g0 - mg) : R(0);
+            const R z0 = wave_allsum(w0);
+            feasible = mg > R(-1e29) && z0 > R(0);                    // infeasible alignment -> no posterior anywhere
+            Sd = feasible ? (double) mg + (double) Num<R>::log2(z0) + K[0] : 0.0;
+            calibrated = true;
+        }
+        R p2v[kGS];
+#pragma unroll
+        for (int q = 0; q < kGS; ++q) {
+            const R arg = (R) ((double) (own[q] + oth[q]) + (K[q] - Sd));
+            p2v[q] = (feasible && sl) ? Num<R>::exp2(arg) : R(0);
+        }
+        {
+            typedef unsigned u4 __attribute__((ext_vector_type(4)));
+            const unsigned qoff = (unsigned) ((n - h) >> 2) * (unsigned) S * 16u;
+            u4 a = {__float_as_uint(p2v[0]), __float_as_uint(p2v[1]), __float_as_uint(p2v[2]), __float_as_uint(p2v[3])};
+            u4 c = {__float_as_uint(p2v[4]), __float_as_uint(p2v[5]), __float_as_uint(p2v[6]), __float_as_uint(p2v[7])};
+            __builtin_amdgcn_raw_buffer_store_b128(a, rp, vQ, qoff, kSc1);
+            if (g > 4) __builtin_amdgcn_raw_buffer_store_b128(c, rp, vQ, qoff + (unsigned) S * 16u, kSc1);
+        }
+#pragma unroll
+        for (int q = 0; q < kGS; ++q) {
+            if (q < g) {
+                const int f = frame(n + q);
+                const R post2 = p2v[q];
+                if (f >= 1) {
+                    // posterior of the STAY edge into (f, s) = post2 / (1 + 2^(arrive - stay)); needs alpha-bar of frame f-1
+                    const R abprev = BETA ? ((q + 1 < g) ? oth[(q + 1) & (kGS - 1)] : obelow) : ownp[q];
+                    const R ap = sl ? abprev : LZ;
+                    const R d = (prev_lane_or_zero<R>(ap) + Dprev) - (ap + H2);
+                    accH += post2 * Num<R>::rcp(R(1) + Num<R>::exp2(d));
+                    accS += post2;
+                }
+            }
+        }
+        // one VMEM queue, in order, 11 operations per group (9 loads, 2 stores): once at most 11 are in flight, every
+        // store of this wavefront's PREVIOUS group (kAF groups ago: long acknowledged) has been written through -- publish
+        // that group
+        PRB_WAIT(2, __builtin_amdgcn_s_waitcnt(0x0F7B);)       // vmcnt(11)
+        if (lane == 0 && n - kAF * kGS >= h)
+            __hip_atomic_store(prog, (unsigned) (n - kAF * kGS + kGS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int q = 0; q < kGS; ++q) oth[q] = othn[q];
+        n += kAF * kGS;
+    }
+    lds_store_rlx(&L.fd[fw], len + kAF * kGS);
+    // edge posteriors of this side: [stay | arrive] per target position
+    {
+        R *ed = (R *) F.edges + (((int64_t) b * 2 + (BETA ? 1 : 0)) * kAF + fw) * 128;
+        __amdgpu_buffer_rsrc_t re = make_rsrc(ed, 128u * (unsigned) sizeof(R));
+        buf_store_sc1(accH, re, (unsigned) lane * 4u, 0u);
+        buf_store_sc1(accS - accH, re, (unsigned) lane * 4u, 256u);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_store(prog, (unsigned) (len + kAF * kGS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (fw == 0) { PRB_END(W.dbg, BETA ? 7 : 6) }
+}
+
+// ------------------------------------------------------------------ row finisher of the full workgroup
+// final row of every second-half frame of this side: gscale * (full posterior - aligned posterior scattered to labels)
+template <bool BETA>
+__device__ __forceinline__ void fused_rowfin(const Problem &P, const State &W, const FusedArgs &F, int b, FusedSide &L,
+                                             FusedSide &O, int len, int h, UttSync *us, const int rw) {
+    typedef float R;
+    const int lane = threadIdx.x & 63;
+    const int N = P.N, T = P.T, S = P.S;
+    const unsigned rbS = (unsigned) S * sizeof(R);
+    // label of target position `lane` (clamped like aligned_setup); positions >= target length carry posterior 0
+    int tgt = 0;
+    {
+        const int ol = P.tg_len ? clampi(P.tg_len[b], 0, S) : S;
+        const int sc = lane < ol ? lane : 0;
+        tgt = clampi(P.targets[(int64_t) b * P.gs0 + (int64_t) sc * P.gs1], 0, N - 1);
+    }
+    __amdgpu_buffer_rsrc_t rp = make_rsrc((R *) F.p2 + ((int64_t) b * 2 + (BETA ? 1 : 0)) * (T + 8) * S, (unsigned) (T + 8) * rbS);
+    const unsigned vQ = lane < S ? (unsigned) lane * 16u : kOobOffset;                        // out of range reads 0
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    auto load_group = [&](int nn, R (&dst)[kGS]) {           // aligned posteriors of indices nn .. nn+7 of this side (see fused_afin)
+        const unsigned qoff = (unsigned) ((nn - h) >> 2) * (unsigned) S * 16u;
+        const u4 a = __builtin_amdgcn_raw_buffer_load_b128(rp, vQ, qoff, kSc1);
+        const u4 c = __builtin_amdgcn_raw_buffer_load_b128(rp, vQ, qoff + (unsigned) S * 16u, kSc1);
+        dst[0] = __uint_as_float(a.x); dst[1] = __uint_as_float(a.y); dst[2] = __uint_as_float(a.z); dst[3] = __uint_as_float(a.w);
+        dst[4] = __uint_as_float(c.x); dst[5] = __uint_as_float(c.y); dst[6] = __uint_as_float(c.z); dst[7] = __uint_as_float(c.w);
+    };
     __amdgpu_buffer_rsrc_t rs_g = make_rsrc((R *) F.grad_inputs + (int64_t) b * N,
                                             (unsigned) ((int64_t) (T - 1) * P.B * N + N) * (unsigned) sizeof(R));
     const unsigned voff = lane < N ? (unsigned) lane * sizeof(R) : kOobOffset;
     const unsigned grow_bytes = (unsigned) P.B * N * sizeof(R);
     const R gscale = F.gscale;
+    unsigned *progs = &us->prog[BETA ? 1 : 0][0];
+    unsigned seen[kAF] = {0, 0, 0};
     auto frame = [&](int m) { return BETA ? len - 1 - m : m; };
-    accH = 0;
-    accD = 0;
+    // aligned posteriors of the group starting at nn are published by aligned finisher ((nn - h) / 8) % kAF
+    auto wait_p2 = [&](int nn) -> bool {
+        const int gi = (nn - h) / kGS;
+        const unsigned need = (unsigned) min(nn + kGS, len);
+        const int w = gi % kAF;
+        bool ok = true;
+        if (w == 0) ok = wait_global_ge(progs + 0, need, seen[0], L, O);
+        else if (w == 1) ok = wait_global_ge(progs + 1, need, seen[1], L, O);
+        else ok = wait_global_ge(progs + 2, need, seen[2], L, O);
+        return ok;
+    };
     PRB_DECL
+    unsigned (*fx)[64] = L.fx[rw];
 #pragma unroll
-    for (int q = 0; q < kGS; ++q) L.fx[q][lane] = 0;
-    PRB_WAIT(0, if (!wait_ge(&O.ast_done, len - h, L, O)) return;)      // the other side's aligned first half is visible
-    int n = h;
-    // other side's aligned state of the group's frames; the beta side (frames descending) also needs ab of the frame
-    // below each frame for the edge posteriors: that is the next frame of the group / the first of the next group
-    R oth[kGS];
-#pragma unroll
-    for (int q = 0; q < kGS; ++q) oth[q] = buf_load_sc1(ro, vS, (unsigned) max(frame(min(n + q, len - 1)), 0) * rbS);
+    for (int q = 0; q < kGS; ++q) fx[q][lane] = 0;
+    int n = h + rw * kGS;                 // this wavefront's groups: rw, rw + kRF, ...
+    // the aligned posteriors of a group are fetched one (own) group ahead, behind the aligned workgroup's progress words
+    R p2n[kGS];
+    if (n < len) {
+        PRB_WAIT(0, if (!wait_p2(n)) return;)
+        load_group(n, p2n);
+    }
     while (n < len) {
         const int g = min(kGS, len - n);
-        PRB_WAIT(1, if (!wait_ge(&L.row_done, n + g, L, O)) return;)
-        PRB_WAIT(2, if (!wait_ge(&L.ar_done, n + g, L, O)) return;)
-        R rowv[kGS], own[kGS], ownp[kGS];
+        R p2[kGS];
 #pragma unroll
-        for (int q = 0; q < kGS; ++q) {
-            const int m = n + min(q, g - 1);
-            rowv[q] = lds_ldf(&L.row[m & (kRow - 1)][lane]);
-            own[q] = lds_ldf(&L.ar[m & (kAR - 1)][lane]);
-            ownp[q] = lds_ldf(&L.ar[(m - 1) & (kAR - 1)][lane]);     // alpha side: ab of the previous frame (m >= h >= 1)
+        for (int q = 0; q < kGS; ++q) p2[q] = p2n[q];
+        if (n + kRF * kGS < len) {
+            PRB_WAIT(1, if (!wait_p2(n + kRF * kGS)) return;)
+            load_group(n + kRF * kGS, p2n);
         }
-        R othn[kGS];
+        PRB_WAIT(2, if (!wait_ge(&L.rd[((n - h) / kGS) & 1], n + g, L, O)) return;)
+        R rowv[kGS];
 #pragma unroll
-        for (int q = 0; q < kGS; ++q) othn[q] = buf_load_sc1(ro, vS, (unsigned) max(frame(min(n + g + q, len - 1)), 0) * rbS);
+        for (int q = 0; q < kGS; ++q) rowv[q] = L.row[(n + min(q, g - 1)) & (kRow - 1)][lane];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        lds_store_rlx(&L.fin_done, n + g);
-        // aligned posteriors of the group's frames, two frames per reduction pass
-        R post2[kGS];
-#pragma unroll
-        for (int q = 0; q < kGS; q += 2) {
-            R g0 = sl ? own[q] + oth[q] : LZ, g1 = sl ? own[q + 1] + oth[q + 1] : LZ;
-            R m0 = g0, m1 = g1;
-            wave_allmax2(m0, m1);
-            R w0 = (m0 > R(-1e29)) ? Num<R>::exp2(g0 - m0) : R(0);       // infeasible alignment -> no posterior
-            R w1 = (m1 > R(-1e29)) ? Num<R>::exp2(g1 - m1) : R(0);
-            R z0 = w0, z1 = w1;
-            wave_allsum2(z0, z1);
-            post2[q] = (z0 > 0) ? w0 * Num<R>::rcp(z0) : R(0);
-            post2[q + 1] = (z1 > 0) ? w1 * Num<R>::rcp(z1) : R(0);
-        }
+        lds_store_rlx(&L.fd[rw], n + g + (kRF - 1) * kGS);
         // scatter to labels: integer LDS adds commute -> repeated labels give bit-identical sums run to run.  The eight
         // frames of the group go through eight separate arrays, so the adds, reads and resets of the whole group
         // are three back-to-back bursts (one wavefront's LDS operations execute in order)
 #pragma unroll
-        for (int q = 0; q < kGS; ++q) atomicAdd(&L.fx[q][tgt], FrameFix<R>::to(q < g ? post2[q] : R(0)));
+        for (int q = 0; q < kGS; ++q) atomicAdd(&fx[q][tgt], FrameFix<R>::to(q < g ? p2[q] : R(0)));
         __builtin_amdgcn_wave_barrier();
         unsigned fv[kGS];
 #pragma unroll
-        for (int q = 0; q < kGS; ++q) fv[q] = L.fx[q][lane];
+        for (int q = 0; q < kGS; ++q) fv[q] = fx[q][lane];
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int q = 0; q < kGS; ++q) L.fx[q][lane] = 0;
+        for (int q = 0; q < kGS; ++q) fx[q][lane] = 0;
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int q = 0; q < kGS; ++q) {
-            if (q < g) {
-                const int f = frame(n + q);
-                buf_store(rowv[q] - gscale * FrameFix<R>::from(fv[q]), rs_g, voff, (unsigned) f * grow_bytes);
-                if (f >= 1) {
-                    // stay / arrive posteriors of the edge into (f, s): needs alpha-bar of frame f-1
-                    const R abprev = BETA ? ((q + 1 < kGS) ? ((q + 1 < g) ? oth[(q + 1) & (kGS - 1)] : othn[0]) : othn[0]) : ownp[q];
-                    const R ap = sl ? abprev : LZ;
-                    const R pc0 = ap + H2;
-                    const R pc1 = prev_lane_or_zero<R>(ap) + Dprev;
-                    const R l = lse2<R>(pc0, pc1);
-                    accH += post2[q] * Num<R>::exp2(pc0 - l);
-                    accD += post2[q] * Num<R>::exp2(pc1 - l);
-                }
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < kGS; ++q) oth[q] = othn[q];
-        n += g;
+        for (int q = 0; q < kGS; ++q)
+            if (q < g) buf_store(rowv[q] - gscale * FrameFix<R>::from(fv[q]), rs_g, voff, (unsigned) frame(n + q) * grow_bytes);
+        n += kRF * kGS;
     }
-    PRB_END(W.dbg, BETA ? 7 : 6)
+    lds_store_rlx(&L.fd[rw], len + kRF * kGS);
+    if (rw == 0) { PRB_END(W.dbg, BETA ? 9 : 8) }
 }
 
 // exact full-lattice score of one utterance by ONE wavefront (log-domain beta recursion, max-shifted log-sum-exps)
@@ -560,31 +873,102 @@ __device__ __forceinline__ double slow_full_score(const Problem &P, int b, int l
 
 // ------------------------------------------------------------------ the fused forward kernel
 template <int NP>
-__global__ void __launch_bounds__(kFusedThreads, 3) fused_fwd_kernel(Problem P, State W, FusedArgs F) {
+__device__ __forceinline__ void aligned_workgroup(int b, FusedShared<NP> &SH) {
     typedef float R;
-    constexpr int NT = (NP + 15) / 16;
-    __shared__ FusedShared<NP> SH;
-    FusedSide &LA = SH.u.g.A, &LB = SH.u.g.B;
-    const int b = blockIdx.x;
+    const Problem P = ld_problem(kernarg_params());
+    const FusedArgs F = ld_fargs(kernarg_params());
+    AliSide &LA = SH.u.h.A, &LB = SH.u.h.B;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int N = P.N, T = P.T, S = P.S;
+    const int N = P.N, T = P.T;
     const int len = __builtin_amdgcn_readfirstlane(P.in_len ? clampi(P.in_len[b], 0, T) : T);
     const int mid = len / 2;
     const bool fused = len >= kMinFused;
+    UttSync *us = reinterpret_cast<UttSync *>(F.sync + 64) + b;
+    if (threadIdx.x == 0) {
+        LA.kill = 0; LA.ast_done = 0; LA.ar_done = 0;
+        LB.kill = 0; LB.ast_done = 0; LB.ar_done = 0;
+        for (int k = 0; k < kAF; ++k) { LA.fd[k] = mid + k * kGS; LB.fd[k] = len - mid + k * kGS; }
+        SH.score_ali = -1e300;
+    }
+    __syncthreads();
+    double sc2 = -1e300;
+    if (fused) {
+        const Problem P = ld_problem(kernarg_params());        // per role: see FusedParams
+        const State W = ld_state(kernarg_params());
+        const FusedArgs F = ld_fargs(kernarg_params());
+        switch (wave) {
+            case 0: fused_aligned<false>(P, W, b, LA, LB, len, mid, sc2, (double *) F.aoff + ((int64_t) b * 2 + 0) * ((T + kPF - 1) / kPF + 1) * 2); break;
+            case 1: fused_aligned<true>(P, W, b, LB, LA, len, len - mid, sc2, (double *) F.aoff + ((int64_t) b * 2 + 1) * ((T + kPF - 1) / kPF + 1) * 2); break;
+#ifndef ASG_X_NOFIN
+            case 2: case 6: case 10: fused_afin<false>(P, W, F, b, LA, LB, len, mid, us, (wave - 2) >> 2); break;
+            case 3: case 7: case 11: fused_afin<true>(P, W, F, b, LB, LA, len, len - mid, us, (wave - 3) >> 2); break;
+#endif
+            default: break;
+        }
+        if (wave == 1 && lane == 0) SH.score_ali = sc2;
+    }
+    if (wave == 4 && b == 0) {
+        // normalised transition rows for the exact stand-alone code (asg_assemble.h reads them)
+        const State W = ld_state(kernarg_params());
+        const bool act = lane < N;
+        const int lc = act ? lane : 0;
+        V2<R> e2[NP / 2];
+        R Ri;
+        load_norm_row<R, NP>((const R *) P.transition + (int64_t) lc * P.ts0, P.ts1, N, act, e2, Ri);
+        if (act) {
+            V2<R> *erow = reinterpret_cast<V2<R> *>((R *) W.ehat + (int64_t) lane * W.npad);
+#pragma unroll
+            for (int j = 0; j < NP / 2; ++j) erow[j] = e2[j];
+            ((R *) W.rmax)[lane] = Ri;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const bool gave_up = !fused || LA.stop() || LB.stop();
+        ((double *) F.ascore)[b] = SH.score_ali;          // read back by the full workgroup with an agent-scope load
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&us->adone, gave_up ? 2u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <int NP>
+__device__ __forceinline__ void full_epilogue(int b, FusedShared<NP> &SH, bool fused,
+                                              V4<float> (&acc)[((NP + 15) / 16) * ((NP + 15) / 16)]);
+
+template <int NP>
+__device__ __forceinline__ void full_workgroup(int b, FusedShared<NP> &SH) {
+    typedef float R;
+    constexpr int NT = (NP + 15) / 16;
+    const Problem P = ld_problem(kernarg_params());
+    const State W = ld_state(kernarg_params());
+    const FusedArgs F = ld_fargs(kernarg_params());
+    FusedSide &LA = SH.u.g.A, &LB = SH.u.g.B;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int N = P.N, T = P.T;
+    const int len = __builtin_amdgcn_readfirstlane(P.in_len ? clampi(P.in_len[b], 0, T) : T);
+    const int mid = len / 2;
+    const bool fused = len >= kMinFused;
+    UttSync *us = reinterpret_cast<UttSync *>(F.sync + 64) + b;
 
     if (threadIdx.x == 0) {
         FusedSide *sd[2] = {&LA, &LB};
         for (int k = 0; k < 2; ++k) {
             FusedSide &L = *sd[k];
             const int h = k == 0 ? mid : len - mid;
-            L.e_prod = 0; L.csum = 0; L.main_done = 0; L.c_done = 0; L.prod_done = 0; L.kill = 0;
-            L.st_done = 0; L.row_done = h; L.ast_done = 0; L.ar_done = 0; L.fin_done = h;
+            L.e_prod = 0; L.csum = 0; L.main_done = 0; L.prod_done = 0; L.kill = 0;
+            L.cd[0] = 0; L.cd[1] = 1 << 30; L.rd[0] = h; L.rd[1] = h;
+            L.st_done = 0; L.fd[0] = h; L.fd[1] = h + kGS;
         }
         SH.score_full = -1e300;
-        SH.score_ali = -1e300;
-        SH.flagged = fused ? 0 : 1;
+        SH.adone = 0;
     }
+#ifdef ASG_PROBE
+    const long long ep_t0 = clock64();
+    if (b == 0 && threadIdx.x == 0) ((long long *) W.dbg)[50] = ep_t0;
+#endif
     if (b == 0 && threadIdx.x < 64) F.ticket2[threadIdx.x] = 0;        // for the backward launch
     for (int q = threadIdx.x; q < kRing * 64; q += kFusedThreads) {
         (&LA.s[0][0])[q] = __uint_as_float(kSentinel);
@@ -595,54 +979,80 @@ __global__ void __launch_bounds__(kFusedThreads, 3) fused_fwd_kernel(Problem P, 
     V4<float> acc[NT * NT];
 #pragma unroll
     for (int q = 0; q < NT * NT; ++q) acc[q] = V4<float>{0, 0, 0, 0};
-    float accH = 0, accD = 0;
     double sc2 = -1e300;
+#ifdef ASG_PROBE
+    if (b == 0 && threadIdx.x == 0) ((long long *) W.dbg)[51] = clock64();
+#endif
 
     // ---- phase 1: the roles.  Control flow is uniform per wavefront; nothing in here uses a workgroup barrier.
     if (wave == 8) {
         // padded frames get exactly-zero gradients (the reference: roll_to_end + masked softmax, utils.cpp:11-66)
+        const Problem P = ld_problem(kernarg_params());
+        const FusedArgs F = ld_fargs(kernarg_params());
         __amdgpu_buffer_rsrc_t rs_g = make_rsrc((R *) F.grad_inputs + (int64_t) b * N,
                                                 (unsigned) ((int64_t) (T - 1) * P.B * N + N) * (unsigned) sizeof(R));
         const unsigned voff = lane < N ? (unsigned) lane * sizeof(R) : kOobOffset;
         const unsigned grow_bytes = (unsigned) P.B * N * sizeof(R);
         for (int t = len; t < T; ++t) buf_store(R(0), rs_g, voff, (unsigned) t * grow_bytes);
-    } else if (wave == 9) {
-        if (b == 0) {
-            // normalised transition rows for the exact stand-alone code (asg_assemble.h reads them)
-            const bool act = lane < N;
-            const int lc = act ? lane : 0;
-            V2<R> e2[NP / 2];
-            R Ri;
-            load_norm_row<R, NP>((const R *) P.transition + (int64_t) lc * P.ts0, P.ts1, N, act, e2, Ri);
-            if (act) {
-                V2<R> *erow = reinterpret_cast<V2<R> *>((R *) W.ehat + (int64_t) lane * W.npad);
-#pragma unroll
-                for (int j = 0; j < NP / 2; ++j) erow[j] = e2[j];
-                ((R *) W.rmax)[lane] = Ri;
-            }
-        }
-    } else if (fused) {
+    }
+    if (fused) {
+        const Problem P = ld_problem(kernarg_params());        // per role: see FusedParams
+        const State W = ld_state(kernarg_params());
+        const FusedArgs F = ld_fargs(kernarg_params());
         switch (wave) {
             case 0: fused_main<NP, false>(P, b, LA, LB, len, W.dbg); break;
             case 1: fused_main<NP, true>(P, b, LB, LA, len, W.dbg); break;
-            case 6: duo_producer<NP, false>(P, b, LA); break;
-            case 7: duo_producer<NP, true>(P, b, LB); break;
-            case 2: fused_consumer<NP, false>(P, W, F, b, LA, LB, len, mid, acc, sc2); break;
-            case 3: fused_consumer<NP, true>(P, W, F, b, LB, LA, len, len - mid, acc, sc2); break;
-            case 4: fused_aligned<false>(P, W, b, LA, LB, len, mid, sc2); break;
-            case 5: fused_aligned<true>(P, W, b, LB, LA, len, len - mid, sc2); break;
-            case 10: fused_finisher<false>(P, W, F, b, LA, LB, len, mid, accH, accD); break;
-            case 11: fused_finisher<true>(P, W, F, b, LB, LA, len, len - mid, accH, accD); break;
+            case 4: duo_producer<NP, false>(P, b, LA); break;
+            case 5: duo_producer<NP, true>(P, b, LB); break;
+            case 2: case 6: fused_consumer<NP, false>(P, W, F, b, LA, LB, len, mid, acc, sc2, wave == 6 ? 1 : 0); break;
+            case 3: case 7: fused_consumer<NP, true>(P, W, F, b, LB, LA, len, len - mid, acc, sc2, wave == 7 ? 1 : 0); break;
+#ifndef ASG_X_NOROWFIN
+            case 8: case 10: fused_rowfin<false>(P, W, F, b, LA, LB, len, mid, us, (wave - 8) >> 1); break;
+            case 9: case 11: fused_rowfin<true>(P, W, F, b, LB, LA, len, len - mid, us, (wave - 9) >> 1); break;
+#endif
             default: break;
         }
-        if (wave == 3 && lane == 0) SH.score_full = sc2;
-        if (wave == 5 && lane == 0) SH.score_ali = sc2;
-        if (wave == 6) SH.xa[lane] = LA.x[lane];      // the producers wrote them first thing
-        if (wave == 7) SH.xb[lane] = LB.x[lane];
+        if ((wave == 3 || wave == 7) && lane == 0 && sc2 > -1e299) SH.score_full = sc2;
+        if (wave == 4) SH.xa[lane] = LA.x[lane];      // the producers wrote them first thing
+        if (wave == 5) SH.xb[lane] = LB.x[lane];
     }
     __syncthreads();
-    const bool flagged = !fused || LA.stop() || LB.stop();
+    return full_epilogue<NP>(b, SH, fused, acc);
+}
+
+template <int NP>
+__device__ __forceinline__ void full_epilogue(int b, FusedShared<NP> &SH, bool fused,
+                                              V4<float> (&acc)[((NP + 15) / 16) * ((NP + 15) / 16)]) {
+    typedef float R;
+    constexpr int NT = (NP + 15) / 16;
+    const Problem P = ld_problem(kernarg_params());
+    const State W = ld_state(kernarg_params());
+    const FusedArgs F = ld_fargs(kernarg_params());
+    FusedSide &LA = SH.u.g.A, &LB = SH.u.g.B;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int N = P.N, T = P.T;
+    const int len = __builtin_amdgcn_readfirstlane(P.in_len ? clampi(P.in_len[b], 0, T) : T);
+    UttSync *us = reinterpret_cast<UttSync *>(F.sync + 64) + b;
+#ifdef ASG_PROBE
+    if (b == 0 && threadIdx.x == 0) ((long long *) W.dbg)[52] = clock64();
+#endif
+    const bool own_trouble = !fused || LA.stop() || LB.stop();
+    // the aligned workgroup's verdict, edge posteriors and score (it finishes about when this one does)
+    if (threadIdx.x == 0) {
+        unsigned v = 0;
+        int spins = 0;
+        while ((v = __hip_atomic_load(&us->adone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
+            if (++spins > (1 << 24)) { v = 3; break; }       // cannot happen: that workgroup waits for nobody
+            __builtin_amdgcn_s_sleep(4);
+        }
+        SH.adone = (int) v;
+    }
     __syncthreads();
+#ifdef ASG_PROBE
+    if (b == 0 && threadIdx.x == 0) ((long long *) W.dbg)[53] = clock64();
+#endif
+    const bool flagged = own_trouble || SH.adone != 1;
     if (flagged) {
         // exact scores here (so that the loss of this launch is right), exact gradients in the backward launch
         if (wave == 0) {
@@ -658,13 +1068,12 @@ __global__ void __launch_bounds__(kFusedThreads, 3) fused_fwd_kernel(Problem P, 
     } else {
         // ---- phase 2: this utterance's [N][N] tile.  The rings are dead: their memory becomes the tile.
         TileLds<NP> &TL = SH.u.t;
-        for (int k = threadIdx.x; k < 64 * (NP + 1); k += kFusedThreads) (&TL.tileF[0][0])[k] = 0;
+        for (int k = threadIdx.x; k < 64 * (NP + 1); k += kFusedThreads) { (&TL.sa[0][0])[k] = 0; (&TL.sb[0][0])[k] = 0; }
         for (int k = threadIdx.x; k < NP * NP; k += kFusedThreads) TL.fxT[k] = 0;
         __syncthreads();
-        const R L2E = Num<R>::log2e();
-        const R *tr = (const R *) P.transition;
-        if (wave == 2) {
-            // alpha side: acc[i][j] * E[i][j],  E = exp2(Tr2[i][j] - rowmax_i)
+        // the two consumer wavefronts of a side add their MFMA accumulators in a fixed order (0 then 1); element
+        // (16 r + 4 (lane >> 4) + q, 16 c + (lane & 15)) of tile (r, c) -- rows of the beta-side tile are SOURCE labels
+        auto add_acc = [&](float (*dst)[NP + 1]) {
 #pragma unroll
             for (int r = 0; r < NT; ++r)
 #pragma unroll
@@ -672,54 +1081,62 @@ __global__ void __launch_bounds__(kFusedThreads, 3) fused_fwd_kernel(Problem P, 
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int i = 16 * r + 4 * (lane >> 4) + q, j = 16 * c + (lane & 15);
-                        if (i < N && j < N) {
-                            const R e = Num<R>::exp2(tr[(int64_t) i * P.ts0 + (int64_t) j * P.ts1] * L2E - SH.xa[i]);
-                            TL.tileF[i][j] = acc[r * NT + c][q] * e;
-                        }
+                        if (j <= NP) dst[i][j] += acc[r * NT + c][q];
                     }
-        }
+        };
+        if (wave == 2) add_acc(TL.sa);
+        if (wave == 3) add_acc(TL.sb);
         __syncthreads();
-        if (wave == 3) {
-            // beta side: acc'[j][i] * F[j][i],  F = exp2(Tr2[i][j] - colmax_j)   (rows of acc' are SOURCE labels j)
-#pragma unroll
-            for (int r = 0; r < NT; ++r)
-#pragma unroll
-                for (int c = 0; c < NT; ++c)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int j = 16 * r + 4 * (lane >> 4) + q, i = 16 * c + (lane & 15);
-                        if (i < N && j < N) {
-                            const R f = Num<R>::exp2(tr[(int64_t) i * P.ts0 + (int64_t) j * P.ts1] * L2E - SH.xb[j]);
-                            TL.tileF[i][j] += acc[r * NT + c][q] * f;
-                        }
-                    }
-        }
-        if (wave == 10 || wave == 11) {
+        if (wave == 6) add_acc(TL.sa);
+        if (wave == 7) add_acc(TL.sb);
+        if (wave == 8 || wave == 9) {
+            // aligned edge posteriors of the alpha-side (wave 8) / beta-side (wave 9) frames, scattered to [to][from]
             const AlignedSetup<R> A = aligned_setup<R>(P, b, lane);
+            const R *ed = (const R *) F.edges + ((int64_t) b * 2 + (wave - 8)) * kAF * 128;
+            R stay = 0, arrive = 0;
+            for (int k = 0; k < kAF; ++k) {          // fixed order
+                stay += __hip_atomic_load(ed + k * 128 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                arrive += __hip_atomic_load(ed + k * 128 + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             if (A.act) {
-                if (accH != R(0)) atomicAdd(&TL.fxT[A.tgt * N + A.tgt], to_fix<R>(accH));
-                if (lane >= 1 && accD != R(0)) atomicAdd(&TL.fxT[A.tgt * N + A.prv], to_fix<R>(accD));
+                if (stay != R(0)) atomicAdd(&TL.fxT[A.tgt * N + A.tgt], to_fix<R>(stay));
+                if (lane >= 1 && arrive != R(0)) atomicAdd(&TL.fxT[A.tgt * N + A.prv], to_fix<R>(arrive));
             }
         }
         __syncthreads();
+        // tile[i][j] = E[i][j] * sa[i][j] + F[j][i] * sb[j][i] - aligned edges,   E = exp2(Tr2[i][j] - rowmax_i),
+        // F = exp2(Tr2[i][j] - colmax_j): one coalesced pass of the whole workgroup over the transition matrix
+        const R L2E = Num<R>::log2e();
+        const R *tr = (const R *) P.transition;
         R *tile_out = (R *) F.tiles + (int64_t) b * N * N;
         for (int k = threadIdx.x; k < N * N; k += kFusedThreads) {
             const int i = k / N, j = k - i * N;
-            R v = TL.tileF[i][j];
-            const unsigned long long fv = TL.fxT[k];
-            if (fv != 0) v -= from_fix<R>(fv);
+            const R t2 = tr[(int64_t) i * P.ts0 + (int64_t) j * P.ts1] * L2E;
+            R v = Num<R>::exp2(t2 - SH.xa[i]) * TL.sa[i][j] + Num<R>::exp2(t2 - SH.xb[j]) * TL.sb[j][i];
+            const long long fv = (long long) TL.fxT[k];
+            if (fv != 0) v -= from_fix<R>((unsigned long long) fv);
             tile_out[k] = v * F.gscale;
         }
     }
+#ifdef ASG_PROBE
+    if (b == 0 && threadIdx.x == 0) ((long long *) W.dbg)[54] = clock64();
+#endif
     // ---- phase 3: loss of this utterance; the last workgroup to arrive reduces the batch (fixed order)
     if (wave == 0) {
-        R full = score_out<R>(SH.score_full);
-        R ali = flagged ? __hip_atomic_load((R *) F.scores + P.B + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                        : score_out<R>(SH.score_ali);
+        const R full = score_out<R>(SH.score_full);
+        R ali;
+        if (flagged) ali = __hip_atomic_load((R *) F.scores + P.B + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else ali = score_out<R>(__hip_atomic_load((double *) F.ascore + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         if (lane == 0) {
             ((R *) F.scores)[b] = full;
             if (!flagged) ((R *) F.scores)[P.B + b] = ali;
             F.flags[b] = flagged ? 1 : 0;
+            // the cross-workgroup words of this utterance go back to zero (the aligned workgroup is done with them)
+            for (int k = 0; k < kAF; ++k) {
+                __hip_atomic_store(&us->prog[0][k], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&us->prog[1][k], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __hip_atomic_store(&us->adone, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         R *lossb = (R *) F.dump;                    // [B] per-utterance losses for the reducing workgroup
         const R l = full - ali;
@@ -730,7 +1147,7 @@ __global__ void __launch_bounds__(kFusedThreads, 3) fused_fwd_kernel(Problem P, 
             if (lane == 0) {
                 __hip_atomic_store(lossb + b, l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                ticket = __hip_atomic_fetch_add(F.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ticket = __hip_atomic_fetch_add(F.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             ticket = __builtin_amdgcn_readfirstlane(ticket);
             if (ticket == (unsigned) (P.B - 1)) {
@@ -740,11 +1157,21 @@ __global__ void __launch_bounds__(kFusedThreads, 3) fused_fwd_kernel(Problem P, 
                 s = wave_allsum(s);
                 if (lane == 0) {
                     ((R *) F.loss)[0] = (R) (F.reduction == 2 ? s / P.B : s);
-                    __hip_atomic_store(F.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(F.sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
         }
     }
+}
+
+// grid = 2B: blocks [0, B) are the aligned workgroups (dispatched first: nothing they do waits on another workgroup),
+// blocks [B, 2B) the full workgroups.
+template <int NP>
+__global__ void __launch_bounds__(kFusedThreads, 3) fused_fwd_kernel(FusedParams KP) {
+    __shared__ FusedShared<NP> SH;
+    const int B = kernarg_params()->P.B;
+    if ((int) blockIdx.x < B) aligned_workgroup<NP>(blockIdx.x, SH);
+    else full_workgroup<NP>((int) blockIdx.x - B, SH);
 }
 
 // ------------------------------------------------------------------ the backward kernel
@@ -844,7 +1271,8 @@ __global__ void __launch_bounds__(256) fused_bwd_kernel(Problem P, State W, Fuse
 template <int NP>
 hipError_t launch_fused_np(const Problem &P, const State &W, const FusedArgs &F, bool backward, hipStream_t st) {
     if (!backward) {
-        hipLaunchKernelGGL((fused_fwd_kernel<NP>), dim3(P.B), dim3(kFusedThreads), 0, st, P, W, F);
+        FusedParams KP{P, W, F};
+        hipLaunchKernelGGL((fused_fwd_kernel<NP>), dim3(2 * P.B), dim3(kFusedThreads), 0, st, KP);
     } else {
         const int R = (P.N * P.N + kBwdSlice - 1) / kBwdSlice;
         hipLaunchKernelGGL((fused_bwd_kernel<NP>), dim3(P.B + R), dim3(256), 0, st, P, W, F);

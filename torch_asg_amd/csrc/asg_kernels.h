@@ -75,7 +75,12 @@ struct FusedArgs {
     void *tiles;                 // [B][N][N] per-utterance transition-gradient tiles (times gscale)
     int *flags;                  // [B]: 1 = the fused path declined this utterance (range guard, very short, time-out)
     void *dump;                  // [2][B] scratch scores for the exact redo
-    unsigned *ticket;            // 256 B, caller-zeroed, returned zeroed: arrival ticket of the forward loss reduction
+    void *p2;                    // [B][T][S] aligned posteriors, aligned workgroup -> full workgroup
+    void *edges;                 // [B][2][2][64] aligned edge posteriors (stay | arrive) of the alpha-/beta-side frames
+    void *ascore;                // [B] double: aligned scores (log2 units)
+    void *aoff;                  // [B][2][T/16 + 2][2] double: per-block offsets of the stored aligned states
+    unsigned *sync;              // caller-zeroed, returned zeroed: 64 words (word 0 = arrival ticket of the loss reduction)
+                                 // + 4 words per utterance (UttSync in asg_fused.hip)
     unsigned *ticket2;           // 256 B, zeroed by the forward launch for the backward launch
     const void *grad_loss;       // backward: [B] (none) or [1]
     void *grad_transition;       // backward: [N,N]
