@@ -44,7 +44,7 @@ if os.environ.get("ASG_DBG"):
     torch.cuda.synchronize()
     d = sv2.tensors[0][sc + off: sc + off + 512].view(torch.int64).cpu().numpy()
     names = ["main-a", "main-b", "cons-a", "cons-b", "ali-a", "ali-b", "afin-a", "afin-b", "rowfin-a", "rowfin-b"]
-    what = {"main": ["poll e"], "cons": ["slot 1st half", "other side st_done", "slot 2nd half", "row ring space"],
+    what = {"main": ["poll e 1st half", "poll e 2nd half"], "cons": ["slot 1st half", "other side st_done", "slot 2nd half", "row ring space"],
             "ali": ["ring space"], "afin": ["other ast_done", "ar_done", "vmcnt(20) before publish", "loads+lds landed"], "rowfin": ["P2 progress (first)", "P2 progress", "row_done"]}
     for r, nm in enumerate(names):
         v = d[r * 5: r * 5 + 5]

@@ -875,6 +875,7 @@ struct DuoLds {
     double zsum;       // producer -> consumer: sum of the block scales
     float x[64];       // producer -> consumer: row / column maxima
     // the buffer main broadcasts step n's vector through, and the helpers' common "stop" test
+    static constexpr int kR = kRing;       // ring depth in frames (a multiple of 32)
     __device__ __forceinline__ float *pslot(int) { return p; }
     __device__ __forceinline__ int consumed() { return __hip_atomic_load(&c_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
     __device__ __forceinline__ bool stop() {
@@ -921,7 +922,8 @@ template <int NP, bool GUARD, class LdsT>
 __device__ __forceinline__ void duo_main_block(LdsT &L, int n0, int nsteps, const V2<float> (&e2)[NP / 2], int N, int lane,
                                                float e_cur, float &s_prev, int &csum, int need_next, bool &next_ready,
                                                float &e_next_first) {
-    const int half = (n0 & 16);                    // ring half of this block (n0 is a multiple of 16)
+    constexpr int KR = LdsT::kR;
+    const int half = (n0 & (KR - 16));             // ring position of this block (n0 is a multiple of 16)
     int ex = 0;
     int ep_early = 0;
     next_ready = false;
@@ -933,15 +935,15 @@ __device__ __forceinline__ void duo_main_block(LdsT &L, int n0, int nsteps, cons
             V4<float> pv[NP / 4];
             bcast_issue<float, NP>(v, L.pslot(half + j), lane, pv);
             // hand s_{n-1} to the helper (slot (n-1) & 31; nothing to hand over before the first step)
-            if (j > 0) lds_stf(&L.s[(half + j - 1) & (kRing - 1)][lane], s_prev);
-            else if (n0 > 0) lds_stf(&L.s[(half + kRing - 1) & (kRing - 1)][lane], s_prev);
+            if (j > 0) lds_stf(&L.s[(half + j - 1) & (KR - 1)][lane], s_prev);
+            else if (n0 > 0) lds_stf(&L.s[(half + KR - 1) & (KR - 1)][lane], s_prev);
             float e_nxt = e_cur;
             if (j + 1 < kPF) e_nxt = lds_ldf(&L.e[half + j + 1][lane]);     // within this block's produced half
             // look ahead: is the NEXT block's e already there?  Asked at step 12, known at step 14, and then step 15
             // fetches that block's first e like any other -- the block boundary costs no LDS round trip
             if (!GUARD && j == kPF - 4) ep_early = lds_load_rlx(&L.e_prod);
             if (!GUARD && j == kPF - 2) next_ready = __builtin_amdgcn_readfirstlane(ep_early) >= need_next;
-            if (!GUARD && j == kPF - 1) e_next_first = lds_ldf(&L.e[half ^ 16][lane]);
+            if (!GUARD && j == kPF - 1) e_next_first = lds_ldf(&L.e[(half + 16) & (KR - 1)][lane]);
             __builtin_amdgcn_sched_barrier(0);
             if ((j % kRenorm) == kRenorm - 2 && (!GUARD || j + 1 < nsteps)) {
                 ex = __builtin_amdgcn_readlane(Rng<float>::expo(s_prev), N);
@@ -1107,7 +1109,7 @@ __device__ __forceinline__ void duo_producer(const Problem &P, int b, LdsT &L) {
         for (int j = 1; j < kPF; ++j) zl = (j < nv) ? fmax(zl, em[j]) : zl;
         const R zb = fmax(wave_allmax(fma(zl, L2E, XX)), LZ);
         const R Xz = XX - zb;
-        const int half = (K & 1) * kPF;
+        const int half = (K * kPF) & (LdsT::kR - 1);
 #pragma unroll
         for (int j = 0; j < kPF; ++j) {
             const R arg = fma(em[j], L2E, Xz);
@@ -1121,13 +1123,14 @@ __device__ __forceinline__ void duo_producer(const Problem &P, int b, LdsT &L) {
     };
     produce(0, blk0);
     if (nblk > 1) produce(1, nxt);
+    constexpr int kAhead = LdsT::kR / kPF;          // blocks the ring holds
     for (int K = 2; K < nblk; ++K) {
 #pragma unroll
         for (int j = 0; j < kPF; ++j) nxt[j] = buf_load<R>(rin, vin, (unsigned) frame(K * kPF + j) * fstride);
-        // block K reuses the ring half of block K-2: wait until the consumer has seen s_{16(K-1)-1}, i.e. main has
-        // finished block K-2
+        // block K reuses the ring slots of block K - kAhead: wait until the consumer has seen s_{16(K-kAhead+1)-1},
+        // i.e. main has finished block K - kAhead   (kAhead = 2: the consumer has seen s_{16(K-1)-1})
         int spins = 0;
-        while (L.consumed() < (K - 1) * kPF) {
+        while (L.consumed() < (K - kAhead + 1) * kPF) {
             if (L.stop() || ++spins > kSpinCap) return;
             __builtin_amdgcn_s_sleep(2);
         }

@@ -156,6 +156,32 @@ __device__ __forceinline__ void wave_allsum2(float &a, float &b) {
     a = readlane(ra, 63);
     b = readlane(rb, 63);
 }
+
+// Four independent fp32 sum reductions interleaved: with four chains in flight every DPP source is four instructions
+// old, which satisfies the VALU-write -> DPP-read wait states without a single s_nop.
+__device__ __forceinline__ void wave_allsum4(float &a, float &b, float &c, float &d) {
+    float ra, rb, rc, rd;
+#define ASG_DPP_STEP4(op, ctl) \
+    op " %0, %0, %0 " ctl "\n" op " %1, %1, %1 " ctl "\n" op " %2, %2, %2 " ctl "\n" op " %3, %3, %3 " ctl "\n"
+    asm volatile(
+        "s_nop 1\n"
+        "v_add_f32_dpp %0, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %1, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %2, %6, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+        "v_add_f32_dpp %3, %7, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+        ASG_DPP_STEP4("v_add_f32_dpp", "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+        ASG_DPP_STEP4("v_add_f32_dpp", "row_half_mirror row_mask:0xf bank_mask:0xf")
+        ASG_DPP_STEP4("v_add_f32_dpp", "row_mirror row_mask:0xf bank_mask:0xf")
+        ASG_DPP_STEP4("v_add_f32_dpp", "row_bcast:15 row_mask:0xa bank_mask:0xf")
+        ASG_DPP_STEP4("v_add_f32_dpp", "row_bcast:31 row_mask:0xc bank_mask:0xf")
+        "s_nop 1\n"
+        : "=&v"(ra), "=&v"(rb), "=&v"(rc), "=&v"(rd) : "v"(a), "v"(b), "v"(c), "v"(d));
+#undef ASG_DPP_STEP4
+    a = readlane(ra, 63);
+    b = readlane(rb, 63);
+    c = readlane(rc, 63);
+    d = readlane(rd, 63);
+}
 __device__ __forceinline__ void wave_allmax2(double &a, double &b);
 __device__ __forceinline__ void wave_allsum2(double &a, double &b);
 

@@ -38,23 +38,26 @@
 namespace asg {
 namespace {
 
-constexpr int kRow = 64;        // consumer -> row finisher ring of grad_inputs rows (frames)
+constexpr int kRow = 32;        // consumer -> row finisher ring of grad_inputs rows (frames)
 constexpr int kAR = 32;         // aligned chain -> finisher ring of aligned states (frames)
 constexpr int kGS = 8;          // frames per poll of the consumers / finishers
 constexpr int kMinFused = 4;
 constexpr int kAF = 3;          // aligned finisher wavefronts per side (round-robin over 8-index groups)
-constexpr int kRF = 2;          // row finisher wavefronts per side
+constexpr int kRF = 1;          // row finisher wavefronts per side
 constexpr int kFusedThreads = 768;
 constexpr unsigned kSc1 = 16;   // buffer load/store aux bit: agent scope (served by / written through to L2)
 
+constexpr int kFR = 64;                                   // ring depth of the full workgroup (frames): two consumers that
+                                                          // alternate need more slack than the 32 of the stand-alone kernel
 struct FusedSide {                                        // one direction (alpha / beta) of the FULL workgroup
-    __attribute__((aligned(16))) float p[kRing][64];   // step n's broadcast vector v_n (slot n & 31)
-    float s[kRing][64];                                  // row sums s_n, main -> consumer (self-describing: NaN sentinel)
-    float e[kRing][64];                                  // emission factors, producer -> main
-    float a[kRing][64];                                  // their log2 (alpha side), producer -> consumer
+    static constexpr int kR = kFR;
+    __attribute__((aligned(16))) float p[kFR][64];     // step n's broadcast vector v_n (slot n & 63)
+    float s[kFR][64];                                    // row sums s_n, main -> consumer (self-describing: NaN sentinel)
+    float e[kFR][64];                                    // emission factors, producer -> main
+    float a[kFR][64];                                    // their log2 (alpha side), producer -> consumer
     float row[kRow][64];                                 // gscale * full posterior of a frame, consumer -> row finisher
     float x[64];                                         // row / column maxima of the transition matrix
-    unsigned fx[2][kGS][64];                             // row finisher k: fixed-point scatter of the aligned posteriors
+    unsigned fx[kRF][kGS][64];                           // row finisher k: fixed-point scatter of the aligned posteriors
     double zsum;
     int e_prod, csum, main_done, prod_done, kill;
     // TWO consumer wavefronts per side: wave 0 takes the whole first half and the even 8-index groups of the second
@@ -66,14 +69,15 @@ struct FusedSide {                                        // one direction (alph
     int fd[kRF];      // row finisher k: (count of indices through its latest group) + 8 * (kRF - 1); the row ring is free
                       // up to min over k (same prefix rule as cd)
     __device__ __forceinline__ int finished() {
-        return min(__hip_atomic_load(&fd[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP),
-                   __hip_atomic_load(&fd[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        int v = __hip_atomic_load(&fd[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (kRF > 1) v = min(v, __hip_atomic_load(&fd[kRF - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        return v;
     }
     __device__ __forceinline__ int consumed() {
         return min(__hip_atomic_load(&cd[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP),
                    __hip_atomic_load(&cd[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
     }
-    __device__ __forceinline__ float *pslot(int n) { return p[n & (kRing - 1)]; }
+    __device__ __forceinline__ float *pslot(int n) { return p[n & (kFR - 1)]; }
     __device__ __forceinline__ bool stop() { return __hip_atomic_load(&kill, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0; }
 };
 
@@ -177,10 +181,16 @@ __device__ __forceinline__ FusedArgs ld_fargs(KParams k) {
 #define PRB_END(dbgp, role)
 #endif
 
+#ifdef ASG_PROBE
+__device__ unsigned g_abort_code[4];      // developer builds: site number of the last abort, and how many there were
+#endif
 template <class SideT>
-__device__ __forceinline__ void abort_all(SideT &L, SideT &O) {
+__device__ __forceinline__ void abort_all(SideT &L, SideT &O, int site = 0) {
     lds_store_rlx(&L.kill, 1);
     lds_store_rlx(&O.kill, 1);
+#ifdef ASG_PROBE
+    if ((threadIdx.x & 63) == 0) { g_abort_code[0] = (unsigned) site; atomicAdd(&g_abort_code[1], 1u); g_abort_code[2] = blockIdx.x; }
+#endif
 }
 
 // bounded wait until *p >= need; false on abort / time-out (then everything is aborted)
@@ -189,8 +199,8 @@ __device__ __forceinline__ bool wait_ge(int *p, int need, SideT &L, SideT &O) {
     int spins = 0;
     while (lds_load_rlx(p) < need) {
         if (L.stop()) return false;
-        if (++spins > kSpinCap) { abort_all(L, O); return false; }
-        __builtin_amdgcn_s_sleep(2);
+        if (++spins > kSpinCap) { abort_all(L, O, 1); return false; }
+        __builtin_amdgcn_s_sleep(6);
     }
     asm volatile("" ::: "memory");
     return true;
@@ -202,8 +212,8 @@ __device__ __forceinline__ bool wait_finished(int need, SideT &L, SideT &O) {
     int spins = 0;
     while (L.finished() < need) {
         if (L.stop()) return false;
-        if (++spins > kSpinCap) { abort_all(L, O); return false; }
-        __builtin_amdgcn_s_sleep(2);
+        if (++spins > kSpinCap) { abort_all(L, O, 2); return false; }
+        __builtin_amdgcn_s_sleep(6);
     }
     asm volatile("" ::: "memory");
     return true;
@@ -223,8 +233,8 @@ __device__ __forceinline__ bool wait_global_ge(unsigned *p, unsigned need, unsig
         seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         if (seen >= need) break;
         if (L.stop()) return false;
-        if (++spins > kSpinCap) { abort_all(L, O); return false; }
-        __builtin_amdgcn_s_sleep(4);
+        if (++spins > kSpinCap) { abort_all(L, O, 3); return false; }
+        __builtin_amdgcn_s_sleep(16);
     }
     return true;
 }
@@ -256,14 +266,14 @@ __device__ __forceinline__ void fused_main(const Problem &P, int b, FusedSide &L
         const int need = min(n0 + kPF, len);
         int spins = 0;
         R e_first = e_next_first;
-        PRB_WAIT(0, while (!next_ready) {
+        PRB_WAIT((n0 < len / 2 ? 0 : 1), while (!next_ready) {
             const int ep = lds_load_rlx(&L.e_prod);
             const int kl = lds_load_rlx(&L.kill);
-            e_first = lds_ldf(&L.e[n0 & 16][lane]);
+            e_first = lds_ldf(&L.e[n0 & (kFR - 16)][lane]);
             asm volatile("" ::: "memory");
             if (kl) return;
             if (ep >= need) break;
-            if (++spins > kSpinCap) { abort_all(L, O); return; }
+            if (++spins > kSpinCap) { abort_all(L, O, 4); return; }
             __builtin_amdgcn_s_sleep(1);
         })
         const int need_next = min(n0 + 2 * kPF, len);
@@ -272,7 +282,7 @@ __device__ __forceinline__ void fused_main(const Problem &P, int b, FusedSide &L
         else
             duo_main_block<NP, true>(L, n0, nsteps, e2, N, lane, e_first, s_prev, csum, need_next, next_ready, e_next_first);
     }
-    lds_stf(&L.s[(nst - 1) & (kRing - 1)][lane], s_prev);
+    lds_stf(&L.s[(nst - 1) & (kFR - 1)][lane], s_prev);
     lds_store_rlx(&L.csum, csum);
     lds_store_rel(&L.main_done, 1);
     PRB_END(dbg, BETA ? 1 : 0)
@@ -306,14 +316,14 @@ __device__ __forceinline__ void fused_consumer(const Problem &P, const State &W,
     const R XX = lds_ldf(&L.x[lane]);
     R sv = act ? Num<R>::exp2(-XX) : R(0);
     auto wait_slot = [&](int m) {                             // until main has written s_m (main writes in order)
-        float *slot = &L.s[m & (kRing - 1)][lane];
+        float *slot = &L.s[m & (kFR - 1)][lane];
         int spins = 0;
         while (true) {
             const R v = lds_ldf(slot);
             if (__ballot(__float_as_uint(v) != kSentinel) == ~0ull) return true;
             if (L.stop()) return false;
-            if (++spins > kSpinCap) { abort_all(L, O); return false; }
-            __builtin_amdgcn_s_sleep(1);
+            if (++spins > kSpinCap) { abort_all(L, O, 5); return false; }
+            __builtin_amdgcn_s_sleep(3);          // ~1 recursion step: every poll is an LDS access the recursion waits behind
         }
     };
     int n = 1;
@@ -327,21 +337,21 @@ __device__ __forceinline__ void fused_consumer(const Problem &P, const State &W,
 #pragma unroll
         for (int q = 0; q < kGS; ++q) {
             const int m = n + min(q, g - 1);
-            sg[q] = lds_ldf(&L.s[(m - 1) & (kRing - 1)][lane]);
-            ag[q] = BETA ? XX : lds_ldf(&L.a[m & (kRing - 1)][lane]);
+            sg[q] = lds_ldf(&L.s[(m - 1) & (kFR - 1)][lane]);
+            ag[q] = BETA ? XX : lds_ldf(&L.a[m & (kFR - 1)][lane]);
         }
         unsigned lo = 0xffffffffu, hi = 0;
 #pragma unroll
         for (int q = 0; q < kGS; ++q) {
             const int m = n + min(q, g - 1);
-            lds_stf(&L.s[(m - 1) & (kRing - 1)][lane], __uint_as_float(kSentinel));
+            lds_stf(&L.s[(m - 1) & (kFR - 1)][lane], __uint_as_float(kSentinel));
             const unsigned sb = Rng<R>::bits(sg[q]);
             lo = min(lo, sb);
             hi = max(hi, sb);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         lds_store_rlx(&L.cd[0], n + g - 1);
-        if ((__ballot(lo < Rng<R>::lo || hi > Rng<R>::hi) & actmask) != 0) { abort_all(L, O); return; }
+        if ((__ballot(lo < Rng<R>::lo || hi > Rng<R>::hi) & actmask) != 0) { abort_all(L, O, 6); return; }
 #pragma unroll
         for (int q = 0; q < kGS; ++q)
             buf_store(ag[q] + Num<R>::log2(sg[q]), rs, voff, (unsigned) frame(n + min(q, g - 1)) * row_bytes);
@@ -364,27 +374,35 @@ __device__ __forceinline__ void fused_consumer(const Problem &P, const State &W,
     for (int q = 0; q < kGS; ++q) oth[q] = buf_load<R>(ro, vld, (unsigned) frame(min(n + q, len - 1)) * row_bytes);
     while (n < len) {
         const int g = min(kGS, len - n);
-        PRB_WAIT(2, if (!wait_slot(n + g - 2)) return;)
+        // ring data of the group in ONE LDS round trip: main writes s in order, so once the group's LAST row sum is
+        // there (no sentinel) everything read with it is valid; otherwise sleep and read again
         R sg[kGS], ag[kGS], pg[kGS];
+#ifdef ASG_PROBE
+        const long long prb_slot0 = clock64();
+#endif
+        if (!wait_slot(n + g - 2)) return;
 #pragma unroll
         for (int q = 0; q < kGS; ++q) {
             const int m = n + min(q, g - 1);
-            sg[q] = lds_ldf(&L.s[(m - 1) & (kRing - 1)][lane]);
-            ag[q] = BETA ? XX : lds_ldf(&L.a[m & (kRing - 1)][lane]);
-            pg[q] = lds_ldf(&L.p[(m - 1) & (kRing - 1)][lane]);
+            sg[q] = lds_ldf(&L.s[(m - 1) & (kFR - 1)][lane]);
+            ag[q] = BETA ? XX : lds_ldf(&L.a[m & (kFR - 1)][lane]);
+            pg[q] = lds_ldf(&L.p[(m - 1) & (kFR - 1)][lane]);
         }
+#ifdef ASG_PROBE
+        prb_w[2] += clock64() - prb_slot0;
+#endif
         unsigned lo = 0xffffffffu, hi = 0;
 #pragma unroll
         for (int q = 0; q < kGS; ++q) {
             const int m = n + min(q, g - 1);
-            lds_stf(&L.s[(m - 1) & (kRing - 1)][lane], __uint_as_float(kSentinel));
+            lds_stf(&L.s[(m - 1) & (kFR - 1)][lane], __uint_as_float(kSentinel));
             const unsigned sb = Rng<R>::bits(sg[q]);
             lo = min(lo, sb);
             hi = max(hi, sb);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the values are in registers before the producer may refill
         lds_store_rlx(&L.cd[cw], n + g - 1 + kGS);
-        if ((__ballot(lo < Rng<R>::lo || hi > Rng<R>::hi) & actmask) != 0) { abort_all(L, O); return; }
+        if ((__ballot(lo < Rng<R>::lo || hi > Rng<R>::hi) & actmask) != 0) { abort_all(L, O, 7); return; }
         // posterior of the frame: softmax of (own state + other side's state); both are stored relative to offsets
         // that keep each frame's largest term near 1, so no max-shift -- a normaliser outside [2^-100, 2^100] aborts
         R w[kGS];
@@ -393,49 +411,47 @@ __device__ __forceinline__ void fused_consumer(const Problem &P, const State &W,
             const R gam = act ? (ag[q] + Num<R>::log2(sg[q])) + oth[q] : NINF;
             w[q] = Num<R>::exp2(gam);
         }
-        // the next group's rows of the other side: plain loads (its first half was complete in L2 before st_done was
-        // published, and this compute unit has not touched those lines before)
+        // the next own group's rows of the other side: plain loads (its first half was complete in L2 before st_done
+        // was published, and this compute unit has not touched those lines before)
         R othn[kGS];
 #pragma unroll
         for (int q = 0; q < kGS; ++q) othn[q] = buf_load<R>(ro, vld, (unsigned) frame(min(n + 2 * kGS + q, len - 1)) * row_bytes);
-        R Z[kGS];
-#pragma unroll
-        for (int q = 0; q < kGS; q += 2) {
-            Z[q] = w[q];
-            Z[q + 1] = w[q + 1];
-            wave_allsum2(Z[q], Z[q + 1]);
-        }
-        unsigned zlo = 0xffffffffu, zhi = 0;
-#pragma unroll
-        for (int q = 0; q < kGS; ++q) {
-            const unsigned zb = Rng<R>::bits(Z[q]);
-            zlo = min(zlo, zb);
-            zhi = max(zhi, zb);
-        }
-        if (zlo < Rng<R>::lo || zhi > Rng<R>::hi) { abort_all(L, O); return; }
-        // ring space: the row finisher has taken index n + g - 1 - kRow
+        // ring space for the rows (the row finishers have taken index n + g - 1 - kRow): normally long true
 #ifndef ASG_X_NOROWFIN
         PRB_WAIT(3, if (!wait_finished(n + g - kRow, L, O)) return;)
 #endif
+        // frames 0-3: normalisers, rows, u, first MFMA batch; then frames 4-7 while those MFMAs run
         R u[kGS];
+        auto half_group = [&](const int q0) -> bool {
+            R z0 = w[q0], z1 = w[q0 + 1], z2 = w[q0 + 2], z3 = w[q0 + 3];
+            wave_allsum4(z0, z1, z2, z3);
+            const R Z[4] = {z0, z1, z2, z3};
+            unsigned zlo = 0xffffffffu, zhi = 0;
 #pragma unroll
-        for (int q = 0; q < kGS; ++q) {
-            const R post = w[q] * Num<R>::rcp(Z[q]);
-            const int m = n + min(q, g - 1);
-            lds_stf(&L.row[m & (kRow - 1)][lane], post * gscale);
-            // xi: alpha side skips its first assembled index (the beta side's last one covers that transition)
-            const bool take = q < g && (BETA || n + q > h);
-            u[q] = (take && act) ? post * Num<R>::rcp(sg[q]) : R(0);
-            pg[q] = act ? pg[q] : R(0);
-        }
+            for (int q = 0; q < 4; ++q) {
+                const unsigned zb = Rng<R>::bits(Z[q]);
+                zlo = min(zlo, zb);
+                zhi = max(zhi, zb);
+            }
+            if (zlo < Rng<R>::lo || zhi > Rng<R>::hi) return false;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const R post = w[q0 + q] * Num<R>::rcp(Z[q]);
+                const int m = n + min(q0 + q, g - 1);
+                lds_stf(&L.row[m & (kRow - 1)][lane], post * gscale);
+                // xi: alpha side skips its first assembled index (the beta side's last one covers that transition)
+                const bool take = q0 + q < g && (BETA || n + q0 + q > h);
+                u[q0 + q] = (take && act) ? post * Num<R>::rcp(sg[q0 + q]) : R(0);
+                pg[q0 + q] = act ? pg[q0 + q] : R(0);
+            }
+            float ua[4] = {u[q0], u[q0 + 1], u[q0 + 2], u[q0 + 3]}, va[4] = {pg[q0], pg[q0 + 1], pg[q0 + 2], pg[q0 + 3]};
+            outer4_accumulate<NT>(ua, va, acc);
+            return true;
+        };
+        if (!half_group(0)) { abort_all(L, O, 8); return; }
+        if (!half_group(4)) { abort_all(L, O, 9); return; }
         asm volatile("" ::: "memory");
         lds_store_rlx(&L.rd[cw], n + g);
-        {
-            float ua[4] = {u[0], u[1], u[2], u[3]}, va[4] = {pg[0], pg[1], pg[2], pg[3]};
-            outer4_accumulate<NT>(ua, va, acc);
-            float ub[4] = {u[4], u[5], u[6], u[7]}, vb[4] = {pg[4], pg[5], pg[6], pg[7]};
-            outer4_accumulate<NT>(ub, vb, acc);
-        }
 #pragma unroll
         for (int q = 0; q < kGS; ++q) oth[q] = othn[q];
         sv = sg[kGS - 1];
@@ -449,17 +465,17 @@ __device__ __forceinline__ void fused_consumer(const Problem &P, const State &W,
         int spins = 0;
         while (!(lds_load_acq(&L.main_done) && lds_load_acq(&L.prod_done))) {
             if (L.stop()) return;
-            if (++spins > kSpinCap) { abort_all(L, O); return; }
+            if (++spins > kSpinCap) { abort_all(L, O, 10); return; }
             __builtin_amdgcn_s_sleep(1);
         }
     }
     if (BETA) {
         const int csum = lds_load_rlx(&L.csum);
         const double zsum = L.zsum;
-        const R vlast = sv * lds_ldf(&L.e[(len - 1) & (kRing - 1)][lane]);
+        const R vlast = sv * lds_ldf(&L.e[(len - 1) & (kFR - 1)][lane]);
         const R sm = wave_allsum(act ? vlast : R(0));
         const unsigned smb = Rng<R>::bits(sm);
-        if (!(smb >= Rng<R>::lo && smb <= Rng<R>::hi)) { abort_all(L, O); return; }
+        if (!(smb >= Rng<R>::lo && smb <= Rng<R>::hi)) { abort_all(L, O, 11); return; }
         score_out2 = zsum + (double) csum + (double) Num<R>::log2(sm);
     }
     PRB_END(W.dbg, BETA ? 3 : 2)
@@ -771,6 +787,8 @@ __device__ __forceinline__ void fused_rowfin(const Problem &P, const State &W, c
         const int ol = P.tg_len ? clampi(P.tg_len[b], 0, S) : S;
         const int sc = lane < ol ? lane : 0;
         tgt = clampi(P.targets[(int64_t) b * P.gs0 + (int64_t) sc * P.gs1], 0, N - 1);
+        // lanes past the target add 0: give each its OWN word (all of them on one address would serialise the LDS add)
+        if (lane >= ol) tgt = lane;
     }
     __amdgpu_buffer_rsrc_t rp = make_rsrc((R *) F.p2 + ((int64_t) b * 2 + (BETA ? 1 : 0)) * (T + 8) * S, (unsigned) (T + 8) * rbS);
     const unsigned vQ = lane < S ? (unsigned) lane * 16u : kOobOffset;                        // out of range reads 0
@@ -960,7 +978,8 @@ __device__ __forceinline__ void full_workgroup(int b, FusedShared<NP> &SH) {
             const int h = k == 0 ? mid : len - mid;
             L.e_prod = 0; L.csum = 0; L.main_done = 0; L.prod_done = 0; L.kill = 0;
             L.cd[0] = 0; L.cd[1] = 1 << 30; L.rd[0] = h; L.rd[1] = h;
-            L.st_done = 0; L.fd[0] = h; L.fd[1] = h + kGS;
+            L.st_done = 0;
+            for (int k2 = 0; k2 < kRF; ++k2) L.fd[k2] = h + k2 * kGS;
         }
         SH.score_full = -1e300;
         SH.adone = 0;
@@ -969,8 +988,8 @@ __device__ __forceinline__ void full_workgroup(int b, FusedShared<NP> &SH) {
     const long long ep_t0 = clock64();
     if (b == 0 && threadIdx.x == 0) ((long long *) W.dbg)[50] = ep_t0;
 #endif
-    if (b == 0 && threadIdx.x < 64) F.ticket2[threadIdx.x] = 0;        // for the backward launch
-    for (int q = threadIdx.x; q < kRing * 64; q += kFusedThreads) {
+    if (b == 0 && threadIdx.x < 64 && threadIdx.x != 1) F.ticket2[threadIdx.x] = 0;        // for the backward launch
+    for (int q = threadIdx.x; q < kFR * 64; q += kFusedThreads) {
         (&LA.s[0][0])[q] = __uint_as_float(kSentinel);
         (&LB.s[0][0])[q] = __uint_as_float(kSentinel);
     }
@@ -1000,15 +1019,15 @@ __device__ __forceinline__ void full_workgroup(int b, FusedShared<NP> &SH) {
         const State W = ld_state(kernarg_params());
         const FusedArgs F = ld_fargs(kernarg_params());
         switch (wave) {
-            case 0: fused_main<NP, false>(P, b, LA, LB, len, W.dbg); break;
-            case 1: fused_main<NP, true>(P, b, LB, LA, len, W.dbg); break;
+            case 0: __builtin_amdgcn_s_setprio(3); fused_main<NP, false>(P, b, LA, LB, len, W.dbg); break;
+            case 1: __builtin_amdgcn_s_setprio(3); fused_main<NP, true>(P, b, LB, LA, len, W.dbg); break;
             case 4: duo_producer<NP, false>(P, b, LA); break;
             case 5: duo_producer<NP, true>(P, b, LB); break;
             case 2: case 6: fused_consumer<NP, false>(P, W, F, b, LA, LB, len, mid, acc, sc2, wave == 6 ? 1 : 0); break;
             case 3: case 7: fused_consumer<NP, true>(P, W, F, b, LB, LA, len, len - mid, acc, sc2, wave == 7 ? 1 : 0); break;
 #ifndef ASG_X_NOROWFIN
-            case 8: case 10: fused_rowfin<false>(P, W, F, b, LA, LB, len, mid, us, (wave - 8) >> 1); break;
-            case 9: case 11: fused_rowfin<true>(P, W, F, b, LB, LA, len, len - mid, us, (wave - 9) >> 1); break;
+            case 10: __builtin_amdgcn_s_setprio(2); fused_rowfin<false>(P, W, F, b, LA, LB, len, mid, us, 0); break;      // beside the alpha consumers
+            case 11: __builtin_amdgcn_s_setprio(2); fused_rowfin<true>(P, W, F, b, LB, LA, len, len - mid, us, 0); break;
 #endif
             default: break;
         }
@@ -1130,7 +1149,7 @@ __device__ __forceinline__ void full_epilogue(int b, FusedShared<NP> &SH, bool f
         if (lane == 0) {
             ((R *) F.scores)[b] = full;
             if (!flagged) ((R *) F.scores)[P.B + b] = ali;
-            F.flags[b] = flagged ? 1 : 0;
+            __hip_atomic_store(F.flags + b, flagged ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // the cross-workgroup words of this utterance go back to zero (the aligned workgroup is done with them)
             for (int k = 0; k < kAF; ++k) {
                 __hip_atomic_store(&us->prog[0][k], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1138,27 +1157,31 @@ __device__ __forceinline__ void full_epilogue(int b, FusedShared<NP> &SH, bool f
             }
             __hip_atomic_store(&us->adone, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        // the last full workgroup to arrive (fixed order inside): reduces the loss over the batch and counts the flagged
+        // utterances for the backward launch (its reducers wait for exactly that many exact redos)
         R *lossb = (R *) F.dump;                    // [B] per-utterance losses for the reducing workgroup
         const R l = full - ali;
-        if (F.reduction == 0) {
-            if (lane == 0) ((R *) F.loss)[b] = l;
-        } else {
-            unsigned ticket = 0;
-            if (lane == 0) {
-                __hip_atomic_store(lossb + b, l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                ticket = __hip_atomic_fetch_add(F.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (F.reduction == 0 && lane == 0) ((R *) F.loss)[b] = l;
+        unsigned ticket = 0;
+        if (lane == 0) {
+            __hip_atomic_store(lossb + b, l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ticket = __hip_atomic_fetch_add(F.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        ticket = __builtin_amdgcn_readfirstlane(ticket);
+        if (ticket == (unsigned) (P.B - 1)) {
+            double s = 0;
+            int nf = 0;
+            for (int q = lane; q < P.B; q += 64) {
+                s += (double) __hip_atomic_load(lossb + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                nf += __hip_atomic_load(F.flags + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ? 1 : 0;
             }
-            ticket = __builtin_amdgcn_readfirstlane(ticket);
-            if (ticket == (unsigned) (P.B - 1)) {
-                double s = 0;
-                for (int q = lane; q < P.B; q += 64)
-                    s += (double) __hip_atomic_load(lossb + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s = wave_allsum(s);
-                if (lane == 0) {
-                    ((R *) F.loss)[0] = (R) (F.reduction == 2 ? s / P.B : s);
-                    __hip_atomic_store(F.sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+            s = wave_allsum(s);
+            nf = (int) wave_allsum((float) nf);          // exact: B < 2^24
+            if (lane == 0) {
+                if (F.reduction != 0) ((R *) F.loss)[0] = (R) (F.reduction == 2 ? s / P.B : s);
+                F.ticket2[1] = (unsigned) nf;
+                __hip_atomic_store(F.sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
@@ -1226,17 +1249,18 @@ __global__ void __launch_bounds__(256) fused_bwd_kernel(Problem P, State W, Fuse
             }
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
+        if (flagged && threadIdx.x == 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_fetch_add(F.ticket2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         return;
     }
-    // ---- reducers
+    // ---- reducers: wait for the exact redos of the flagged utterances (normally none: no wait at all)
     const int r = (int) blockIdx.x - B;
     {
+        const unsigned nflag = F.ticket2[1];
         int spins = 0;
-        while (__hip_atomic_load(F.ticket2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned) B) {
+        while (__hip_atomic_load(F.ticket2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nflag) {
             if (++spins > (1 << 24)) break;               // cannot happen: arrivals never wait on anything
             __builtin_amdgcn_s_sleep(8);
         }
@@ -1298,6 +1322,14 @@ hipError_t launch_fused(const Problem &P, const State &W, const FusedArgs &F, bo
 }
 
 }  // namespace
+
+#ifdef ASG_PROBE
+extern "C" void asg_dev_abort_codes(unsigned *out) {
+    (void) hipMemcpyFromSymbol(out, HIP_SYMBOL(g_abort_code), sizeof(unsigned) * 4);
+    unsigned z[4] = {0, 0, 0, 0};
+    (void) hipMemcpyToSymbol(HIP_SYMBOL(g_abort_code), z, sizeof(z));
+}
+#endif
 
 hipError_t launch_fused_forward(const Problem &P, const State &W, const FusedArgs &F, hipStream_t stream) {
     // the recursion wavefronts address emission frames with 32-bit buffer offsets (as launch_fwd_small)
