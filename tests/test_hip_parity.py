@@ -345,13 +345,19 @@ def test_determinism_and_mode_equality():
     again = run_hip(x, tg, tr, il, tl, "mean")
     for k in base:
         assert np.array_equal(base[k], again[k]), "run-to-run " + k
-    for kw in MODES[1:3]:     # same kernels, different launch arrangement: bit-identical
+    # 'streams' and 'serial' run the same stand-alone kernels in different launch arrangements: bit-identical to
+    # each other and run to run; 'single' is the fused training step (gradients assembled inside the forward
+    # launch, other summation order): equal to rounding
+    s1 = run_hip(x, tg, tr, il, tl, "mean", **MODES[1])
+    for kw in (MODES[1], MODES[2]):
         r = run_hip(x, tg, tr, il, tl, "mean", **kw)
-        for k in base:
-            assert np.array_equal(base[k], r[k]), "%s differs in mode %s" % (k, kw)
+        for k in s1:
+            assert np.array_equal(s1[k], r[k]), "%s differs in mode %s" % (k, kw)
+    for k in base:
+        util.assert_close(s1[k], base[k], 2e-6, "fused vs stand-alone kernels " + k)
     r = run_hip(x, tg, tr, il, tl, "mean", **MODES[3])   # FCC + FAC summed by autograd: equal to rounding
     for k in base:
-        util.assert_close(r[k], base[k], 1e-6, "serial route " + k)
+        util.assert_close(r[k], base[k], 2e-6, "serial route " + k)
 
 
 def test_fused_loss_function_equals_reference_style_composition():

@@ -15,7 +15,7 @@ loss, saved = be.loss_forward(x, tg, tr, il, tl, "mean", _lib.FLAG_SINGLE_LAUNCH
 torch.cuda.synchronize()
 ws, gin = saved.tensors
 sc, stb, fs = saved.sizes
-tiles = (B * N * N * 4 + 255) // 256 * 256
+tiles = (B * 2 * N * N * 4 + 255) // 256 * 256
 flags = ws[sc + stb + tiles: sc + stb + tiles + 4 * B].view(torch.int32).cpu().numpy()
 print("mode", saved.mode, "flagged", int(flags.sum()), "of", B, "loss", float(loss))
 one = torch.ones((), device=dev)

@@ -11,7 +11,7 @@ g = torch.Generator().manual_seed(0)
 tr = torch.rand(N, N, generator=g).to(dev); x = torch.randn(T, B, N, generator=g).to(dev); tg = torch.randint(0, N, (B, L), generator=g).to(dev)
 il = torch.full((B,), T, dtype=torch.int64, device=dev); tl = torch.full((B,), L, dtype=torch.int64, device=dev)
 be = torch_asg_amd.asg.native()
-tiles = (B * N * N * 4 + 255) // 256 * 256
+tiles = (B * 2 * N * N * 4 + 255) // 256 * 256
 ts = []
 for it in range(300):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

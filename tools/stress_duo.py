@@ -9,7 +9,7 @@ from oracle import asg_oracle as orc
 dev = "cuda:0"
 
 
-def run(seed=0, ncase=150, dtype=torch.float32, generic=False, regime="all"):
+def run(seed=0, ncase=150, dtype=torch.float32, generic=False, regime="all", only=None):
     """regime: "plain" = emission spread <= 5 nats and no common offset, judged by the plain parity rule;
     "extended" = the rest (offsets -40/+60, spread 30), judged by the documented extended rule; "all" = both, each
     case by the rule of its own regime."""
@@ -37,6 +37,8 @@ def run(seed=0, ncase=150, dtype=torch.float32, generic=False, regime="all"):
         tg = torch.randint(0, N, (B, L), generator=g)
         il = torch.randint(max(1, T // 2), T + 1, (B,), generator=g)
         tl = torch.minimum(torch.randint(1, L + 1, (B,), generator=g), il)
+        if only is not None and case != only:
+            continue
         o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il.numpy(), tl.numpy(), "none")
         m = torch_asg_amd.ASGLoss(N, reduction="none").to(dev).to(dtype)
         with torch.no_grad(): m.transition.copy_(tr)
@@ -45,6 +47,16 @@ def run(seed=0, ncase=150, dtype=torch.float32, generic=False, regime="all"):
             xd = x.to(dev).to(dtype).requires_grad_(True); m.transition.grad = None
             loss = m(xd, tg.to(dev), il.to(dev), tl.to(dev)); loss.sum().backward(); torch.cuda.synchronize()
             outs.append((loss.detach().cpu().numpy(), xd.grad.cpu().numpy(), m.transition.grad.cpu().numpy()))
+        if only is not None:
+            print("case", case, "T B N L", T, B, N, L, "scale", scale, "offset", offset, "il", il.tolist(), "tl", tl.tolist(), "tr", tr.flatten()[:4].tolist())
+            for k, a in zip(("loss", "grad_inputs", "grad_transition"), outs[0]):
+                print(k, "max abs err", float(np.abs(a - o[k]).max()), "max |ref|", float(np.abs(o[k]).max()))
+            for mode in ("streams",):
+                m2 = torch_asg_amd.ASGLoss(N, reduction="none", launch_mode=mode).to(dev).to(dtype)
+                with torch.no_grad(): m2.transition.copy_(tr)
+                xd = x.to(dev).to(dtype).requires_grad_(True)
+                m2(xd, tg.to(dev), il.to(dev), tl.to(dev)).sum().backward(); torch.cuda.synchronize()
+                print(mode, "grad_transition err", float(np.abs(m2.transition.grad.cpu().numpy() - o["grad_transition"]).max()))
         for a, b_ in zip(outs[0], outs[1]):
             assert np.array_equal(a, b_, equal_nan=True), ("non-deterministic", case, T, B, N, L)
         for k, a in zip(("loss", "grad_inputs", "grad_transition"), outs[0]):
@@ -74,5 +86,6 @@ def run(seed=0, ncase=150, dtype=torch.float32, generic=False, regime="all"):
 if __name__ == "__main__":
     n, w, dt = run(int(sys.argv[1]) if len(sys.argv) > 1 else 0, int(sys.argv[2]) if len(sys.argv) > 2 else 150,
                    torch.float64 if (len(sys.argv) > 3 and "f64" in sys.argv[3]) else torch.float32,
-                   generic=(len(sys.argv) > 3 and "generic" in sys.argv[3]))
+                   generic=(len(sys.argv) > 3 and "generic" in sys.argv[3]), regime=(sys.argv[4] if len(sys.argv) > 4 else "all"),
+                   only=(int(sys.argv[5]) if len(sys.argv) > 5 else None))
     print("stress ok: %d cases, worst scaled error %.2e, %.0f s" % (n, w, dt))

@@ -441,17 +441,19 @@ int asg_loss_backward(asg_ctx *ctx, const asg_problem *p, const void *state, siz
 /* ---- fused training step (asg_fused.hip) ------------------------------------------------------------------ */
 
 namespace {
-struct FusedLayout { size_t tiles, flags, dump, ticket2, p2, edges, ascore, aoff, total; };
+struct FusedLayout { size_t tiles, flags, dump, ticket2, p2, edges, ascore, fscore, xstate, aoff, total; };
 FusedLayout fused_layout(const asg_problem *p) {
     FusedLayout L{};
     size_t off = 0;
-    L.tiles = off; off = align_up(off + (size_t) p->B * p->N * p->N * 4);
+    L.tiles = off; off = align_up(off + (size_t) p->B * 2 * p->N * p->N * 4);
     L.flags = off; off = align_up(off + (size_t) p->B * 4);
     L.dump = off; off = align_up(off + (size_t) p->B * 3 * 4);
     L.ticket2 = off; off = align_up(off + 256);
     L.p2 = off; off = align_up(off + (size_t) p->B * 2 * (p->T + 8) * (p->S < 1 ? 1 : p->S) * 4);
-    L.edges = off; off = align_up(off + (size_t) p->B * 2 * 3 * 128 * 4);
+    L.edges = off; off = align_up(off + (size_t) p->B * 2 * 3 * 128 * 8);
     L.ascore = off; off = align_up(off + (size_t) p->B * 8);
+    L.fscore = off; off = align_up(off + (size_t) p->B * 8);
+    L.xstate = off; off = align_up(off + (size_t) p->B * 2 * ((p->T + 7) / 8 + 2) * 2048);
     L.aoff = off; off = align_up(off + (size_t) p->B * 2 * ((p->T + 15) / 16 + 1) * 2 * 8);
     L.total = off;
     return L;
@@ -467,6 +469,8 @@ FusedArgs fused_args(const asg_problem *p, void *scratch, int reduction) {
     F.p2 = base + L.p2;
     F.edges = base + L.edges;
     F.ascore = base + L.ascore;
+    F.fscore = base + L.fscore;
+    F.xstate = base + L.xstate;
     F.aoff = base + L.aoff;
     F.reduction = reduction;
     F.gscale = reduction == 2 ? (float) (1.0 / (double) p->B) : 1.0f;
@@ -491,7 +495,7 @@ size_t asg_loss_fused_scratch_bytes(const asg_problem *p) {
 
 size_t asg_loss_fused_sync_bytes(const asg_problem *p) {
     if (!p || p->B < 1) return 0;
-    return align_up(256 + (size_t) p->B * 32);
+    return align_up(256 + (size_t) p->B * 64);
 }
 
 int asg_loss_fused_forward(const asg_problem *p, void *state, size_t state_bytes, int reduction, void *loss, void *scores,

@@ -7,27 +7,29 @@
 // split "both recursions in forward, no recursion in backward" is kept and taken one step further -- the
 // non-recursive assembly happens inside the forward launch too, and backward only scales by the upstream gradient.
 //
-// Two workgroups per utterance, on two compute units (grid = 2B, 768 threads):
-//   * the ALIGNED workgroup (block b < B) owns the force-aligned lattice: both chains, their crossing, the aligned
-//     posteriors and the edge posteriors.  It depends on nothing and never waits for another workgroup.
-//   * the FULL workgroup (block B + b) owns the fully-connected lattice and writes the final grad_inputs rows; it reads
-//     the aligned posteriors of a frame from HBM/L2 behind a progress word (one-way dependency on a workgroup with a
-//     LOWER block index, i.e. dispatched earlier -- and every wait is bounded anyway).
-// In both, the alpha chain walks frames 0 -> len-1 and the beta chain len-1 -> 0; they cross at mid = len/2.  Before the
+// Three workgroups per utterance, each alone on a compute unit (grid = 24 * ceil(B / 8), 768 threads; the three of
+// an utterance have block indices that are equal mod 8, which puts them behind the same L2 in practice -- speed only):
+//   * the ALIGNED workgroup owns the force-aligned lattice: both chains, their crossing, the aligned posteriors and the
+//     edge posteriors.  It depends on nothing and never waits for another workgroup.
+//   * the FULL-ALPHA and FULL-BETA workgroups each own one direction of the fully-connected lattice.  One compute unit
+//     per direction because the recursion's LDS broadcast (10 ds_read_b128 per step) takes a third of a compute unit's
+//     LDS bandwidth: with both directions behind one LDS the step was 317 cycles instead of 240 (measured, round 2).
+// The alpha chain walks frames 0 -> len-1 and the beta chain len-1 -> 0; they cross at mid = len/2.  Before the
 // crossing each chain stores its state for the other side (frames < mid from alpha, >= mid from beta: half of what the
-// stand-alone kernels store); after it, the side that reaches a frame SECOND holds everything the frame's gradient needs:
+// stand-alone kernels store; write-through 16-byte stores, four frames per lane and store, behind ONE progress word);
+// after it, the side that reaches a frame SECOND holds everything the frame's gradient needs:
 //   posterior_t = softmax(alpha_t + beta_t)                      -> grad_inputs row (minus the scattered aligned posterior)
 //   alpha side:  xi_t(i,j)    = posterior_t[i]   / s_i  * E[i][j] * v_{t-1}[j]     s = E v_{t-1}  (this step's row sums)
 //   beta side:   xi_{t+1}(i,j) = posterior_t[j] / s'_j * F[j][i] * y_{t+1}[i]      s' = F y_{t+1}
 // i.e. the recursion's OWN row sums and broadcast vector -- the stand-alone assembly kernel's second mat-vec is gone, and
 // the sum over frames of the outer products (posterior / s) (x) v runs on the matrix cores (asg_outer.h).
-// Wave roles of the full workgroup (waves with equal index % 4 share a SIMD):
-//   0/1  recursion wavefronts alpha/beta   (critical path only; as fwd_duo_kernel)       4/5  producers (emission factors)
-//   2,6 / 3,7  consumers alpha / beta: first half = log-domain state -> HBM (one of the pair); second half = posterior ->
-//        LDS row ring, xi accumulation (MFMA), the two of a pair taking alternate groups of 8 frames
-//   8/9  row finishers: aligned posterior of the frame (from the aligned workgroup) scattered to labels with
-//        deterministic fixed-point LDS adds, final grad_inputs row
-// of the aligned workgroup:  0/1 chains alpha/beta   2/3 finishers (aligned posterior -> HBM, edge posteriors)
+// Wave roles of a full workgroup (waves with equal index % 4 share a SIMD; the recursion wavefront has SIMD 0 to itself):
+//   0  recursion wavefront (critical path only; as fwd_duo_kernel)        1  producer (emission factors)
+//   2, 3  consumers: first half = log-domain state -> HBM (consumer 0); second half = posterior -> LDS row ring, xi
+//         accumulation (MFMA), the two taking alternate groups of 8 frames
+//   5  row finisher: aligned posterior of the frame (from the aligned workgroup) scattered to labels with deterministic
+//      fixed-point LDS adds, final grad_inputs row
+// of the aligned workgroup:  0/1 chains alpha/beta   2,6,10 / 3,7,11 finishers (aligned posterior -> HBM, edge posteriors)
 // Everything is bit-deterministic: no float atomics, fixed accumulation orders.
 // An utterance whose row sums leave the safe range (or shorter than kMinFused frames, or any bounded wait that runs
 // out) is FLAGGED: its scores are recomputed here with exact log-sum-exps, its gradients by the exact stand-alone code
@@ -38,12 +40,16 @@
 namespace asg {
 namespace {
 
-constexpr int kRow = 32;        // consumer -> row finisher ring of grad_inputs rows (frames)
-constexpr int kAR = 32;         // aligned chain -> finisher ring of aligned states (frames)
+constexpr int kRow = 64;        // consumer -> row finisher ring of grad_inputs rows (frames)
+constexpr int kAR = 64;         // aligned chain -> finisher ring of aligned states (frames)
 constexpr int kGS = 8;          // frames per poll of the consumers / finishers
 constexpr int kMinFused = 4;
 constexpr int kAF = 3;          // aligned finisher wavefronts per side (round-robin over 8-index groups)
-constexpr int kRF = 1;          // row finisher wavefronts per side
+#ifndef ASG_X_NC
+#define ASG_X_NC 2
+#endif
+constexpr int kNC = ASG_X_NC;   // consumer wavefronts per full workgroup (round-robin over 8-index groups of the second half)
+constexpr int kRF = 2;          // row finisher wavefronts per side
 constexpr int kFusedThreads = 768;
 constexpr unsigned kSc1 = 16;   // buffer load/store aux bit: agent scope (served by / written through to L2)
 
@@ -60,11 +66,11 @@ struct FusedSide {                                        // one direction (alph
     unsigned fx[kRF][kGS][64];                           // row finisher k: fixed-point scatter of the aligned posteriors
     double zsum;
     int e_prod, csum, main_done, prod_done, kill;
-    // TWO consumer wavefronts per side: wave 0 takes the whole first half and the even 8-index groups of the second
-    // half, wave 1 the odd groups.  cd[k] = (last index of wave k's latest group) + 8: everything up to
-    // min(cd[0], cd[1]) has been taken out of the rings (wave 1 counts as "infinitely far" during the first half).
-    int cd[2];
-    int rd[2];        // consumer k: rows of its groups up to index rd[k] - 1 are in `row`
+    // kNC consumer wavefronts: wave 0 takes the whole first half; in the second half wave k takes the 8-index groups
+    // k, k + kNC, ...  cd[k] = (last index of wave k's latest group) + 8 (kNC - 1): everything up to the minimum over k has
+    // been taken out of the rings (waves 1.. count as "infinitely far" during the first half).
+    int cd[kNC];
+    int rd[kNC];      // consumer k: rows of its groups up to index rd[k] - 1 are in `row`
     int st_done;      // consumer 0: state rows of indices [0, st_done) are in HBM/L2 and visible
     int fd[kRF];      // row finisher k: (count of indices through its latest group) + 8 * (kRF - 1); the row ring is free
                       // up to min over k (same prefix rule as cd)
@@ -74,8 +80,10 @@ struct FusedSide {                                        // one direction (alph
         return v;
     }
     __device__ __forceinline__ int consumed() {
-        return min(__hip_atomic_load(&cd[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP),
-                   __hip_atomic_load(&cd[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        int v = __hip_atomic_load(&cd[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+        for (int k = 1; k < kNC; ++k) v = min(v, __hip_atomic_load(&cd[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        return v;
     }
     __device__ __forceinline__ float *pslot(int n) { return p[n & (kFR - 1)]; }
     __device__ __forceinline__ bool stop() { return __hip_atomic_load(&kill, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0; }
@@ -83,7 +91,7 @@ struct FusedSide {                                        // one direction (alph
 
 constexpr int kMaxBlk = 128;                              // blocks of 16 indices per half whose offsets the finisher keeps in LDS
 struct AliSide {                                          // one direction of the ALIGNED workgroup
-    float ar[kAR][64];                                   // aligned states, chain -> finisher (slot (index - 1) & 31)
+    float ar[kAR][64];                                   // aligned states, chain -> finisher (slot (index - 1) & (kAR - 1))
     double cb[4][2];                                     // per 16-index block (slot j & 3): offset at block entry, per-index step
     double ob[kMaxBlk][2];                               // finisher: the OTHER side's first-half block offsets (from HBM, once);
                                                          // entry j + 1 = block j, entry 0 = {0, 0} for index 0
@@ -104,26 +112,40 @@ struct AliSide {                                          // one direction of th
 struct UttSync {
     unsigned prog[2][kAF];  // aligned finisher k of a side: the aligned posteriors of ITS groups up to index prog - 1 are in P2
     unsigned adone;         // aligned workgroup: 1 = finished (edges + score written), 2 = finished but gave up
-    unsigned pad;
+    unsigned st_done[2];    // full workgroup alpha / beta: the states of its indices [0, st_done) are visible (xstate)
+    unsigned kill;          // any of the three workgroups gave up on the fused path for this utterance
+    unsigned arrive;        // full workgroups that have finished (the second one closes the utterance)
+    unsigned pad[5];
 };
+static_assert(sizeof(UttSync) == 64, "asg_loss_fused_sync_bytes");
+
+// First-half states of a full chain for the other side: blocks of 8 indices, [block][quad][lane][4 indices] floats, so a
+// lane stores / loads four consecutive indices of its label with ONE 16-byte write-through access.  Index m of a side
+// with first-half length h sits at position m + ((-h) & 7): the LAST block of the half is full and aligned, and the
+// other side -- which walks these indices downwards, 8 per group, starting from the last -- reads whole blocks.
+constexpr int kXBlockBytes = 2 * 64 * 16;
+__host__ __device__ __forceinline__ int xstate_blocks(int T) { return (T + 7) / 8 + 2; }
 
 template <int NP>
 struct TileLds {
-    float sa[64][NP + 1];               // alpha-side xi sums  [to i][from j]   (before the E[i][j] factor)
-    float sb[64][NP + 1];               // beta-side xi sums   [from j][to i]   (before the F[j][i] factor)
-    unsigned long long fxT[NP * NP];    // aligned edge posteriors, fixed point, [to][from]
+    float sx[kNC][64][NP + 1];          // xi sums of consumer 0 .. kNC-1: alpha side [to i][from j], beta side [from j][to i]
+                                        // (before the E / F factor)
+    unsigned long long fxT[NP * NP];    // aligned edge posteriors, fixed point, [to][from]  (alpha workgroup)
 };
 
 template <int NP>
 struct FusedShared {
     union U {
-        struct G { FusedSide A, B; } g;
+        FusedSide g;
         struct H { AliSide A, B; } h;
-        TileLds<NP> t;
     } u;
-    float xa[64], xb[64];
+    TileLds<NP> t;       // beside the rings, not over them: each consumer adds its accumulators as its LAST act, so they are
+                         // not live across the roles (as values handed to the epilogue they were spilled inside the loop)
     double score_full, score_ali;
-    int adone;
+    int adone, last;
+    float xs[64];
+    // one workgroup per compute unit (160 KB of LDS): see the header
+    char pad[(sizeof(U) + sizeof(TileLds<NP>) + 512 < 84 * 1024) ? 84 * 1024 - sizeof(U) - sizeof(TileLds<NP>) - 512 : 16];
 };
 
 // ---- kernel parameters ------------------------------------------------------------------------------------------
@@ -164,7 +186,7 @@ __device__ __forceinline__ FusedArgs ld_fargs(KParams k) {
     FusedArgs F;
     F.loss = k->F.loss; F.scores = k->F.scores; F.grad_inputs = k->F.grad_inputs; F.tiles = k->F.tiles;
     F.flags = k->F.flags; F.dump = k->F.dump; F.p2 = k->F.p2; F.edges = k->F.edges; F.ascore = k->F.ascore;
-    F.aoff = k->F.aoff; F.sync = k->F.sync; F.ticket2 = k->F.ticket2; F.grad_loss = k->F.grad_loss;
+    F.aoff = k->F.aoff; F.sync = k->F.sync; F.xstate = k->F.xstate; F.fscore = k->F.fscore; F.ticket2 = k->F.ticket2; F.grad_loss = k->F.grad_loss;
     F.grad_transition = k->F.grad_transition; F.reduction = k->F.reduction; F.gscale = k->F.gscale;
     return F;
 }
@@ -184,22 +206,46 @@ __device__ __forceinline__ FusedArgs ld_fargs(KParams k) {
 #ifdef ASG_PROBE
 __device__ unsigned g_abort_code[4];      // developer builds: site number of the last abort, and how many there were
 #endif
-template <class SideT>
-__device__ __forceinline__ void abort_all(SideT &L, SideT &O, int site = 0) {
-    lds_store_rlx(&L.kill, 1);
-    lds_store_rlx(&O.kill, 1);
+__device__ __forceinline__ void note_abort(int site) {
 #ifdef ASG_PROBE
     if ((threadIdx.x & 63) == 0) { g_abort_code[0] = (unsigned) site; atomicAdd(&g_abort_code[1], 1u); g_abort_code[2] = blockIdx.x; }
 #endif
 }
 
+// How a role gives up / learns that somebody else has.  Inside a workgroup the word is in LDS (polled by every bounded
+// wait); across the three workgroups of an utterance it is UttSync::kill, polled by every wait on a global word.
+struct FullCtl {
+    FusedSide *L;
+    UttSync *us;
+    __device__ __forceinline__ bool stop() const { return L->stop(); }
+    __device__ __forceinline__ void abort(int site) const {
+        lds_store_rlx(&L->kill, 1);
+        __hip_atomic_store(&us->kill, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        note_abort(site);
+    }
+    __device__ __forceinline__ bool killed_elsewhere() const {
+        return __hip_atomic_load(&us->kill, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    }
+};
+struct AliCtl {
+    AliSide *L, *O;
+    UttSync *us;
+    __device__ __forceinline__ bool stop() const { return L->stop(); }
+    __device__ __forceinline__ void abort(int site) const {
+        lds_store_rlx(&L->kill, 1);
+        lds_store_rlx(&O->kill, 1);
+        __hip_atomic_store(&us->kill, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        note_abort(site);
+    }
+};
+
 // bounded wait until *p >= need; false on abort / time-out (then everything is aborted)
-template <class SideT>
-__device__ __forceinline__ bool wait_ge(int *p, int need, SideT &L, SideT &O) {
+template <class Ctl>
+__device__ __forceinline__ bool wait_ge(int *p, int need, const Ctl &c) {
     int spins = 0;
     while (lds_load_rlx(p) < need) {
-        if (L.stop()) return false;
-        if (++spins > kSpinCap) { abort_all(L, O, 1); return false; }
+        if (c.stop()) return false;
+        if (++spins > kSpinCap) { c.abort(1); return false; }
         __builtin_amdgcn_s_sleep(6);
     }
     asm volatile("" ::: "memory");
@@ -207,16 +253,24 @@ __device__ __forceinline__ bool wait_ge(int *p, int need, SideT &L, SideT &O) {
 }
 
 // bounded wait until L.finished() >= need
-template <class SideT>
-__device__ __forceinline__ bool wait_finished(int need, SideT &L, SideT &O) {
+template <class Ctl>
+__device__ __forceinline__ bool wait_finished(int need, const Ctl &c) {
     int spins = 0;
-    while (L.finished() < need) {
-        if (L.stop()) return false;
-        if (++spins > kSpinCap) { abort_all(L, O, 2); return false; }
+    while (c.L->finished() < need) {
+        if (c.stop()) return false;
+        if (++spins > kSpinCap) { c.abort(2); return false; }
         __builtin_amdgcn_s_sleep(6);
     }
     asm volatile("" ::: "memory");
     return true;
+}
+
+// v_rcp_f32 is good to 1 ulp but not unbiased: sums of thousands of posteriors that should cancel exactly (tiny alphabets:
+// the full-lattice and the aligned edge posteriors are the same numbers) see the bias.  One Newton step removes it.
+__device__ __forceinline__ float rcp_nr(float x) {
+    const float r = Num<float>::rcp(x);
+    const float e = fmaf(-x, r, 1.0f);              // NaN for x = 0, inf (r = inf, 0): keep r then
+    return (e == e) ? fmaf(e, r, r) : r;
 }
 
 __device__ __forceinline__ float buf_load_sc1(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
@@ -225,15 +279,16 @@ __device__ __forceinline__ float buf_load_sc1(__amdgpu_buffer_rsrc_t rs, unsigne
 __device__ __forceinline__ void buf_store_sc1(float v, __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, voff, soff, kSc1);
 }
-// global progress word of another workgroup: bounded relaxed agent-scope poll (one lane's value, uniform)
-template <class SideT>
-__device__ __forceinline__ bool wait_global_ge(unsigned *p, unsigned need, unsigned &seen, SideT &L, SideT &O) {
+// global progress word of another workgroup: bounded relaxed agent-scope poll (one lane's value, uniform); the
+// utterance's kill word (same cache line) is polled with it
+__device__ __forceinline__ bool wait_global_ge(unsigned *p, unsigned need, unsigned &seen, const FullCtl &c) {
     int spins = 0;
     while (seen < need) {
         seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         if (seen >= need) break;
-        if (L.stop()) return false;
-        if (++spins > kSpinCap) { abort_all(L, O, 3); return false; }
+        if (c.stop()) return false;
+        if (c.killed_elsewhere()) { c.abort(12); return false; }
+        if (++spins > (kSpinCap >> 4)) { c.abort(3); return false; }
         __builtin_amdgcn_s_sleep(16);
     }
     return true;
@@ -241,7 +296,8 @@ __device__ __forceinline__ bool wait_global_ge(unsigned *p, unsigned need, unsig
 
 // ------------------------------------------------------------------ recursion wavefront
 template <int NP, bool BETA>
-__device__ __forceinline__ void fused_main(const Problem &P, int b, FusedSide &L, FusedSide &O, int len, void *dbg) {
+__device__ __forceinline__ void fused_main(const Problem &P, int b, FusedSide &L, UttSync *us, int len, void *dbg) {
+    const FullCtl ctl{&L, us};
     typedef float R;
     PRB_DECL
     const int lane = threadIdx.x & 63;
@@ -273,7 +329,7 @@ __device__ __forceinline__ void fused_main(const Problem &P, int b, FusedSide &L
             asm volatile("" ::: "memory");
             if (kl) return;
             if (ep >= need) break;
-            if (++spins > kSpinCap) { abort_all(L, O, 4); return; }
+            if (++spins > kSpinCap) { ctl.abort(4); return; }
             __builtin_amdgcn_s_sleep(1);
         })
         const int need_next = min(n0 + 2 * kPF, len);
@@ -293,26 +349,32 @@ __device__ __forceinline__ void fused_main(const Problem &P, int b, FusedSide &L
 // that lead to index m, v_{m-1} (= p slot m-1) the vector that produced them.  Indices < h are the side's first half.
 template <int NP, bool BETA>
 __device__ __forceinline__ void fused_consumer(const Problem &P, const State &W, const FusedArgs &F, int b, FusedSide &L,
-                                               FusedSide &O, int len, int h, V4<float> (&acc)[((NP + 15) / 16) * ((NP + 15) / 16)],
-                                               double &score_out2, const int cw) {
+                                               UttSync *us, int len, int h, float (&sx)[64][NP + 1], double &score_out2, const int cw) {
     typedef float R;
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
     constexpr int NT = (NP + 15) / 16;
+    const FullCtl ctl{&L, us};
     const int lane = threadIdx.x & 63;
     const int N = P.N, T = P.T;
     const R NINF = Num<R>::ninf();
     const bool act = lane < N;
     const unsigned long long actmask = __ballot(act);
     const int lc = act ? lane : 0;
-    const unsigned row_bytes = (unsigned) N * sizeof(R);
-    __amdgpu_buffer_rsrc_t rs = make_rsrc((R *) (BETA ? W.bh : W.ah) + (int64_t) b * T * N, (unsigned) T * row_bytes);
-    __amdgpu_buffer_rsrc_t ro = make_rsrc((R *) (BETA ? W.ah : W.bh) + (int64_t) b * T * N, (unsigned) T * row_bytes);
-    const unsigned voff = act ? (unsigned) lane * sizeof(R) : kOobOffset;
-    const unsigned vld = (unsigned) lc * (unsigned) sizeof(R);
-    auto frame = [&](int n) { return BETA ? len - 1 - n : n; };
+    // exchanged first-half states (see kXBlockBytes): own region written in the first half, the other side's read in the second
+    const int xb = xstate_blocks(T);
+    char *xbase = (char *) F.xstate + (int64_t) b * 2 * xb * kXBlockBytes;
+    __amdgpu_buffer_rsrc_t rs = make_rsrc(xbase + (int64_t) (BETA ? 1 : 0) * xb * kXBlockBytes, (unsigned) xb * kXBlockBytes);
+    __amdgpu_buffer_rsrc_t ro = make_rsrc(xbase + (int64_t) (BETA ? 0 : 1) * xb * kXBlockBytes, (unsigned) xb * kXBlockBytes);
+    const unsigned voff = act ? (unsigned) lane * 16u : kOobOffset;
+    const unsigned vld = (unsigned) lc * 16u;
+    const int phi = (-h) & 7, phiO = (-(len - h)) & 7;
     const R gscale = F.gscale;
     score_out2 = -1e300;
+    V4<float> acc[NT * NT];
+#pragma unroll
+    for (int q = 0; q < NT * NT; ++q) acc[q] = V4<float>{0, 0, 0, 0};
     PRB_DECL
-    if (!wait_ge(&L.e_prod, 1, L, O)) return;                 // X and block 0 of the rings are there
+    if (!wait_ge(&L.e_prod, 1, ctl)) return;                  // X and block 0 of the rings are there
     const R XX = lds_ldf(&L.x[lane]);
     R sv = act ? Num<R>::exp2(-XX) : R(0);
     auto wait_slot = [&](int m) {                             // until main has written s_m (main writes in order)
@@ -322,56 +384,81 @@ __device__ __forceinline__ void fused_consumer(const Problem &P, const State &W,
             const R v = lds_ldf(slot);
             if (__ballot(__float_as_uint(v) != kSentinel) == ~0ull) return true;
             if (L.stop()) return false;
-            if (++spins > kSpinCap) { abort_all(L, O, 5); return false; }
+            if (++spins > kSpinCap) { ctl.abort(5); return false; }
             __builtin_amdgcn_s_sleep(3);          // ~1 recursion step: every poll is an LDS access the recursion waits behind
         }
     };
-    int n = 1;
     if (cw == 0) {
-    buf_store((BETA ? XX : lds_ldf(&L.a[0][lane])) + Num<R>::log2(sv), rs, voff, (unsigned) frame(0) * row_bytes);
-    // ---- first half (consumer 0 only): log-domain state of indices 1 .. h-1 to HBM for the other side
-    while (n < h) {
-        const int g = min(kGS, h - n);
-        PRB_WAIT(0, if (!wait_slot(n + g - 2)) return;)
-        R sg[kGS], ag[kGS];
+        // ---- first half (consumer 0 only): log-domain state of indices 0 .. h-1 for the other side, 8 positions per block
+        const R v0 = (BETA ? XX : lds_ldf(&L.a[0][lane])) + Num<R>::log2(sv);
+        const int last_blk = (h - 1 + phi) >> 3;
+        for (int K = 0; K <= last_blk; ++K) {
+            const int lo = max(8 * K - phi, 1), hi = min(8 * K + 7 - phi, h - 1);     // ring indices of the block
+            R val[kGS];
+            if (hi >= lo) {
+                PRB_WAIT(0, if (!wait_slot(hi - 1)) return;)
+                R sg[kGS], ag[kGS];
 #pragma unroll
-        for (int q = 0; q < kGS; ++q) {
-            const int m = n + min(q, g - 1);
-            sg[q] = lds_ldf(&L.s[(m - 1) & (kFR - 1)][lane]);
-            ag[q] = BETA ? XX : lds_ldf(&L.a[m & (kFR - 1)][lane]);
+                for (int q = 0; q < kGS; ++q) {
+                    const int m = min(max(8 * K + q - phi, lo), hi);
+                    sg[q] = lds_ldf(&L.s[(m - 1) & (kFR - 1)][lane]);
+                    ag[q] = BETA ? XX : lds_ldf(&L.a[m & (kFR - 1)][lane]);
+                }
+                unsigned rlo = 0xffffffffu, rhi = 0;
+#pragma unroll
+                for (int q = 0; q < kGS; ++q) {
+                    const int m = min(max(8 * K + q - phi, lo), hi);
+                    lds_stf(&L.s[(m - 1) & (kFR - 1)][lane], __uint_as_float(kSentinel));
+                    const unsigned sb = Rng<R>::bits(sg[q]);
+                    rlo = min(rlo, sb);
+                    rhi = max(rhi, sb);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                lds_store_rlx(&L.cd[0], hi);
+                if ((__ballot(rlo < Rng<R>::lo || rhi > Rng<R>::hi) & actmask) != 0) { ctl.abort(6); return; }
+#pragma unroll
+                for (int q = 0; q < kGS; ++q) val[q] = ag[q] + Num<R>::log2(sg[q]);
+                sv = sg[kGS - 1];
+            } else {
+#pragma unroll
+                for (int q = 0; q < kGS; ++q) val[q] = v0;
+            }
+            if (K == 0) {
+#pragma unroll
+                for (int q = 0; q < kGS; ++q) val[q] = (q == phi) ? v0 : val[q];
+            }
+            const u4 lo4 = {__float_as_uint(val[0]), __float_as_uint(val[1]), __float_as_uint(val[2]), __float_as_uint(val[3])};
+            const u4 hi4 = {__float_as_uint(val[4]), __float_as_uint(val[5]), __float_as_uint(val[6]), __float_as_uint(val[7])};
+            __builtin_amdgcn_raw_buffer_store_b128(lo4, rs, voff, (unsigned) K * kXBlockBytes, kSc1);
+            __builtin_amdgcn_raw_buffer_store_b128(hi4, rs, voff, (unsigned) K * kXBlockBytes + 1024u, kSc1);
         }
-        unsigned lo = 0xffffffffu, hi = 0;
+        // from here on the other consumers count: consumer k's first own group starts at index h + 8 k
 #pragma unroll
-        for (int q = 0; q < kGS; ++q) {
-            const int m = n + min(q, g - 1);
-            lds_stf(&L.s[(m - 1) & (kFR - 1)][lane], __uint_as_float(kSentinel));
-            const unsigned sb = Rng<R>::bits(sg[q]);
-            lo = min(lo, sb);
-            hi = max(hi, sb);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        lds_store_rlx(&L.cd[0], n + g - 1);
-        if ((__ballot(lo < Rng<R>::lo || hi > Rng<R>::hi) & actmask) != 0) { abort_all(L, O, 6); return; }
-#pragma unroll
-        for (int q = 0; q < kGS; ++q)
-            buf_store(ag[q] + Num<R>::log2(sg[q]), rs, voff, (unsigned) frame(n + min(q, g - 1)) * row_bytes);
-        sv = sg[kGS - 1];
-        n += g;
-    }
-    // from here on consumer 1 counts: its "previous group" ends at h - 1
-    lds_store_rlx(&L.cd[1], h - 1 + kGS);
-    // the first half is complete in L2 before the other side (and consumer 1) is told so
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    lds_store_rel(&L.st_done, h);
+        for (int k = 1; k < kNC; ++k) lds_store_rlx(&L.cd[k], h - 1 + k * kGS);
+        // the first half has been written through before the other side (and consumer 1) is told so
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(&us->st_done[BETA ? 1 : 0], (unsigned) h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        lds_store_rel(&L.st_done, h);
     } else {
-        PRB_WAIT(0, if (!wait_ge(&L.st_done, h, L, O)) return;)
+        PRB_WAIT(0, if (!wait_ge(&L.st_done, h, ctl)) return;)
     }
-    n = h + cw * kGS;                     // this wavefront's first group of the second half
-    PRB_WAIT(1, if (!wait_ge(&O.st_done, len - h, L, O)) return;)
+    int n = h + cw * kGS;                 // this wavefront's first group of the second half
+    {
+        unsigned seen = 0;
+        PRB_WAIT(1, if (!wait_global_ge(&us->st_done[BETA ? 0 : 1], (unsigned) (len - h), seen, ctl)) return;)
+    }
+    // the other side's states of own indices nn .. nn+7 = ITS indices len-1-nn .. len-8-nn = one whole block (see above);
+    // write-through stores there, L2-served loads here: no fence on either side
+    auto load_other = [&](int nn, R (&dst)[kGS]) {
+        const int Kr = max((len - 1 - nn + phiO) >> 3, 0);
+        const u4 a = __builtin_amdgcn_raw_buffer_load_b128(ro, vld, (unsigned) Kr * kXBlockBytes, kSc1);
+        const u4 c = __builtin_amdgcn_raw_buffer_load_b128(ro, vld, (unsigned) Kr * kXBlockBytes + 1024u, kSc1);
+        dst[7] = __uint_as_float(a.x); dst[6] = __uint_as_float(a.y); dst[5] = __uint_as_float(a.z); dst[4] = __uint_as_float(a.w);
+        dst[3] = __uint_as_float(c.x); dst[2] = __uint_as_float(c.y); dst[1] = __uint_as_float(c.z); dst[0] = __uint_as_float(c.w);
+    };
     // ---- second half: indices h .. len-1; the other side's state of the same frames is prefetched one group ahead
     R oth[kGS];
-#pragma unroll
-    for (int q = 0; q < kGS; ++q) oth[q] = buf_load<R>(ro, vld, (unsigned) frame(min(n + q, len - 1)) * row_bytes);
+    load_other(n, oth);
     while (n < len) {
         const int g = min(kGS, len - n);
         // ring data of the group in ONE LDS round trip: main writes s in order, so once the group's LAST row sum is
@@ -401,8 +488,11 @@ __device__ __forceinline__ void fused_consumer(const Problem &P, const State &W,
             hi = max(hi, sb);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the values are in registers before the producer may refill
-        lds_store_rlx(&L.cd[cw], n + g - 1 + kGS);
-        if ((__ballot(lo < Rng<R>::lo || hi > Rng<R>::hi) & actmask) != 0) { abort_all(L, O, 7); return; }
+        lds_store_rlx(&L.cd[cw], n + g - 1 + (kNC - 1) * kGS);
+        if ((__ballot(lo < Rng<R>::lo || hi > Rng<R>::hi) & actmask) != 0) { ctl.abort(7); return; }
+        // a short last group re-processes its last frame in the unused positions (the block holds nothing there)
+#pragma unroll
+        for (int q = 1; q < kGS; ++q) oth[q] = (q < g) ? oth[q] : oth[q - 1];
         // posterior of the frame: softmax of (own state + other side's state); both are stored relative to offsets
         // that keep each frame's largest term near 1, so no max-shift -- a normaliser outside [2^-100, 2^100] aborts
         R w[kGS];
@@ -411,14 +501,12 @@ __device__ __forceinline__ void fused_consumer(const Problem &P, const State &W,
             const R gam = act ? (ag[q] + Num<R>::log2(sg[q])) + oth[q] : NINF;
             w[q] = Num<R>::exp2(gam);
         }
-        // the next own group's rows of the other side: plain loads (its first half was complete in L2 before st_done
-        // was published, and this compute unit has not touched those lines before)
+        // the next own group's block of the other side
         R othn[kGS];
-#pragma unroll
-        for (int q = 0; q < kGS; ++q) othn[q] = buf_load<R>(ro, vld, (unsigned) frame(min(n + 2 * kGS + q, len - 1)) * row_bytes);
+        load_other(n + kNC * kGS, othn);
         // ring space for the rows (the row finishers have taken index n + g - 1 - kRow): normally long true
 #ifndef ASG_X_NOROWFIN
-        PRB_WAIT(3, if (!wait_finished(n + g - kRow, L, O)) return;)
+        PRB_WAIT(3, if (!wait_finished(n + g - kRow, ctl)) return;)
 #endif
         // frames 0-3: normalisers, rows, u, first MFMA batch; then frames 4-7 while those MFMAs run
         R u[kGS];
@@ -436,36 +524,46 @@ __device__ __forceinline__ void fused_consumer(const Problem &P, const State &W,
             if (zlo < Rng<R>::lo || zhi > Rng<R>::hi) return false;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const R post = w[q0 + q] * Num<R>::rcp(Z[q]);
+                const R post = w[q0 + q] * rcp_nr(Z[q]);
                 const int m = n + min(q0 + q, g - 1);
                 lds_stf(&L.row[m & (kRow - 1)][lane], post * gscale);
                 // xi: alpha side skips its first assembled index (the beta side's last one covers that transition)
                 const bool take = q0 + q < g && (BETA || n + q0 + q > h);
-                u[q0 + q] = (take && act) ? post * Num<R>::rcp(sg[q0 + q]) : R(0);
+                u[q0 + q] = (take && act) ? post * rcp_nr(sg[q0 + q]) : R(0);
                 pg[q0 + q] = act ? pg[q0 + q] : R(0);
             }
             float ua[4] = {u[q0], u[q0 + 1], u[q0 + 2], u[q0 + 3]}, va[4] = {pg[q0], pg[q0 + 1], pg[q0 + 2], pg[q0 + 3]};
             outer4_accumulate<NT>(ua, va, acc);
             return true;
         };
-        if (!half_group(0)) { abort_all(L, O, 8); return; }
-        if (!half_group(4)) { abort_all(L, O, 9); return; }
+        if (!half_group(0)) { ctl.abort(8); return; }
+        if (!half_group(4)) { ctl.abort(9); return; }
         asm volatile("" ::: "memory");
         lds_store_rlx(&L.rd[cw], n + g);
 #pragma unroll
         for (int q = 0; q < kGS; ++q) oth[q] = othn[q];
         sv = sg[kGS - 1];
-        n += 2 * kGS;
+        n += kNC * kGS;
     }
     // (a consumer without a last group still has to let the producer's bookkeeping see "everything taken")
-    lds_store_rlx(&L.cd[cw], len + 2 * kGS);
+    lds_store_rlx(&L.cd[cw], len + kNC * kGS);
+    // this wavefront's xi sums: element (16 r + 4 (lane >> 4) + q, 16 c + (lane & 15)) of tile (r, c)
+#pragma unroll
+    for (int r = 0; r < NT; ++r)
+#pragma unroll
+        for (int c = 0; c < NT; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = 16 * r + 4 * (lane >> 4) + q, j = 16 * c + (lane & 15);
+                if (j <= NP) sx[i][j] = acc[r * NT + c][q];
+            }
     // ---- end of the chain: score (beta side), by the consumer that took the last group; as the three-wavefront kernel
-    if (((((len - h + kGS - 1) / kGS) - 1) & 1) != cw) return;
+    if (((((len - h + kGS - 1) / kGS) - 1) % kNC) != cw) return;
     {
         int spins = 0;
         while (!(lds_load_acq(&L.main_done) && lds_load_acq(&L.prod_done))) {
             if (L.stop()) return;
-            if (++spins > kSpinCap) { abort_all(L, O, 10); return; }
+            if (++spins > kSpinCap) { ctl.abort(10); return; }
             __builtin_amdgcn_s_sleep(1);
         }
     }
@@ -475,13 +573,13 @@ __device__ __forceinline__ void fused_consumer(const Problem &P, const State &W,
         const R vlast = sv * lds_ldf(&L.e[(len - 1) & (kFR - 1)][lane]);
         const R sm = wave_allsum(act ? vlast : R(0));
         const unsigned smb = Rng<R>::bits(sm);
-        if (!(smb >= Rng<R>::lo && smb <= Rng<R>::hi)) { abort_all(L, O, 11); return; }
+        if (!(smb >= Rng<R>::lo && smb <= Rng<R>::hi)) { ctl.abort(11); return; }
         score_out2 = zsum + (double) csum + (double) Num<R>::log2(sm);
     }
     PRB_END(W.dbg, BETA ? 3 : 2)
 }
 
-// 16 (GUARD: nsteps) steps of an aligned chain; the state of index m0 + k goes to ring slot (m0 + k - 1) & 31 -- blocks
+// 16 (GUARD: nsteps) steps of an aligned chain; the state of index m0 + k goes to ring slot (m0 + k - 1) & (kAR - 1) -- blocks
 // start at m0 = 1 + 16 j, so the 16 slots of a block are consecutive and every ring store is base + constant -- and to HBM
 // (every index, as the stand-alone chains do: a per-step "first half only" test costs more than the bytes).
 // Branch-free inside a full block so that consecutive steps overlap.
@@ -519,8 +617,9 @@ __device__ __forceinline__ void aligned_steps(const float (&cur)[kPF], int nstep
 // finisher of this side, and only the first half goes to HBM (for the finisher of the other side).
 template <bool BETA>
 __device__ __forceinline__ void fused_aligned(const Problem &P, const State &W, int b, AliSide &L, AliSide &O, int len,
-                                              int h, double &score_out2, void *aoff) {
+                                              int h, double &score_out2, void *aoff, UttSync *us) {
     typedef float R;
+    const AliCtl ctl{&L, &O, us};
     const int lane = threadIdx.x & 63;
     const int T = P.T, S = P.S;
     const AlignedSetup<R> A = aligned_setup<R>(P, b, lane);
@@ -538,7 +637,7 @@ __device__ __forceinline__ void fused_aligned(const Problem &P, const State &W, 
     else st = (lane == A.ol - 1) ? 0.0 : kLZd;
     {
         const R v = to_state<R>(st);
-        L.ar[kAR - 1][lane] = v;                         // slot (0 - 1) & 31
+        L.ar[kAR - 1][lane] = v;                         // slot (0 - 1) & (kAR - 1)
         buf_store(v, rs, voff, (unsigned) frame(0) * row_bytes);
     }
     bool told = false;
@@ -560,11 +659,12 @@ __device__ __forceinline__ void fused_aligned(const Problem &P, const State &W, 
     R last_raw = cur[0];
     // block prologue: ring space, renormalisation, block scale, per-block offsets; returns the emission bias of the block
     auto block_begin = [&](int done, int nsteps, bool &ok) -> double {
-        // ring space: the slots this block overwrites held indices m0-32 .. m0-17, last needed (as "previous") by m0-16
+        // ring space: the slots this block overwrites held indices m0-kAR .. m0-kAR+15, last needed (as "previous") by
+        // index m0-kAR+16
         const int m0 = 1 + done;
         ok = true;
 #ifndef ASG_X_NOFIN
-        PRB_WAIT(0, ok = wait_finished(m0 - 15, L, O);)
+        PRB_WAIT(0, ok = wait_finished(m0 + 17 - kAR, ctl);)
 #endif
         {
             const R m = wave_allmax((R) st);
@@ -640,6 +740,7 @@ template <bool BETA>
 __device__ __forceinline__ void fused_afin(const Problem &P, const State &W, const FusedArgs &F, int b, AliSide &L,
                                            AliSide &O, int len, int h, UttSync *us, const int fw) {
     typedef float R;
+    const AliCtl ctl{&L, &O, us};
     const int lane = threadIdx.x & 63;
     const int T = P.T, S = P.S;
     const R LZ = Num<R>::logzero();
@@ -668,9 +769,11 @@ __device__ __forceinline__ void fused_afin(const Problem &P, const State &W, con
         const V2<double> c = *reinterpret_cast<const V2<double> *>(&L.ob[j + 1][0]);
         return c.x + c.y * (double) (k + 1);
     };
-    R accH = 0, accS = 0;          // sum of stay-edge posteriors; sum of state posteriors of frames >= 1 (arrive = accS - accH)
+    // sum of stay-edge posteriors; sum of state posteriors of frames >= 1 (arrive = accS - accH).  In double: a position
+    // the alignment dwells on collects ~100 posteriors of ~1 per finisher, and fp32 would round each add at 4e-6
+    double accH = 0, accS = 0;
     PRB_DECL
-    PRB_WAIT(0, if (!wait_ge(&O.ast_done, len - h, L, O)) return;)      // the other side's aligned first half is visible
+    PRB_WAIT(0, if (!wait_ge(&O.ast_done, len - h, ctl)) return;)      // the other side's aligned first half is visible
     // its block offsets, once, into LDS (launch_fused_forward admits at most kMaxBlk - 1 blocks per half)
     {
         const int oblk = (len - h + kPF - 1) / kPF;
@@ -692,7 +795,7 @@ __device__ __forceinline__ void fused_afin(const Problem &P, const State &W, con
     bool feasible = false, calibrated = false;
     while (n < len) {
         const int g = min(kGS, len - n);
-        PRB_WAIT(1, if (!wait_ge(&L.ar_done, n + g, L, O)) return;)
+        PRB_WAIT(1, if (!wait_ge(&L.ar_done, n + g, ctl)) return;)
         R own[kGS], ownp[kGS];
         double K[kGS];
 #pragma unroll
@@ -726,6 +829,21 @@ __device__ __forceinline__ void fused_afin(const Problem &P, const State &W, con
             const R arg = (R) ((double) (own[q] + oth[q]) + (K[q] - Sd));
             p2v[q] = (feasible && sl) ? Num<R>::exp2(arg) : R(0);
         }
+        // The offsets give the posterior up to 1 + O(1e-6) per position (fp32 rounding of the two stored states); over
+        // hundreds of frames of a lattice whose edge posteriors must cancel against the full lattice's (tiny alphabets)
+        // that shows.  Renormalise every frame over the positions, as the reference's softmax does
+        // (force_aligned_lattice.cpp:164-166); a sum far from 1 can only be an infeasible or underflowed frame: left alone.
+#ifndef ASG_X_NORENORM
+        {
+            R z0 = p2v[0], z1 = p2v[1], z2 = p2v[2], z3 = p2v[3];
+            wave_allsum4(z0, z1, z2, z3);
+            R z4 = p2v[4], z5 = p2v[5], z6 = p2v[6], z7 = p2v[7];
+            wave_allsum4(z4, z5, z6, z7);
+            const R Z[kGS] = {z0, z1, z2, z3, z4, z5, z6, z7};
+#pragma unroll
+            for (int q = 0; q < kGS; ++q) p2v[q] *= (Z[q] > R(0.99) && Z[q] < R(1.01)) ? R(2) - Z[q] : R(1);    // 1/Z to 1e-8
+        }
+#endif
         {
             typedef unsigned u4 __attribute__((ext_vector_type(4)));
             const unsigned qoff = (unsigned) ((n - h) >> 2) * (unsigned) S * 16u;
@@ -744,8 +862,9 @@ __device__ __forceinline__ void fused_afin(const Problem &P, const State &W, con
                     const R abprev = BETA ? ((q + 1 < g) ? oth[(q + 1) & (kGS - 1)] : obelow) : ownp[q];
                     const R ap = sl ? abprev : LZ;
                     const R d = (prev_lane_or_zero<R>(ap) + Dprev) - (ap + H2);
-                    accH += post2 * Num<R>::rcp(R(1) + Num<R>::exp2(d));
-                    accS += post2;
+                    // (plain v_rcp: its bias only moves 1e-7 of the posterior between the stay and the arrive edge)
+                    accH += (double) (post2 * Num<R>::rcp(R(1) + Num<R>::exp2(d)));
+                    accS += (double) post2;
                 }
             }
         }
@@ -762,10 +881,9 @@ __device__ __forceinline__ void fused_afin(const Problem &P, const State &W, con
     lds_store_rlx(&L.fd[fw], len + kAF * kGS);
     // edge posteriors of this side: [stay | arrive] per target position
     {
-        R *ed = (R *) F.edges + (((int64_t) b * 2 + (BETA ? 1 : 0)) * kAF + fw) * 128;
-        __amdgpu_buffer_rsrc_t re = make_rsrc(ed, 128u * (unsigned) sizeof(R));
-        buf_store_sc1(accH, re, (unsigned) lane * 4u, 0u);
-        buf_store_sc1(accS - accH, re, (unsigned) lane * 4u, 256u);
+        double *ed = (double *) F.edges + (((int64_t) b * 2 + (BETA ? 1 : 0)) * kAF + fw) * 128;
+        __hip_atomic_store(ed + lane, accH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(ed + 64 + lane, accS - accH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) __hip_atomic_store(prog, (unsigned) (len + kAF * kGS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -776,8 +894,9 @@ __device__ __forceinline__ void fused_afin(const Problem &P, const State &W, con
 // final row of every second-half frame of this side: gscale * (full posterior - aligned posterior scattered to labels)
 template <bool BETA>
 __device__ __forceinline__ void fused_rowfin(const Problem &P, const State &W, const FusedArgs &F, int b, FusedSide &L,
-                                             FusedSide &O, int len, int h, UttSync *us, const int rw) {
+                                             int len, int h, UttSync *us, const int rw) {
     typedef float R;
+    const FullCtl ctl{&L, us};
     const int lane = threadIdx.x & 63;
     const int N = P.N, T = P.T, S = P.S;
     const unsigned rbS = (unsigned) S * sizeof(R);
@@ -814,9 +933,9 @@ __device__ __forceinline__ void fused_rowfin(const Problem &P, const State &W, c
         const unsigned need = (unsigned) min(nn + kGS, len);
         const int w = gi % kAF;
         bool ok = true;
-        if (w == 0) ok = wait_global_ge(progs + 0, need, seen[0], L, O);
-        else if (w == 1) ok = wait_global_ge(progs + 1, need, seen[1], L, O);
-        else ok = wait_global_ge(progs + 2, need, seen[2], L, O);
+        if (w == 0) ok = wait_global_ge(progs + 0, need, seen[0], ctl);
+        else if (w == 1) ok = wait_global_ge(progs + 1, need, seen[1], ctl);
+        else ok = wait_global_ge(progs + 2, need, seen[2], ctl);
         return ok;
     };
     PRB_DECL
@@ -839,7 +958,7 @@ __device__ __forceinline__ void fused_rowfin(const Problem &P, const State &W, c
             PRB_WAIT(1, if (!wait_p2(n + kRF * kGS)) return;)
             load_group(n + kRF * kGS, p2n);
         }
-        PRB_WAIT(2, if (!wait_ge(&L.rd[((n - h) / kGS) & 1], n + g, L, O)) return;)
+        PRB_WAIT(2, if (!wait_ge(&L.rd[((n - h) / kGS) % kNC], n + g, ctl)) return;)
         R rowv[kGS];
 #pragma unroll
         for (int q = 0; q < kGS; ++q) rowv[q] = L.row[(n + min(q, g - 1)) & (kRow - 1)][lane];
@@ -916,11 +1035,19 @@ __device__ __forceinline__ void aligned_workgroup(int b, FusedShared<NP> &SH) {
         const State W = ld_state(kernarg_params());
         const FusedArgs F = ld_fargs(kernarg_params());
         switch (wave) {
-            case 0: fused_aligned<false>(P, W, b, LA, LB, len, mid, sc2, (double *) F.aoff + ((int64_t) b * 2 + 0) * ((T + kPF - 1) / kPF + 1) * 2); break;
-            case 1: fused_aligned<true>(P, W, b, LB, LA, len, len - mid, sc2, (double *) F.aoff + ((int64_t) b * 2 + 1) * ((T + kPF - 1) / kPF + 1) * 2); break;
+            case 0: __builtin_amdgcn_s_setprio(3); fused_aligned<false>(P, W, b, LA, LB, len, mid, sc2, (double *) F.aoff + ((int64_t) b * 2 + 0) * ((T + kPF - 1) / kPF + 1) * 2, us); break;
+            case 1: __builtin_amdgcn_s_setprio(3); fused_aligned<true>(P, W, b, LB, LA, len, len - mid, sc2, (double *) F.aoff + ((int64_t) b * 2 + 1) * ((T + kPF - 1) / kPF + 1) * 2, us); break;
 #ifndef ASG_X_NOFIN
+#ifdef ASG_X_FIN_SPREAD
+            // third finisher of a side beside the OTHER side's chain (low priority there), not on its own side's SIMD
+            case 2: case 6: fused_afin<false>(P, W, F, b, LA, LB, len, mid, us, (wave - 2) >> 2); break;
+            case 3: case 7: fused_afin<true>(P, W, F, b, LB, LA, len, len - mid, us, (wave - 3) >> 2); break;
+            case 9: fused_afin<false>(P, W, F, b, LA, LB, len, mid, us, 2); break;
+            case 8: fused_afin<true>(P, W, F, b, LB, LA, len, len - mid, us, 2); break;
+#else
             case 2: case 6: case 10: fused_afin<false>(P, W, F, b, LA, LB, len, mid, us, (wave - 2) >> 2); break;
             case 3: case 7: case 11: fused_afin<true>(P, W, F, b, LB, LA, len, len - mid, us, (wave - 3) >> 2); break;
+#endif
 #endif
             default: break;
         }
@@ -941,73 +1068,62 @@ __device__ __forceinline__ void aligned_workgroup(int b, FusedShared<NP> &SH) {
             ((R *) W.rmax)[lane] = Ri;
         }
     }
+    if (wave == 5 && b == 0 && lane != 1) F.ticket2[lane] = 0;        // for the backward launch (word 1: see the closing workgroup)
     __syncthreads();
     if (threadIdx.x == 0) {
         const bool gave_up = !fused || LA.stop() || LB.stop();
-        ((double *) F.ascore)[b] = SH.score_ali;          // read back by the full workgroup with an agent-scope load
+        ((double *) F.ascore)[b] = SH.score_ali;          // read back by the closing full workgroup with an agent-scope load
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_store(&us->adone, gave_up ? 2u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
-template <int NP>
-__device__ __forceinline__ void full_epilogue(int b, FusedShared<NP> &SH, bool fused,
-                                              V4<float> (&acc)[((NP + 15) / 16) * ((NP + 15) / 16)]);
-
-template <int NP>
+// One direction of the fully-connected lattice of utterance b.
+template <int NP, bool BETA>
 __device__ __forceinline__ void full_workgroup(int b, FusedShared<NP> &SH) {
     typedef float R;
     constexpr int NT = (NP + 15) / 16;
     const Problem P = ld_problem(kernarg_params());
-    const State W = ld_state(kernarg_params());
     const FusedArgs F = ld_fargs(kernarg_params());
-    FusedSide &LA = SH.u.g.A, &LB = SH.u.g.B;
+    FusedSide &L = SH.u.g;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int N = P.N, T = P.T;
     const int len = __builtin_amdgcn_readfirstlane(P.in_len ? clampi(P.in_len[b], 0, T) : T);
     const int mid = len / 2;
+    const int h = BETA ? len - mid : mid;
     const bool fused = len >= kMinFused;
     UttSync *us = reinterpret_cast<UttSync *>(F.sync + 64) + b;
 
     if (threadIdx.x == 0) {
-        FusedSide *sd[2] = {&LA, &LB};
-        for (int k = 0; k < 2; ++k) {
-            FusedSide &L = *sd[k];
-            const int h = k == 0 ? mid : len - mid;
-            L.e_prod = 0; L.csum = 0; L.main_done = 0; L.prod_done = 0; L.kill = 0;
-            L.cd[0] = 0; L.cd[1] = 1 << 30; L.rd[0] = h; L.rd[1] = h;
-            L.st_done = 0;
-            for (int k2 = 0; k2 < kRF; ++k2) L.fd[k2] = h + k2 * kGS;
-        }
+        L.e_prod = 0; L.csum = 0; L.main_done = 0; L.prod_done = 0; L.kill = 0;
+        for (int k = 0; k < kNC; ++k) { L.cd[k] = k == 0 ? 0 : 1 << 30; L.rd[k] = h; }
+        L.st_done = 0;
+        for (int k2 = 0; k2 < kRF; ++k2) L.fd[k2] = h + k2 * kGS;
         SH.score_full = -1e300;
         SH.adone = 0;
+        SH.last = 0;
     }
 #ifdef ASG_PROBE
     const long long ep_t0 = clock64();
-    if (b == 0 && threadIdx.x == 0) ((long long *) W.dbg)[50] = ep_t0;
+    if (b == 0 && !BETA && threadIdx.x == 0) ((long long *) ld_state(kernarg_params()).dbg)[50] = ep_t0;
 #endif
-    if (b == 0 && threadIdx.x < 64 && threadIdx.x != 1) F.ticket2[threadIdx.x] = 0;        // for the backward launch
-    for (int q = threadIdx.x; q < kFR * 64; q += kFusedThreads) {
-        (&LA.s[0][0])[q] = __uint_as_float(kSentinel);
-        (&LB.s[0][0])[q] = __uint_as_float(kSentinel);
-    }
+    for (int q = threadIdx.x; q < kFR * 64; q += kFusedThreads) (&L.s[0][0])[q] = __uint_as_float(kSentinel);
+    TileLds<NP> &TL = SH.t;
+    for (int k = threadIdx.x; k < kNC * 64 * (NP + 1); k += kFusedThreads) (&TL.sx[0][0][0])[k] = 0;
+    for (int k = threadIdx.x; k < NP * NP; k += kFusedThreads) TL.fxT[k] = 0;
     __syncthreads();
 
-    V4<float> acc[NT * NT];
-#pragma unroll
-    for (int q = 0; q < NT * NT; ++q) acc[q] = V4<float>{0, 0, 0, 0};
     double sc2 = -1e300;
 #ifdef ASG_PROBE
-    if (b == 0 && threadIdx.x == 0) ((long long *) W.dbg)[51] = clock64();
+    if (b == 0 && !BETA && threadIdx.x == 0) ((long long *) ld_state(kernarg_params()).dbg)[51] = clock64();
 #endif
 
     // ---- phase 1: the roles.  Control flow is uniform per wavefront; nothing in here uses a workgroup barrier.
-    if (wave == 8) {
+    // Wavefront 4 (the recursion wavefront's SIMD) and 6 .. 11 go straight to the barrier: a waiting wavefront issues nothing.
+    if (!BETA && wave == 10) {
         // padded frames get exactly-zero gradients (the reference: roll_to_end + masked softmax, utils.cpp:11-66)
-        const Problem P = ld_problem(kernarg_params());
-        const FusedArgs F = ld_fargs(kernarg_params());
         __amdgpu_buffer_rsrc_t rs_g = make_rsrc((R *) F.grad_inputs + (int64_t) b * N,
                                                 (unsigned) ((int64_t) (T - 1) * P.B * N + N) * (unsigned) sizeof(R));
         const unsigned voff = lane < N ? (unsigned) lane * sizeof(R) : kOobOffset;
@@ -1019,64 +1135,106 @@ __device__ __forceinline__ void full_workgroup(int b, FusedShared<NP> &SH) {
         const State W = ld_state(kernarg_params());
         const FusedArgs F = ld_fargs(kernarg_params());
         switch (wave) {
-            case 0: __builtin_amdgcn_s_setprio(3); fused_main<NP, false>(P, b, LA, LB, len, W.dbg); break;
-            case 1: __builtin_amdgcn_s_setprio(3); fused_main<NP, true>(P, b, LB, LA, len, W.dbg); break;
-            case 4: duo_producer<NP, false>(P, b, LA); break;
-            case 5: duo_producer<NP, true>(P, b, LB); break;
-            case 2: case 6: fused_consumer<NP, false>(P, W, F, b, LA, LB, len, mid, acc, sc2, wave == 6 ? 1 : 0); break;
-            case 3: case 7: fused_consumer<NP, true>(P, W, F, b, LB, LA, len, len - mid, acc, sc2, wave == 7 ? 1 : 0); break;
+            case 0: __builtin_amdgcn_s_setprio(3); fused_main<NP, BETA>(P, b, L, us, len, W.dbg); break;
+            case 1: duo_producer<NP, BETA>(P, b, L); break;
+            case 2: fused_consumer<NP, BETA>(P, W, F, b, L, us, len, h, TL.sx[0], sc2, 0); break;
+            case 3: fused_consumer<NP, BETA>(P, W, F, b, L, us, len, h, TL.sx[1], sc2, 1); break;
+            case 6: if (kNC > 2) fused_consumer<NP, BETA>(P, W, F, b, L, us, len, h, TL.sx[2 % kNC], sc2, 2); break;
+            case 7: if (kNC > 3) fused_consumer<NP, BETA>(P, W, F, b, L, us, len, h, TL.sx[3 % kNC], sc2, 3); break;
 #ifndef ASG_X_NOROWFIN
-            case 10: __builtin_amdgcn_s_setprio(2); fused_rowfin<false>(P, W, F, b, LA, LB, len, mid, us, 0); break;      // beside the alpha consumers
-            case 11: __builtin_amdgcn_s_setprio(2); fused_rowfin<true>(P, W, F, b, LB, LA, len, len - mid, us, 0); break;
+            case 5: fused_rowfin<BETA>(P, W, F, b, L, len, h, us, 0); break;
+            case 9: fused_rowfin<BETA>(P, W, F, b, L, len, h, us, 1); break;
 #endif
             default: break;
         }
-        if ((wave == 3 || wave == 7) && lane == 0 && sc2 > -1e299) SH.score_full = sc2;
-        if (wave == 4) SH.xa[lane] = LA.x[lane];      // the producers wrote them first thing
-        if (wave == 5) SH.xb[lane] = LB.x[lane];
+        if (BETA && lane == 0 && sc2 > -1e299) SH.score_full = sc2;
     }
     __syncthreads();
-    return full_epilogue<NP>(b, SH, fused, acc);
-}
-
-template <int NP>
-__device__ __forceinline__ void full_epilogue(int b, FusedShared<NP> &SH, bool fused,
-                                              V4<float> (&acc)[((NP + 15) / 16) * ((NP + 15) / 16)]) {
-    typedef float R;
-    constexpr int NT = (NP + 15) / 16;
-    const Problem P = ld_problem(kernarg_params());
-    const State W = ld_state(kernarg_params());
-    const FusedArgs F = ld_fargs(kernarg_params());
-    FusedSide &LA = SH.u.g.A, &LB = SH.u.g.B;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int N = P.N, T = P.T;
-    const int len = __builtin_amdgcn_readfirstlane(P.in_len ? clampi(P.in_len[b], 0, T) : T);
-    UttSync *us = reinterpret_cast<UttSync *>(F.sync + 64) + b;
 #ifdef ASG_PROBE
-    if (b == 0 && threadIdx.x == 0) ((long long *) W.dbg)[52] = clock64();
+    if (b == 0 && !BETA && threadIdx.x == 0) ((long long *) ld_state(kernarg_params()).dbg)[52] = clock64();
 #endif
-    const bool own_trouble = !fused || LA.stop() || LB.stop();
-    // the aligned workgroup's verdict, edge posteriors and score (it finishes about when this one does)
-    if (threadIdx.x == 0) {
-        unsigned v = 0;
-        int spins = 0;
-        while ((v = __hip_atomic_load(&us->adone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
-            if (++spins > (1 << 24)) { v = 3; break; }       // cannot happen: that workgroup waits for nobody
-            __builtin_amdgcn_s_sleep(4);
+    const bool own_trouble = !fused || L.stop();
+    const R xx = L.x[lane & 63];                       // row / column maxima (the producer wrote them first thing)
+    // the aligned workgroup's verdict, edge posteriors and score (it finishes about when this one does): the alpha
+    // workgroup needs the edges for its tile; whoever closes the utterance needs the verdict
+    auto wait_aligned = [&]() {
+        if (threadIdx.x == 0 && SH.adone == 0) {
+            unsigned v = 0;
+            int spins = 0;
+            while ((v = __hip_atomic_load(&us->adone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
+                if (++spins > (1 << 24)) { v = 3; break; }       // cannot happen: that workgroup waits for nobody
+                __builtin_amdgcn_s_sleep(4);
+            }
+            SH.adone = (int) v;
         }
-        SH.adone = (int) v;
+        __syncthreads();
+    };
+    wait_aligned();
+#ifdef ASG_PROBE
+    if (b == 0 && !BETA && threadIdx.x == 0) ((long long *) ld_state(kernarg_params()).dbg)[53] = clock64();
+#endif
+    if (!own_trouble && SH.adone == 1) {
+        // ---- phase 2: this side's share of the utterance's [N][N] tile
+        if (wave == 8) {
+            // aligned edge posteriors of THIS side's frames, scattered to [to][from]: with them the tile is a small
+            // residual (full-lattice and aligned edge posteriors of the same frames nearly cancel for peaked lattices),
+            // so the sum over tiles in the backward launch does not lose what the cancellation leaves
+            const AlignedSetup<R> A = aligned_setup<R>(P, b, lane);
+            const double *ed = (const double *) F.edges + ((int64_t) b * 2 + (BETA ? 1 : 0)) * kAF * 128;
+            double stay = 0, arrive = 0;
+            for (int k = 0; k < kAF; ++k) {          // fixed order
+                stay += __hip_atomic_load(ed + k * 128 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                arrive += __hip_atomic_load(ed + k * 128 + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (A.act) {
+                if (stay != 0.0) atomicAdd(&TL.fxT[A.tgt * N + A.tgt], (unsigned long long) __double2ll_rn(stay * Num<R>::kFix));
+                if (lane >= 1 && arrive != 0.0) atomicAdd(&TL.fxT[A.tgt * N + A.prv], (unsigned long long) __double2ll_rn(arrive * Num<R>::kFix));
+            }
+        }
+        // alpha: tile[i][j] = E[i][j] * sx[i][j] - aligned edges,   E = exp2(Tr2[i][j] - rowmax_i)
+        // beta:  tile[i][j] = F[j][i] * sx[j][i] - aligned edges,   F = exp2(Tr2[i][j] - colmax_j)
+        // (sx = the consumers' sums, added in the order 0, 1, ...)
+        // one coalesced pass of the whole workgroup over the transition matrix
+        const R L2E = Num<R>::log2e();
+        const R *tr = (const R *) P.transition;
+        R *tile_out = (R *) F.tiles + ((int64_t) b * 2 + (BETA ? 1 : 0)) * N * N;
+        // (xx sits in a register of lane i; the tile loop wants it by index: back through LDS, behind the sums)
+        R *xs = SH.xs;
+        if (wave == 0) xs[lane] = xx;
+        __syncthreads();
+        for (int k = threadIdx.x; k < N * N; k += kFusedThreads) {
+            const int i = k / N, j = k - i * N;
+            const R t2 = tr[(int64_t) i * P.ts0 + (int64_t) j * P.ts1] * L2E;
+            R v;
+            R sum = 0;
+#pragma unroll
+            for (int c = 0; c < kNC; ++c) sum += BETA ? TL.sx[c][j][i] : TL.sx[c][i][j];
+            v = Num<R>::exp2(t2 - xs[BETA ? j : i]) * sum;
+            const long long fv = (long long) TL.fxT[k];
+            if (fv != 0) v -= from_fix<R>((unsigned long long) fv);
+            tile_out[k] = v * F.gscale;
+        }
+    }
+    // ---- phase 3: arrive; the SECOND full workgroup of the utterance closes it (score, loss, verdict, sync words)
+    if (threadIdx.x == 0) {
+        if (BETA) __hip_atomic_store((double *) F.fscore + b, SH.score_full, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (own_trouble) __hip_atomic_store(&us->kill, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        SH.last = __hip_atomic_fetch_add(&us->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u ? 1 : 0;
     }
     __syncthreads();
 #ifdef ASG_PROBE
-    if (b == 0 && threadIdx.x == 0) ((long long *) W.dbg)[53] = clock64();
+    if (b == 0 && !BETA && threadIdx.x == 0) ((long long *) ld_state(kernarg_params()).dbg)[54] = clock64();
 #endif
-    const bool flagged = own_trouble || SH.adone != 1;
+    if (!SH.last) return;
+    wait_aligned();
+    const bool flagged = !fused || SH.adone != 1 || __hip_atomic_load(&us->kill, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
     if (flagged) {
         // exact scores here (so that the loss of this launch is right), exact gradients in the backward launch
+        const State W = ld_state(kernarg_params());
         if (wave == 0) {
-            const double s = slow_full_score<NP>(P, b, len);
-            if (lane == 0) SH.score_full = s;
+            const double sx = slow_full_score<NP>(P, b, len);
+            if (lane == 0) SH.score_full = sx;
         } else if (wave == 1) {
             // the stand-alone aligned beta chain, forward-only; its score lands in scores[B + b]
             FwdOut O{};
@@ -1084,65 +1242,10 @@ __device__ __forceinline__ void full_epilogue(int b, FusedShared<NP> &SH, bool f
             aligned_beta_chain<R, false>(P, W, O, b);
         }
         __syncthreads();
-    } else {
-        // ---- phase 2: this utterance's [N][N] tile.  The rings are dead: their memory becomes the tile.
-        TileLds<NP> &TL = SH.u.t;
-        for (int k = threadIdx.x; k < 64 * (NP + 1); k += kFusedThreads) { (&TL.sa[0][0])[k] = 0; (&TL.sb[0][0])[k] = 0; }
-        for (int k = threadIdx.x; k < NP * NP; k += kFusedThreads) TL.fxT[k] = 0;
-        __syncthreads();
-        // the two consumer wavefronts of a side add their MFMA accumulators in a fixed order (0 then 1); element
-        // (16 r + 4 (lane >> 4) + q, 16 c + (lane & 15)) of tile (r, c) -- rows of the beta-side tile are SOURCE labels
-        auto add_acc = [&](float (*dst)[NP + 1]) {
-#pragma unroll
-            for (int r = 0; r < NT; ++r)
-#pragma unroll
-                for (int c = 0; c < NT; ++c)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int i = 16 * r + 4 * (lane >> 4) + q, j = 16 * c + (lane & 15);
-                        if (j <= NP) dst[i][j] += acc[r * NT + c][q];
-                    }
-        };
-        if (wave == 2) add_acc(TL.sa);
-        if (wave == 3) add_acc(TL.sb);
-        __syncthreads();
-        if (wave == 6) add_acc(TL.sa);
-        if (wave == 7) add_acc(TL.sb);
-        if (wave == 8 || wave == 9) {
-            // aligned edge posteriors of the alpha-side (wave 8) / beta-side (wave 9) frames, scattered to [to][from]
-            const AlignedSetup<R> A = aligned_setup<R>(P, b, lane);
-            const R *ed = (const R *) F.edges + ((int64_t) b * 2 + (wave - 8)) * kAF * 128;
-            R stay = 0, arrive = 0;
-            for (int k = 0; k < kAF; ++k) {          // fixed order
-                stay += __hip_atomic_load(ed + k * 128 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                arrive += __hip_atomic_load(ed + k * 128 + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if (A.act) {
-                if (stay != R(0)) atomicAdd(&TL.fxT[A.tgt * N + A.tgt], to_fix<R>(stay));
-                if (lane >= 1 && arrive != R(0)) atomicAdd(&TL.fxT[A.tgt * N + A.prv], to_fix<R>(arrive));
-            }
-        }
-        __syncthreads();
-        // tile[i][j] = E[i][j] * sa[i][j] + F[j][i] * sb[j][i] - aligned edges,   E = exp2(Tr2[i][j] - rowmax_i),
-        // F = exp2(Tr2[i][j] - colmax_j): one coalesced pass of the whole workgroup over the transition matrix
-        const R L2E = Num<R>::log2e();
-        const R *tr = (const R *) P.transition;
-        R *tile_out = (R *) F.tiles + (int64_t) b * N * N;
-        for (int k = threadIdx.x; k < N * N; k += kFusedThreads) {
-            const int i = k / N, j = k - i * N;
-            const R t2 = tr[(int64_t) i * P.ts0 + (int64_t) j * P.ts1] * L2E;
-            R v = Num<R>::exp2(t2 - SH.xa[i]) * TL.sa[i][j] + Num<R>::exp2(t2 - SH.xb[j]) * TL.sb[j][i];
-            const long long fv = (long long) TL.fxT[k];
-            if (fv != 0) v -= from_fix<R>((unsigned long long) fv);
-            tile_out[k] = v * F.gscale;
-        }
     }
-#ifdef ASG_PROBE
-    if (b == 0 && threadIdx.x == 0) ((long long *) W.dbg)[54] = clock64();
-#endif
-    // ---- phase 3: loss of this utterance; the last workgroup to arrive reduces the batch (fixed order)
     if (wave == 0) {
-        const R full = score_out<R>(SH.score_full);
+        const double fs = flagged ? SH.score_full : __hip_atomic_load((double *) F.fscore + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const R full = score_out<R>(fs);
         R ali;
         if (flagged) ali = __hip_atomic_load((R *) F.scores + P.B + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else ali = score_out<R>(__hip_atomic_load((double *) F.ascore + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -1150,14 +1253,12 @@ __device__ __forceinline__ void full_epilogue(int b, FusedShared<NP> &SH, bool f
             ((R *) F.scores)[b] = full;
             if (!flagged) ((R *) F.scores)[P.B + b] = ali;
             __hip_atomic_store(F.flags + b, flagged ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // the cross-workgroup words of this utterance go back to zero (the aligned workgroup is done with them)
-            for (int k = 0; k < kAF; ++k) {
-                __hip_atomic_store(&us->prog[0][k], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&us->prog[1][k], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            __hip_atomic_store(&us->adone, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // the cross-workgroup words of this utterance go back to zero (all three workgroups are done with them)
+            unsigned *w = reinterpret_cast<unsigned *>(us);
+            for (int k = 0; k < (int) (sizeof(UttSync) / sizeof(unsigned)); ++k)
+                __hip_atomic_store(w + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        // the last full workgroup to arrive (fixed order inside): reduces the loss over the batch and counts the flagged
+        // the last utterance to close (fixed order inside): reduces the loss over the batch and counts the flagged
         // utterances for the backward launch (its reducers wait for exactly that many exact redos)
         R *lossb = (R *) F.dump;                    // [B] per-utterance losses for the reducing workgroup
         const R l = full - ali;
@@ -1187,21 +1288,27 @@ __device__ __forceinline__ void full_epilogue(int b, FusedShared<NP> &SH, bool f
     }
 }
 
-// grid = 2B: blocks [0, B) are the aligned workgroups (dispatched first: nothing they do waits on another workgroup),
-// blocks [B, 2B) the full workgroups.
+// grid = 24 * ceil(B / 8): blocks come in groups of 24 = 8 utterances x {aligned, full alpha, full beta}; the three
+// workgroups of utterance b = 8 G + u have indices 24 G + {0, 8, 16} + u -- equal mod 8 (same XCD / L2 in practice) and
+// close together in dispatch order (the alpha and beta workgroups wait for each other's first half).
 template <int NP>
 __global__ void __launch_bounds__(kFusedThreads, 3) fused_fwd_kernel(FusedParams KP) {
     __shared__ FusedShared<NP> SH;
     const int B = kernarg_params()->P.B;
-    if ((int) blockIdx.x < B) aligned_workgroup<NP>(blockIdx.x, SH);
-    else full_workgroup<NP>((int) blockIdx.x - B, SH);
+    const int G = (int) blockIdx.x / 24, w = (int) blockIdx.x - 24 * G;
+    const int role = w >> 3, b = 8 * G + (w & 7);
+    if (b >= B) return;
+    if (role == 0) aligned_workgroup<NP>(b, SH);
+    else if (role == 1) full_workgroup<NP, false>(b, SH);
+    else full_workgroup<NP, true>(b, SH);
 }
 
 // ------------------------------------------------------------------ the backward kernel
 // grid = B + R workgroups of 256 threads.
 //   workgroup b < B:   redo utterance b exactly if it is flagged; scale its grad_inputs rows by the upstream gradient
 //                      (nothing when that is 1); arrive.
-//   workgroup B + r:   once all B have arrived, grad_transition[slice r] = sum_b g_b * tile[b][slice r], b ascending.
+//   workgroup B + r:   once all B have arrived, grad_transition[slice r] = sum_b g_b * (tile[b][alpha] + tile[b][beta])[slice r],
+//                      tiles in ascending order.
 constexpr int kBwdSlice = 64;
 template <int NP>
 __global__ void __launch_bounds__(256) fused_bwd_kernel(Problem P, State W, FusedArgs F) {
@@ -1235,7 +1342,8 @@ __global__ void __launch_bounds__(256) fused_bwd_kernel(Problem P, State W, Fuse
             A.grad_inputs = F.grad_inputs;
             A.chunk = T;
             A.nchunks = 1;
-            assemble_frames<R, NP, 4>(P, W, A, 3, b, 0, (R *) F.tiles + (int64_t) b * N * N, S);
+            assemble_frames<R, NP, 4>(P, W, A, 3, b, 0, (R *) F.tiles + (int64_t) b * 2 * N * N, S);
+            for (int k = threadIdx.x; k < N * N; k += 256) ((R *) F.tiles)[((int64_t) b * 2 + 1) * N * N + k] = R(0);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             __syncthreads();
         }
@@ -1269,18 +1377,19 @@ __global__ void __launch_bounds__(256) fused_bwd_kernel(Problem P, State W, Fuse
     const int k = min(r * kBwdSlice + lane, n2 - 1);
     const R *tiles = (const R *) F.tiles;
     const R *gl = (const R *) F.grad_loss;
-    // wave w sums utterances b = w, w+4, ... (16 loads in flight), then a fixed-order combine over the four waves
+    // wave w sums tiles w, w+4, ... (two per utterance; 16 loads in flight), then a fixed-order combine over the four waves
     R a[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) a[q] = 0;
-    for (int b0 = wave; b0 < B; b0 += 64) {
+    const int NTILE = 2 * B;
+    for (int b0 = wave; b0 < NTILE; b0 += 64) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int bb = b0 + 4 * q;
-            const int bc = min(bb, B - 1);
+            const int bc = min(bb, NTILE - 1);
             const R v = __hip_atomic_load(tiles + (int64_t) bc * n2 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const R g = gl[F.reduction == 0 ? bc : 0];
-            a[q] += (bb < B) ? v * g : R(0);
+            const R g = gl[F.reduction == 0 ? (bc >> 1) : 0];
+            a[q] += (bb < NTILE) ? v * g : R(0);
         }
     }
     R s = 0;
@@ -1296,7 +1405,7 @@ template <int NP>
 hipError_t launch_fused_np(const Problem &P, const State &W, const FusedArgs &F, bool backward, hipStream_t st) {
     if (!backward) {
         FusedParams KP{P, W, F};
-        hipLaunchKernelGGL((fused_fwd_kernel<NP>), dim3(2 * P.B), dim3(kFusedThreads), 0, st, KP);
+        hipLaunchKernelGGL((fused_fwd_kernel<NP>), dim3(24 * ((P.B + 7) / 8)), dim3(kFusedThreads), 0, st, KP);
     } else {
         const int R = (P.N * P.N + kBwdSlice - 1) / kBwdSlice;
         hipLaunchKernelGGL((fused_bwd_kernel<NP>), dim3(P.B + R), dim3(256), 0, st, P, W, F);

@@ -72,15 +72,17 @@ struct FusedArgs {
     void *loss;                  // [B] (reduction none) or [1]
     void *scores;                // [2][B]: full, aligned
     void *grad_inputs;           // [T,B,N] contiguous
-    void *tiles;                 // [B][N][N] per-utterance transition-gradient tiles (times gscale)
+    void *tiles;                 // [B][2][N][N] per-utterance transition-gradient tiles (times gscale): alpha-side, beta-side frames
     int *flags;                  // [B]: 1 = the fused path declined this utterance (range guard, very short, time-out)
     void *dump;                  // [2][B] scratch scores for the exact redo
     void *p2;                    // [B][T][S] aligned posteriors, aligned workgroup -> full workgroup
-    void *edges;                 // [B][2][2][64] aligned edge posteriors (stay | arrive) of the alpha-/beta-side frames
+    void *edges;                 // [B][2][3][2][64] double: aligned edge posteriors (stay | arrive) of the alpha-/beta-side frames, per finisher
     void *ascore;                // [B] double: aligned scores (log2 units)
+    void *fscore;                // [B] double: full-lattice scores (log2 units), beta workgroup -> closing workgroup
+    void *xstate;                // [B][2][xstate_blocks(T)][2][64][4] first-half states each full chain hands to the other
     void *aoff;                  // [B][2][T/16 + 2][2] double: per-block offsets of the stored aligned states
     unsigned *sync;              // caller-zeroed, returned zeroed: 64 words (word 0 = arrival ticket of the loss reduction)
-                                 // + 4 words per utterance (UttSync in asg_fused.hip)
+                                 // + 16 words per utterance (UttSync in asg_fused.hip)
     unsigned *ticket2;           // 256 B, zeroed by the forward launch for the backward launch
     const void *grad_loss;       // backward: [B] (none) or [1]
     void *grad_transition;       // backward: [N,N]
