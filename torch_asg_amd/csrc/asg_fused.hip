@@ -25,11 +25,11 @@
 // the sum over frames of the outer products (posterior / s) (x) v runs on the matrix cores (asg_outer.h).
 // Wave roles of a full workgroup (waves with equal index % 4 share a SIMD; the recursion wavefront has SIMD 0 to itself):
 //   0  recursion wavefront (critical path only; as fwd_duo_kernel)        1  producer (emission factors)
-//   2, 3  consumers: first half = log-domain state -> HBM (consumer 0); second half = posterior -> LDS row ring, xi
-//         accumulation (MFMA), the two taking alternate groups of 8 frames
-//   5  row finisher: aligned posterior of the frame (from the aligned workgroup) scattered to labels with deterministic
-//      fixed-point LDS adds, final grad_inputs row
-// of the aligned workgroup:  0/1 chains alpha/beta   2,6,10 / 3,7,11 finishers (aligned posterior -> HBM, edge posteriors)
+//   2, 3, 6 (, 7)  consumers: first half = log-domain state -> HBM (consumer 0); second half = full-lattice posterior ->
+//         grad_inputs row, xi accumulation (MFMA, double accumulators), taking the groups of 8 frames round-robin
+// of the aligned workgroup:  0/1 chains alpha/beta   2,6,5 / 3,7,4 finishers (aligned posterior -> HBM, edge posteriors)
+// The backward launch finishes the grad_inputs rows: minus the aligned posteriors scattered to labels, times the upstream
+// gradient.
 // Everything is bit-deterministic: no float atomics, fixed accumulation orders.
 // An utterance whose row sums leave the safe range (or shorter than kMinFused frames, or any bounded wait that runs
 // out) is FLAGGED: its scores are recomputed here with exact log-sum-exps, its gradients by the exact stand-alone code
@@ -40,17 +40,20 @@
 namespace asg {
 namespace {
 
-constexpr int kRow = 64;        // consumer -> row finisher ring of grad_inputs rows (frames)
 constexpr int kAR = 64;         // aligned chain -> finisher ring of aligned states (frames)
 constexpr int kGS = 8;          // frames per poll of the consumers / finishers
 constexpr int kMinFused = 4;
 constexpr int kAF = 3;          // aligned finisher wavefronts per side (round-robin over 8-index groups)
 #ifndef ASG_X_NC
-#define ASG_X_NC 2
+#define ASG_X_NC 4
 #endif
-constexpr int kNC = ASG_X_NC;   // consumer wavefronts per full workgroup (round-robin over 8-index groups of the second half)
-constexpr int kRF = 2;          // row finisher wavefronts per side
-constexpr int kFusedThreads = 768;
+// consumer wavefronts per full workgroup (round-robin over 8-index groups of the second half): what the LDS holds
+constexpr int kMaxNC = 4;
+template <int NP> struct Consumers {          // each has a [64][NP + 1] double tile beside the 64 KB of rings
+    static constexpr int fit = NP <= 40 ? 4 : NP <= 56 ? 3 : 2;
+    static constexpr int n = ASG_X_NC < fit ? ASG_X_NC : fit;
+};
+constexpr int kFusedThreads = 512;   // 8 wavefronts: two per SIMD, 256 VGPRs each (the consumers keep 72 of double accumulators)
 constexpr unsigned kSc1 = 16;   // buffer load/store aux bit: agent scope (served by / written through to L2)
 
 constexpr int kFR = 64;                                   // ring depth of the full workgroup (frames): two consumers that
@@ -61,28 +64,18 @@ struct FusedSide {                                        // one direction (alph
     float s[kFR][64];                                    // row sums s_n, main -> consumer (self-describing: NaN sentinel)
     float e[kFR][64];                                    // emission factors, producer -> main
     float a[kFR][64];                                    // their log2 (alpha side), producer -> consumer
-    float row[kRow][64];                                 // gscale * full posterior of a frame, consumer -> row finisher
     float x[64];                                         // row / column maxima of the transition matrix
-    unsigned fx[kRF][kGS][64];                           // row finisher k: fixed-point scatter of the aligned posteriors
     double zsum;
     int e_prod, csum, main_done, prod_done, kill;
     // kNC consumer wavefronts: wave 0 takes the whole first half; in the second half wave k takes the 8-index groups
     // k, k + kNC, ...  cd[k] = (last index of wave k's latest group) + 8 (kNC - 1): everything up to the minimum over k has
     // been taken out of the rings (waves 1.. count as "infinitely far" during the first half).
-    int cd[kNC];
-    int rd[kNC];      // consumer k: rows of its groups up to index rd[k] - 1 are in `row`
+    int cd[kMaxNC];
     int st_done;      // consumer 0: state rows of indices [0, st_done) are in HBM/L2 and visible
-    int fd[kRF];      // row finisher k: (count of indices through its latest group) + 8 * (kRF - 1); the row ring is free
-                      // up to min over k (same prefix rule as cd)
-    __device__ __forceinline__ int finished() {
-        int v = __hip_atomic_load(&fd[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (kRF > 1) v = min(v, __hip_atomic_load(&fd[kRF - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-        return v;
-    }
     __device__ __forceinline__ int consumed() {
         int v = __hip_atomic_load(&cd[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
-        for (int k = 1; k < kNC; ++k) v = min(v, __hip_atomic_load(&cd[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        for (int k = 1; k < kMaxNC; ++k) v = min(v, __hip_atomic_load(&cd[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
         return v;
     }
     __device__ __forceinline__ float *pslot(int n) { return p[n & (kFR - 1)]; }
@@ -110,12 +103,11 @@ struct AliSide {                                          // one direction of th
 
 // Cross-workgroup words of one utterance (FusedArgs::sync, after the 64-word ticket block).  Zero on entry, zero on exit.
 struct UttSync {
-    unsigned prog[2][kAF];  // aligned finisher k of a side: the aligned posteriors of ITS groups up to index prog - 1 are in P2
     unsigned adone;         // aligned workgroup: 1 = finished (edges + score written), 2 = finished but gave up
     unsigned st_done[2];    // full workgroup alpha / beta: the states of its indices [0, st_done) are visible (xstate)
     unsigned kill;          // any of the three workgroups gave up on the fused path for this utterance
     unsigned arrive;        // full workgroups that have finished (the second one closes the utterance)
-    unsigned pad[5];
+    unsigned pad[11];
 };
 static_assert(sizeof(UttSync) == 64, "asg_loss_fused_sync_bytes");
 
@@ -128,9 +120,12 @@ __host__ __device__ __forceinline__ int xstate_blocks(int T) { return (T + 7) / 
 
 template <int NP>
 struct TileLds {
-    float sx[kNC][64][NP + 1];          // xi sums of consumer 0 .. kNC-1: alpha side [to i][from j], beta side [from j][to i]
+    double sx[Consumers<NP>::n][64][NP + 1];   // xi sums of consumer 0 .. kNC-1 (double: asg_outer.h): alpha side [to i][from j], beta side [from j][to i]
                                         // (before the E / F factor)
-    unsigned long long fxT[NP * NP];    // aligned edge posteriors, fixed point, [to][from]  (alpha workgroup)
+};
+template <int NP>
+struct EdgeLds {
+    unsigned long long fxT[NP * NP];    // aligned edge posteriors of this side's frames, fixed point, [to][from]
 };
 
 template <int NP>
@@ -138,6 +133,7 @@ struct FusedShared {
     union U {
         FusedSide g;
         struct H { AliSide A, B; } h;
+        EdgeLds<NP> e;       // epilogue only: the rings are dead by then
     } u;
     TileLds<NP> t;       // beside the rings, not over them: each consumer adds its accumulators as its LAST act, so they are
                          // not live across the roles (as values handed to the epilogue they were spilled inside the loop)
@@ -273,6 +269,15 @@ __device__ __forceinline__ float rcp_nr(float x) {
     return (e == e) ? fmaf(e, r, r) : r;
 }
 
+// a / b correctly rounded (b finite, nonzero, well inside the fp32 range): v_rcp_f32 and one residual step ON THE QUOTIENT.
+// a * rcp(b) alone is biased where it matters most: for a == b (the posterior of a one-label alphabet) it gives 1 or
+// 1 - 2^-24, never 1 + anything, and thousands of such terms no longer cancel against the aligned lattice's.
+__device__ __forceinline__ float div_nr(float a, float b) {
+    const float r = Num<float>::rcp(b);
+    const float q = a * r;
+    return fmaf(fmaf(-q, b, a), r, q);
+}
+
 __device__ __forceinline__ float buf_load_sc1(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
     return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, kSc1));
 }
@@ -349,10 +354,11 @@ __device__ __forceinline__ void fused_main(const Problem &P, int b, FusedSide &L
 // that lead to index m, v_{m-1} (= p slot m-1) the vector that produced them.  Indices < h are the side's first half.
 template <int NP, bool BETA>
 __device__ __forceinline__ void fused_consumer(const Problem &P, const State &W, const FusedArgs &F, int b, FusedSide &L,
-                                               UttSync *us, int len, int h, float (&sx)[64][NP + 1], double &score_out2, const int cw) {
+                                               UttSync *us, int len, int h, double (&sx)[64][NP + 1], double &score_out2, const int cw) {
     typedef float R;
     typedef unsigned u4 __attribute__((ext_vector_type(4)));
     constexpr int NT = (NP + 15) / 16;
+    constexpr int kNC = Consumers<NP>::n;
     const FullCtl ctl{&L, us};
     const int lane = threadIdx.x & 63;
     const int N = P.N, T = P.T;
@@ -369,10 +375,20 @@ __device__ __forceinline__ void fused_consumer(const Problem &P, const State &W,
     const unsigned vld = (unsigned) lc * 16u;
     const int phi = (-h) & 7, phiO = (-(len - h)) & 7;
     const R gscale = F.gscale;
-    score_out2 = -1e300;
-    V4<float> acc[NT * NT];
+    // rows of the full-lattice posterior go straight to grad_inputs; the backward launch subtracts the aligned posteriors
+    __amdgpu_buffer_rsrc_t rs_g = make_rsrc((R *) F.grad_inputs + (int64_t) b * N,
+                                            (unsigned) ((int64_t) (T - 1) * P.B * N + N) * (unsigned) sizeof(R));
+    const unsigned voffg = act ? (unsigned) lane * (unsigned) sizeof(R) : kOobOffset;
+    const unsigned grow_bytes = (unsigned) P.B * N * sizeof(R);
+    auto frame = [&](int m) { return BETA ? len - 1 - m : m; };
+    // xi sums in DOUBLE accumulators (asg_outer.h): tile (r, c), register q, lane l = element (16 r + (l >> 4) + 4 q, 16 c + (l & 15))
+    V4d acc[NT * NT];
 #pragma unroll
-    for (int q = 0; q < NT * NT; ++q) acc[q] = V4<float>{0, 0, 0, 0};
+    for (int q = 0; q < NT * NT; ++q) acc[q] = V4d{0, 0, 0, 0};
+    score_out2 = -1e300;
+#ifdef ASG_PROBE
+    long long prb_seg[5] = {0, 0, 0, 0, 0};
+#endif
     PRB_DECL
     if (!wait_ge(&L.e_prod, 1, ctl)) return;                  // X and block 0 of the rings are there
     const R XX = lds_ldf(&L.x[lane]);
@@ -477,6 +493,7 @@ __device__ __forceinline__ void fused_consumer(const Problem &P, const State &W,
         }
 #ifdef ASG_PROBE
         prb_w[2] += clock64() - prb_slot0;
+        const long long seg_a = clock64();
 #endif
         unsigned lo = 0xffffffffu, hi = 0;
 #pragma unroll
@@ -504,9 +521,8 @@ __device__ __forceinline__ void fused_consumer(const Problem &P, const State &W,
         // the next own group's block of the other side
         R othn[kGS];
         load_other(n + kNC * kGS, othn);
-        // ring space for the rows (the row finishers have taken index n + g - 1 - kRow): normally long true
-#ifndef ASG_X_NOROWFIN
-        PRB_WAIT(3, if (!wait_finished(n + g - kRow, ctl)) return;)
+#ifdef ASG_PROBE
+        const long long seg_b = clock64();
 #endif
         // frames 0-3: normalisers, rows, u, first MFMA batch; then frames 4-7 while those MFMAs run
         R u[kGS];
@@ -524,22 +540,29 @@ __device__ __forceinline__ void fused_consumer(const Problem &P, const State &W,
             if (zlo < Rng<R>::lo || zhi > Rng<R>::hi) return false;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const R post = w[q0 + q] * rcp_nr(Z[q]);
+                const R post = div_nr(w[q0 + q], Z[q]);
                 const int m = n + min(q0 + q, g - 1);
-                lds_stf(&L.row[m & (kRow - 1)][lane], post * gscale);
+                if (q0 + q < g) buf_store(post * gscale, rs_g, voffg, (unsigned) frame(m) * grow_bytes);
                 // xi: alpha side skips its first assembled index (the beta side's last one covers that transition)
                 const bool take = q0 + q < g && (BETA || n + q0 + q > h);
-                u[q0 + q] = (take && act) ? post * rcp_nr(sg[q0 + q]) : R(0);
+                u[q0 + q] = (take && act) ? div_nr(post, sg[q0 + q]) : R(0);
                 pg[q0 + q] = act ? pg[q0 + q] : R(0);
             }
             float ua[4] = {u[q0], u[q0 + 1], u[q0 + 2], u[q0 + 3]}, va[4] = {pg[q0], pg[q0 + 1], pg[q0 + 2], pg[q0 + 3]};
-            outer4_accumulate<NT>(ua, va, acc);
+            outer4_accumulate_f64<NT>(ua, va, acc);
             return true;
         };
         if (!half_group(0)) { ctl.abort(8); return; }
+#ifdef ASG_PROBE
+        const long long seg_c = clock64();
+#endif
         if (!half_group(4)) { ctl.abort(9); return; }
-        asm volatile("" ::: "memory");
-        lds_store_rlx(&L.rd[cw], n + g);
+#ifdef ASG_PROBE
+        const long long seg_d = clock64();
+#endif
+#ifdef ASG_PROBE
+        prb_seg[0] += seg_b - seg_a; prb_seg[1] += seg_c - seg_b; prb_seg[2] += seg_d - seg_c; prb_seg[3] += clock64() - seg_d; prb_seg[4] += 1;
+#endif
 #pragma unroll
         for (int q = 0; q < kGS; ++q) oth[q] = othn[q];
         sv = sg[kGS - 1];
@@ -547,14 +570,14 @@ __device__ __forceinline__ void fused_consumer(const Problem &P, const State &W,
     }
     // (a consumer without a last group still has to let the producer's bookkeeping see "everything taken")
     lds_store_rlx(&L.cd[cw], len + kNC * kGS);
-    // this wavefront's xi sums: element (16 r + 4 (lane >> 4) + q, 16 c + (lane & 15)) of tile (r, c)
+    // this wavefront's sums into its tile
 #pragma unroll
     for (int r = 0; r < NT; ++r)
 #pragma unroll
         for (int c = 0; c < NT; ++c)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int i = 16 * r + 4 * (lane >> 4) + q, j = 16 * c + (lane & 15);
+                const int i = 16 * r + (lane >> 4) + 4 * q, j = 16 * c + (lane & 15);
                 if (j <= NP) sx[i][j] = acc[r * NT + c][q];
             }
     // ---- end of the chain: score (beta side), by the consumer that took the last group; as the three-wavefront kernel
@@ -577,6 +600,9 @@ __device__ __forceinline__ void fused_consumer(const Problem &P, const State &W,
         score_out2 = zsum + (double) csum + (double) Num<R>::log2(sm);
     }
     PRB_END(W.dbg, BETA ? 3 : 2)
+#ifdef ASG_PROBE
+    if (b == 0 && lane == 0) { long long *d = (long long *) W.dbg + (BETA ? 9 : 8) * 5; for (int k = 0; k < 5; ++k) d[k] = prb_seg[k]; }
+#endif
 }
 
 // 16 (GUARD: nsteps) steps of an aligned chain; the state of index m0 + k goes to ring slot (m0 + k - 1) & (kAR - 1) -- blocks
@@ -728,7 +754,8 @@ __device__ __forceinline__ void fused_aligned(const Problem &P, const State &W, 
 }
 
 // ------------------------------------------------------------------ finisher of the aligned workgroup
-// Aligned posterior of every second-half frame of this side -> P2[b][frame][s] (write-through, behind a progress word)
+// Aligned posterior of every second-half frame of this side -> P2[b][side][quad][s][4] (for the backward launch, which
+// subtracts them, scattered to labels, from the rows the full workgroups wrote)
 // and the stay / arrive edge posteriors accumulated per target position.
 //
 // No per-frame normalisation: sum_s alpha_t(s) beta_t(s) is the SAME number for every frame -- the aligned score -- so it
@@ -754,7 +781,6 @@ __device__ __forceinline__ void fused_afin(const Problem &P, const State &W, con
     __amdgpu_buffer_rsrc_t rp = make_rsrc((R *) F.p2 + ((int64_t) b * 2 + (BETA ? 1 : 0)) * (T + 8) * S, (unsigned) (T + 8) * rbS);
     const unsigned vS = (unsigned) (sl ? lane : 0) * (unsigned) sizeof(R);
     const unsigned vQ = sl ? (unsigned) lane * 16u : kOobOffset;
-    unsigned *prog = &us->prog[BETA ? 1 : 0][fw];
     const int nblk = (T + kPF - 1) / kPF + 1;
     const double *ao = (const double *) F.aoff + ((int64_t) b * 2 + (BETA ? 0 : 1)) * nblk * 2;    // the OTHER side's
     auto frame = [&](int m) { return BETA ? len - 1 - m : m; };
@@ -868,12 +894,6 @@ __device__ __forceinline__ void fused_afin(const Problem &P, const State &W, con
                 }
             }
         }
-        // one VMEM queue, in order, 11 operations per group (9 loads, 2 stores): once at most 11 are in flight, every
-        // store of this wavefront's PREVIOUS group (kAF groups ago: long acknowledged) has been written through -- publish
-        // that group
-        PRB_WAIT(2, __builtin_amdgcn_s_waitcnt(0x0F7B);)       // vmcnt(11)
-        if (lane == 0 && n - kAF * kGS >= h)
-            __hip_atomic_store(prog, (unsigned) (n - kAF * kGS + kGS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int q = 0; q < kGS; ++q) oth[q] = othn[q];
         n += kAF * kGS;
@@ -886,104 +906,7 @@ __device__ __forceinline__ void fused_afin(const Problem &P, const State &W, con
         __hip_atomic_store(ed + 64 + lane, accS - accH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) __hip_atomic_store(prog, (unsigned) (len + kAF * kGS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (fw == 0) { PRB_END(W.dbg, BETA ? 7 : 6) }
-}
-
-// ------------------------------------------------------------------ row finisher of the full workgroup
-// final row of every second-half frame of this side: gscale * (full posterior - aligned posterior scattered to labels)
-template <bool BETA>
-__device__ __forceinline__ void fused_rowfin(const Problem &P, const State &W, const FusedArgs &F, int b, FusedSide &L,
-                                             int len, int h, UttSync *us, const int rw) {
-    typedef float R;
-    const FullCtl ctl{&L, us};
-    const int lane = threadIdx.x & 63;
-    const int N = P.N, T = P.T, S = P.S;
-    const unsigned rbS = (unsigned) S * sizeof(R);
-    // label of target position `lane` (clamped like aligned_setup); positions >= target length carry posterior 0
-    int tgt = 0;
-    {
-        const int ol = P.tg_len ? clampi(P.tg_len[b], 0, S) : S;
-        const int sc = lane < ol ? lane : 0;
-        tgt = clampi(P.targets[(int64_t) b * P.gs0 + (int64_t) sc * P.gs1], 0, N - 1);
-        // lanes past the target add 0: give each its OWN word (all of them on one address would serialise the LDS add)
-        if (lane >= ol) tgt = lane;
-    }
-    __amdgpu_buffer_rsrc_t rp = make_rsrc((R *) F.p2 + ((int64_t) b * 2 + (BETA ? 1 : 0)) * (T + 8) * S, (unsigned) (T + 8) * rbS);
-    const unsigned vQ = lane < S ? (unsigned) lane * 16u : kOobOffset;                        // out of range reads 0
-    typedef unsigned u4 __attribute__((ext_vector_type(4)));
-    auto load_group = [&](int nn, R (&dst)[kGS]) {           // aligned posteriors of indices nn .. nn+7 of this side (see fused_afin)
-        const unsigned qoff = (unsigned) ((nn - h) >> 2) * (unsigned) S * 16u;
-        const u4 a = __builtin_amdgcn_raw_buffer_load_b128(rp, vQ, qoff, kSc1);
-        const u4 c = __builtin_amdgcn_raw_buffer_load_b128(rp, vQ, qoff + (unsigned) S * 16u, kSc1);
-        dst[0] = __uint_as_float(a.x); dst[1] = __uint_as_float(a.y); dst[2] = __uint_as_float(a.z); dst[3] = __uint_as_float(a.w);
-        dst[4] = __uint_as_float(c.x); dst[5] = __uint_as_float(c.y); dst[6] = __uint_as_float(c.z); dst[7] = __uint_as_float(c.w);
-    };
-    __amdgpu_buffer_rsrc_t rs_g = make_rsrc((R *) F.grad_inputs + (int64_t) b * N,
-                                            (unsigned) ((int64_t) (T - 1) * P.B * N + N) * (unsigned) sizeof(R));
-    const unsigned voff = lane < N ? (unsigned) lane * sizeof(R) : kOobOffset;
-    const unsigned grow_bytes = (unsigned) P.B * N * sizeof(R);
-    const R gscale = F.gscale;
-    unsigned *progs = &us->prog[BETA ? 1 : 0][0];
-    unsigned seen[kAF] = {0, 0, 0};
-    auto frame = [&](int m) { return BETA ? len - 1 - m : m; };
-    // aligned posteriors of the group starting at nn are published by aligned finisher ((nn - h) / 8) % kAF
-    auto wait_p2 = [&](int nn) -> bool {
-        const int gi = (nn - h) / kGS;
-        const unsigned need = (unsigned) min(nn + kGS, len);
-        const int w = gi % kAF;
-        bool ok = true;
-        if (w == 0) ok = wait_global_ge(progs + 0, need, seen[0], ctl);
-        else if (w == 1) ok = wait_global_ge(progs + 1, need, seen[1], ctl);
-        else ok = wait_global_ge(progs + 2, need, seen[2], ctl);
-        return ok;
-    };
-    PRB_DECL
-    unsigned (*fx)[64] = L.fx[rw];
-#pragma unroll
-    for (int q = 0; q < kGS; ++q) fx[q][lane] = 0;
-    int n = h + rw * kGS;                 // this wavefront's groups: rw, rw + kRF, ...
-    // the aligned posteriors of a group are fetched one (own) group ahead, behind the aligned workgroup's progress words
-    R p2n[kGS];
-    if (n < len) {
-        PRB_WAIT(0, if (!wait_p2(n)) return;)
-        load_group(n, p2n);
-    }
-    while (n < len) {
-        const int g = min(kGS, len - n);
-        R p2[kGS];
-#pragma unroll
-        for (int q = 0; q < kGS; ++q) p2[q] = p2n[q];
-        if (n + kRF * kGS < len) {
-            PRB_WAIT(1, if (!wait_p2(n + kRF * kGS)) return;)
-            load_group(n + kRF * kGS, p2n);
-        }
-        PRB_WAIT(2, if (!wait_ge(&L.rd[((n - h) / kGS) % kNC], n + g, ctl)) return;)
-        R rowv[kGS];
-#pragma unroll
-        for (int q = 0; q < kGS; ++q) rowv[q] = L.row[(n + min(q, g - 1)) & (kRow - 1)][lane];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        lds_store_rlx(&L.fd[rw], n + g + (kRF - 1) * kGS);
-        // scatter to labels: integer LDS adds commute -> repeated labels give bit-identical sums run to run.  The eight
-        // frames of the group go through eight separate arrays, so the adds, reads and resets of the whole group
-        // are three back-to-back bursts (one wavefront's LDS operations execute in order)
-#pragma unroll
-        for (int q = 0; q < kGS; ++q) atomicAdd(&fx[q][tgt], FrameFix<R>::to(q < g ? p2[q] : R(0)));
-        __builtin_amdgcn_wave_barrier();
-        unsigned fv[kGS];
-#pragma unroll
-        for (int q = 0; q < kGS; ++q) fv[q] = fx[q][lane];
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int q = 0; q < kGS; ++q) fx[q][lane] = 0;
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int q = 0; q < kGS; ++q)
-            if (q < g) buf_store(rowv[q] - gscale * FrameFix<R>::from(fv[q]), rs_g, voff, (unsigned) frame(n + q) * grow_bytes);
-        n += kRF * kGS;
-    }
-    lds_store_rlx(&L.fd[rw], len + kRF * kGS);
-    if (rw == 0) { PRB_END(W.dbg, BETA ? 9 : 8) }
 }
 
 // exact full-lattice score of one utterance by ONE wavefront (log-domain beta recursion, max-shifted log-sum-exps)
@@ -1038,16 +961,11 @@ __device__ __forceinline__ void aligned_workgroup(int b, FusedShared<NP> &SH) {
             case 0: __builtin_amdgcn_s_setprio(3); fused_aligned<false>(P, W, b, LA, LB, len, mid, sc2, (double *) F.aoff + ((int64_t) b * 2 + 0) * ((T + kPF - 1) / kPF + 1) * 2, us); break;
             case 1: __builtin_amdgcn_s_setprio(3); fused_aligned<true>(P, W, b, LB, LA, len, len - mid, sc2, (double *) F.aoff + ((int64_t) b * 2 + 1) * ((T + kPF - 1) / kPF + 1) * 2, us); break;
 #ifndef ASG_X_NOFIN
-#ifdef ASG_X_FIN_SPREAD
-            // third finisher of a side beside the OTHER side's chain (low priority there), not on its own side's SIMD
+            // two finishers of a side on a SIMD of their own pair, the third beside the OTHER side's chain (which has priority)
             case 2: case 6: fused_afin<false>(P, W, F, b, LA, LB, len, mid, us, (wave - 2) >> 2); break;
             case 3: case 7: fused_afin<true>(P, W, F, b, LB, LA, len, len - mid, us, (wave - 3) >> 2); break;
-            case 9: fused_afin<false>(P, W, F, b, LA, LB, len, mid, us, 2); break;
-            case 8: fused_afin<true>(P, W, F, b, LB, LA, len, len - mid, us, 2); break;
-#else
-            case 2: case 6: case 10: fused_afin<false>(P, W, F, b, LA, LB, len, mid, us, (wave - 2) >> 2); break;
-            case 3: case 7: case 11: fused_afin<true>(P, W, F, b, LB, LA, len, len - mid, us, (wave - 3) >> 2); break;
-#endif
+            case 5: fused_afin<false>(P, W, F, b, LA, LB, len, mid, us, 2); break;
+            case 4: fused_afin<true>(P, W, F, b, LB, LA, len, len - mid, us, 2); break;
 #endif
             default: break;
         }
@@ -1084,6 +1002,7 @@ template <int NP, bool BETA>
 __device__ __forceinline__ void full_workgroup(int b, FusedShared<NP> &SH) {
     typedef float R;
     constexpr int NT = (NP + 15) / 16;
+    constexpr int kNC = Consumers<NP>::n;
     const Problem P = ld_problem(kernarg_params());
     const FusedArgs F = ld_fargs(kernarg_params());
     FusedSide &L = SH.u.g;
@@ -1098,9 +1017,8 @@ __device__ __forceinline__ void full_workgroup(int b, FusedShared<NP> &SH) {
 
     if (threadIdx.x == 0) {
         L.e_prod = 0; L.csum = 0; L.main_done = 0; L.prod_done = 0; L.kill = 0;
-        for (int k = 0; k < kNC; ++k) { L.cd[k] = k == 0 ? 0 : 1 << 30; L.rd[k] = h; }
+        for (int k = 0; k < kMaxNC; ++k) L.cd[k] = k == 0 ? 0 : 1 << 30;      // (slots >= kNC stay "infinitely far")
         L.st_done = 0;
-        for (int k2 = 0; k2 < kRF; ++k2) L.fd[k2] = h + k2 * kGS;
         SH.score_full = -1e300;
         SH.adone = 0;
         SH.last = 0;
@@ -1111,8 +1029,7 @@ __device__ __forceinline__ void full_workgroup(int b, FusedShared<NP> &SH) {
 #endif
     for (int q = threadIdx.x; q < kFR * 64; q += kFusedThreads) (&L.s[0][0])[q] = __uint_as_float(kSentinel);
     TileLds<NP> &TL = SH.t;
-    for (int k = threadIdx.x; k < kNC * 64 * (NP + 1); k += kFusedThreads) (&TL.sx[0][0][0])[k] = 0;
-    for (int k = threadIdx.x; k < NP * NP; k += kFusedThreads) TL.fxT[k] = 0;
+    for (int k = threadIdx.x; k < kNC * 64 * (NP + 1); k += kFusedThreads) (&TL.sx[0][0][0])[k] = 0.0;
     __syncthreads();
 
     double sc2 = -1e300;
@@ -1122,7 +1039,7 @@ __device__ __forceinline__ void full_workgroup(int b, FusedShared<NP> &SH) {
 
     // ---- phase 1: the roles.  Control flow is uniform per wavefront; nothing in here uses a workgroup barrier.
     // Wavefront 4 (the recursion wavefront's SIMD) and 6 .. 11 go straight to the barrier: a waiting wavefront issues nothing.
-    if (!BETA && wave == 10) {
+    if (!BETA && wave == 5) {
         // padded frames get exactly-zero gradients (the reference: roll_to_end + masked softmax, utils.cpp:11-66)
         __amdgpu_buffer_rsrc_t rs_g = make_rsrc((R *) F.grad_inputs + (int64_t) b * N,
                                                 (unsigned) ((int64_t) (T - 1) * P.B * N + N) * (unsigned) sizeof(R));
@@ -1141,10 +1058,6 @@ __device__ __forceinline__ void full_workgroup(int b, FusedShared<NP> &SH) {
             case 3: fused_consumer<NP, BETA>(P, W, F, b, L, us, len, h, TL.sx[1], sc2, 1); break;
             case 6: if (kNC > 2) fused_consumer<NP, BETA>(P, W, F, b, L, us, len, h, TL.sx[2 % kNC], sc2, 2); break;
             case 7: if (kNC > 3) fused_consumer<NP, BETA>(P, W, F, b, L, us, len, h, TL.sx[3 % kNC], sc2, 3); break;
-#ifndef ASG_X_NOROWFIN
-            case 5: fused_rowfin<BETA>(P, W, F, b, L, len, h, us, 0); break;
-            case 9: fused_rowfin<BETA>(P, W, F, b, L, len, h, us, 1); break;
-#endif
             default: break;
         }
         if (BETA && lane == 0 && sc2 > -1e299) SH.score_full = sc2;
@@ -1175,7 +1088,10 @@ __device__ __forceinline__ void full_workgroup(int b, FusedShared<NP> &SH) {
 #endif
     if (!own_trouble && SH.adone == 1) {
         // ---- phase 2: this side's share of the utterance's [N][N] tile
-        if (wave == 8) {
+        EdgeLds<NP> &EL = SH.u.e;
+        for (int k = threadIdx.x; k < NP * NP; k += kFusedThreads) EL.fxT[k] = 0;
+        __syncthreads();
+        if (wave == 4) {
             // aligned edge posteriors of THIS side's frames, scattered to [to][from]: with them the tile is a small
             // residual (full-lattice and aligned edge posteriors of the same frames nearly cancel for peaked lattices),
             // so the sum over tiles in the backward launch does not lose what the cancellation leaves
@@ -1187,8 +1103,8 @@ __device__ __forceinline__ void full_workgroup(int b, FusedShared<NP> &SH) {
                 arrive += __hip_atomic_load(ed + k * 128 + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (A.act) {
-                if (stay != 0.0) atomicAdd(&TL.fxT[A.tgt * N + A.tgt], (unsigned long long) __double2ll_rn(stay * Num<R>::kFix));
-                if (lane >= 1 && arrive != 0.0) atomicAdd(&TL.fxT[A.tgt * N + A.prv], (unsigned long long) __double2ll_rn(arrive * Num<R>::kFix));
+                if (stay != 0.0) atomicAdd(&EL.fxT[A.tgt * N + A.tgt], (unsigned long long) __double2ll_rn(stay * Num<R>::kFix));
+                if (lane >= 1 && arrive != 0.0) atomicAdd(&EL.fxT[A.tgt * N + A.prv], (unsigned long long) __double2ll_rn(arrive * Num<R>::kFix));
             }
         }
         // alpha: tile[i][j] = E[i][j] * sx[i][j] - aligned edges,   E = exp2(Tr2[i][j] - rowmax_i)
@@ -1205,14 +1121,13 @@ __device__ __forceinline__ void full_workgroup(int b, FusedShared<NP> &SH) {
         for (int k = threadIdx.x; k < N * N; k += kFusedThreads) {
             const int i = k / N, j = k - i * N;
             const R t2 = tr[(int64_t) i * P.ts0 + (int64_t) j * P.ts1] * L2E;
-            R v;
-            R sum = 0;
+            double sum = 0;
 #pragma unroll
             for (int c = 0; c < kNC; ++c) sum += BETA ? TL.sx[c][j][i] : TL.sx[c][i][j];
-            v = Num<R>::exp2(t2 - xs[BETA ? j : i]) * sum;
-            const long long fv = (long long) TL.fxT[k];
-            if (fv != 0) v -= from_fix<R>((unsigned long long) fv);
-            tile_out[k] = v * F.gscale;
+            // the difference in double: for peaked lattices it is a small residual of two sums of ~len / 2
+            const double vd = (double) Num<R>::exp2(t2 - xs[BETA ? j : i]) * sum
+                              - (double) (long long) EL.fxT[k] * (1.0 / Num<R>::kFix);
+            tile_out[k] = (R) (vd * (double) F.gscale);
         }
     }
     // ---- phase 3: arrive; the SECOND full workgroup of the utterance closes it (score, loss, verdict, sync words)
@@ -1292,7 +1207,7 @@ __device__ __forceinline__ void full_workgroup(int b, FusedShared<NP> &SH) {
 // workgroups of utterance b = 8 G + u have indices 24 G + {0, 8, 16} + u -- equal mod 8 (same XCD / L2 in practice) and
 // close together in dispatch order (the alpha and beta workgroups wait for each other's first half).
 template <int NP>
-__global__ void __launch_bounds__(kFusedThreads, 3) fused_fwd_kernel(FusedParams KP) {
+__global__ void __launch_bounds__(kFusedThreads, 2) fused_fwd_kernel(FusedParams KP) {
     __shared__ FusedShared<NP> SH;
     const int B = kernarg_params()->P.B;
     const int G = (int) blockIdx.x / 24, w = (int) blockIdx.x - 24 * G;
@@ -1304,26 +1219,33 @@ __global__ void __launch_bounds__(kFusedThreads, 3) fused_fwd_kernel(FusedParams
 }
 
 // ------------------------------------------------------------------ the backward kernel
-// grid = B + R workgroups of 256 threads.
-//   workgroup b < B:   redo utterance b exactly if it is flagged; scale its grad_inputs rows by the upstream gradient
-//                      (nothing when that is 1); arrive.
-//   workgroup B + r:   once all B have arrived, grad_transition[slice r] = sum_b g_b * (tile[b][alpha] + tile[b][beta])[slice r],
+// grid = kCH B + R workgroups of 256 threads.
+//   workgroup kCH b + c:  utterance b.  Not flagged: the rows the forward launch left in grad_inputs hold gscale * (full
+//                      posterior); finish them -- minus the aligned posteriors (P2) scattered to labels with deterministic
+//                      fixed-point LDS adds, times the upstream gradient -- wave by wave, four frames (one P2 quad) at a
+//                      time.  Flagged: workgroup c = 0 redoes the utterance exactly, scales, arrives.
+//   workgroup kCH B + r:  once the redos have arrived, grad_transition[slice r] = sum_b g_b * (tile[b][alpha] + tile[b][beta])[slice r],
 //                      tiles in ascending order.
 constexpr int kBwdSlice = 64;
+constexpr int kCH = 8;          // workgroups per utterance in the row pass
+constexpr int kQB = 4;          // quads a wavefront has in flight
 template <int NP>
 __global__ void __launch_bounds__(256) fused_bwd_kernel(Problem P, State W, FusedArgs F) {
     typedef float R;
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
     __shared__ AssembleLds<R, NP, 4> S;
     __shared__ __attribute__((aligned(16))) R lds4[4][64];
     __shared__ R part[4][kBwdSlice];
+    __shared__ unsigned fxs[4][4][64];
     const int N = P.N, T = P.T, B = P.B;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if ((int) blockIdx.x < B) {
-        const int b = blockIdx.x;
+    if ((int) blockIdx.x < B * kCH) {
+        const int b = (int) blockIdx.x / kCH, c = (int) blockIdx.x - b * kCH;
         const R g = ((const R *) F.grad_loss)[F.reduction == 0 ? b : 0];
         const bool flagged = F.flags[b] != 0;
         if (flagged) {
+            if (c != 0) return;
             FwdOut O{};
             O.full_scores = (R *) F.dump + B;            // scratch: the scores of this launch's forward stay as they are
             O.aligned_scores = (R *) F.dump + 2 * B;
@@ -1346,25 +1268,94 @@ __global__ void __launch_bounds__(256) fused_bwd_kernel(Problem P, State W, Fuse
             for (int k = threadIdx.x; k < N * N; k += 256) ((R *) F.tiles)[((int64_t) b * 2 + 1) * N * N + k] = R(0);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             __syncthreads();
-        }
-        if (g != R(1)) {
-            R *gi = (R *) F.grad_inputs + (int64_t) b * N;
-            const int total = T * N;
-            for (int k = threadIdx.x; k < total; k += 256) {
-                const int t = k / N, i = k - t * N;
-                R *ptr = gi + (int64_t) t * B * N + i;
-                *ptr = *ptr * g;
+            if (g != R(1)) {
+                R *gi = (R *) F.grad_inputs + (int64_t) b * N;
+                const int total = T * N;
+                for (int k = threadIdx.x; k < total; k += 256) {
+                    const int t = k / N, i = k - t * N;
+                    R *ptr = gi + (int64_t) t * B * N + i;
+                    *ptr = *ptr * g;
+                }
             }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_fetch_add(F.ticket2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
         }
-        __syncthreads();
-        if (flagged && threadIdx.x == 0) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_fetch_add(F.ticket2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // ---- the rows of utterance b
+        const int Sx = P.S;
+        const int len = __builtin_amdgcn_readfirstlane(P.in_len ? clampi(P.in_len[b], 0, T) : T);
+        const int mid = len / 2;
+        // label of target position `lane` (clamped like aligned_setup); positions >= target length carry posterior 0
+        int tgt = 0;
+        {
+            const int ol = P.tg_len ? clampi(P.tg_len[b], 0, Sx) : Sx;
+            const int sc = lane < ol ? lane : 0;
+            tgt = clampi(P.targets[(int64_t) b * P.gs0 + (int64_t) sc * P.gs1], 0, N - 1);
+            // lanes past the target add 0: give each its OWN word (all of them on one address would serialise the LDS add)
+            if (lane >= ol) tgt = lane;
+        }
+        const unsigned rbS = (unsigned) Sx * sizeof(R);
+        __amdgpu_buffer_rsrc_t rg = make_rsrc((R *) F.grad_inputs + (int64_t) b * N,
+                                              (unsigned) ((int64_t) (T - 1) * B * N + N) * (unsigned) sizeof(R));
+        const unsigned voff = lane < N ? (unsigned) lane * sizeof(R) : kOobOffset;          // out of range: loads 0, stores nothing
+        const unsigned vQ = lane < Sx ? (unsigned) lane * 16u : kOobOffset;
+        const unsigned grow_bytes = (unsigned) B * N * sizeof(R);
+        const R gscale = F.gscale;
+        unsigned (*fx)[64] = fxs[wave];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) fx[r][lane] = 0;
+        // quads: the alpha side's (indices mid .. len-1 = frames, ascending), then the beta side's (indices len-mid .. len-1 =
+        // frames mid-1 .. 0)
+        const int nqa = (len - mid + 3) >> 2, nq = nqa + ((mid + 3) >> 2);
+        for (int q0 = c * 4 + wave; q0 < nq; q0 += 4 * kCH * kQB) {
+            u4 p2[kQB];
+            R row[kQB][4];
+            int fr[kQB][4], cnt[kQB];
+#pragma unroll
+            for (int u = 0; u < kQB; ++u) {
+                const int q = q0 + u * 4 * kCH;
+                const bool live = q < nq;
+                const int side = (live && q >= nqa) ? 1 : 0, k = live ? (side ? q - nqa : q) : 0;
+                const int h = side ? len - mid : mid;
+                const int base = h + 4 * k;
+                cnt[u] = live ? min(4, len - base) : 0;
+                __amdgpu_buffer_rsrc_t rp = make_rsrc((R *) F.p2 + ((int64_t) b * 2 + side) * (T + 8) * Sx, (unsigned) (T + 8) * rbS);
+                p2[u] = __builtin_amdgcn_raw_buffer_load_b128(rp, vQ, (unsigned) k * (unsigned) Sx * 16u, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = base + min(r, max(cnt[u] - 1, 0));
+                    fr[u][r] = clampi(side ? len - 1 - m : m, 0, T - 1);
+                    row[u][r] = buf_load<R>(rg, voff, (unsigned) fr[u][r] * grow_bytes);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kQB; ++u) {
+                if (cnt[u] > 0) {
+                    const R pv[4] = {__uint_as_float(p2[u].x), __uint_as_float(p2[u].y), __uint_as_float(p2[u].z), __uint_as_float(p2[u].w)};
+                    // scatter to labels: integer LDS adds commute -> repeated labels give bit-identical sums run to run
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) atomicAdd(&fx[r][tgt], FrameFix<R>::to(r < cnt[u] ? pv[r] : R(0)));
+                    __builtin_amdgcn_wave_barrier();
+                    unsigned fv[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) fv[r] = fx[r][lane];
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) fx[r][lane] = 0;
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (r < cnt[u]) buf_store(g * (row[u][r] - gscale * FrameFix<R>::from(fv[r])), rg, voff, (unsigned) fr[u][r] * grow_bytes);
+                }
+            }
         }
         return;
     }
     // ---- reducers: wait for the exact redos of the flagged utterances (normally none: no wait at all)
-    const int r = (int) blockIdx.x - B;
+    const int r = (int) blockIdx.x - B * kCH;
     {
         const unsigned nflag = F.ticket2[1];
         int spins = 0;
@@ -1408,7 +1399,7 @@ hipError_t launch_fused_np(const Problem &P, const State &W, const FusedArgs &F,
         hipLaunchKernelGGL((fused_fwd_kernel<NP>), dim3(24 * ((P.B + 7) / 8)), dim3(kFusedThreads), 0, st, KP);
     } else {
         const int R = (P.N * P.N + kBwdSlice - 1) / kBwdSlice;
-        hipLaunchKernelGGL((fused_bwd_kernel<NP>), dim3(P.B + R), dim3(256), 0, st, P, W, F);
+        hipLaunchKernelGGL((fused_bwd_kernel<NP>), dim3(P.B * kCH + R), dim3(256), 0, st, P, W, F);
     }
     return hipGetLastError();
 }

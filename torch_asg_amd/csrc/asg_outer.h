@@ -49,4 +49,23 @@ __device__ __forceinline__ void outer4_accumulate(float (&u)[4], float (&v)[4], 
             acc[r * NT + c] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[r], v[c], acc[r * NT + c], 0, 0, 0);
 }
 
+// The same sum with double accumulators (v_mfma_f64_16x16x4_f64, operands widened after the transposes): a hundred
+// products of ~1 summed in fp32 lose 4e-6 per add, which tiny alphabets -- whose transition gradient is an exact
+// cancellation against the aligned lattice -- expose.  Accumulator tile (r, c), register q, lane l holds
+// acc[16 r + (l >> 4) + 4 q][16 c + (l & 15)]   (NOT the fp32 form's row mapping).
+typedef double V4d __attribute__((ext_vector_type(4)));
+template <int NT>
+__device__ __forceinline__ void outer4_accumulate_f64(float (&u)[4], float (&v)[4], V4d (&acc)[NT * NT]) {
+    frames_to_operands(u);
+    frames_to_operands(v);
+    double ud[NT], vd[NT];
+#pragma unroll
+    for (int r = 0; r < NT; ++r) { ud[r] = (double) u[r]; vd[r] = (double) v[r]; }
+#pragma unroll
+    for (int r = 0; r < NT; ++r)
+#pragma unroll
+        for (int c = 0; c < NT; ++c)
+            acc[r * NT + c] = __builtin_amdgcn_mfma_f64_16x16x4f64(ud[r], vd[c], acc[r * NT + c], 0, 0, 0);
+}
+
 }  // namespace asg
