@@ -44,7 +44,7 @@ if os.environ.get("ASG_DBG"):
     torch.cuda.synchronize()
     d = sv2.tensors[0][sc + off: sc + off + 512].view(torch.int64).cpu().numpy()
     names = ["main-a", "main-b", "cons-a", "cons-b", "ali-a", "ali-b", "afin-a", "afin-b", "rowfin-a", "rowfin-b"]
-    what = {"main": ["poll e 1st half", "poll e 2nd half"], "cons": ["slot 1st half", "other side st_done", "slot 2nd half", "row ring space"],
+    what = {"main": ["poll e 1st half", "poll e 2nd half", "wall ticks (100 MHz)"], "cons": ["slot 1st half", "other side st_done", "slot 2nd half", "row ring space"],
             "ali": ["ring space"], "afin": ["other ast_done", "ar_done", "vmcnt(20) before publish", "loads+lds landed"], "rowfin": ["(per own group, cycles: exp stage)", "half-group 0", "half-group 4", "flush"]}
     for r, nm in enumerate(names):
         v = d[r * 5: r * 5 + 5]
@@ -52,6 +52,8 @@ if os.environ.get("ASG_DBG"):
         if r == 0:
             e = d[50:55]
             print("full WG phases (cycles): init %d  roles %d  wait aligned-done %d  tile+epilogue %d" % (e[1] - e[0], e[2] - e[1], e[3] - e[2], e[4] - e[3]))
+            print("   role end (cycles since the roles began): " + " ".join("wave%d %d" % (k, d[57 + k] - e[1]) for k in (2, 3, 4, 5, 6)))
+            print("   since the roles began: aligned workgroup done at %d (other compute unit: clocks may be offset), adone seen at %d after %d polls, edge fetch done at %d" % (d[55] - e[1], d[57] - e[1], d[58], d[56] - e[1]))
         if nm.startswith("rowfin"):
             ng = max(int(v[4]), 1)
             print("cons-%s per own group (%d groups): reads->exp %d  half-group(0) %d  half-group(4) %d  flush %d" % (nm[-1], ng, v[0] // ng, v[1] // ng, v[2] // ng, v[3] // ng))

@@ -44,13 +44,16 @@ constexpr int kAR = 64;         // aligned chain -> finisher ring of aligned sta
 constexpr int kGS = 8;          // frames per poll of the consumers / finishers
 constexpr int kMinFused = 4;
 constexpr int kAF = 3;          // aligned finisher wavefronts per side (round-robin over 8-index groups)
+#ifndef ASG_X_ALIPRIO
+#define ASG_X_ALIPRIO 3
+#endif
 #ifndef ASG_X_NC
-#define ASG_X_NC 4
+#define ASG_X_NC 3
 #endif
 // consumer wavefronts per full workgroup (round-robin over 8-index groups of the second half): what the LDS holds
 constexpr int kMaxNC = 4;
-template <int NP> struct Consumers {          // each has a [64][NP + 1] double tile beside the 64 KB of rings
-    static constexpr int fit = NP <= 40 ? 4 : NP <= 56 ? 3 : 2;
+template <int NP> struct Consumers {          // each has a [16 NT][16 NT + 1] double tile beside the 64 KB of rings
+    static constexpr int fit = NP <= 48 ? 4 : 2;
     static constexpr int n = ASG_X_NC < fit ? ASG_X_NC : fit;
 };
 constexpr int kFusedThreads = 512;   // 8 wavefronts: two per SIMD, 256 VGPRs each (the consumers keep 72 of double accumulators)
@@ -115,12 +118,27 @@ static_assert(sizeof(UttSync) == 64, "asg_loss_fused_sync_bytes");
 // lane stores / loads four consecutive indices of its label with ONE 16-byte write-through access.  Index m of a side
 // with first-half length h sits at position m + ((-h) & 7): the LAST block of the half is full and aligned, and the
 // other side -- which walks these indices downwards, 8 per group, starting from the last -- reads whole blocks.
+// Where the two chains of an utterance cross.  Near the middle, placed so that the LAST 8-frame group of both second
+// halves is short: what is left to do when the recursions end is one group's latency, and a group of <= 4 frames takes
+// half of it.  (All three workgroups and the backward launch must agree on it.)
+__host__ __device__ __forceinline__ int crossing(int len) {
+    int mid = len / 2;
+    if (len < 64) return mid;
+    const int base = (mid >> 3) << 3;
+    int best = mid, cost = 99;
+    for (int r = 1; r <= 5; ++r) {
+        const int m = base + r, ra = (len - m) & 7, c = max(r, ra == 0 ? 8 : ra);
+        if (c < cost) { cost = c; best = m; }
+    }
+    return best;
+}
+
 constexpr int kXBlockBytes = 2 * 64 * 16;
 __host__ __device__ __forceinline__ int xstate_blocks(int T) { return (T + 7) / 8 + 2; }
 
 template <int NP>
 struct TileLds {
-    double sx[Consumers<NP>::n][64][NP + 1];   // xi sums of consumer 0 .. kNC-1 (double: asg_outer.h): alpha side [to i][from j], beta side [from j][to i]
+    double sx[Consumers<NP>::n][16 * ((NP + 15) / 16)][16 * ((NP + 15) / 16) + 1];   // (padded to whole MFMA tiles: the dump needs no bounds checks)   // xi sums of consumer 0 .. kNC-1 (double: asg_outer.h): alpha side [to i][from j], beta side [from j][to i]
                                         // (before the E / F factor)
 };
 template <int NP>
@@ -305,6 +323,9 @@ __device__ __forceinline__ void fused_main(const Problem &P, int b, FusedSide &L
     const FullCtl ctl{&L, us};
     typedef float R;
     PRB_DECL
+#ifdef ASG_PROBE
+    const long long prb_wall0 = (long long) wall_clock64();
+#endif
     const int lane = threadIdx.x & 63;
     const int N = P.N;
     const bool act = lane < N;
@@ -346,6 +367,12 @@ __device__ __forceinline__ void fused_main(const Problem &P, int b, FusedSide &L
     lds_stf(&L.s[(nst - 1) & (kFR - 1)][lane], s_prev);
     lds_store_rlx(&L.csum, csum);
     lds_store_rel(&L.main_done, 1);
+#ifdef ASG_PROBE_TAIL
+    if (b == 0 && !BETA && lane == 0) ((long long *) dbg)[40] = clock64();
+#endif
+#ifdef ASG_PROBE
+    prb_w[2] = (long long) wall_clock64() - prb_wall0;        // 100 MHz ticks: the shader clock this launch really ran at
+#endif
     PRB_END(dbg, BETA ? 1 : 0)
 }
 
@@ -354,7 +381,8 @@ __device__ __forceinline__ void fused_main(const Problem &P, int b, FusedSide &L
 // that lead to index m, v_{m-1} (= p slot m-1) the vector that produced them.  Indices < h are the side's first half.
 template <int NP, bool BETA>
 __device__ __forceinline__ void fused_consumer(const Problem &P, const State &W, const FusedArgs &F, int b, FusedSide &L,
-                                               UttSync *us, int len, int h, double (&sx)[64][NP + 1], double &score_out2, const int cw) {
+                                               UttSync *us, int len, int h,
+                                               double (&sx)[16 * ((NP + 15) / 16)][16 * ((NP + 15) / 16) + 1], double &score_out2, const int cw) {
     typedef float R;
     typedef unsigned u4 __attribute__((ext_vector_type(4)));
     constexpr int NT = (NP + 15) / 16;
@@ -483,7 +511,28 @@ __device__ __forceinline__ void fused_consumer(const Problem &P, const State &W,
 #ifdef ASG_PROBE
         const long long prb_slot0 = clock64();
 #endif
+#ifdef ASG_PROBE_TAIL
+        long long tl[8]; tl[0] = clock64();
+#endif
+#ifndef ASG_X_FINEPOLL
+        // every poll is an LDS access the recursion wavefront's broadcast reads queue behind, and kNC - 1 consumers are
+        // waiting at any time: sleep in long steps until the group's FIRST row sum is there, then through most of the
+        // seven recursion steps that follow, and only then poll closely
+        if (g > 2 && n + g < len) {
+            float *first = &L.s[(n - 1) & (kFR - 1)][lane];
+            int spins = 0;
+            while (__ballot(__float_as_uint(lds_ldf(first)) != kSentinel) != ~0ull) {
+                if (L.stop()) return;
+                if (++spins > kSpinCap) { ctl.abort(13); return; }
+                __builtin_amdgcn_s_sleep(10);
+            }
+            __builtin_amdgcn_s_sleep(2 * (kGS - 2));
+        }
+#endif
         if (!wait_slot(n + g - 2)) return;
+#ifdef ASG_PROBE_TAIL
+        tl[1] = clock64();
+#endif
 #pragma unroll
         for (int q = 0; q < kGS; ++q) {
             const int m = n + min(q, g - 1);
@@ -507,20 +556,28 @@ __device__ __forceinline__ void fused_consumer(const Problem &P, const State &W,
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the values are in registers before the producer may refill
         lds_store_rlx(&L.cd[cw], n + g - 1 + (kNC - 1) * kGS);
         if ((__ballot(lo < Rng<R>::lo || hi > Rng<R>::hi) & actmask) != 0) { ctl.abort(7); return; }
+#ifdef ASG_X_NOCONSUME
+        sv = sg[kGS - 1]; n += kNC * kGS; continue;      // developer experiment: how fast is the recursion left alone?
+#endif
         // a short last group re-processes its last frame in the unused positions (the block holds nothing there)
 #pragma unroll
         for (int q = 1; q < kGS; ++q) oth[q] = (q < g) ? oth[q] : oth[q - 1];
         // posterior of the frame: softmax of (own state + other side's state); both are stored relative to offsets
         // that keep each frame's largest term near 1, so no max-shift -- a normaliser outside [2^-100, 2^100] aborts
-        R w[kGS];
+        // w = 2^(own + other) with own = arg + log2 s: as s * 2^(arg + other), no logarithm (|log2 s| <= 100 was just checked)
+        R w[kGS], ex[kGS];
 #pragma unroll
         for (int q = 0; q < kGS; ++q) {
-            const R gam = act ? (ag[q] + Num<R>::log2(sg[q])) + oth[q] : NINF;
-            w[q] = Num<R>::exp2(gam);
+            ex[q] = Num<R>::exp2(act ? ag[q] + oth[q] : NINF);
+            w[q] = sg[q] * ex[q];
         }
         // the next own group's block of the other side
-        R othn[kGS];
-        load_other(n + kNC * kGS, othn);
+#ifdef ASG_PROBE_TAIL
+        tl[2] = clock64();
+#endif
+        // the next own group's block of the other side, straight into `oth` (its last use in this iteration is above):
+        // nothing waits for these loads until the next iteration's exponentials, a whole round of the consumers away
+        load_other(n + kNC * kGS, oth);
 #ifdef ASG_PROBE
         const long long seg_b = clock64();
 #endif
@@ -528,7 +585,9 @@ __device__ __forceinline__ void fused_consumer(const Problem &P, const State &W,
         R u[kGS];
         auto half_group = [&](const int q0) -> bool {
             R z0 = w[q0], z1 = w[q0 + 1], z2 = w[q0 + 2], z3 = w[q0 + 3];
+#ifndef ASG_X_NOSUM
             wave_allsum4(z0, z1, z2, z3);
+#endif
             const R Z[4] = {z0, z1, z2, z3};
             unsigned zlo = 0xffffffffu, zhi = 0;
 #pragma unroll
@@ -540,31 +599,43 @@ __device__ __forceinline__ void fused_consumer(const Problem &P, const State &W,
             if (zlo < Rng<R>::lo || zhi > Rng<R>::hi) return false;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const R post = div_nr(w[q0 + q], Z[q]);
+                // u = posterior / s = 2^(arg + other) / Z (correctly rounded: its products with v = the recursion's vector sum
+                // over the frames and must not be biased), posterior = s * u
+                const R uq = div_nr(ex[q0 + q], Z[q]);
+                const R post = sg[q0 + q] * uq;
                 const int m = n + min(q0 + q, g - 1);
                 if (q0 + q < g) buf_store(post * gscale, rs_g, voffg, (unsigned) frame(m) * grow_bytes);
                 // xi: alpha side skips its first assembled index (the beta side's last one covers that transition)
                 const bool take = q0 + q < g && (BETA || n + q0 + q > h);
-                u[q0 + q] = (take && act) ? div_nr(post, sg[q0 + q]) : R(0);
+                u[q0 + q] = (take && act) ? uq : R(0);
                 pg[q0 + q] = act ? pg[q0 + q] : R(0);
             }
             float ua[4] = {u[q0], u[q0 + 1], u[q0 + 2], u[q0 + 3]}, va[4] = {pg[q0], pg[q0 + 1], pg[q0 + 2], pg[q0 + 3]};
+#ifndef ASG_X_NOMFMA
             outer4_accumulate_f64<NT>(ua, va, acc);
+#else
+            acc[0][0] += (double) (ua[0] + va[1]);
+#endif
             return true;
         };
         if (!half_group(0)) { ctl.abort(8); return; }
 #ifdef ASG_PROBE
         const long long seg_c = clock64();
 #endif
-        if (!half_group(4)) { ctl.abort(9); return; }
+#ifdef ASG_PROBE_TAIL
+        tl[3] = clock64();
+#endif
+        if (g > 4 && !half_group(4)) { ctl.abort(9); return; }
+#ifdef ASG_PROBE_TAIL
+        tl[4] = clock64();
+        if (b == 0 && !BETA && lane == 0) { long long *d = (long long *) W.dbg + cw * 8; for (int k = 0; k < 5; ++k) d[k] = tl[k]; d[5] = n; }
+#endif
 #ifdef ASG_PROBE
         const long long seg_d = clock64();
 #endif
 #ifdef ASG_PROBE
         prb_seg[0] += seg_b - seg_a; prb_seg[1] += seg_c - seg_b; prb_seg[2] += seg_d - seg_c; prb_seg[3] += clock64() - seg_d; prb_seg[4] += 1;
 #endif
-#pragma unroll
-        for (int q = 0; q < kGS; ++q) oth[q] = othn[q];
         sv = sg[kGS - 1];
         n += kNC * kGS;
     }
@@ -578,7 +649,7 @@ __device__ __forceinline__ void fused_consumer(const Problem &P, const State &W,
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int i = 16 * r + (lane >> 4) + 4 * q, j = 16 * c + (lane & 15);
-                if (j <= NP) sx[i][j] = acc[r * NT + c][q];
+                sx[i][j] = acc[r * NT + c][q];
             }
     // ---- end of the chain: score (beta side), by the consumer that took the last group; as the three-wavefront kernel
     if (((((len - h + kGS - 1) / kGS) - 1) % kNC) != cw) return;
@@ -727,7 +798,9 @@ __device__ __forceinline__ void fused_aligned(const Problem &P, const State &W, 
         bool ok;
         const double ebias = block_begin(done, kPF, ok);
         if (!ok) return;
-        aligned_steps<BETA, false>(cur, kPF, 1 + done, len, H2, BETA ? Dn : Dp, ebias, &L.ar[done & (kAR - 1)][lane], rs, voff, row_bytes, st);
+        // (HBM gets the first half only -- what the other side's finishers read; later blocks store out of bounds = nowhere)
+        aligned_steps<BETA, false>(cur, kPF, 1 + done, len, H2, BETA ? Dn : Dp, ebias, &L.ar[done & (kAR - 1)][lane], rs,
+                                   1 + done < h ? voff : kOobOffset, row_bytes, st);
         block_end(done, kPF);
 #pragma unroll
         for (int k = 0; k < kPF; ++k) cur[k] = nxt[k];
@@ -738,7 +811,8 @@ __device__ __forceinline__ void fused_aligned(const Problem &P, const State &W, 
         bool ok;
         const double ebias = block_begin(done, r, ok);
         if (!ok) return;
-        aligned_steps<BETA, true>(cur, r, 1 + done, len, H2, BETA ? Dn : Dp, ebias, &L.ar[done & (kAR - 1)][lane], rs, voff, row_bytes, st);
+        aligned_steps<BETA, true>(cur, r, 1 + done, len, H2, BETA ? Dn : Dp, ebias, &L.ar[done & (kAR - 1)][lane], rs,
+                                  1 + done < h ? voff : kOobOffset, row_bytes, st);
         block_end(done, r);
 #pragma unroll
         for (int k = 1; k < kPF; ++k) last_raw = (k == r) ? cur[k] : last_raw;
@@ -942,7 +1016,7 @@ __device__ __forceinline__ void aligned_workgroup(int b, FusedShared<NP> &SH) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int N = P.N, T = P.T;
     const int len = __builtin_amdgcn_readfirstlane(P.in_len ? clampi(P.in_len[b], 0, T) : T);
-    const int mid = len / 2;
+    const int mid = crossing(len);
     const bool fused = len >= kMinFused;
     UttSync *us = reinterpret_cast<UttSync *>(F.sync + 64) + b;
     if (threadIdx.x == 0) {
@@ -958,8 +1032,8 @@ __device__ __forceinline__ void aligned_workgroup(int b, FusedShared<NP> &SH) {
         const State W = ld_state(kernarg_params());
         const FusedArgs F = ld_fargs(kernarg_params());
         switch (wave) {
-            case 0: __builtin_amdgcn_s_setprio(3); fused_aligned<false>(P, W, b, LA, LB, len, mid, sc2, (double *) F.aoff + ((int64_t) b * 2 + 0) * ((T + kPF - 1) / kPF + 1) * 2, us); break;
-            case 1: __builtin_amdgcn_s_setprio(3); fused_aligned<true>(P, W, b, LB, LA, len, len - mid, sc2, (double *) F.aoff + ((int64_t) b * 2 + 1) * ((T + kPF - 1) / kPF + 1) * 2, us); break;
+            case 0: __builtin_amdgcn_s_setprio(ASG_X_ALIPRIO); fused_aligned<false>(P, W, b, LA, LB, len, mid, sc2, (double *) F.aoff + ((int64_t) b * 2 + 0) * ((T + kPF - 1) / kPF + 1) * 2, us); break;
+            case 1: __builtin_amdgcn_s_setprio(ASG_X_ALIPRIO); fused_aligned<true>(P, W, b, LB, LA, len, len - mid, sc2, (double *) F.aoff + ((int64_t) b * 2 + 1) * ((T + kPF - 1) / kPF + 1) * 2, us); break;
 #ifndef ASG_X_NOFIN
             // two finishers of a side on a SIMD of their own pair, the third beside the OTHER side's chain (which has priority)
             case 2: case 6: fused_afin<false>(P, W, F, b, LA, LB, len, mid, us, (wave - 2) >> 2); break;
@@ -990,10 +1064,15 @@ __device__ __forceinline__ void aligned_workgroup(int b, FusedShared<NP> &SH) {
     __syncthreads();
     if (threadIdx.x == 0) {
         const bool gave_up = !fused || LA.stop() || LB.stop();
-        ((double *) F.ascore)[b] = SH.score_ali;          // read back by the closing full workgroup with an agent-scope load
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        // Everything another workgroup reads from this one (P2, the edge posteriors, this score) is stored write-through and
+        // drained by its writer: NO release fence here -- it would write back the whole L2 (the ~100 KB of aligned states
+        // this workgroup left dirty there: measured 5-6 us, on the path of the full workgroups' epilogue).
+        __hip_atomic_store((double *) F.ascore + b, SH.score_ali, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_store(&us->adone, gave_up ? 2u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef ASG_PROBE
+        if (b == 0) ((long long *) ld_state(kernarg_params()).dbg)[55] = clock64();
+#endif
     }
 }
 
@@ -1010,7 +1089,7 @@ __device__ __forceinline__ void full_workgroup(int b, FusedShared<NP> &SH) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int N = P.N, T = P.T;
     const int len = __builtin_amdgcn_readfirstlane(P.in_len ? clampi(P.in_len[b], 0, T) : T);
-    const int mid = len / 2;
+    const int mid = crossing(len);
     const int h = BETA ? len - mid : mid;
     const bool fused = len >= kMinFused;
     UttSync *us = reinterpret_cast<UttSync *>(F.sync + 64) + b;
@@ -1029,7 +1108,7 @@ __device__ __forceinline__ void full_workgroup(int b, FusedShared<NP> &SH) {
 #endif
     for (int q = threadIdx.x; q < kFR * 64; q += kFusedThreads) (&L.s[0][0])[q] = __uint_as_float(kSentinel);
     TileLds<NP> &TL = SH.t;
-    for (int k = threadIdx.x; k < kNC * 64 * (NP + 1); k += kFusedThreads) (&TL.sx[0][0][0])[k] = 0.0;
+    // (the consumers' tiles need no zeroing: each writes every element of its own as its last act)
     __syncthreads();
 
     double sc2 = -1e300;
@@ -1037,9 +1116,19 @@ __device__ __forceinline__ void full_workgroup(int b, FusedShared<NP> &SH) {
     if (b == 0 && !BETA && threadIdx.x == 0) ((long long *) ld_state(kernarg_params()).dbg)[51] = clock64();
 #endif
 
+    // what the epilogue needs from HBM is fetched now, not after the recursion: this thread's elements of the transition
+    // matrix (tile pass) ...
+    constexpr int KT = (NP * NP + kFusedThreads - 1) / kFusedThreads;
+    R trv[KT];
+#pragma unroll
+    for (int m = 0; m < KT; ++m) {
+        const int k = min((int) threadIdx.x + m * kFusedThreads, N * N - 1), i = k / N, j = k - i * N;
+        trv[m] = ((const R *) P.transition)[(int64_t) i * P.ts0 + (int64_t) j * P.ts1];
+    }
+    double est = 0, ear = 0;          // ... and (wavefront 4, while the roles run) the aligned edge posteriors of this side
     // ---- phase 1: the roles.  Control flow is uniform per wavefront; nothing in here uses a workgroup barrier.
-    // Wavefront 4 (the recursion wavefront's SIMD) and 6 .. 11 go straight to the barrier: a waiting wavefront issues nothing.
-    if (!BETA && wave == 5) {
+    // Idle wavefronts go straight to the barrier: a waiting wavefront issues nothing.
+    if (!BETA && wave == 7) {
         // padded frames get exactly-zero gradients (the reference: roll_to_end + masked softmax, utils.cpp:11-66)
         __amdgpu_buffer_rsrc_t rs_g = make_rsrc((R *) F.grad_inputs + (int64_t) b * N,
                                                 (unsigned) ((int64_t) (T - 1) * P.B * N + N) * (unsigned) sizeof(R));
@@ -1056,13 +1145,60 @@ __device__ __forceinline__ void full_workgroup(int b, FusedShared<NP> &SH) {
             case 1: duo_producer<NP, BETA>(P, b, L); break;
             case 2: fused_consumer<NP, BETA>(P, W, F, b, L, us, len, h, TL.sx[0], sc2, 0); break;
             case 3: fused_consumer<NP, BETA>(P, W, F, b, L, us, len, h, TL.sx[1], sc2, 1); break;
-            case 6: if (kNC > 2) fused_consumer<NP, BETA>(P, W, F, b, L, us, len, h, TL.sx[2 % kNC], sc2, 2); break;
-            case 7: if (kNC > 3) fused_consumer<NP, BETA>(P, W, F, b, L, us, len, h, TL.sx[3 % kNC], sc2, 3); break;
+            // (consumers on three SIMDs: the third beside the producer, which is light)
+            case 5: if (kNC > 2) fused_consumer<NP, BETA>(P, W, F, b, L, us, len, h, TL.sx[2 % kNC], sc2, 2); break;
+#ifdef ASG_X_C4_ON_SIMD0
+            case 4: if (kNC > 3) fused_consumer<NP, BETA>(P, W, F, b, L, us, len, h, TL.sx[3 % kNC], sc2, 3); break;
+#else
+            case 6: if (kNC > 3) fused_consumer<NP, BETA>(P, W, F, b, L, us, len, h, TL.sx[3 % kNC], sc2, 3); break;
+#endif
+#ifdef ASG_X_C4_ON_SIMD0
+            case 6: {
+#else
+            case 4: {
+#endif
+                // the aligned workgroup's verdict and the edge posteriors of THIS side's frames (it finishes a little
+                // before the recursion does; slow polls beside the recursion wavefront)
+                unsigned v = 0;
+                int spins = 0;
+                while ((v = __hip_atomic_load(&us->adone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
+                    if (L.stop() || ++spins > (1 << 18)) break;
+                    __builtin_amdgcn_s_sleep(32);
+                }
+                v = __builtin_amdgcn_readfirstlane(v);
+#ifdef ASG_PROBE
+                if (b == 0 && !BETA && lane == 0) { ((long long *) W.dbg)[57] = clock64(); ((long long *) W.dbg)[58] = spins; }
+#endif
+                if (v == 1) {
+                    const double *ed = (const double *) F.edges + ((int64_t) b * 2 + (BETA ? 1 : 0)) * kAF * 128;
+                    for (int k = 0; k < kAF; ++k) {          // fixed order
+                        est += __hip_atomic_load(ed + k * 128 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ear += __hip_atomic_load(ed + k * 128 + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                if (v != 0 && lane == 0) SH.adone = (int) v;
+#ifdef ASG_PROBE
+                if (b == 0 && !BETA && lane == 0) ((long long *) W.dbg)[56] = clock64();
+#endif
+                break;
+            }
             default: break;
         }
         if (BETA && lane == 0 && sc2 > -1e299) SH.score_full = sc2;
     }
+#ifdef ASG_PROBE
+    if (b == 0 && !BETA && lane == 0 && wave >= 2 && wave <= 6) ((long long *) ld_state(kernarg_params()).dbg)[57 + wave] = clock64();
+#endif
+#ifdef ASG_PROBE_TAIL
+    if (b == 0 && !BETA && lane == 0 && wave >= 2 && wave <= 6) ((long long *) ld_state(kernarg_params()).dbg)[41 + wave] = clock64();
+#endif
+    // LDS-only barrier: what the epilogue reads from the roles is in LDS; the consumers' last row stores (a microsecond or
+    // two from acknowledgement) need not have landed -- nothing in this launch reads them
+#ifdef ASG_X_FULLBARRIER
     __syncthreads();
+#else
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
 #ifdef ASG_PROBE
     if (b == 0 && !BETA && threadIdx.x == 0) ((long long *) ld_state(kernarg_params()).dbg)[52] = clock64();
 #endif
@@ -1091,17 +1227,16 @@ __device__ __forceinline__ void full_workgroup(int b, FusedShared<NP> &SH) {
         EdgeLds<NP> &EL = SH.u.e;
         for (int k = threadIdx.x; k < NP * NP; k += kFusedThreads) EL.fxT[k] = 0;
         __syncthreads();
+#ifdef ASG_X_C4_ON_SIMD0
+        if (wave == 6) {
+#else
         if (wave == 4) {
+#endif
             // aligned edge posteriors of THIS side's frames, scattered to [to][from]: with them the tile is a small
             // residual (full-lattice and aligned edge posteriors of the same frames nearly cancel for peaked lattices),
             // so the sum over tiles in the backward launch does not lose what the cancellation leaves
             const AlignedSetup<R> A = aligned_setup<R>(P, b, lane);
-            const double *ed = (const double *) F.edges + ((int64_t) b * 2 + (BETA ? 1 : 0)) * kAF * 128;
-            double stay = 0, arrive = 0;
-            for (int k = 0; k < kAF; ++k) {          // fixed order
-                stay += __hip_atomic_load(ed + k * 128 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                arrive += __hip_atomic_load(ed + k * 128 + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            const double stay = est, arrive = ear;
             if (A.act) {
                 if (stay != 0.0) atomicAdd(&EL.fxT[A.tgt * N + A.tgt], (unsigned long long) __double2ll_rn(stay * Num<R>::kFix));
                 if (lane >= 1 && arrive != 0.0) atomicAdd(&EL.fxT[A.tgt * N + A.prv], (unsigned long long) __double2ll_rn(arrive * Num<R>::kFix));
@@ -1112,15 +1247,17 @@ __device__ __forceinline__ void full_workgroup(int b, FusedShared<NP> &SH) {
         // (sx = the consumers' sums, added in the order 0, 1, ...)
         // one coalesced pass of the whole workgroup over the transition matrix
         const R L2E = Num<R>::log2e();
-        const R *tr = (const R *) P.transition;
         R *tile_out = (R *) F.tiles + ((int64_t) b * 2 + (BETA ? 1 : 0)) * N * N;
         // (xx sits in a register of lane i; the tile loop wants it by index: back through LDS, behind the sums)
         R *xs = SH.xs;
         if (wave == 0) xs[lane] = xx;
         __syncthreads();
-        for (int k = threadIdx.x; k < N * N; k += kFusedThreads) {
+#pragma unroll
+        for (int m = 0; m < KT; ++m) {
+            const int k = (int) threadIdx.x + m * kFusedThreads;
+            if (k >= N * N) break;
             const int i = k / N, j = k - i * N;
-            const R t2 = tr[(int64_t) i * P.ts0 + (int64_t) j * P.ts1] * L2E;
+            const R t2 = trv[m] * L2E;
             double sum = 0;
 #pragma unroll
             for (int c = 0; c < kNC; ++c) sum += BETA ? TL.sx[c][j][i] : TL.sx[c][i][j];
@@ -1287,7 +1424,7 @@ __global__ void __launch_bounds__(256) fused_bwd_kernel(Problem P, State W, Fuse
         // ---- the rows of utterance b
         const int Sx = P.S;
         const int len = __builtin_amdgcn_readfirstlane(P.in_len ? clampi(P.in_len[b], 0, T) : T);
-        const int mid = len / 2;
+        const int mid = crossing(len);
         // label of target position `lane` (clamped like aligned_setup); positions >= target length carry posterior 0
         int tgt = 0;
         {
