@@ -2,12 +2,19 @@
 """bench.py -- utterances/s of the ASG forward+backward hot path on MI355X (BASELINE.json metric).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--mode graph|eager] [--launch single|streams|serial]
+                    [--graph-steps G]
 
 One "step" = ASGLoss(inputs, targets, input_lengths, target_lengths) + loss.backward() on one batch of
 synthetic utterances already resident in HBM (SURVEY.md 8d inputs: cfg 3, T=400 B=64 N=40 L=30, fp32).
 With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank owns its own B=64 shard of a
 B=64*N batch (= cfg 4 at N=8), and the step ends with the single RCCL all-reduce of transition.grad
 (SURVEY.md 8e): weak scaling, no other collective.
+
+In graph mode G consecutive steps (default: the largest divisor of K up to 10) are captured into ONE hipGraph and the
+timed region replays it K/G times: every step's kernels run in full, back to back on the stream, as they do inside a
+training loop whose host runs ahead of the GPU; with G = 1 every step also pays the ~8 us fixed latency of a graph
+launch that nothing overlaps in this loop (measured: rocprofv3 trace, profiles/r02_summary.md).  `config.step_mode`
+names G.
 
 Rank 0 prints ONE JSON line.  Besides the driver's contract fields it carries
   roofline     -- dominant kernel (the recursion kernel): algorithmic bytes / measured kernel time vs HBM peak
@@ -112,6 +119,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--mode", choices=["graph", "eager"], default="graph")
     ap.add_argument("--launch", choices=["single", "streams", "serial"], default="single")
+    ap.add_argument("--graph-steps", type=int, default=0, help="steps per captured hipGraph (0 = largest divisor of --steps <= 10)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="init the process group even with one rank (testing)")
     args = ap.parse_args()
@@ -163,8 +171,15 @@ def main():
         if use_dist:
             dist.all_reduce(loss_mod.transition.grad, op=dist.ReduceOp.SUM)   # the one collective of the step
 
+    gsteps = 1
+    if args.mode == "graph":
+        gsteps = args.graph_steps if args.graph_steps > 0 else max(g for g in range(1, 11) if args.steps % g == 0)
+        if args.steps % gsteps or args.warmup % gsteps:
+            gsteps = 1
+
     # ---- optional hipGraph capture of the compute part of the step (static shapes)
     graph = None
+    graph_has_collective = False
     mode = args.mode
     if mode == "graph":
         try:
@@ -175,34 +190,52 @@ def main():
                     one_step()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                static_loss = one_step()
-            graph.replay()
-            torch.cuda.synchronize()
+            def capture(with_collective):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    for _ in range(gsteps):
+                        one_step()
+                        if with_collective:
+                            sync_grads()
+                g.replay()
+                torch.cuda.synchronize()
+                return g
+            if use_dist and gsteps > 1:
+                try:                     # the all-reduce inside the graph, so that G steps stay one replay
+                    graph = capture(True)
+                    graph_has_collective = True
+                except Exception as e:
+                    sys.stderr.write("[bench] could not capture the all-reduce (%s); one step per graph\n" % (e,))
+                    gsteps = 1
+                    graph = None
+            if graph is None:
+                graph = capture(False)
         except Exception as e:           # capture unsupported in this environment: fall back, say so
             sys.stderr.write("[bench] hipGraph capture failed (%s); running eager\n" % (e,))
             graph = None
             mode = "eager"
+            gsteps = 1
 
-    def step():
+    def step_group():                    # gsteps steps
         if graph is not None:
             graph.replay()
+            if not graph_has_collective:
+                sync_grads()
         else:
             one_step()
-        sync_grads()
+            sync_grads()
 
     def fence():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for _ in range(args.warmup // gsteps):
+        step_group()
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for _ in range(args.steps // gsteps):
+        step_group()
     fence()
     dt = time.perf_counter() - t0
     if use_dist:
@@ -219,15 +252,23 @@ def main():
     lflags = {"streams": lib_mod.FLAG_STREAMS, "single": lib_mod.FLAG_SINGLE_LAUNCH, "serial": 0}[args.launch]
     xd = x.detach()
     trd = loss_mod.transition.detach()
+    fused_step = args.launch == "single"      # ASGLoss' default route: recursions AND gradient assembly in one launch
+
+    def dominant_launch():
+        if fused_step:
+            be.loss_forward(xd, tg, trd, il, tl, "mean", lflags)
+        else:
+            be.forward(xd, tg, trd, il, tl, lflags)
+
     for _ in range(5):
-        be.forward(xd, tg, trd, il, tl, lflags)
+        dominant_launch()
     torch.cuda.synchronize()
     nk = min(max(args.steps, 20), 200)
     for _ in range(nk):
         torch.cuda._sleep(400000)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        be.forward(xd, tg, trd, il, tl, lflags)
+        dominant_launch()
         e1.record()
         ev_pairs.append((e0, e1))
     torch.cuda.synchronize()
@@ -242,13 +283,13 @@ def main():
         side.wait_stream(torch.cuda.current_stream())
         kg = torch.cuda.CUDAGraph()
         with torch.cuda.stream(side):
-            be.forward(xd, tg, trd, il, tl, lflags)
+            dominant_launch()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         per_graph = 25
         with torch.cuda.graph(kg):
             for _ in range(per_graph):
-                be.forward(xd, tg, trd, il, tl, lflags)
+                dominant_launch()
         for _ in range(3):
             kg.replay()
         torch.cuda.synchronize()
@@ -275,13 +316,18 @@ def main():
         value = global_batch * args.steps / dt
         achieved = a_alg / (kern_ms_med * 1e-3) / 1e9
         traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_cfg3.json")
-        if os.path.exists(pmc_path):
-            try:
-                with open(pmc_path) as f:
-                    traffic = json.load(f).get("recursion_kernel_hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        # HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc, separate runs:
+        # profiles/r02_summary.md); the file is named in the line so that a stale number is detectable
+        traffic_source = None
+        for name, key in (("r02_pmc_cfg3.json", "dominant_kernel_hbm_bytes_per_launch"),):
+            pmc_path = os.path.join(ROOT, "profiles", name)
+            if fused_step and os.path.exists(pmc_path):
+                try:
+                    with open(pmc_path) as f:
+                        traffic = json.load(f).get(key)
+                    traffic_source = "profiles/" + name
+                except Exception:
+                    traffic = None
         out = {
             "metric": "utterances/sec fwd+bwd, T=400 B=64 N=40; achieved HBM GB/s vs roofline",
             "value": value,
@@ -300,13 +346,14 @@ def main():
                                                             "; global batch %d sharded over %d GPUs, one RCCL "
                                                             "all-reduce of transition.grad per step" % (global_batch, world)),
                        "global_batch": global_batch, "per_gpu_batch": B, "T": T, "N": N, "L": L,
-                       "step_mode": mode, "launch_mode": args.launch,
+                       "step_mode": mode if mode != "graph" else "graph (%d consecutive steps per hipGraph replay)" % gsteps,
+                       "launch_mode": args.launch,
                        "parallelism": "batch-sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "fwd_duo_kernel (alpha/beta recursions, all four passes in one launch; "
-                                   "three wavefronts per full-lattice chain)"
-                                   if args.launch == "single" else "asg_forward launches (recursion kernels)",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel": "fused_fwd_kernel (all four recursions of every utterance AND the gradient assembly in "
+                                   "one launch: three workgroups per utterance)"
+                                   if fused_step else "asg_forward launches (recursion kernels)",
                          "kernel_ms": kern_ms_med, "kernel_ms_avg": kern_ms_avg, "kernel_timing": kern_method,
                          "algorithmic_bytes_per_launch": a_alg,
                          "step_achieved": a_alg / (ms_per_step * 1e-3) / 1e9,
