@@ -112,6 +112,88 @@ def cpu_baseline(budget_s=24.0):
                          ", ".join("%d:%.0f" % (n, results[n][0] * 1e3) for n in cands), default_threads)}
 
 
+CFG5 = dict(T=2000, B=32, N=10000, L=60)      # BASELINE.json configs[4]: large alphabet, variable lengths
+
+
+def run_cfg5(args, real_stdout):
+    """`--config cfg5`: the large-alphabet workload on the generic kernels (csrc/asg_generic.hip), same JSON contract.
+    A step is ASGLoss forward + backward on one batch (eager: a step is ~1.5 s of GPU time, launch overhead is nothing).
+    The reference cannot run this size at all: fully_connected_lattice.cpp:77 allocates a [T-1,B,N,N] tensor = 25.6 TB."""
+    import torch_asg_amd
+    from torch_asg_amd import asg as asg_mod, _lib as lib_mod
+    T5, B5, N5, L5 = CFG5["T"], CFG5["B"], CFG5["N"], CFG5["L"]
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    g = torch.Generator(device=dev).manual_seed(0)     # drawn on the device: 2.6 GB of emissions
+    tr = torch.rand(N5, N5, generator=g, device=dev)
+    x = torch.randn(T5, B5, N5, generator=g, device=dev).requires_grad_(True)
+    tg = torch.randint(0, N5, (B5, L5), generator=g, device=dev)
+    il = torch.randint(T5 // 2, T5 + 1, (B5,), generator=g, device=dev)
+    tl = torch.randint(max(1, L5 // 2), L5 + 1, (B5,), generator=g, device=dev)
+    m = torch_asg_amd.ASGLoss(N5, reduction="mean").to(dev)
+    with torch.no_grad():
+        m.transition.copy_(tr)
+
+    def one_step():
+        m.transition.grad = None
+        x.grad = None
+        loss = m(x, tg, il, tl)
+        loss.backward()
+        return loss
+
+    for _ in range(max(args.warmup, 1)):
+        one_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = one_step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    # dominant kernel: fwd_step_kernel, one launch per frame (alpha of frame n and beta of frame len-1-n together):
+    # forward alone between HIP events / (T - 1) launches
+    be = asg_mod.native()
+    xd, trd = x.detach(), m.transition.detach()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    be.forward(xd, tg, trd, il, tl, 0)
+    torch.cuda.synchronize()
+    e0.record()
+    be.forward(xd, tg, trd, il, tl, 0)
+    e1.record()
+    torch.cuda.synchronize()
+    fwd_ms = e0.elapsed_time(e1)
+    step_launches = T5 - 1
+    kern_ms = fwd_ms / step_launches
+    w = 4
+    a_alg_step = 2 * N5 * N5 * w + 2 * 2 * B5 * N5 * w        # one frame, both directions: E and F once, vectors in/out
+    a_alg = 3 * (T5 - 1) * N5 * N5 * w + 2 * T5 * B5 * N5 * w      # SURVEY.md 8(d): alpha, beta and gradient passes over Tr
+    ms_per_step = dt / args.steps * 1e3
+    achieved = a_alg_step / (kern_ms * 1e-3) / 1e9
+    out = {
+        "metric": "utterances/sec fwd+bwd, T=2000 B=32 N=10000 (cfg 5, large alphabet); achieved HBM GB/s vs roofline",
+        "value": B5 * args.steps / dt, "unit": "utterances/s", "n_gpus": 1, "steps": args.steps, "warmup": max(args.warmup, 1),
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "cfg5: T=%d B=%d N=%d L=%d fp32, variable input/target lengths, ASGLoss(reduction=mean) "
+                               "forward+backward on the generic (large-alphabet) kernels" % (T5, B5, N5, L5),
+                   "global_batch": B5, "T": T5, "N": N5, "L": L5, "step_mode": "eager", "parallelism": "single GPU"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None,
+                     "kernel": "fwd_step_kernel (one frame of the full-lattice alpha AND beta recursions for the whole batch: "
+                               "the row- and column-normalised transition matrices streamed once each)",
+                     "kernel_ms": kern_ms, "kernel_timing": "HIP events around the forward launch sequence / (T-1) step launches "
+                                                            "(includes the aligned chains and the prologue: < 2 %)",
+                     "algorithmic_bytes_per_launch": a_alg_step,
+                     "step_algorithmic_bytes": a_alg, "step_achieved": a_alg / (ms_per_step * 1e-3) / 1e9,
+                     "note": "A_alg(step) = 3 (T-1) N^2 w + 2 T B N w (SURVEY.md 8d: alpha, beta, gradient passes over Tr; the "
+                             "gradient products here are two tiled contractions, compute-bound on the VALU)"},
+        "cpu_baseline": None,
+        "cpu_baseline_note": "the reference cannot run cfg 5 (fully_connected_lattice.cpp:77: 25.6 TB of path_contrib)",
+        "loss": float(loss),
+    }
+    sys.stdout.flush()
+    os.write(real_stdout, (json.dumps(out) + "\n").encode())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -122,12 +204,20 @@ def main():
     ap.add_argument("--graph-steps", type=int, default=0, help="steps per captured hipGraph (0 = largest divisor of --steps <= 10)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="init the process group even with one rank (testing)")
+    ap.add_argument("--config", choices=["cfg3", "cfg5"], default="cfg3",
+                    help="cfg3 = BASELINE.json's headline workload (default); cfg5 = the large-alphabet workload, 1 GPU")
     args = ap.parse_args()
 
     # keep stdout clean for the ONE JSON line: anything libraries print (RCCL banners etc.) goes to stderr
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
+    if args.config == "cfg5":
+        if "--steps" not in sys.argv:
+            args.steps = 3
+        if "--warmup" not in sys.argv:
+            args.warmup = 1
+        return run_cfg5(args, real_stdout)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -713,3 +713,46 @@ def test_scale_modes(mode):
         util.assert_close(m.transition.grad.cpu().numpy(), o["grad_transition"] * k, 1e-9, mode + "/gt")
     with pytest.raises(ValueError):
         A.ASGLoss(4, scale_mode="bogus")
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.float64, 1e-9)])
+def test_input_is_logits(dtype, tol):
+    """ASGLoss(input_is_logits=True)(logits) == ASGLoss()(log_softmax(logits)) -- loss and the
+    gradients w.r.t. the LOGITS (autograd through torch.log_softmax on the reference-style side), and the loss also
+    against the oracle fed log_softmax(logits)."""
+    A = _asg()
+    tr, x, tg, il, tl = util.synth(90, 7, 33, 12, 21, True, torch.float64)
+    x = x * 3.0 + 1.5                                     # unnormalised, with a common offset
+    lp = torch.log_softmax(x, dim=2)
+    o = orc.asg_loss(lp.numpy(), tg.numpy(), tr.numpy(), il.numpy(), tl.numpy(), "mean")
+    m = A.ASGLoss(33, input_is_logits=True).to(DEV).to(dtype)
+    ref = A.ASGLoss(33).to(DEV).to(dtype)
+    with torch.no_grad():
+        m.transition.copy_(tr.to(dtype))
+        ref.transition.copy_(tr.to(dtype))
+    xa = x.to(dtype).to(DEV).requires_grad_(True)
+    xb = x.to(dtype).to(DEV).requires_grad_(True)
+    la = m(xa, tg.to(DEV), il.to(DEV), tl.to(DEV))
+    la.backward()
+    lb = ref(torch.log_softmax(xb, dim=2), tg.to(DEV), il.to(DEV), tl.to(DEV))
+    lb.backward()
+    util.assert_close(la.detach().cpu().numpy(), o["loss"], tol, "loss vs oracle(log_softmax)")
+    util.assert_close(la.detach().cpu().numpy(), lb.detach().cpu().numpy(), tol, "loss vs composition")
+    util.assert_close(xa.grad.cpu().numpy(), xb.grad.cpu().numpy(), tol, "d loss / d logits")
+    util.assert_close(m.transition.grad.cpu().numpy(), ref.transition.grad.cpu().numpy(), tol, "grad_transition")
+    # the oracle's gradient w.r.t. the log-probabilities sums to zero over the labels of every frame: what makes the
+    # softmax Jacobian's correction vanish
+    assert np.abs(o["grad_inputs"].sum(axis=2)).max() < 1e-12
+
+
+def test_large_batch_routes_to_standalone_kernels_and_agrees():
+    """Above ~CUs/2 utterances the 'single' launch mode uses the stand-alone kernels (the fused step wants three compute
+    units per utterance); both routes must agree with the oracle at a batch on either side of the switch."""
+    A = _asg()
+    be = A.asg.native()
+    for B in (96, 160):
+        tr, x, tg, il, tl = util.synth(40, B, 13, 6, 3, True)
+        r = run_hip(x, tg, tr, il, tl, "sum")
+        o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il.numpy(), tl.numpy(), "sum")
+        for k in ("loss", "grad_inputs", "grad_transition"):
+            util.assert_close(r[k], o[k], 1e-4, "B=%d %s" % (B, k))

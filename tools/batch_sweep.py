@@ -5,12 +5,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, torch_asg_amd
 T, N, L = 400, 40, 30
 dev = "cuda:0"
-for B in (64, 128, 256, 512, 1024, 2048, 4096):
+modes = sys.argv[1:] or ["single", "streams"]
+for B, mode in [(B, m) for B in (16, 32, 64, 80, 96, 128, 192, 256, 512, 1024, 2048, 4096) for m in modes]:
     g = torch.Generator().manual_seed(0)
     tr = torch.rand(N, N, generator=g).to(dev); x = torch.randn(T, B, N, generator=g).to(dev).requires_grad_(True)
     tg = torch.randint(0, N, (B, L), generator=g).to(dev)
     il = torch.full((B,), T, dtype=torch.int64, device=dev); tl = torch.full((B,), L, dtype=torch.int64, device=dev)
-    m = torch_asg_amd.ASGLoss(N, launch_mode="single").to(dev)
+    m = torch_asg_amd.ASGLoss(N, launch_mode=mode).to(dev)
     with torch.no_grad(): m.transition.copy_(tr)
     one = torch.ones((), device=dev)
     def step():
@@ -21,11 +22,12 @@ for B in (64, 128, 256, 512, 1024, 2048, 4096):
         for _ in range(3): step()
         torch.cuda.synchronize()
         gr = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gr): step()
-    for _ in range(5): gr.replay()
+        with torch.cuda.graph(gr):
+            for _ in range(5): step()
+    for _ in range(3): gr.replay()
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    K = 50
+    K = 10
     for _ in range(K): gr.replay()
-    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K / 5
     abytes = 2 * T * B * N * 4 + 2 * N * N * 4 + B * (8 * L + 20)
-    print("B=%5d  %8.1f us/step  %9.0f utt/s  algorithmic %.1f GB/s (%.2f%% of 8 TB/s)" % (B, dt * 1e6, B / dt, abytes / dt / 1e9, abytes / dt / 8e12 * 100))
+    print("%-8s B=%5d  %8.1f us/step  %9.0f utt/s  algorithmic %.1f GB/s (%.2f%% of 8 TB/s)" % (mode, B, dt * 1e6, B / dt, abytes / dt / 1e9, abytes / dt / 8e12 * 100))

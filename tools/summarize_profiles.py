@@ -66,7 +66,8 @@ def main():
                   "MI355X_MICROARCH.md section HBM says), WRITE_SIZE reads %s KB (exact)." % (cal_f, cal_w), "",
                   "| kernel | FETCH_SIZE raw KB | fetch bytes (x2 x1024) | WRITE_SIZE KB | write bytes | HBM bytes / launch |", "|---|---|---|---|---|---|"]
         summary = {}
-        for key, label in (("fwd_duo_kernel", "recursion_kernel"), ("fwd_small_kernel", "recursion_kernel"),
+        for key, label in (("fused_fwd_kernel", "dominant_kernel"), ("fused_bwd_kernel", "backward_kernel"),
+                           ("fwd_duo_kernel", "recursion_kernel"), ("fwd_small_kernel", "recursion_kernel"),
                            ("bwd_small_kernel", "assembly_kernel"), ("reduce_tiles_kernel", "reduce_kernel")):
             if label + "_hbm_bytes_per_launch" in summary:
                 continue
@@ -82,6 +83,10 @@ def main():
         lines.append("")
         summary["note"] = "FETCH_SIZE doubled (gfx950 counts 128-B requests as 64 B; verified on a 256 MiB copy in the same run); WRITE_SIZE as read"
         summary["step_hbm_bytes"] = sum(v for k, v in summary.items() if k.endswith("_hbm_bytes_per_launch"))
+        summary["algorithmic_bytes_per_step"] = 8221440
+        summary["step_traffic_over_algorithmic"] = summary["step_hbm_bytes"] / 8221440.0
+        lines += ["Step traffic (sum of the kernels of one step) = %.0f bytes = %.2fx the algorithmic 8 221 440 bytes (SURVEY.md 8d)."
+                  % (summary["step_hbm_bytes"], summary["step_traffic_over_algorithmic"]), ""]
         json.dump(summary, open(os.path.join(prof, "%s_pmc_cfg3.json" % tag), "w"), indent=1)
     open(os.path.join(prof, "%s_summary.md" % tag), "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))

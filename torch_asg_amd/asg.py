@@ -38,6 +38,7 @@ class HipBackend:
     def __init__(self):
         self._ctx = {}
         self._sizes = {}
+        self._cus = {}
         self._lock = threading.Lock()
         self._tickets = {}
         self._pools = {}
@@ -291,6 +292,17 @@ class HipBackend:
     def fused_supported(self, p):
         return bool(_lib.lib().asg_loss_fused_supported(ctypes.byref(p)))
 
+    def fused_preferred(self, p, device):
+        """The fused step gives every utterance three compute units of its own (latency regime: it is what makes the
+        cfg-3 step fast); once 3 B exceeds ~1.5x the compute units the launch runs in several rounds and the
+        stand-alone kernels, which pack one chain per wavefront, are faster (measured cross-over on MI355X, 256 CUs:
+        between B = 128 and B = 192; tools/batch_sweep.py)."""
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        cus = self._cus.get(idx)
+        if cus is None:
+            cus = self._cus[idx] = int(torch.cuda.get_device_properties(idx).multi_processor_count)
+        return 2 * int(p.B) <= cus
+
     def loss_forward(self, inputs, targets, transition, input_lengths, target_lengths, reduction,
                      flags=_lib.FLAG_STREAMS):
         """loss = reduce(full - aligned).  Returns (loss, saved): `saved` is what loss_backward needs --
@@ -308,7 +320,7 @@ class HipBackend:
             p, keep = self._problem(inputs, transition, targets, input_lengths, target_lengths)
             state_bytes = self._bytes(p)[0]
             loss = torch.empty((B,) if red == 0 else (), dtype=inputs.dtype, device=dev)
-            if (flags & _lib.FLAG_SINGLE_LAUNCH) and self.fused_supported(p):
+            if (flags & _lib.FLAG_SINGLE_LAUNCH) and self.fused_supported(p) and self.fused_preferred(p, dev):
                 key = ("fs", p.T, p.B, p.N, p.S)
                 fsz = self._sizes.get(key)
                 if fsz is None:
@@ -534,6 +546,16 @@ class ASGLoss(nn.Module):
                    test_asg.py:169-173): every utterance's loss is multiplied by 1/len or 1/sqrt(len) of its input or
                    target before the reduction -- 'none' (default, = the reference), 'input_size', 'input_size_sqrt',
                    'target_size', 'target_size_sqrt' (SURVEY.md 8(f)4).
+      input_is_logits   the acoustic model's final `log_softmax` fused away: pass the UNNORMALISED
+                   logits and get the loss and gradients of `ASGLoss(...)(log_softmax(inputs, dim=2), ...)` without the
+                   [T,B,N] round trips of that op and of its backward.  No kernel has anything to do for it: shifting
+                   every emission of a frame by the same amount (here -logsumexp of the frame) shifts the full-lattice
+                   and the force-aligned score of every path through that frame by that amount, so `full - aligned` does
+                   not change; and the gradient of the loss w.r.t. the log-probabilities sums to 0 over the labels of
+                   every frame (both posteriors sum to 1), so the softmax Jacobian's correction term vanishes and
+                   d loss / d logits = d loss / d log-probs.  The flag records the caller's intent and is what the
+                   parity test pins (tests/test_hip_parity.py::test_input_is_logits); the individual scores returned by
+                   FCC / FAC are NOT shift-invariant and take log-probabilities as in the reference.
     `gpu_no_stream_impl=True` selects the reference's "serial" route (separate FAC and FCC Functions).
     Batch-major activations need no copy: pass `acts.transpose(0, 1)` ([B,T,N] -> a [T,B,N] view); the kernels take
     arbitrary strides.
@@ -542,7 +564,7 @@ class ASGLoss(nn.Module):
     _LAUNCH_FLAGS = {'streams': _lib.FLAG_STREAMS, 'single': _lib.FLAG_SINGLE_LAUNCH, 'serial': 0}
 
     def __init__(self, num_labels, reduction='mean', forward_only=False, gpu_no_stream_impl=False,
-                 launch_mode='single', scale_mode='none'):
+                 launch_mode='single', scale_mode='none', input_is_logits=False):
         super().__init__()
         if scale_mode not in self.SCALE_MODES:
             raise ValueError("scale_mode must be one of %s" % (self.SCALE_MODES,))
@@ -554,6 +576,7 @@ class ASGLoss(nn.Module):
         self.gpu_no_stream_impl = gpu_no_stream_impl
         self.launch_mode = launch_mode
         self.scale_mode = scale_mode
+        self.input_is_logits = bool(input_is_logits)
         # transition[i, j] scores the move from label j to label i; starts at zero like the reference's (asg.py:105)
         self.transition = nn.Parameter(torch.zeros(num_labels, num_labels))
 

@@ -1364,8 +1364,14 @@ __global__ void __launch_bounds__(kFusedThreads, 2) fused_fwd_kernel(FusedParams
 //   workgroup kCH B + r:  once the redos have arrived, grad_transition[slice r] = sum_b g_b * (tile[b][alpha] + tile[b][beta])[slice r],
 //                      tiles in ascending order.
 constexpr int kBwdSlice = 64;
-constexpr int kCH = 8;          // workgroups per utterance in the row pass
-constexpr int kQB = 4;          // quads a wavefront has in flight
+#ifndef ASG_X_KCH
+#define ASG_X_KCH 8
+#endif
+#ifndef ASG_X_KQB
+#define ASG_X_KQB 4
+#endif
+constexpr int kCH = ASG_X_KCH;  // workgroups per utterance in the row pass
+constexpr int kQB = ASG_X_KQB;  // quads a wavefront has in flight
 template <int NP>
 __global__ void __launch_bounds__(256) fused_bwd_kernel(Problem P, State W, FusedArgs F) {
     typedef float R;
