@@ -542,9 +542,10 @@ def test_cfg4_shard_equals_whole():
         acc += part["grad_transition"]
         loss += float(part["loss"])
         lo, hi = r * (B // W), (r + 1) * (B // W)
-        # the dispatcher may pick a different recursion kernel for 512 co-resident chains than for 64 (same maths, other
-        # summation order): equal to fp32 rounding, not necessarily bit for bit
-        assert np.abs(part["grad_inputs"] - whole["grad_inputs"][:, lo:hi]).max() < 1e-6
+        # the dispatcher takes the fused training step for 64 utterances and the stand-alone kernels for 512 co-resident
+        # chains (same maths, other summation order; the aligned posteriors go through fp32 log-domain states either
+        # way): equal to fp32 rounding of values <= 1, not bit for bit
+        assert np.abs(part["grad_inputs"] - whole["grad_inputs"][:, lo:hi]).max() < 4e-6
         o = orc.asg_loss(xs.double().numpy(), tgs.numpy(), tr.double().numpy(), ils.numpy(), tls.numpy(), "sum")
         for k in ("loss", "grad_inputs", "grad_transition"):
             util.assert_close(part[k], o[k], 1e-4, "cfg4 shard %d/%s vs fp64 oracle" % (r, k))

@@ -45,7 +45,7 @@ inline int hip_status(hipError_t e) { return e == hipSuccess ? ASG_OK : ASG_ERR_
 inline size_t align_up(size_t x) { return (x + 255) & ~(size_t) 255; }
 
 struct Layout {
-    size_t ah, bh, ab, bb, ehat, fhat, rmax, cmax, asu, asi, dbg, ticket, work, total;
+    size_t ah, bh, ab, bb, ehat, fhat, rmax, cmax, etile, ftile, asu, asi, dbg, ticket, work, total;
     int npad;
 };
 
@@ -67,6 +67,9 @@ Layout make_layout(const asg_problem *p) {
     if (!small_full(p->N)) {
         L.fhat = off; off = align_up(off + N * L.npad * e);
         L.cmax = off; off = align_up(off + N * e);
+        const size_t tb = step_tile_bytes_generic((int) e, (int) N);
+        L.etile = off; off = align_up(off + tb);
+        L.ftile = off; off = align_up(off + tb);
     }
     L.asu = off; off = align_up(off + B * S * 2 * e);
     L.asi = off; off = align_up(off + B * S * 2 * sizeof(int));
@@ -115,7 +118,7 @@ State to_state(const asg_problem *p, const void *state) {
     if (base) {
         W.ah = base + L.ah; W.bh = base + L.bh; W.ab = base + L.ab; W.bb = base + L.bb;
         W.ehat = base + L.ehat; W.rmax = base + L.rmax;
-        if (!small_full(p->N)) { W.fhat = base + L.fhat; W.cmax = base + L.cmax; }
+        if (!small_full(p->N)) { W.fhat = base + L.fhat; W.cmax = base + L.cmax; W.etile = base + L.etile; W.ftile = base + L.ftile; }
         W.asu = base + L.asu; W.asi = (int *) (base + L.asi);
         W.dbg = base + L.dbg;
         W.ticket = (unsigned *) (base + L.ticket);

@@ -1350,6 +1350,13 @@ __global__ void __launch_bounds__(kFusedThreads, 2) fused_fwd_kernel(FusedParams
     const int G = (int) blockIdx.x / 24, w = (int) blockIdx.x - 24 * G;
     const int role = w >> 3, b = 8 * G + (w & 7);
     if (b >= B) return;
+#ifdef ASG_PROBE_XCC
+    if (threadIdx.x == 0 && b < 16) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        ((long long *) kernarg_params()->W.dbg)[b * 3 + role] = (long long) (xcc & 0xf);
+    }
+#endif
     if (role == 0) aligned_workgroup<NP>(b, SH);
     else if (role == 1) full_workgroup<NP, false>(b, SH);
     else full_workgroup<NP, true>(b, SH);

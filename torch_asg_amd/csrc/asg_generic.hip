@@ -94,6 +94,7 @@ struct StepBuf {
     const R *emax;    // [T][B]
     R *state;         // ah or bh  [B][T][N]
     const R *ehat;    // [N][npad] (alpha: rows, beta: columns)
+    const R *etile;   // fp32: the same matrix in the MFMA step's operand order (tile_kernel)
     const R *hmax;    // [N]
     int npad;
 };
@@ -265,12 +266,229 @@ __device__ __forceinline__ void fwd_step_body(const Problem &P, const StepBuf<R>
     }
 }
 
+// ---- the same frame on the matrix cores (fp32 only) ------------------------------------------------------------
+// The large-alphabet step IS a dense product, [N x N] (normalised transitions) x [N x B] (the batch's vectors), 8 FMAs
+// per byte of E streamed: at B = 32 the HBM and the fp32 arithmetic ceilings of MI355X coincide (~100 us per frame and
+// direction pair at N = 10^4).  The LDS-staged VALU body above reaches a fifth of either (LDS operand traffic: one
+// ds_read_b64 + one ds_read_b128 per 8 FMAs).  v_mfma_f32_16x16x4_f32 is exact fp32 (a k-ordered fmaf chain) at the
+// vector peak rate and takes its operands straight from the registers the global loads fill:
+//   workgroup = 16 kStepMB rows of E x 32 utterances, K split over its 4 wavefronts (partial sums meet in LDS)
+//   lane l of a wavefront loads E[row i0 + (l & 15)][k + 8 (l >> 4) .. +7] (two float4; a row's 128 contiguous bytes per
+//   32 k) and V[utterance (l & 15) (+16)][same k]; component c of one of those float4 is the A / B operand of one MFMA:
+//   A[m = l & 15][kk = l >> 4], B[kk = l >> 4][n = l & 15] -- the four k of an instruction are {c, 8+c, 16+c, 24+c}
+//   (+4 for the second float4), the same set on both sides, which is all the contraction needs.
+// grid = (ceil(N / (16 kStepMB)), ceil(B/32), directions).  Tile height decides two things: every workgroup reads the
+// batch's whole vector set (1.3 MB, from L2), and the workgroup count has to divide evenly over 256 compute units.
+// Measured at cfg 5 (us per frame, both directions; tools/cfg5_fwd_time.py): 16 rows 356 (1250 workgroups, 3.2 GB of
+// vectors per frame) - 48 rows 213 (418 workgroups = 1.6 per compute unit: half the chip waits for the other half) -
+// 80 rows 151 (250 workgroups, one per compute unit) - 96 rows 161.  The VALU body above: 509 (314 workgroups).
+typedef float V4f __attribute__((ext_vector_type(4)));
+#ifndef ASG_X_STEP_PF
+#define ASG_X_STEP_PF 1
+#endif
+#ifndef ASG_X_STEP_MB
+#define ASG_X_STEP_MB 5
+#endif
+constexpr int kStepMB = ASG_X_STEP_MB;      // 16-row blocks per workgroup: every workgroup reads the batch's whole vector
+                                            // set once (L2 traffic = row tiles x 1.3 MB), so tiles must not be too small
+// The MFMA step's E operand, laid out so that every wavefront load is ONE contiguous kilobyte and a workgroup streams
+// its K quarter front to back: [row tile of 16 kStepMB rows][chunk of 32 k][row block m][half h][lane][4 floats], lane l =
+// row (l & 15) of the block, k = 32 chunk + 8 (l >> 4) + 4 h .. +3.  Row-major E handed the memory system 16 kStepMB x 4
+// interleaved 128-byte streams per workgroup (80 000 on the chip): 3 TB/s; zero-padded to whole tiles and chunks.
+__host__ __device__ inline size_t step_tile_floats(int N) {
+    const size_t npad = (size_t) (N + 3) / 4 * 4;
+    const size_t tiles = ((size_t) N + 16 * kStepMB - 1) / (16 * kStepMB), chunks = (npad + 31) / 32;
+    return tiles * chunks * kStepMB * 2 * 64 * 4;
+}
+__global__ void __launch_bounds__(256) tile_kernel(const float *src, int N, int npad, float *dst) {
+    const size_t chunks = ((size_t) npad + 31) / 32;
+    const size_t total = step_tile_floats(N) / 4;                 // float4 elements
+    for (size_t idx = (size_t) blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t) gridDim.x * 256) {
+        const int lane = (int) (idx & 63);
+        size_t rest = idx >> 6;
+        const int h = (int) (rest & 1); rest >>= 1;
+        const int m = (int) (rest % kStepMB); rest /= kStepMB;
+        const size_t c = rest % chunks, tile = rest / chunks;
+        const size_t row = tile * 16 * kStepMB + 16 * m + (lane & 15), k = 32 * c + 8 * (lane >> 4) + 4 * h;
+        V4f v = {0, 0, 0, 0};
+        if (row < (size_t) N && k < (size_t) npad) v = *reinterpret_cast<const V4f *>(src + row * npad + k);
+        reinterpret_cast<V4f *>(dst)[idx] = v;
+    }
+}
+
+template <bool BETA>
+__device__ __forceinline__ void fwd_step_mfma(const Problem &P, const StepBuf<float> &S, int n) {
+    typedef float R;
+    constexpr int MB = kStepMB;
+    __shared__ float red[4][MB * 8][64];
+    const int N = P.N, T = P.T, B = P.B, npad = S.npad;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i0 = blockIdx.x * (16 * MB), b0 = blockIdx.y * 32;
+    const R *pcur = S.pbuf + (int64_t) (n & 1) * B * npad;
+    R *pnext = S.pbuf + (int64_t) ((n + 1) & 1) * B * npad;
+    {
+        // lane l: row / utterance (l & 15), k sub-range 8 (l >> 4) .. +7 of every 32-k chunk: two float4 per operand, so a
+        // row's whole 128-byte line goes to one wavefront at once
+        const int r = lane & 15, kq = lane >> 4;
+        const size_t nchunks = ((size_t) npad + 31) / 32;
+        const V4f *et = reinterpret_cast<const V4f *>(S.etile) + (size_t) blockIdx.x * nchunks * (MB * 2 * 64) + lane;
+        const R *va = pcur + (int64_t) min(b0 + r, B - 1) * npad + 8 * kq;
+        const R *vb = pcur + (int64_t) min(b0 + 16 + r, B - 1) * npad + 8 * kq;
+        // K in chunks of 32: the FULL chunks go through a two-stage software pipeline of unconditional loads (a bounds
+        // test per load makes hipcc wait for every load before the first MFMA); the tail (npad is a multiple of 4, not
+        // of 32) is one guarded chunk done by the last wavefront
+        const int full = npad / 32, cpw = (full + 3) / 4;
+        const int c0 = min(wave * cpw, full), c1 = min(c0 + cpw, full);
+        const V4f zero4 = {0, 0, 0, 0};
+        V4f acc[MB][2];
+#pragma unroll
+        for (int m = 0; m < MB; ++m) { acc[m][0] = zero4; acc[m][1] = zero4; }
+        struct Stage { V4f e[MB][2], a[2], b[2]; };
+        auto load = [&](Stage &st, int c) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                st.a[h] = *reinterpret_cast<const V4f *>(va + 32 * c + 4 * h);
+                st.b[h] = *reinterpret_cast<const V4f *>(vb + 32 * c + 4 * h);
+#pragma unroll
+                for (int m = 0; m < MB; ++m) st.e[m][h] = et[((size_t) c * MB * 2 + m * 2 + h) * 64];
+            }
+        };
+        auto multiply = [&](const Stage &st) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int m = 0; m < MB; ++m) {
+                    acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(st.e[m][h].x, st.a[h].x, acc[m][0], 0, 0, 0);
+                    acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(st.e[m][h].x, st.b[h].x, acc[m][1], 0, 0, 0);
+                    acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(st.e[m][h].y, st.a[h].y, acc[m][0], 0, 0, 0);
+                    acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(st.e[m][h].y, st.b[h].y, acc[m][1], 0, 0, 0);
+                    acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(st.e[m][h].z, st.a[h].z, acc[m][0], 0, 0, 0);
+                    acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(st.e[m][h].z, st.b[h].z, acc[m][1], 0, 0, 0);
+                    acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(st.e[m][h].w, st.a[h].w, acc[m][0], 0, 0, 0);
+                    acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(st.e[m][h].w, st.b[h].w, acc[m][1], 0, 0, 0);
+                }
+        };
+        if (c0 < c1) {
+            // STG stages: STG - 1 chunks of loads in flight while one is multiplied.  (A compute unit holds only one or
+            // two of these workgroups = one or two wavefronts per SIMD: the depth has to come from the pipeline.)
+            constexpr int STG = ASG_X_STEP_PF + 1;
+            Stage st[STG];
+#pragma unroll
+            for (int u = 0; u < STG - 1; ++u) load(st[u], min(c0 + u, c1 - 1));
+            for (int c = c0; c < c1; c += STG) {
+#pragma unroll
+                for (int u = 0; u < STG; ++u) {
+                    // (pinned: left alone, the scheduler sinks each stage's loads next to their MFMAs and the pipeline is gone)
+                    __builtin_amdgcn_sched_barrier(0);
+                    load(st[(u + STG - 1) % STG], min(c + u + STG - 1, c1 - 1));
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (c + u < c1) multiply(st[u]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (wave == 3 && 32 * full < npad) {
+            Stage st;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const bool in = 32 * full + 8 * kq + 4 * h < npad;
+                st.a[h] = in ? *reinterpret_cast<const V4f *>(va + 32 * full + 4 * h) : zero4;
+                st.b[h] = in ? *reinterpret_cast<const V4f *>(vb + 32 * full + 4 * h) : zero4;
+#pragma unroll
+                for (int m = 0; m < MB; ++m) st.e[m][h] = et[((size_t) full * MB * 2 + m * 2 + h) * 64];      // (zero-padded)
+            }
+            multiply(st);
+        }
+        // element (row 16 m + 4 (l >> 4) + q, utterance (l & 15) [+ 16]) of the tile sits in register q of lane l
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { red[wave][8 * m + q][lane] = acc[m][0][q]; red[wave][8 * m + 4 + q][lane] = acc[m][1][q]; }
+    }
+    __syncthreads();
+    // ---- epilogue: thread -> utterance b0 + (tid >> 3), rows i0 + 2 (tid & 7) + {0, 1} (+ 16 per row block); as the VALU body's
+    const R L2E = Num<R>::log2e(), LZ = Num<R>::logzero();
+    const int ut = threadIdx.x >> 3, b = b0 + ut;
+    const bool bvalid = b < B;
+    const int bc = bvalid ? b : 0;
+    const int len = P.in_len ? gclampi(P.in_len[bc], 0, T) : T;
+    const int t = BETA ? len - 1 - n : n + 1;          // frame whose q is consumed (beta) / produced (alpha)
+    const bool active = bvalid && (BETA ? (t >= 1) : (t < len));
+    const R muprev = fmax((R) funkey(S.mu[(n % 3) * B + bc]), LZ);
+    const int tw = active ? (BETA ? t - 1 : t) : 0;    // frame written
+    const R emw = S.emax[(int64_t) tw * B + bc];
+    float qkey = -__builtin_inff();
+#pragma unroll
+    for (int rr2 = 0; rr2 < 2 * MB; ++rr2) {
+        const int row = 16 * (rr2 >> 1) + 2 * (threadIdx.x & 7) + (rr2 & 1), i = i0 + row;
+        if (!active || i >= N) continue;
+        const int sl = 16 * ((row & 15) >> 2) + (ut & 15), sq = 8 * (row >> 4) + (row & 3) + 4 * (ut >> 4);
+        const R a = (red[0][sq][sl] + red[1][sq][sl]) + (red[2][sq][sl] + red[3][sq][sl]);
+        R lg = Num<R>::log2(a);
+        R rr = S.hmax[i] + lg;
+        if (!(fabs(lg) < Num<R>::lg_limit())) {
+            // exact rare path: log2-sum-exp2 over j of (Tr2[.][.] + q_j) from the log-domain state
+            const R *tr = (const R *) P.transition;
+            const int tq = BETA ? t : t - 1;
+            const R *stq = S.state + ((int64_t) b * T + tq) * N;
+            const R *inq = (const R *) P.inputs + (int64_t) tq * P.is0 + (int64_t) b * P.is1;
+            const R emq = S.emax[(int64_t) tq * B + b];
+            R mx = Num<R>::ninf();
+            for (int j = 0; j < N; ++j) {
+                R qj = BETA ? inq[(int64_t) j * P.is2] * L2E - emq + stq[j] : stq[j];
+                R trv = BETA ? tr[(int64_t) j * P.ts0 + (int64_t) i * P.ts1] : tr[(int64_t) i * P.ts0 + (int64_t) j * P.ts1];
+                R v = trv * L2E + qj;
+                mx = (v == v) ? fmax(mx, v) : mx;
+            }
+            R sm = 0;
+            for (int j = 0; j < N; ++j) {
+                R qj = BETA ? inq[(int64_t) j * P.is2] * L2E - emq + stq[j] : stq[j];
+                R trv = BETA ? tr[(int64_t) j * P.ts0 + (int64_t) i * P.ts1] : tr[(int64_t) i * P.ts0 + (int64_t) j * P.ts1];
+                R v = trv * L2E + qj;
+                sm += (v == v && mx != Num<R>::ninf()) ? Num<R>::exp2(v - mx) : R(0);
+            }
+            rr = (mx == Num<R>::ninf()) ? mx : mx + Num<R>::log2(sm);
+        }
+        const R emis = ((const R *) P.inputs)[(int64_t) tw * P.is0 + (int64_t) b * P.is1 + (int64_t) i * P.is2] * L2E - emw;
+        R stv, q;
+        if (BETA) { stv = rr - muprev; q = emis + stv; }
+        else { stv = emis + rr - muprev; q = stv; }
+        S.state[((int64_t) b * T + tw) * N + i] = stv;
+        pnext[(int64_t) b * npad + i] = Num<R>::exp2(q);
+        qkey = fmaxf(qkey, (float) q);
+        if (i == 0) {
+            S.off[b] += (double) muprev + (double) emw;
+            S.mu[((n + 2) % 3) * B + b] = fkey(-__builtin_inff());
+        }
+    }
+    // one atomic per utterance and workgroup at most (max is order-independent: deterministic), and only if it can
+    // change the word: the eight lanes of an utterance reduce with three DPP steps
+    qkey = fmaxf(qkey, dpp_mov<kDppXor1>(qkey, qkey));
+    qkey = fmaxf(qkey, dpp_mov<kDppXor2>(qkey, qkey));
+    qkey = fmaxf(qkey, dpp_mov<kDppHalfMirror>(qkey, qkey));
+    if (active && (threadIdx.x & 7) == 0) {
+        unsigned *word = &S.mu[((n + 1) % 3) * B + b];
+        const unsigned key = fkey(qkey);
+        if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < key) atomicMax(word, key);
+    }
+}
+
+template <typename R> struct StepUsesMfma { static constexpr bool v = false; };
+#ifndef ASG_X_NO_STEP_MFMA
+template <> struct StepUsesMfma<float> { static constexpr bool v = true; };
+#endif
+
 // blockIdx.z selects the direction, so the alpha and beta frames of one step share a launch (they are
 // independent chains): twice the workgroups in flight, half the launches.
 template <typename R>
 __global__ void __launch_bounds__(256) fwd_step_kernel(Problem P, StepBuf<R> Sa, StepBuf<R> Sb, int n, int dir_base) {
-    if ((int) blockIdx.z + dir_base == 0) fwd_step_body<R, false>(P, Sa, n);
-    else fwd_step_body<R, true>(P, Sb, n);
+    if constexpr (StepUsesMfma<R>::v) {
+        if ((int) blockIdx.z + dir_base == 0) fwd_step_mfma<false>(P, Sa, n);
+        else fwd_step_mfma<true>(P, Sb, n);
+    } else {
+        if ((int) blockIdx.z + dir_base == 0) fwd_step_body<R, false>(P, Sa, n);
+        else fwd_step_body<R, true>(P, Sb, n);
+    }
 }
 
 // scores: grid = B, block = 256.  alpha: A + LSE_i(ah[len-1]);  beta: C_0 + LSE_i(q_0), q_0 = I2[0]-emax[0]+bh[0]
@@ -737,7 +955,16 @@ hipError_t launch_prep_generic(const Problem &P, const State &W, hipStream_t str
                        P.N, W.npad, (R *) W.ehat, (R *) W.rmax);
     hipLaunchKernelGGL((prep_kernel<R, true>), dim3(P.N), dim3(256), 0, stream, (const R *) P.transition, P.ts0, P.ts1,
                        P.N, W.npad, (R *) W.fhat, (R *) W.cmax);
+    if constexpr (StepUsesMfma<R>::v) {
+        if (!W.etile || !W.ftile) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(tile_kernel, dim3(4096), dim3(256), 0, stream, (const float *) W.ehat, P.N, W.npad, (float *) W.etile);
+        hipLaunchKernelGGL(tile_kernel, dim3(4096), dim3(256), 0, stream, (const float *) W.fhat, P.N, W.npad, (float *) W.ftile);
+    }
     return hipGetLastError();
+}
+
+size_t step_tile_bytes_generic(int elem, int N) {
+    return (elem == 4 && StepUsesMfma<float>::v) ? step_tile_floats(N) * sizeof(float) : 0;
 }
 
 // forward work buffers live behind the saved state (see fwd_work_bytes_generic): emax, pbuf x2 dirs, mu, off
@@ -777,13 +1004,15 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
             const bool beta = dir == 1;
             S.state = (R *) (beta ? W.bh : W.ah);
             S.ehat = (const R *) (beta ? W.fhat : W.ehat);
+            S.etile = (const R *) (beta ? W.ftile : W.etile);
             S.hmax = (const R *) (beta ? W.cmax : W.rmax);
             Sd[dir] = S;
         }
         const bool do_a = full_mask & kFullAlpha, do_b = full_mask & kFullBeta;
         if (do_a) hipLaunchKernelGGL((fwd_init_kernel<R, false>), dim3(P.B), dim3(256), 0, stream, P, Sd[0]);
         if (do_b) hipLaunchKernelGGL((fwd_init_kernel<R, true>), dim3(P.B), dim3(256), 0, stream, P, Sd[1]);
-        dim3 sgrid((P.N + 63) / 64, (P.B + 31) / 32, (do_a && do_b) ? 2 : 1);
+        const int srows = StepUsesMfma<R>::v ? 16 * kStepMB : 64;
+        dim3 sgrid((P.N + srows - 1) / srows, (P.B + 31) / 32, (do_a && do_b) ? 2 : 1);
         for (int n = 0; n + 1 < P.T; ++n)
             hipLaunchKernelGGL((fwd_step_kernel<R>), sgrid, dim3(256), 0, stream, P, Sd[0], Sd[1], n, do_a ? 0 : 1);
         if (do_b)

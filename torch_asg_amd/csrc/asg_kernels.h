@@ -31,6 +31,7 @@ struct Problem {
 struct State {
     void *ah, *bh, *ab, *bb;
     void *ehat, *fhat, *rmax, *cmax;
+    void *etile, *ftile;   // generic path, fp32: ehat / fhat again in the MFMA step kernel's operand order (asg_generic.hip)
     void *asu;
     int *asi;
     void *dbg;
@@ -122,5 +123,6 @@ hipError_t launch_viterbi_small(const Problem &P, void *work, void *scores, void
 size_t bwd_scratch_bytes_small(int elem, int T, int B, int N, int S, int *chunk, int *nchunks);
 size_t bwd_scratch_bytes_generic(int elem, int T, int B, int N, int S);
 size_t fwd_work_bytes_generic(int elem, int T, int B, int N);
+size_t step_tile_bytes_generic(int elem, int N);      // one tiled copy of the normalised transition matrix (0: not used)
 
 }  // namespace asg
