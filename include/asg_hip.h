@@ -150,15 +150,19 @@ int asg_loss_backward(asg_ctx *ctx, const asg_problem *p, const void *state, siz
 /* ---- fused training step: the whole criterion, forward AND gradient assembly, in one launch -----------------
  * The reference's GPU fast route runs every recursion in forward and none in backward
  * (fast_asg_gpu_forward / fast_asg_gpu_backward, streamlined_fast_gpu.cpp:104-297); this pair goes one step further:
- * asg_loss_fused_forward also assembles d(loss)/d(inputs) and the per-utterance transition-gradient tiles for an
- * upstream gradient of 1, as the alpha and beta recursions cross (only half of the lattice state and the aligned
- * posteriors ever go to HBM); asg_loss_fused_backward multiplies by the actual upstream gradient (a no-op when that is 1), reduces the
- * tiles in a fixed order into grad_transition and redoes, exactly, any utterance the fused path declined
- * (row sums outside the fp32-safe range, fewer than 4 frames).  Results are bit-deterministic.
- *   supported: float32, N < 64, S <= 64 (asg_loss_fused_supported returns 1); otherwise use asg_loss_forward/backward.
+ * asg_loss_fused_forward also assembles, as the alpha and beta recursions cross, the full-lattice part of
+ * d(loss)/d(inputs) and the per-utterance transition-gradient tiles (two per utterance: the frames each direction
+ * reached second), and leaves the aligned posteriors beside them; asg_loss_fused_backward finishes the grad_inputs rows
+ * (minus the aligned posteriors scattered to labels, times the actual upstream gradient), reduces the tiles in a fixed
+ * order into grad_transition and redoes, exactly, any utterance the fused path declined (row sums outside the
+ * fp32-safe range, fewer than 4 frames).  Results are bit-deterministic.  Only half of the lattice state ever goes to
+ * device memory.
+ *   supported: float32, N < 64, S <= 64, T <= 4000 (asg_loss_fused_supported returns 1); otherwise use
+ *              asg_loss_forward/backward.  The launch gives every utterance three compute units of its own: it is the
+ *              fast route while 2 B <= compute units (the Python binding routes larger batches to asg_loss_forward).
  *   state:     asg_state_bytes(p) bytes, as for asg_loss_forward; the SAME buffer must be passed to backward.
  *   scratch:   asg_loss_fused_scratch_bytes(p) bytes; the SAME buffer must be passed to backward.
- *   grad_inputs [T,B,N] contiguous: written by forward, rescaled in place by backward.
+ *   grad_inputs [T,B,N] contiguous: partly written by forward, completed in place by backward.
  *   sync:      asg_loss_fused_sync_bytes(p) bytes of device memory that are ZERO on entry; the call leaves them
  *              zero.  They hold the words through which the workgroups of the launch talk to each other.  Calls that
  *              may run concurrently (different streams) need different regions; calls on one stream may share one.
