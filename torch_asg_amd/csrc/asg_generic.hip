@@ -745,6 +745,103 @@ __global__ void __launch_bounds__(256) bwd_gemm_kernel(const R *ehat, const R *P
         }
 }
 
+// The same two products on the matrix cores (fp32 only): 128 x 128 tile per workgroup, 64 x 64 per wavefront (4 x 4
+// blocks of v_mfma_f32_16x16x4_f32: exact fp32), BK = 16 staged global -> registers -> LDS with the next tile's loads in
+// flight.  Operands come out of LDS in the MFMA's own order: A[m = l & 15][k = l >> 4] = As[k][m], B likewise.
+template <int MODE>
+__global__ void __launch_bounds__(256) bwd_gemm_mfma(const float *ehat, const float *Pm, float *Gm, float *out, int N, int npad,
+                                                     int K, int *anybad) {
+    typedef float R;
+    constexpr int BK = 16, TS = 128, LD = TS + 4;
+    __shared__ __attribute__((aligned(16))) R As[BK][LD];
+    __shared__ __attribute__((aligned(16))) R Bs[BK][LD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64;
+    const int m0 = blockIdx.x * TS, n0 = blockIdx.y * TS;
+    const int Mdim = N, Ndim = MODE == 0 ? K : N, Kdim = MODE == 0 ? npad : K;
+    const V4f zero4 = {0, 0, 0, 0};
+    V4f acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[a][c] = zero4;
+    // staging: two float4 of A and two of B per thread and tile
+    //   MODE 0: rows of ehat / Pm (k contiguous): element e -> row e >> 2, k quad e & 3      (transposed into As[k][m])
+    //   MODE 1: rows of Gm / Pm (m / n contiguous): element e -> k row e >> 5, column quad e & 31
+    auto fetchA = [&](int k0, int e) -> V4f {
+        if (MODE == 0) {
+            const int mm = m0 + (e >> 2), kk = k0 + 4 * (e & 3);
+            return (mm < Mdim && kk < Kdim) ? *reinterpret_cast<const V4f *>(ehat + (int64_t) mm * npad + kk) : zero4;
+        } else {
+            const int kk = k0 + (e >> 5), mm = m0 + 4 * (e & 31);
+            V4f v = (kk < Kdim && mm < npad) ? *reinterpret_cast<const V4f *>(Gm + (int64_t) kk * npad + mm) : zero4;
+            const float ninf = -__builtin_inff();                      // markers of the row-sum pass read as 0
+            v.x = v.x == ninf ? 0.f : v.x; v.y = v.y == ninf ? 0.f : v.y; v.z = v.z == ninf ? 0.f : v.z; v.w = v.w == ninf ? 0.f : v.w;
+            return v;
+        }
+    };
+    auto fetchB = [&](int k0, int e) -> V4f {
+        if (MODE == 0) {
+            const int nn = n0 + (e >> 2), kk = k0 + 4 * (e & 3);
+            return (nn < Ndim && kk < Kdim) ? *reinterpret_cast<const V4f *>(Pm + (int64_t) nn * npad + kk) : zero4;
+        } else {
+            const int kk = k0 + (e >> 5), nn = n0 + 4 * (e & 31);
+            return (kk < Kdim && nn < npad) ? *reinterpret_cast<const V4f *>(Pm + (int64_t) kk * npad + nn) : zero4;
+        }
+    };
+    auto put = [&](R (*dst)[LD], int e, const V4f &v) {
+        if (MODE == 0) {
+            const int mm = e >> 2, kq = 4 * (e & 3);
+            dst[kq + 0][mm] = v.x; dst[kq + 1][mm] = v.y; dst[kq + 2][mm] = v.z; dst[kq + 3][mm] = v.w;
+        } else {
+            *reinterpret_cast<V4f *>(&dst[e >> 5][4 * (e & 31)]) = v;
+        }
+    };
+    const int e0 = threadIdx.x, e1 = threadIdx.x + 256;
+    V4f a0 = fetchA(0, e0), a1 = fetchA(0, e1), b0 = fetchB(0, e0), b1 = fetchB(0, e1);
+    for (int k0 = 0; k0 < Kdim; k0 += BK) {
+        __syncthreads();
+        put(As, e0, a0); put(As, e1, a1); put(Bs, e0, b0); put(Bs, e1, b1);
+        __syncthreads();
+        if (k0 + BK < Kdim) { a0 = fetchA(k0 + BK, e0); a1 = fetchA(k0 + BK, e1); b0 = fetchB(k0 + BK, e0); b1 = fetchB(k0 + BK, e1); }
+#pragma unroll
+        for (int ks = 0; ks < BK; ks += 4) {
+            float av[4], bv[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) av[a] = As[ks + (lane >> 4)][wm + 16 * a + (lane & 15)];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) bv[c] = Bs[ks + (lane >> 4)][wn + 16 * c + (lane & 15)];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[c], acc[a][c], 0, 0, 0);
+        }
+    }
+    // element (m = 16 a + 4 (l >> 4) + q, n = 16 c + (l & 15)) of the wavefront's 64 x 64 sits in acc[a][c][q]
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int gm0 = m0 + wm + 16 * a + 4 * (lane >> 4), gn = n0 + wn + 16 * c + (lane & 15);
+            if (gn >= Ndim) continue;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int gm_ = gm0 + q;
+                if (gm_ >= Mdim) continue;
+                if (MODE == 0) {
+                    const R g = Gm[(int64_t) gn * npad + gm_];
+                    const R sden = acc[a][c][q];
+                    const bool ok = fabs(Num<R>::log2(sden)) < Num<R>::lg_limit();
+                    const bool mark = !ok && g != R(0);
+                    Gm[(int64_t) gn * npad + gm_] = ok ? g / sden : (mark ? Num<R>::ninf() : R(0));
+                    if (mark) *anybad = 1;
+                } else {
+                    out[(int64_t) gm_ * N + gn] = acc[a][c][q] * ehat[(int64_t) gm_ * npad + gn];
+                }
+            }
+        }
+}
+
 // exact fix-up of marked rows (rare; exits at once unless the row-sum pass raised `anybad`).
 // grid = (T, B), block = 256: recomputes the posterior of each marked (b,t,i) and adds
 // gi * softmax_j(Tr2[i][j] + ah[t-1][j]) into grad_transition.  Different (b,t) can hit the same (i,j), so this
@@ -1060,10 +1157,17 @@ hipError_t launch_bwd_generic(const Problem &P, const State &W, const BwdArgs &A
         const int K = P.B * P.T;
         hipMemsetAsync(anybad, 0, sizeof(int), stream);
         hipLaunchKernelGGL((bwd_post_kernel<R>), dim3(P.T, P.B), dim3(256), 0, stream, P, W, A, Pm, Gm, npad);
-        hipLaunchKernelGGL((bwd_gemm_kernel<R, 0>), dim3((P.N + 63) / 64, (K + 63) / 64), dim3(256), 0, stream,
-                           (const R *) W.ehat, Pm, Gm, gtr, P.N, npad, K, anybad);
-        hipLaunchKernelGGL((bwd_gemm_kernel<R, 1>), dim3((P.N + 63) / 64, (P.N + 63) / 64), dim3(256), 0, stream,
-                           (const R *) W.ehat, Pm, Gm, gtr, P.N, npad, K, anybad);
+        if constexpr (StepUsesMfma<R>::v) {
+            hipLaunchKernelGGL((bwd_gemm_mfma<0>), dim3((P.N + 127) / 128, (K + 127) / 128), dim3(256), 0, stream,
+                               (const float *) W.ehat, (const float *) Pm, (float *) Gm, (float *) gtr, P.N, npad, K, anybad);
+            hipLaunchKernelGGL((bwd_gemm_mfma<1>), dim3((P.N + 127) / 128, (P.N + 127) / 128), dim3(256), 0, stream,
+                               (const float *) W.ehat, (const float *) Pm, (float *) Gm, (float *) gtr, P.N, npad, K, anybad);
+        } else {
+            hipLaunchKernelGGL((bwd_gemm_kernel<R, 0>), dim3((P.N + 63) / 64, (K + 63) / 64), dim3(256), 0, stream,
+                               (const R *) W.ehat, Pm, Gm, gtr, P.N, npad, K, anybad);
+            hipLaunchKernelGGL((bwd_gemm_kernel<R, 1>), dim3((P.N + 63) / 64, (P.N + 63) / 64), dim3(256), 0, stream,
+                               (const R *) W.ehat, Pm, Gm, gtr, P.N, npad, K, anybad);
+        }
         hipLaunchKernelGGL((bwd_fix_kernel<R>), dim3(P.T, P.B), dim3(256), 0, stream, P, W, A, Gm, gtr, npad, anybad);
     }
     if (do_ali) {
