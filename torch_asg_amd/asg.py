@@ -294,14 +294,14 @@ class HipBackend:
 
     def fused_preferred(self, p, device):
         """The fused step gives every utterance three compute units of its own (latency regime: it is what makes the
-        cfg-3 step fast); once 3 B exceeds ~1.5x the compute units the launch runs in several rounds and the
-        stand-alone kernels, which pack one chain per wavefront, are faster (measured cross-over on MI355X, 256 CUs:
-        between B = 128 and B = 192; tools/batch_sweep.py)."""
+        cfg-3 step fast); once 3 B exceeds the compute units the launch runs in rounds and the stand-alone kernels,
+        which pack one chain per wavefront, are faster (measured on MI355X, 256 CUs, T=400 N=40: B=80 68 us fused;
+        B=96 117 us fused vs ~85 stand-alone; B=128 125 vs ~90; tools/batch_sweep.py)."""
         idx = device.index if device.index is not None else torch.cuda.current_device()
         cus = self._cus.get(idx)
         if cus is None:
             cus = self._cus[idx] = int(torch.cuda.get_device_properties(idx).multi_processor_count)
-        return 2 * int(p.B) <= cus
+        return 3 * int(p.B) <= cus
 
     def loss_forward(self, inputs, targets, transition, input_lengths, target_lengths, reduction,
                      flags=_lib.FLAG_STREAMS):

@@ -1067,8 +1067,11 @@ __device__ __forceinline__ void duo_main(const Problem &P, const State &W, const
 }
 
 // Producer wavefront: emission loads, block scale, e_n (and arg_n) into the rings.  Only loads on its VMEM queue.
+// tr_lds / tr_ready (fused step): the transition matrix as a compact [N][N] copy that other wavefronts of the workgroup
+// are filling in LDS; *tr_ready reaches tr_need once it is complete.  Waited for AFTER the first emission loads are out.
 template <int NP, bool BETA, class LdsT>
-__device__ __forceinline__ void duo_producer(const Problem &P, int b, LdsT &L) {
+__device__ __forceinline__ void duo_producer(const Problem &P, int b, LdsT &L, const float *tr_lds = nullptr,
+                                             int *tr_ready = nullptr, int tr_need = 0) {
     typedef float R;
     const int lane = threadIdx.x & 63;
     const int N = P.N, T = P.T;
@@ -1091,7 +1094,17 @@ __device__ __forceinline__ void duo_producer(const Problem &P, int b, LdsT &L) {
     R X = NINF;
     {
         const R *tline = (const R *) P.transition + (int64_t) lc * (BETA ? P.ts1 : P.ts0);
-        const int64_t ts = BETA ? P.ts0 : P.ts1;
+        int64_t ts = BETA ? P.ts0 : P.ts1;
+        if (tr_lds) {
+            int spins = 0;
+            while (__hip_atomic_load(tr_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < tr_need) {
+                if (L.stop() || ++spins > kSpinCap) return;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            asm volatile("" ::: "memory");
+            tline = tr_lds + lc * (BETA ? 1 : N);
+            ts = BETA ? N : 1;
+        }
         R raw[NP];
 #pragma unroll
         for (int j = 0; j < NP; ++j) raw[j] = tline[(int64_t) (j < N ? j : 0) * ts];

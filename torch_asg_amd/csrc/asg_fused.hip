@@ -157,9 +157,13 @@ struct FusedShared {
                          // not live across the roles (as values handed to the epilogue they were spilled inside the loop)
     double score_full, score_ali;
     int adone, last;
+    int tr_ready;                 // wavefronts that have written their share of `trl`
     float xs[64];
+    float trl[NP * NP];           // full workgroups: the transition matrix, compact [N][N] (filled by the idle wavefronts while
+                                  // the producer's first emission loads are in flight; read by the recursion wavefront, the
+                                  // producer and the epilogue instead of three rounds of strided global loads)
     // one workgroup per compute unit (160 KB of LDS): see the header
-    char pad[(sizeof(U) + sizeof(TileLds<NP>) + 512 < 84 * 1024) ? 84 * 1024 - sizeof(U) - sizeof(TileLds<NP>) - 512 : 16];
+    char pad[(sizeof(U) + sizeof(TileLds<NP>) + 4 * NP * NP + 512 < 84 * 1024) ? 84 * 1024 - sizeof(U) - sizeof(TileLds<NP>) - 4 * NP * NP - 512 : 16];
 };
 
 // ---- kernel parameters ------------------------------------------------------------------------------------------
@@ -319,7 +323,8 @@ __device__ __forceinline__ bool wait_global_ge(unsigned *p, unsigned need, unsig
 
 // ------------------------------------------------------------------ recursion wavefront
 template <int NP, bool BETA>
-__device__ __forceinline__ void fused_main(const Problem &P, int b, FusedSide &L, UttSync *us, int len, void *dbg) {
+__device__ __forceinline__ void fused_main(const Problem &P, int b, FusedSide &L, UttSync *us, int len, void *dbg,
+                                           const float *tr_lds, int *tr_ready, int tr_need) {
     const FullCtl ctl{&L, us};
     typedef float R;
     PRB_DECL
@@ -330,10 +335,19 @@ __device__ __forceinline__ void fused_main(const Problem &P, int b, FusedSide &L
     const int N = P.N;
     const bool act = lane < N;
     const int lc = act ? lane : 0;
-    const R *tline = (const R *) P.transition + (int64_t) lc * (BETA ? P.ts1 : P.ts0);
+    {
+        int spins = 0;
+        while (__hip_atomic_load(tr_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < tr_need) {
+            if (L.stop()) return;
+            if (++spins > kSpinCap) { ctl.abort(14); return; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        asm volatile("" ::: "memory");
+    }
+    const R *tline = tr_lds + lc * (BETA ? 1 : N);
     V2<R> e2[NP / 2];
     R X;
-    load_norm_row<R, NP>(tline, BETA ? P.ts0 : P.ts1, N, act, e2, X);
+    load_norm_row<R, NP>(tline, BETA ? N : 1, N, act, e2, X);
     if (lane == N) {
 #pragma unroll
         for (int j = 0; j < NP / 2; ++j) e2[j] = V2<R>{1, 1};
@@ -1101,6 +1115,7 @@ __device__ __forceinline__ void full_workgroup(int b, FusedShared<NP> &SH) {
         SH.score_full = -1e300;
         SH.adone = 0;
         SH.last = 0;
+        SH.tr_ready = 0;
     }
 #ifdef ASG_PROBE
     const long long ep_t0 = clock64();
@@ -1116,15 +1131,8 @@ __device__ __forceinline__ void full_workgroup(int b, FusedShared<NP> &SH) {
     if (b == 0 && !BETA && threadIdx.x == 0) ((long long *) ld_state(kernarg_params()).dbg)[51] = clock64();
 #endif
 
-    // what the epilogue needs from HBM is fetched now, not after the recursion: this thread's elements of the transition
-    // matrix (tile pass) ...
-    constexpr int KT = (NP * NP + kFusedThreads - 1) / kFusedThreads;
-    R trv[KT];
-#pragma unroll
-    for (int m = 0; m < KT; ++m) {
-        const int k = min((int) threadIdx.x + m * kFusedThreads, N * N - 1), i = k / N, j = k - i * N;
-        trv[m] = ((const R *) P.transition)[(int64_t) i * P.ts0 + (int64_t) j * P.ts1];
-    }
+    // the transition matrix into LDS, by the six wavefronts that have nothing to do yet (the recursion wavefront and the
+    // producer go ahead: the producer's first emission loads overlap with these)
     double est = 0, ear = 0;          // ... and (wavefront 4, while the roles run) the aligned edge posteriors of this side
     // ---- phase 1: the roles.  Control flow is uniform per wavefront; nothing in here uses a workgroup barrier.
     // Idle wavefronts go straight to the barrier: a waiting wavefront issues nothing.
@@ -1136,13 +1144,23 @@ __device__ __forceinline__ void full_workgroup(int b, FusedShared<NP> &SH) {
         const unsigned grow_bytes = (unsigned) P.B * N * sizeof(R);
         for (int t = len; t < T; ++t) buf_store(R(0), rs_g, voff, (unsigned) t * grow_bytes);
     }
+    constexpr int kFill = 6;                                   // wavefronts 2 .. 7
+    if (wave >= 2) {
+        const R *tr = (const R *) P.transition;
+        for (int k = (int) threadIdx.x - 128; k < N * N; k += 64 * kFill) {
+            const int i = k / N, j = k - i * N;
+            SH.trl[k] = tr[(int64_t) i * P.ts0 + (int64_t) j * P.ts1];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(&SH.tr_ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
     if (fused) {
         const Problem P = ld_problem(kernarg_params());        // per role: see FusedParams
         const State W = ld_state(kernarg_params());
         const FusedArgs F = ld_fargs(kernarg_params());
         switch (wave) {
-            case 0: __builtin_amdgcn_s_setprio(3); fused_main<NP, BETA>(P, b, L, us, len, W.dbg); break;
-            case 1: duo_producer<NP, BETA>(P, b, L); break;
+            case 0: __builtin_amdgcn_s_setprio(3); fused_main<NP, BETA>(P, b, L, us, len, W.dbg, SH.trl, &SH.tr_ready, kFill); break;
+            case 1: duo_producer<NP, BETA>(P, b, L, SH.trl, &SH.tr_ready, kFill); break;
             case 2: fused_consumer<NP, BETA>(P, W, F, b, L, us, len, h, TL.sx[0], sc2, 0); break;
             case 3: fused_consumer<NP, BETA>(P, W, F, b, L, us, len, h, TL.sx[1], sc2, 1); break;
             // (consumers on three SIMDs: the third beside the producer, which is light)
@@ -1252,12 +1270,9 @@ __device__ __forceinline__ void full_workgroup(int b, FusedShared<NP> &SH) {
         R *xs = SH.xs;
         if (wave == 0) xs[lane] = xx;
         __syncthreads();
-#pragma unroll
-        for (int m = 0; m < KT; ++m) {
-            const int k = (int) threadIdx.x + m * kFusedThreads;
-            if (k >= N * N) break;
+        for (int k = (int) threadIdx.x; k < N * N; k += kFusedThreads) {
             const int i = k / N, j = k - i * N;
-            const R t2 = trv[m] * L2E;
+            const R t2 = SH.trl[k] * L2E;
             double sum = 0;
 #pragma unroll
             for (int c = 0; c < kNC; ++c) sum += BETA ? TL.sx[c][j][i] : TL.sx[c][i][j];
