@@ -204,6 +204,8 @@ def main():
     ap.add_argument("--graph-steps", type=int, default=0, help="steps per captured hipGraph (0 = largest divisor of --steps <= 10)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="init the process group even with one rank (testing)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="parse the arguments and the launcher's environment, print the plan as JSON, touch no GPU (tests)")
     ap.add_argument("--config", choices=["cfg3", "cfg5"], default="cfg3",
                     help="cfg3 = BASELINE.json's headline workload (default); cfg5 = the large-alphabet workload, 1 GPU")
     args = ap.parse_args()
@@ -225,6 +227,18 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
                          "--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ..." % (args.gpus, args.gpus))
+    if args.dry_run:
+        gs = 1
+        if args.mode == "graph":
+            gs = args.graph_steps if args.graph_steps > 0 else max(g for g in range(1, 11) if args.steps % g == 0)
+            if args.steps % gs:
+                gs = 1
+        if rank == 0:
+            os.write(real_stdout, (json.dumps({"dry_run": True, "world": world, "gpus": args.gpus, "steps": args.steps,
+                                               "warmup": args.warmup, "mode": args.mode, "steps_per_graph": gs,
+                                               "global_batch": B * world, "uses_dist": world > 1 or args.force_dist,
+                                               "master": os.environ.get("MASTER_ADDR", "127.0.0.1")}) + "\n").encode())
+        return
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist
@@ -264,7 +278,7 @@ def main():
     gsteps = 1
     if args.mode == "graph":
         gsteps = args.graph_steps if args.graph_steps > 0 else max(g for g in range(1, 11) if args.steps % g == 0)
-        if args.steps % gsteps or args.warmup % gsteps:
+        if args.steps % gsteps:
             gsteps = 1
 
     # ---- optional hipGraph capture of the compute part of the step (static shapes)
@@ -322,6 +336,9 @@ def main():
 
     for _ in range(args.warmup // gsteps):
         step_group()
+    for _ in range(args.warmup % gsteps):      # the rest of the W warm-up steps, one at a time
+        one_step()
+        sync_grads()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps // gsteps):

@@ -97,3 +97,46 @@ def test_dtype_checks_match_reference_triggers():
     with pytest.raises(RuntimeError, match="Float or Double"):
         HipBackend._check(FakeCuda(torch.float16, (3, 1, 4)), tr, None, None, None)
     HipBackend._check(x, tr, FakeCuda(torch.int64, (1, 2)), FakeCuda(torch.int64, (1,)), None)
+
+
+def test_bench_launcher_and_argument_path_dry_run():
+    """bench.py's argument / launcher-environment handling without a GPU: single process, and two ranks under
+    torch.distributed.run exactly as the driver launches it (--gpus N must match WORLD_SIZE; rank 0 prints one line)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dry-run", "--steps", "200", "--warmup", "20"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["dry_run"] and d["world"] == 1 and d["steps_per_graph"] == 10 and d["global_batch"] == 64 and not d["uses_dist"]
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dry-run", "--gpus", "2"], capture_output=True,
+                         text=True, timeout=300)
+    assert bad.returncode != 0 and "torch.distributed.run" in (bad.stderr + bad.stdout)
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29611", os.path.join(root, "bench.py"),
+                          "--gpus", "2", "--steps", "20", "--warmup", "4", "--dry-run"], capture_output=True, text=True,
+                         timeout=600, env=env)
+    assert run.returncode == 0, run.stderr[-2000:]
+    lines = [l for l in run.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, run.stdout
+    d = json.loads(lines[0])
+    assert d["world"] == 2 and d["global_batch"] == 128 and d["uses_dist"] and d["steps_per_graph"] == 10
+
+
+def test_fused_route_policy_and_new_options(asg):
+    """The fused training step is taken while 3 B <= compute units (it gives every utterance three of them); the
+    input_is_logits flag is carried by the module."""
+    import torch_asg_amd
+    from torch_asg_amd.asg import HipBackend
+    be = HipBackend()
+    be._cus[0] = 256
+
+    class P:
+        pass
+    dev = torch.device("cuda", 0)
+    for Bq, want in ((1, True), (64, True), (85, True), (86, False), (512, False)):
+        p = P(); p.B = Bq
+        assert be.fused_preferred(p, dev) is want
+    m = torch_asg_amd.ASGLoss(5, input_is_logits=True)
+    assert m.input_is_logits is True and torch_asg_amd.ASGLoss(5).input_is_logits is False

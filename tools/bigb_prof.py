@@ -1,0 +1,18 @@
+#!/usr/bin/env python3
+"""Developer probe (GPU, under rocprofv3): a few stand-alone-route steps at B = 512 and B = 4096."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, torch_asg_amd
+T, N, L = 400, 40, 30
+dev = "cuda:0"
+for B in (512, 4096):
+    g = torch.Generator().manual_seed(0)
+    tr = torch.rand(N, N, generator=g).to(dev); x = torch.randn(T, B, N, generator=g).to(dev).requires_grad_(True)
+    tg = torch.randint(0, N, (B, L), generator=g).to(dev)
+    il = torch.full((B,), T, dtype=torch.int64, device=dev); tl = torch.full((B,), L, dtype=torch.int64, device=dev)
+    m = torch_asg_amd.ASGLoss(N).to(dev)
+    with torch.no_grad(): m.transition.copy_(tr)
+    for _ in range(5):
+        m.transition.grad = None; x.grad = None
+        m(x, tg, il, tl).backward()
+    torch.cuda.synchronize()

@@ -270,9 +270,9 @@ int asg_ctx_create(asg_ctx **out) {
 
 int asg_ctx_destroy(asg_ctx *c) {
     if (!c) return ASG_OK;
-    hipEventDestroy(c->fork);
-    hipEventDestroy(c->join);
-    hipStreamDestroy(c->side);
+    (void) hipEventDestroy(c->fork);
+    (void) hipEventDestroy(c->join);
+    (void) hipStreamDestroy(c->side);
     delete c;
     return ASG_OK;
 }

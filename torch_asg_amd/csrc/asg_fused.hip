@@ -47,6 +47,9 @@ constexpr int kAF = 3;          // aligned finisher wavefronts per side (round-r
 #ifndef ASG_X_ALIPRIO
 #define ASG_X_ALIPRIO 3
 #endif
+#ifndef ASG_X_P2_AUX
+#define ASG_X_P2_AUX 0
+#endif
 #ifndef ASG_X_NC
 #define ASG_X_NC 3
 #endif
@@ -963,8 +966,9 @@ __device__ __forceinline__ void fused_afin(const Problem &P, const State &W, con
             const unsigned qoff = (unsigned) ((n - h) >> 2) * (unsigned) S * 16u;
             u4 a = {__float_as_uint(p2v[0]), __float_as_uint(p2v[1]), __float_as_uint(p2v[2]), __float_as_uint(p2v[3])};
             u4 c = {__float_as_uint(p2v[4]), __float_as_uint(p2v[5]), __float_as_uint(p2v[6]), __float_as_uint(p2v[7])};
-            __builtin_amdgcn_raw_buffer_store_b128(a, rp, vQ, qoff, kSc1);
-            if (g > 4) __builtin_amdgcn_raw_buffer_store_b128(c, rp, vQ, qoff + (unsigned) S * 16u, kSc1);
+            // (plain stores: nothing in THIS launch reads them)
+            __builtin_amdgcn_raw_buffer_store_b128(a, rp, vQ, qoff, ASG_X_P2_AUX);
+            if (g > 4) __builtin_amdgcn_raw_buffer_store_b128(c, rp, vQ, qoff + (unsigned) S * 16u, ASG_X_P2_AUX);
         }
 #pragma unroll
         for (int q = 0; q < kGS; ++q) {
@@ -1240,6 +1244,15 @@ __device__ __forceinline__ void full_workgroup(int b, FusedShared<NP> &SH) {
 #ifdef ASG_PROBE
     if (b == 0 && !BETA && threadIdx.x == 0) ((long long *) ld_state(kernarg_params()).dbg)[53] = clock64();
 #endif
+    // arrive NOW (the second full workgroup of the utterance will close it: score, loss, verdict, sync words): the tile
+    // below is read by the next launch only, so the returning atomic's round trip overlaps with building it
+    unsigned arrived = 0;
+    if (threadIdx.x == 0) {
+        if (BETA) __hip_atomic_store((double *) F.fscore + b, SH.score_full, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (own_trouble) __hip_atomic_store(&us->kill, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        arrived = __hip_atomic_fetch_add(&us->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (!own_trouble && SH.adone == 1) {
         // ---- phase 2: this side's share of the utterance's [N][N] tile
         EdgeLds<NP> &EL = SH.u.e;
@@ -1282,13 +1295,8 @@ __device__ __forceinline__ void full_workgroup(int b, FusedShared<NP> &SH) {
             tile_out[k] = (R) (vd * (double) F.gscale);
         }
     }
-    // ---- phase 3: arrive; the SECOND full workgroup of the utterance closes it (score, loss, verdict, sync words)
-    if (threadIdx.x == 0) {
-        if (BETA) __hip_atomic_store((double *) F.fscore + b, SH.score_full, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (own_trouble) __hip_atomic_store(&us->kill, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        SH.last = __hip_atomic_fetch_add(&us->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u ? 1 : 0;
-    }
+    // ---- phase 3: the SECOND full workgroup to have arrived closes the utterance
+    if (threadIdx.x == 0) SH.last = arrived == 1u ? 1 : 0;
     __syncthreads();
 #ifdef ASG_PROBE
     if (b == 0 && !BETA && threadIdx.x == 0) ((long long *) ld_state(kernarg_params()).dbg)[54] = clock64();
@@ -1405,7 +1413,10 @@ __global__ void __launch_bounds__(256) fused_bwd_kernel(Problem P, State W, Fuse
     const int N = P.N, T = P.T, B = P.B;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if ((int) blockIdx.x < B * kCH) {
+    const int Bp = B;
+    if ((int) blockIdx.x < Bp * kCH) {
+        // (mapping an utterance's blocks onto the XCD whose L2 the forward launch filled with its rows and posteriors was
+        // tried: no measurable difference, 63.9 vs 63.5 us per step)
         const int b = (int) blockIdx.x / kCH, c = (int) blockIdx.x - b * kCH;
         const R g = ((const R *) F.grad_loss)[F.reduction == 0 ? b : 0];
         const bool flagged = F.flags[b] != 0;
@@ -1520,7 +1531,7 @@ __global__ void __launch_bounds__(256) fused_bwd_kernel(Problem P, State W, Fuse
         return;
     }
     // ---- reducers: wait for the exact redos of the flagged utterances (normally none: no wait at all)
-    const int r = (int) blockIdx.x - B * kCH;
+    const int r = (int) blockIdx.x - Bp * kCH;
     {
         const unsigned nflag = F.ticket2[1];
         int spins = 0;

@@ -1089,7 +1089,7 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
         R *emax = (R *) wk; wk += au((size_t) P.T * P.B * e);
         hipLaunchKernelGGL((emax_kernel<R>), dim3(P.T, P.B), dim3(256), 0, stream, P, emax);
         // the p vectors are npad wide: their pad columns must be (and stay) zero
-        hipMemsetAsync(wk, 0, 2 * (au(2 * (size_t) P.B * W.npad * e) + au(3 * (size_t) P.B * 4) + au((size_t) P.B * 8)), stream);
+        (void) hipMemsetAsync(wk, 0, 2 * (au(2 * (size_t) P.B * W.npad * e) + au(3 * (size_t) P.B * 4) + au((size_t) P.B * 8)), stream);
         StepBuf<R> Sd[2];
         for (int dir = 0; dir < 2; ++dir) {
             StepBuf<R> S{};
@@ -1155,7 +1155,7 @@ hipError_t launch_bwd_generic(const Problem &P, const State &W, const BwdArgs &A
     if (do_full) {
         if (P.N <= 64) return hipErrorInvalidValue;      // the small kernel owns this case
         const int K = P.B * P.T;
-        hipMemsetAsync(anybad, 0, sizeof(int), stream);
+        (void) hipMemsetAsync(anybad, 0, sizeof(int), stream);
         hipLaunchKernelGGL((bwd_post_kernel<R>), dim3(P.T, P.B), dim3(256), 0, stream, P, W, A, Pm, Gm, npad);
         if constexpr (StepUsesMfma<R>::v) {
             hipLaunchKernelGGL((bwd_gemm_mfma<0>), dim3((P.N + 127) / 128, (K + 127) / 128), dim3(256), 0, stream,
@@ -1172,7 +1172,7 @@ hipError_t launch_bwd_generic(const Problem &P, const State &W, const BwdArgs &A
     }
     if (do_ali) {
         if (P.S > 1024) return hipErrorInvalidValue;
-        if (!have_full) hipMemsetAsync(A.grad_inputs, 0, (size_t) P.T * P.B * P.N * e, stream);
+        if (!have_full) (void) hipMemsetAsync(A.grad_inputs, 0, (size_t) P.T * P.B * P.N * e, stream);
         hipLaunchKernelGGL((bwd_aligned_kernel<R>), dim3(P.B, A.nchunks), dim3(256), 0, stream, P, W, A, gHD, 1);
         hipLaunchKernelGGL((aligned_tr_scatter_kernel<R>), dim3(1), dim3(1024), 0, stream, P, W, A, gHD, gtr,
                            have_full ? 1 : 0);
