@@ -757,3 +757,13 @@ def test_large_batch_routes_to_standalone_kernels_and_agrees():
         o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il.numpy(), tl.numpy(), "sum")
         for k in ("loss", "grad_inputs", "grad_transition"):
             util.assert_close(r[k], o[k], 1e-4, "B=%d %s" % (B, k))
+
+
+def test_fused_step_long_utterances():
+    """The fused training step near the top of its supported length (T <= 4000: per-block offset tables of the aligned
+    finishers), variable lengths, against the fp64 oracle."""
+    tr, x, tg, il, tl = util.synth(3100, 3, 19, 37, 8, True)
+    o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il.numpy(), tl.numpy(), "sum")
+    r = run_hip(x, tg, tr, il, tl, "sum")
+    for k in ("loss", "grad_inputs", "grad_transition"):
+        util.assert_close(r[k], o[k], 1e-4, "T=3100 %s" % k)
