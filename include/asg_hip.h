@@ -159,7 +159,7 @@ int asg_loss_backward(asg_ctx *ctx, const asg_problem *p, const void *state, siz
  * device memory.
  *   supported: float32, N < 64, S <= 64, T <= 4000 (asg_loss_fused_supported returns 1); otherwise use
  *              asg_loss_forward/backward.  The launch gives every utterance three compute units of its own: it is the
- *              fast route while 3 B <= compute units (the Python binding routes larger batches to asg_loss_forward).
+ *              fast route while B <= 80 on 256 compute units (every XCD must hold three workgroups per utterance) (the Python binding routes larger batches to asg_loss_forward).
  *   state:     asg_state_bytes(p) bytes, as for asg_loss_forward; the SAME buffer must be passed to backward.
  *   scratch:   asg_loss_fused_scratch_bytes(p) bytes; the SAME buffer must be passed to backward.
  *   grad_inputs [T,B,N] contiguous: partly written by forward, completed in place by backward.

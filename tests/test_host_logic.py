@@ -125,7 +125,7 @@ def test_bench_launcher_and_argument_path_dry_run():
 
 
 def test_fused_route_policy_and_new_options(asg):
-    """The fused training step is taken while 3 B <= compute units (it gives every utterance three of them); the
+    """The fused training step is taken while every XCD can hold three workgroups for each of its utterances (B <= 80 on 256 CUs); the
     input_is_logits flag is carried by the module."""
     import torch_asg_amd
     from torch_asg_amd.asg import HipBackend
@@ -135,7 +135,7 @@ def test_fused_route_policy_and_new_options(asg):
     class P:
         pass
     dev = torch.device("cuda", 0)
-    for Bq, want in ((1, True), (64, True), (85, True), (86, False), (512, False)):
+    for Bq, want in ((1, True), (64, True), (80, True), (81, False), (512, False)):
         p = P(); p.B = Bq
         assert be.fused_preferred(p, dev) is want
     m = torch_asg_amd.ASGLoss(5, input_is_logits=True)

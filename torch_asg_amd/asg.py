@@ -301,7 +301,9 @@ class HipBackend:
         cus = self._cus.get(idx)
         if cus is None:
             cus = self._cus[idx] = int(torch.cuda.get_device_properties(idx).multi_processor_count)
-        return 3 * int(p.B) <= cus
+        # the launch places utterances 2x, 2x+1 on XCD x mod 8 (asg_fused.hip): the fullest XCD must hold its workgroups
+        pairs = (int(p.B) + 1) // 2
+        return ((pairs + 7) // 8) * 2 * 3 <= cus // 8
 
     def loss_forward(self, inputs, targets, transition, input_lengths, target_lengths, reduction,
                      flags=_lib.FLAG_STREAMS):

@@ -7,7 +7,7 @@
 // split "both recursions in forward, no recursion in backward" is kept and taken one step further -- the
 // non-recursive assembly happens inside the forward launch too, and backward only scales by the upstream gradient.
 //
-// Three workgroups per utterance, each alone on a compute unit (grid = 24 * ceil(B / 8), 768 threads; the three of
+// Three workgroups per utterance, each alone on a compute unit (grid = 48 * ceil(B / 16), 512 threads; the three of
 // an utterance have block indices that are equal mod 8, which puts them behind the same L2 in practice -- speed only):
 //   * the ALIGNED workgroup owns the force-aligned lattice: both chains, their crossing, the aligned posteriors and the
 //     edge posteriors.  It depends on nothing and never waits for another workgroup.
@@ -1363,15 +1363,17 @@ __device__ __forceinline__ void full_workgroup(int b, FusedShared<NP> &SH) {
     }
 }
 
-// grid = 24 * ceil(B / 8): blocks come in groups of 24 = 8 utterances x {aligned, full alpha, full beta}; the three
-// workgroups of utterance b = 8 G + u have indices 24 G + {0, 8, 16} + u -- equal mod 8 (same XCD / L2 in practice) and
-// close together in dispatch order (the alpha and beta workgroups wait for each other's first half).
+// grid = 48 * ceil(B / 16): blocks come in groups of 48 = 16 utterances x {aligned, full alpha, full beta}; the three
+// workgroups of utterance b = 16 G + 2 x + j (x < 8, j < 2) have indices 48 G + 24 j + {0, 8, 16} + x -- equal mod 8 (same
+// XCD / L2 in practice) and close together in dispatch order (the alpha and beta workgroups wait for each other's first
+// half).  Utterances 2x and 2x+1 share the XCD: their emission rows share 128-byte lines (a row is N floats), which
+// otherwise every XCD fetches for itself.
 template <int NP>
 __global__ void __launch_bounds__(kFusedThreads, 2) fused_fwd_kernel(FusedParams KP) {
     __shared__ FusedShared<NP> SH;
     const int B = kernarg_params()->P.B;
-    const int G = (int) blockIdx.x / 24, w = (int) blockIdx.x - 24 * G;
-    const int role = w >> 3, b = 8 * G + (w & 7);
+    const int G = (int) blockIdx.x / 48, w = (int) blockIdx.x - 48 * G;
+    const int j = w >= 24 ? 1 : 0, role = (w - 24 * j) >> 3, b = 16 * G + 2 * (w & 7) + j;
     if (b >= B) return;
 #ifdef ASG_PROBE_XCC
     if (threadIdx.x == 0 && b < 16) {
@@ -1572,7 +1574,7 @@ template <int NP>
 hipError_t launch_fused_np(const Problem &P, const State &W, const FusedArgs &F, bool backward, hipStream_t st) {
     if (!backward) {
         FusedParams KP{P, W, F};
-        hipLaunchKernelGGL((fused_fwd_kernel<NP>), dim3(24 * ((P.B + 7) / 8)), dim3(kFusedThreads), 0, st, KP);
+        hipLaunchKernelGGL((fused_fwd_kernel<NP>), dim3(48 * ((P.B + 15) / 16)), dim3(kFusedThreads), 0, st, KP);
     } else {
         const int R = (P.N * P.N + kBwdSlice - 1) / kBwdSlice;
         hipLaunchKernelGGL((fused_bwd_kernel<NP>), dim3(P.B * kCH + R), dim3(256), 0, st, P, W, F);
