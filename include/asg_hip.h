@@ -30,6 +30,7 @@ extern "C" {
 
 #define ASG_DTYPE_F32 0
 #define ASG_DTYPE_F64 1
+#define ASG_DTYPE_BF16 2            /* only as asg_problem::inputs_dtype (see there) */
 
 /* status codes */
 #define ASG_OK 0
@@ -60,7 +61,9 @@ typedef struct asg_problem {
     const int64_t *target_lengths; /* [B] int64, or NULL = all S   (asg.py:113-114)               */
     int64_t T, B, N, S;
     int32_t dtype;                 /* ASG_DTYPE_*                                                  */
-    int32_t reserved;
+    int32_t inputs_dtype;          /* 0: emissions have `dtype`.  ASG_DTYPE_BF16 (with dtype = ASG_DTYPE_F32): emissions are
+                                      bfloat16, everything else float32 (bf16 in, fp32 accumulate), and grad_inputs
+                                      comes back as bfloat16.  Accepted by the asg_loss_fused_* pair only. */
 } asg_problem;
 
 /* Opaque context: the side stream + fork/join events of ASG_FLAG_STREAMS -- host handles only, no device memory and

@@ -767,3 +767,59 @@ def test_fused_step_long_utterances():
     r = run_hip(x, tg, tr, il, tl, "sum")
     for k in ("loss", "grad_inputs", "grad_transition"):
         util.assert_close(r[k], o[k], 1e-4, "T=3100 %s" % k)
+
+
+def test_bf16_emissions_fp32_accumulate():
+    """SURVEY.md 8(f)2, optional half: bfloat16 emissions in, fp32 arithmetic, bfloat16 gradient out (fused training step).
+    Tolerance stated up front: loss and grad_transition against the fp64 oracle fed the SAME bf16-representable values:
+    the usual 1e-4 rule; grad_inputs is rounded to bfloat16 on store (8 mantissa bits): 2^-8 = 4e-3 of max(1, max|ref|).
+    Also the routes that widen (eval, large batch) must agree with a float32 run on the widened values."""
+    A = _asg()
+    for (T, B, N, L, seed) in ((120, 9, 33, 14, 5), (400, 64, 40, 30, 0)):
+        tr, x, tg, il, tl = util.synth(T, B, N, L, seed, True)
+        xb = x.to(torch.bfloat16)
+        o = orc.asg_loss(xb.double().numpy(), tg.numpy(), tr.double().numpy(), il.numpy(), tl.numpy(), "mean")
+        m = A.ASGLoss(N).to(DEV)
+        with torch.no_grad():
+            m.transition.copy_(tr)
+        xd = xb.to(DEV).requires_grad_(True)
+        loss = m(xd, tg.to(DEV), il.to(DEV), tl.to(DEV))
+        loss.backward()
+        assert loss.dtype == torch.float32 and xd.grad.dtype == torch.bfloat16 and m.transition.grad.dtype == torch.float32
+        util.assert_close(loss.detach().cpu().numpy(), o["loss"], 1e-4, "bf16 loss")
+        util.assert_close(m.transition.grad.cpu().numpy(), o["grad_transition"], 1e-4, "bf16 grad_transition")
+        util.assert_close(xd.grad.float().cpu().numpy(), o["grad_inputs"], 2.0 ** -8, "bf16 grad_inputs")
+        assert float(xd.grad.float()[int(il.max()):].abs().sum()) == 0.0 if int(il.max()) < T else True
+        # widening routes: evaluation, and a batch above the fused limit
+        m.eval()
+        with torch.no_grad():
+            le = m(xb.to(DEV), tg.to(DEV), il.to(DEV), tl.to(DEV))
+        util.assert_close(le.cpu().numpy(), o["loss"], 1e-4, "bf16 eval loss")
+    # flagged utterances (fewer than 4 frames: exact stand-alone redo from the widened copy), fp32 call of the same shape first
+    tr, x, tg, _, _ = util.synth(12, 5, 9, 3, 4, False)
+    il = torch.tensor([2, 3, 12, 7, 1]); tl = torch.tensor([1, 2, 3, 3, 1])
+    run_hip(x, tg, tr, il, tl, "none")
+    xb = x.to(torch.bfloat16)
+    o = orc.asg_loss(xb.double().numpy(), tg.numpy(), tr.double().numpy(), il.numpy(), tl.numpy(), "none")
+    m = A.ASGLoss(9, reduction="none").to(DEV)
+    with torch.no_grad():
+        m.transition.copy_(tr)
+    xd = xb.to(DEV).requires_grad_(True)
+    lo = m(xd, tg.to(DEV), il.to(DEV), tl.to(DEV))
+    (lo * torch.linspace(0.5, 1.5, 5, device=DEV)).sum().backward()
+    og = orc.asg_loss(xb.double().numpy(), tg.numpy(), tr.double().numpy(), il.numpy(), tl.numpy(), "none",
+                      grad_out=np.linspace(0.5, 1.5, 5))
+    util.assert_close(lo.detach().cpu().numpy(), o["loss"], 1e-4, "bf16 flagged loss")
+    util.assert_close(xd.grad.float().cpu().numpy(), og["grad_inputs"], 2.0 ** -8, "bf16 flagged grad_inputs")
+    util.assert_close(m.transition.grad.cpu().numpy(), og["grad_transition"], 1e-4, "bf16 flagged grad_transition")
+    tr, x, tg, il, tl = util.synth(30, 96, 11, 5, 2, True)
+    xb = x.to(torch.bfloat16)
+    o = orc.asg_loss(xb.double().numpy(), tg.numpy(), tr.double().numpy(), il.numpy(), tl.numpy(), "sum")
+    m = A.ASGLoss(11, reduction="sum").to(DEV)
+    with torch.no_grad():
+        m.transition.copy_(tr)
+    xd = xb.to(DEV).requires_grad_(True)
+    m(xd, tg.to(DEV), il.to(DEV), tl.to(DEV)).backward()
+    assert xd.grad.dtype == torch.bfloat16
+    util.assert_close(xd.grad.float().cpu().numpy(), o["grad_inputs"], 2.0 ** -8, "bf16 grad_inputs (widened route)")
+    util.assert_close(m.transition.grad.cpu().numpy(), o["grad_transition"], 1e-4, "bf16 grad_transition (widened route)")

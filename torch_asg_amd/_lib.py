@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ASG_HIP_LIB") or os.path.join(_HERE, "csrc", "libasg_hip.so")
 
-ASG_DTYPE_F32, ASG_DTYPE_F64 = 0, 1
+ASG_DTYPE_F32, ASG_DTYPE_F64, ASG_DTYPE_BF16 = 0, 1, 2
 FLAG_STREAMS, FLAG_SINGLE_LAUNCH, FLAG_MATVEC_READLANE, FLAG_ALPHA_SCORES = 1, 2, 4, 8
 
 # every symbol include/asg_hip.h declares
@@ -27,7 +27,7 @@ class AsgProblem(ctypes.Structure):
                 ("targets", ctypes.c_void_p), ("targets_strides", ctypes.c_int64 * 2),
                 ("input_lengths", ctypes.c_void_p), ("target_lengths", ctypes.c_void_p),
                 ("T", ctypes.c_int64), ("B", ctypes.c_int64), ("N", ctypes.c_int64), ("S", ctypes.c_int64),
-                ("dtype", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("dtype", ctypes.c_int32), ("inputs_dtype", ctypes.c_int32)]
 
 
 _LIB = None

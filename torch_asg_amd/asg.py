@@ -60,11 +60,12 @@ class HipBackend:
         if not inputs.is_cuda:
             raise RuntimeError("torch_asg_amd: inputs must live on a ROCm device (got %s); "
                                "there is no CPU implementation in this package" % inputs.device)
-        if inputs.dtype not in (torch.float32, torch.float64):
+        bf16 = inputs.dtype == torch.bfloat16 and transition.dtype == torch.float32     # bf16 in, fp32 accumulate
+        if inputs.dtype not in (torch.float32, torch.float64) and not bf16:
             raise RuntimeError("torch_asg_amd: expected scalar type Float or Double but found %s" % inputs.dtype)
         if inputs.dim() != 3:
             raise RuntimeError("torch_asg_amd: inputs must be [T,B,N]")
-        if transition.dtype != inputs.dtype or transition.device != inputs.device:
+        if (transition.dtype != inputs.dtype and not bf16) or transition.device != inputs.device:
             raise RuntimeError("torch_asg_amd: transition must have the dtype/device of inputs")
         N = inputs.shape[2]
         if tuple(transition.shape) != (N, N):
@@ -111,7 +112,10 @@ class HipBackend:
             else:
                 setattr(p, name, None)
         p.T, p.B, p.N = T, B, N
-        p.dtype = _lib.ASG_DTYPE_F32 if inputs.dtype == torch.float32 else _lib.ASG_DTYPE_F64
+        if inputs.dtype == torch.bfloat16:
+            p.dtype, p.inputs_dtype = _lib.ASG_DTYPE_F32, _lib.ASG_DTYPE_BF16
+        else:
+            p.dtype = _lib.ASG_DTYPE_F32 if inputs.dtype == torch.float32 else _lib.ASG_DTYPE_F64
         return p, keep
 
     def _context(self, device):
@@ -321,9 +325,13 @@ class HipBackend:
         with self._guard(dev):
             p, keep = self._problem(inputs, transition, targets, input_lengths, target_lengths)
             state_bytes = self._bytes(p)[0]
-            loss = torch.empty((B,) if red == 0 else (), dtype=inputs.dtype, device=dev)
-            if (flags & _lib.FLAG_SINGLE_LAUNCH) and self.fused_supported(p) and self.fused_preferred(p, dev):
-                key = ("fs", p.T, p.B, p.N, p.S)
+            loss = torch.empty((B,) if red == 0 else (), dtype=transition.dtype, device=dev)
+            use_fused = (flags & _lib.FLAG_SINGLE_LAUNCH) and self.fused_supported(p) and self.fused_preferred(p, dev)
+            if inputs.dtype == torch.bfloat16 and not use_fused:
+                raise RuntimeError("torch_asg_amd: bfloat16 emissions are taken by the fused training step only "
+                                   "(ASGLoss upcasts them itself when that route does not apply)")
+            if use_fused:
+                key = ("fs", p.T, p.B, p.N, p.S, p.inputs_dtype)
                 fsz = self._sizes.get(key)
                 if fsz is None:
                     fsz = (int(L.asg_loss_fused_scratch_bytes(ctypes.byref(p))), int(L.asg_loss_fused_sync_bytes(ctypes.byref(p))))
@@ -360,11 +368,11 @@ class HipBackend:
                 # the saved tensors came back at other addresses (saved-tensor hooks): rebuild the problem block
                 p, _ = self._problem(inputs, transition, targets, input_lengths, target_lengths)
             g = grad_loss
-            if g.dtype != inputs.dtype:
-                g = g.to(inputs.dtype)
+            if g.dtype != transition.dtype:
+                g = g.to(transition.dtype)
             if not g.is_contiguous():
                 g = g.contiguous()
-            gtr = torch.empty(N, N, dtype=inputs.dtype, device=dev)
+            gtr = torch.empty(N, N, dtype=transition.dtype, device=dev)
             if saved.mode == "fused":
                 ws, gin = tensors
                 sc_bytes, state_bytes, fs = saved.sizes
@@ -558,6 +566,10 @@ class ASGLoss(nn.Module):
                    d loss / d logits = d loss / d log-probs.  The flag records the caller's intent and is what the
                    parity test pins (tests/test_hip_parity.py::test_input_is_logits); the individual scores returned by
                    FCC / FAC are NOT shift-invariant and take log-probabilities as in the reference.
+    bfloat16 `inputs` (with the float32 `transition`): "bf16 in, fp32 accumulate"  -- the fused training step
+    reads them as they are and returns a bfloat16 `inputs.grad`; every other route widens them first.  The loss and
+    `transition.grad` are float32 and match a float32 run on the same (bf16-representable) values to 1e-4; `inputs.grad`
+    is rounded to bfloat16 on store (8 bits of mantissa: 4e-3 relative).
     `gpu_no_stream_impl=True` selects the reference's "serial" route (separate FAC and FCC Functions).
     Batch-major activations need no copy: pass `acts.transpose(0, 1)` ([B,T,N] -> a [T,B,N] view); the kernels take
     arbitrary strides.
@@ -611,7 +623,26 @@ class ASGLoss(nn.Module):
         n = n.to(device=inputs.device, dtype=inputs.dtype).clamp(min=1)
         return (n.rsqrt() if self.scale_mode.endswith('sqrt') else n.reciprocal())
 
+    def _bf16_direct(self, inputs, targets):
+        """bfloat16 emissions go to the kernels as they are (bf16 in, fp32 accumulate, bf16 gradient out: half the
+        compulsory read and write of SURVEY.md 8(d)) on the fused training route; everywhere else they are widened here."""
+        if (self.gpu_no_stream_impl or self.forward_only or not self.training or self.scale_mode != 'none'
+                or self.launch_mode != 'single' or self.reduction not in ('mean', 'sum', 'none')):
+            return False
+        if not inputs.is_cuda or self.transition.dtype != torch.float32 or inputs.dim() != 3:
+            return False
+        T, B, N = inputs.shape
+        S = min(targets.shape[1], T)
+
+        class _P:
+            pass
+        p = _P()
+        p.B = B
+        return N < 64 and S <= 64 and T <= 4000 and T * B * N * 4 < 2 ** 32 and native().fused_preferred(p, inputs.device)
+
     def forward(self, inputs, targets, input_lengths=None, target_lengths=None):
+        if inputs.dtype == torch.bfloat16 and not self._bf16_direct(inputs, targets):
+            inputs = inputs.to(self.transition.dtype)
         targets, input_lengths, target_lengths = self._canonical(inputs, targets, input_lengths, target_lengths)
         weights = self._utterance_weights(inputs, input_lengths, target_lengths)
         args = (targets, input_lengths, target_lengths)

@@ -80,9 +80,11 @@ Layout make_layout(const asg_problem *p) {
     return L;
 }
 
-int check_problem(const asg_problem *p, bool need_targets) {
+int check_problem(const asg_problem *p, bool need_targets, bool allow_bf16 = false) {
     if (!p) return ASG_ERR_INVALID;
     if (p->dtype != ASG_DTYPE_F32 && p->dtype != ASG_DTYPE_F64) return ASG_ERR_INVALID;
+    if (p->inputs_dtype != 0 && !(p->inputs_dtype == ASG_DTYPE_BF16 && p->dtype == ASG_DTYPE_F32)) return ASG_ERR_INVALID;
+    if (p->inputs_dtype != 0 && !allow_bf16) return ASG_ERR_UNSUPPORTED;      // bfloat16 emissions: the fused pair only
     if (p->T < 1 || p->B < 1 || p->N < 1) return ASG_ERR_INVALID;
     if (!p->inputs || !p->transition) return ASG_ERR_INVALID;
     if (need_targets && (p->S < 1 || !p->targets)) return ASG_ERR_INVALID;
@@ -108,6 +110,7 @@ Problem to_problem(const asg_problem *p) {
     P.in_len = p->input_lengths;
     P.tg_len = p->target_lengths;
     P.T = (int) p->T; P.B = (int) p->B; P.N = (int) p->N; P.S = (int) (p->S < 1 ? 1 : p->S);
+    P.in_bf16 = p->inputs_dtype == ASG_DTYPE_BF16 ? 1 : 0;
     return P;
 }
 
@@ -444,7 +447,7 @@ int asg_loss_backward(asg_ctx *ctx, const asg_problem *p, const void *state, siz
 /* ---- fused training step (asg_fused.hip) ------------------------------------------------------------------ */
 
 namespace {
-struct FusedLayout { size_t tiles, flags, dump, ticket2, p2, edges, ascore, fscore, xstate, aoff, total; };
+struct FusedLayout { size_t tiles, flags, dump, ticket2, p2, edges, ascore, fscore, xstate, aoff, rows, in32, total; };
 FusedLayout fused_layout(const asg_problem *p) {
     FusedLayout L{};
     size_t off = 0;
@@ -458,6 +461,10 @@ FusedLayout fused_layout(const asg_problem *p) {
     L.fscore = off; off = align_up(off + (size_t) p->B * 8);
     L.xstate = off; off = align_up(off + (size_t) p->B * 2 * ((p->T + 7) / 8 + 2) * 2048);
     L.aoff = off; off = align_up(off + (size_t) p->B * 2 * ((p->T + 15) / 16 + 1) * 2 * 8);
+    if (p->inputs_dtype == ASG_DTYPE_BF16) {
+        L.rows = off; off = align_up(off + (size_t) p->T * p->B * p->N * 4);
+        L.in32 = off; off = align_up(off + (size_t) p->T * p->B * p->N * 4);
+    }
     L.total = off;
     return L;
 }
@@ -475,6 +482,7 @@ FusedArgs fused_args(const asg_problem *p, void *scratch, int reduction) {
     F.fscore = base + L.fscore;
     F.xstate = base + L.xstate;
     F.aoff = base + L.aoff;
+    if (p->inputs_dtype == ASG_DTYPE_BF16) { F.rows = base + L.rows; F.in32 = base + L.in32; }
     F.reduction = reduction;
     F.gscale = reduction == 2 ? (float) (1.0 / (double) p->B) : 1.0f;
     return F;
@@ -482,7 +490,7 @@ FusedArgs fused_args(const asg_problem *p, void *scratch, int reduction) {
 }  // namespace
 
 int asg_loss_fused_supported(const asg_problem *p) {
-    if (check_problem(p, true) != ASG_OK) return 0;
+    if (check_problem(p, true, true) != ASG_OK) return 0;
     if (p->dtype != ASG_DTYPE_F32 || p->N >= 64 || p->S > 64) return 0;
     const double fr = (double) (p->T - 1) * (double) p->inputs_strides[0] * 4.0, ln = 63.0 * (double) p->inputs_strides[2] * 4.0;
     if (p->inputs_strides[0] < 0 || p->inputs_strides[2] < 0 || fr >= 4294967296.0 || ln >= 2147483648.0) return 0;
@@ -505,12 +513,13 @@ int asg_loss_fused_forward(const asg_problem *p, void *state, size_t state_bytes
                            void *scratch, size_t scratch_bytes, void *grad_inputs, void *sync, int flags, void *stream) {
     (void) flags;
     if (reduction < 0 || reduction > 2 || !loss || !scores || !scratch || !grad_inputs || !sync || !state) return ASG_ERR_INVALID;
-    if (!asg_loss_fused_supported(p)) return check_problem(p, true) != ASG_OK ? check_problem(p, true) : ASG_ERR_UNSUPPORTED;
+    if (!asg_loss_fused_supported(p)) return check_problem(p, true, true) != ASG_OK ? check_problem(p, true, true) : ASG_ERR_UNSUPPORTED;
     if (state_bytes < asg_state_bytes(p) || scratch_bytes < asg_loss_fused_scratch_bytes(p)) return ASG_ERR_WORKSPACE;
     FusedArgs F = fused_args(p, scratch, reduction);
     F.loss = loss;
     F.scores = scores;
     F.grad_inputs = grad_inputs;
+    if (!F.rows) F.rows = grad_inputs;
     F.sync = (unsigned *) sync;
     return hip_status(launch_fused_forward(to_problem(p), to_state(p, state), F, (hipStream_t) stream));
 }
@@ -520,10 +529,11 @@ int asg_loss_fused_backward(const asg_problem *p, void *state, size_t state_byte
                             void *stream) {
     (void) flags;
     if (reduction < 0 || reduction > 2 || !grad_loss || !scratch || !grad_inputs || !grad_transition || !state) return ASG_ERR_INVALID;
-    if (!asg_loss_fused_supported(p)) return check_problem(p, true) != ASG_OK ? check_problem(p, true) : ASG_ERR_UNSUPPORTED;
+    if (!asg_loss_fused_supported(p)) return check_problem(p, true, true) != ASG_OK ? check_problem(p, true, true) : ASG_ERR_UNSUPPORTED;
     if (state_bytes < asg_state_bytes(p) || scratch_bytes < asg_loss_fused_scratch_bytes(p)) return ASG_ERR_WORKSPACE;
     FusedArgs F = fused_args(p, scratch, reduction);
     F.grad_inputs = grad_inputs;
+    if (!F.rows) F.rows = grad_inputs;
     F.grad_loss = grad_loss;
     F.grad_transition = grad_transition;
     return hip_status(launch_fused_backward(to_problem(p), to_state(p, state), F, (hipStream_t) stream));

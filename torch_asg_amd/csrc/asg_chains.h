@@ -1069,7 +1069,15 @@ __device__ __forceinline__ void duo_main(const Problem &P, const State &W, const
 // Producer wavefront: emission loads, block scale, e_n (and arg_n) into the rings.  Only loads on its VMEM queue.
 // tr_lds / tr_ready (fused step): the transition matrix as a compact [N][N] copy that other wavefronts of the workgroup
 // are filling in LDS; *tr_ready reaches tr_need once it is complete.  Waited for AFTER the first emission loads are out.
-template <int NP, bool BETA, class LdsT>
+// bfloat16 -> float is a 16-bit shift (buffer_load_ushort + v_lshlrev)
+__device__ __forceinline__ float bf16_bits_to_float(unsigned short h) { return __uint_as_float((unsigned) h << 16); }
+template <bool BF16>
+__device__ __forceinline__ float emis_load(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+    if constexpr (BF16) return bf16_bits_to_float((unsigned short) __builtin_amdgcn_raw_buffer_load_b16(rs, voff, soff, 0));
+    else return buf_load<float>(rs, voff, soff);
+}
+
+template <int NP, bool BETA, class LdsT, bool BF16 = false>
 __device__ __forceinline__ void duo_producer(const Problem &P, int b, LdsT &L, const float *tr_lds = nullptr,
                                              int *tr_ready = nullptr, int tr_need = 0) {
     typedef float R;
@@ -1080,16 +1088,17 @@ __device__ __forceinline__ void duo_producer(const Problem &P, int b, LdsT &L, c
     const bool act = lane < N;
     const int lc = act ? lane : 0;
     if (len < 1) return;
-    __amdgpu_buffer_rsrc_t rin = make_rsrc((R *) P.inputs + (int64_t) b * P.is1, 0xffffffffu);
-    const unsigned vin = (unsigned) (lc * (int) P.is2) * (unsigned) sizeof(R);
-    const unsigned fstride = (unsigned) P.is0 * (unsigned) sizeof(R);
+    constexpr unsigned ESZ = BF16 ? 2u : (unsigned) sizeof(R);
+    __amdgpu_buffer_rsrc_t rin = make_rsrc((char *) P.inputs + (int64_t) b * P.is1 * ESZ, 0xffffffffu);
+    const unsigned vin = (unsigned) (lc * (int) P.is2) * ESZ;
+    const unsigned fstride = (unsigned) P.is0 * ESZ;
     const int nblk = (len + kPF - 1) / kPF;
     auto frame = [&](int n) { int nn = min(n, len - 1); return BETA ? len - 1 - nn : nn; };
     R blk0[kPF], nxt[kPF];
 #pragma unroll
-    for (int j = 0; j < kPF; ++j) blk0[j] = buf_load<R>(rin, vin, (unsigned) frame(j) * fstride);
+    for (int j = 0; j < kPF; ++j) blk0[j] = emis_load<BF16>(rin, vin, (unsigned) frame(j) * fstride);
 #pragma unroll
-    for (int j = 0; j < kPF; ++j) nxt[j] = buf_load<R>(rin, vin, (unsigned) frame(kPF + j) * fstride);
+    for (int j = 0; j < kPF; ++j) nxt[j] = emis_load<BF16>(rin, vin, (unsigned) frame(kPF + j) * fstride);
     // X = max over the row (alpha) / column (beta) of the transition matrix, log2 units
     R X = NINF;
     {
@@ -1139,7 +1148,7 @@ __device__ __forceinline__ void duo_producer(const Problem &P, int b, LdsT &L, c
     constexpr int kAhead = LdsT::kR / kPF;          // blocks the ring holds
     for (int K = 2; K < nblk; ++K) {
 #pragma unroll
-        for (int j = 0; j < kPF; ++j) nxt[j] = buf_load<R>(rin, vin, (unsigned) frame(K * kPF + j) * fstride);
+        for (int j = 0; j < kPF; ++j) nxt[j] = emis_load<BF16>(rin, vin, (unsigned) frame(K * kPF + j) * fstride);
         // block K reuses the ring slots of block K - kAhead: wait until the consumer has seen s_{16(K-kAhead+1)-1},
         // i.e. main has finished block K - kAhead   (kAhead = 2: the consumer has seen s_{16(K-1)-1})
         int spins = 0;

@@ -192,7 +192,7 @@ __device__ __forceinline__ Problem ld_problem(KParams k) {
     P.transition = k->P.transition; P.ts0 = k->P.ts0; P.ts1 = k->P.ts1;
     P.targets = k->P.targets; P.gs0 = k->P.gs0; P.gs1 = k->P.gs1;
     P.in_len = k->P.in_len; P.tg_len = k->P.tg_len;
-    P.T = k->P.T; P.B = k->P.B; P.N = k->P.N; P.S = k->P.S;
+    P.T = k->P.T; P.B = k->P.B; P.N = k->P.N; P.S = k->P.S; P.in_bf16 = k->P.in_bf16;
     return P;
 }
 __device__ __forceinline__ State ld_state(KParams k) {
@@ -207,7 +207,7 @@ __device__ __forceinline__ FusedArgs ld_fargs(KParams k) {
     FusedArgs F;
     F.loss = k->F.loss; F.scores = k->F.scores; F.grad_inputs = k->F.grad_inputs; F.tiles = k->F.tiles;
     F.flags = k->F.flags; F.dump = k->F.dump; F.p2 = k->F.p2; F.edges = k->F.edges; F.ascore = k->F.ascore;
-    F.aoff = k->F.aoff; F.sync = k->F.sync; F.xstate = k->F.xstate; F.fscore = k->F.fscore; F.ticket2 = k->F.ticket2; F.grad_loss = k->F.grad_loss;
+    F.aoff = k->F.aoff; F.sync = k->F.sync; F.xstate = k->F.xstate; F.fscore = k->F.fscore; F.rows = k->F.rows; F.in32 = k->F.in32; F.ticket2 = k->F.ticket2; F.grad_loss = k->F.grad_loss;
     F.grad_transition = k->F.grad_transition; F.reduction = k->F.reduction; F.gscale = k->F.gscale;
     return F;
 }
@@ -301,6 +301,30 @@ __device__ __forceinline__ float div_nr(float a, float b) {
     const float r = Num<float>::rcp(b);
     const float q = a * r;
     return fmaf(fmaf(-q, b, a), r, q);
+}
+
+// float -> bfloat16, round to nearest even (gradients are finite)
+__device__ __forceinline__ unsigned short float_to_bf16_bits(float x) {
+    unsigned u = __float_as_uint(x);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short) (u >> 16);
+}
+// bfloat16 emissions: the exact stand-alone code (flagged utterances) reads fp32 -- utterance b's emissions, widened, in
+// FusedArgs::in32 ([B][T][N]) and the Problem that points the kernels there
+__device__ __forceinline__ Problem problem_fp32_copy(const Problem &P, const FusedArgs &F) {
+    Problem Q = P;
+    Q.inputs = F.in32;
+    Q.is0 = P.N; Q.is1 = (int64_t) P.T * P.N; Q.is2 = 1;
+    Q.in_bf16 = 0;
+    return Q;
+}
+__device__ __forceinline__ void widen_utterance(const Problem &P, const FusedArgs &F, int b, int nthreads) {
+    const unsigned short *src = (const unsigned short *) P.inputs + (int64_t) b * P.is1;
+    float *dst = (float *) F.in32 + (int64_t) b * P.T * P.N;
+    for (int k = threadIdx.x; k < P.T * P.N; k += nthreads) {
+        const int t = k / P.N, i = k - t * P.N;
+        dst[k] = bf16_bits_to_float(src[(int64_t) t * P.is0 + (int64_t) i * P.is2]);
+    }
 }
 
 __device__ __forceinline__ float buf_load_sc1(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
@@ -421,7 +445,7 @@ __device__ __forceinline__ void fused_consumer(const Problem &P, const State &W,
     const int phi = (-h) & 7, phiO = (-(len - h)) & 7;
     const R gscale = F.gscale;
     // rows of the full-lattice posterior go straight to grad_inputs; the backward launch subtracts the aligned posteriors
-    __amdgpu_buffer_rsrc_t rs_g = make_rsrc((R *) F.grad_inputs + (int64_t) b * N,
+    __amdgpu_buffer_rsrc_t rs_g = make_rsrc((R *) F.rows + (int64_t) b * N,
                                             (unsigned) ((int64_t) (T - 1) * P.B * N + N) * (unsigned) sizeof(R));
     const unsigned voffg = act ? (unsigned) lane * (unsigned) sizeof(R) : kOobOffset;
     const unsigned grow_bytes = (unsigned) P.B * N * sizeof(R);
@@ -729,7 +753,7 @@ __device__ __forceinline__ void aligned_steps(const float (&cur)[kPF], int nstep
 // ------------------------------------------------------------------ aligned chain
 // The stand-alone aligned chains (asg_chains.h) with two changes: every state also goes into the `ar` ring for the
 // finisher of this side, and only the first half goes to HBM (for the finisher of the other side).
-template <bool BETA>
+template <bool BETA, bool BF16>
 __device__ __forceinline__ void fused_aligned(const Problem &P, const State &W, int b, AliSide &L, AliSide &O, int len,
                                               int h, double &score_out2, void *aoff, UttSync *us) {
     typedef float R;
@@ -737,6 +761,9 @@ __device__ __forceinline__ void fused_aligned(const Problem &P, const State &W, 
     const int lane = threadIdx.x & 63;
     const int T = P.T, S = P.S;
     const AlignedSetup<R> A = aligned_setup<R>(P, b, lane);
+    // emission of this lane's label at frame offset `e` (elements): fp32, or bfloat16 widened
+    const unsigned short *inh = (const unsigned short *) P.inputs + (int64_t) b * P.is1 + (int64_t) A.tgt * P.is2;
+    auto emis = [&](int64_t e) -> R { if constexpr (BF16) return bf16_bits_to_float(inh[e]); else return A.in[e]; };
     const unsigned row_bytes = (unsigned) S * sizeof(R);
     __amdgpu_buffer_rsrc_t rs = make_rsrc((R *) (BETA ? W.bb : W.ab) + (int64_t) b * T * S, (unsigned) T * row_bytes);
     const unsigned voff = lane < S ? (unsigned) lane * sizeof(R) : kOobOffset;
@@ -747,7 +774,7 @@ __device__ __forceinline__ void fused_aligned(const Problem &P, const State &W, 
     double C = 0.0;
     // index 0
     double st;
-    if (!BETA) st = (lane == 0) ? fmax(fma((double) A.in[0], L2Ed, (double) A.ebias), kLZd) : kLZd;
+    if (!BETA) st = (lane == 0) ? fmax(fma((double) emis(0), L2Ed, (double) A.ebias), kLZd) : kLZd;
     else st = (lane == A.ol - 1) ? 0.0 : kLZd;
     {
         const R v = to_state<R>(st);
@@ -769,7 +796,7 @@ __device__ __forceinline__ void fused_aligned(const Problem &P, const State &W, 
     // step k of a block starting at `done` reads emission frame ef = (alpha) 1+done+k / (beta) len-1-done-k and produces
     // the state of index 1+done+k
 #pragma unroll
-    for (int k = 0; k < kPF; ++k) cur[k] = A.in[(int64_t) (BETA ? max(len - 1 - k, 0) : min(1 + k, len - 1)) * P.is0];
+    for (int k = 0; k < kPF; ++k) cur[k] = emis((int64_t) (BETA ? max(len - 1 - k, 0) : min(1 + k, len - 1)) * P.is0);
     R last_raw = cur[0];
     // block prologue: ring space, renormalisation, block scale, per-block offsets; returns the emission bias of the block
     auto block_begin = [&](int done, int nsteps, bool &ok) -> double {
@@ -811,7 +838,7 @@ __device__ __forceinline__ void fused_aligned(const Problem &P, const State &W, 
     for (; done + kPF <= nst; done += kPF) {
 #pragma unroll
         for (int k = 0; k < kPF; ++k)
-            nxt[k] = A.in[(int64_t) (BETA ? max(len - 1 - (done + kPF + k), 0) : min(1 + done + kPF + k, len - 1)) * P.is0];
+            nxt[k] = emis((int64_t) (BETA ? max(len - 1 - (done + kPF + k), 0) : min(1 + done + kPF + k, len - 1)) * P.is0);
         bool ok;
         const double ebias = block_begin(done, kPF, ok);
         if (!ok) return;
@@ -1050,8 +1077,16 @@ __device__ __forceinline__ void aligned_workgroup(int b, FusedShared<NP> &SH) {
         const State W = ld_state(kernarg_params());
         const FusedArgs F = ld_fargs(kernarg_params());
         switch (wave) {
-            case 0: __builtin_amdgcn_s_setprio(ASG_X_ALIPRIO); fused_aligned<false>(P, W, b, LA, LB, len, mid, sc2, (double *) F.aoff + ((int64_t) b * 2 + 0) * ((T + kPF - 1) / kPF + 1) * 2, us); break;
-            case 1: __builtin_amdgcn_s_setprio(ASG_X_ALIPRIO); fused_aligned<true>(P, W, b, LB, LA, len, len - mid, sc2, (double *) F.aoff + ((int64_t) b * 2 + 1) * ((T + kPF - 1) / kPF + 1) * 2, us); break;
+            case 0:
+                __builtin_amdgcn_s_setprio(ASG_X_ALIPRIO);
+                if (P.in_bf16) fused_aligned<false, true>(P, W, b, LA, LB, len, mid, sc2, (double *) F.aoff + ((int64_t) b * 2 + 0) * ((T + kPF - 1) / kPF + 1) * 2, us);
+                else fused_aligned<false, false>(P, W, b, LA, LB, len, mid, sc2, (double *) F.aoff + ((int64_t) b * 2 + 0) * ((T + kPF - 1) / kPF + 1) * 2, us);
+                break;
+            case 1:
+                __builtin_amdgcn_s_setprio(ASG_X_ALIPRIO);
+                if (P.in_bf16) fused_aligned<true, true>(P, W, b, LB, LA, len, len - mid, sc2, (double *) F.aoff + ((int64_t) b * 2 + 1) * ((T + kPF - 1) / kPF + 1) * 2, us);
+                else fused_aligned<true, false>(P, W, b, LB, LA, len, len - mid, sc2, (double *) F.aoff + ((int64_t) b * 2 + 1) * ((T + kPF - 1) / kPF + 1) * 2, us);
+                break;
 #ifndef ASG_X_NOFIN
             // two finishers of a side on a SIMD of their own pair, the third beside the OTHER side's chain (which has priority)
             case 2: case 6: fused_afin<false>(P, W, F, b, LA, LB, len, mid, us, (wave - 2) >> 2); break;
@@ -1142,11 +1177,16 @@ __device__ __forceinline__ void full_workgroup(int b, FusedShared<NP> &SH) {
     // Idle wavefronts go straight to the barrier: a waiting wavefront issues nothing.
     if (!BETA && wave == 7) {
         // padded frames get exactly-zero gradients (the reference: roll_to_end + masked softmax, utils.cpp:11-66)
-        __amdgpu_buffer_rsrc_t rs_g = make_rsrc((R *) F.grad_inputs + (int64_t) b * N,
-                                                (unsigned) ((int64_t) (T - 1) * P.B * N + N) * (unsigned) sizeof(R));
-        const unsigned voff = lane < N ? (unsigned) lane * sizeof(R) : kOobOffset;
-        const unsigned grow_bytes = (unsigned) P.B * N * sizeof(R);
-        for (int t = len; t < T; ++t) buf_store(R(0), rs_g, voff, (unsigned) t * grow_bytes);
+        if (P.in_bf16) {
+            unsigned short *gh = (unsigned short *) F.grad_inputs + (int64_t) b * N;
+            if (lane < N) for (int t = len; t < T; ++t) gh[(int64_t) t * P.B * N + lane] = 0;
+        } else {
+            __amdgpu_buffer_rsrc_t rs_g = make_rsrc((R *) F.grad_inputs + (int64_t) b * N,
+                                                    (unsigned) ((int64_t) (T - 1) * P.B * N + N) * (unsigned) sizeof(R));
+            const unsigned voff = lane < N ? (unsigned) lane * sizeof(R) : kOobOffset;
+            const unsigned grow_bytes = (unsigned) P.B * N * sizeof(R);
+            for (int t = len; t < T; ++t) buf_store(R(0), rs_g, voff, (unsigned) t * grow_bytes);
+        }
     }
     constexpr int kFill = 6;                                   // wavefronts 2 .. 7
     if (wave >= 2) {
@@ -1164,7 +1204,10 @@ __device__ __forceinline__ void full_workgroup(int b, FusedShared<NP> &SH) {
         const FusedArgs F = ld_fargs(kernarg_params());
         switch (wave) {
             case 0: __builtin_amdgcn_s_setprio(3); fused_main<NP, BETA>(P, b, L, us, len, W.dbg, SH.trl, &SH.tr_ready, kFill); break;
-            case 1: duo_producer<NP, BETA>(P, b, L, SH.trl, &SH.tr_ready, kFill); break;
+            case 1:
+                if (P.in_bf16) duo_producer<NP, BETA, FusedSide, true>(P, b, L, SH.trl, &SH.tr_ready, kFill);
+                else duo_producer<NP, BETA, FusedSide, false>(P, b, L, SH.trl, &SH.tr_ready, kFill);
+                break;
             case 2: fused_consumer<NP, BETA>(P, W, F, b, L, us, len, h, TL.sx[0], sc2, 0); break;
             case 3: fused_consumer<NP, BETA>(P, W, F, b, L, us, len, h, TL.sx[1], sc2, 1); break;
             // (consumers on three SIMDs: the third beside the producer, which is light)
@@ -1307,14 +1350,20 @@ __device__ __forceinline__ void full_workgroup(int b, FusedShared<NP> &SH) {
     if (flagged) {
         // exact scores here (so that the loss of this launch is right), exact gradients in the backward launch
         const State W = ld_state(kernarg_params());
+        Problem Q = P;
+        if (P.in_bf16) {
+            widen_utterance(P, F, b, kFusedThreads);
+            __syncthreads();
+            Q = problem_fp32_copy(P, F);
+        }
         if (wave == 0) {
-            const double sx = slow_full_score<NP>(P, b, len);
+            const double sx = slow_full_score<NP>(Q, b, len);
             if (lane == 0) SH.score_full = sx;
         } else if (wave == 1) {
             // the stand-alone aligned beta chain, forward-only; its score lands in scores[B + b]
             FwdOut O{};
             O.aligned_scores = (R *) F.scores + P.B;
-            aligned_beta_chain<R, false>(P, W, O, b);
+            aligned_beta_chain<R, false>(Q, W, O, b);
         }
         __syncthreads();
     }
@@ -1427,10 +1476,11 @@ __global__ void __launch_bounds__(256) fused_bwd_kernel(Problem P, State W, Fuse
             FwdOut O{};
             O.full_scores = (R *) F.dump + B;            // scratch: the scores of this launch's forward stay as they are
             O.aligned_scores = (R *) F.dump + 2 * B;
-            if (wave == 0) full_alpha_chain<R, NP, 0, true>(P, W, O, b, lds4[0]);
-            else if (wave == 1) full_beta_chain<R, NP, 0, true>(P, W, O, b, lds4[1]);
-            else if (wave == 2) aligned_alpha_chain<R, true>(P, W, O, b);
-            else aligned_beta_chain<R, true>(P, W, O, b);
+            const Problem Q = P.in_bf16 ? problem_fp32_copy(P, F) : P;     // (widened by the forward launch's closing workgroup)
+            if (wave == 0) full_alpha_chain<R, NP, 0, true>(Q, W, O, b, lds4[0]);
+            else if (wave == 1) full_beta_chain<R, NP, 0, true>(Q, W, O, b, lds4[1]);
+            else if (wave == 2) aligned_alpha_chain<R, true>(Q, W, O, b);
+            else aligned_beta_chain<R, true>(Q, W, O, b);
             // the four chains' state rows are read back by all four wavefronts: make them visible past the L1
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             __syncthreads();
@@ -1439,20 +1489,22 @@ __global__ void __launch_bounds__(256) fused_bwd_kernel(Problem P, State W, Fuse
             A.unit_grad = 1;
             A.neg_aligned = 1;
             A.gscale = (double) F.gscale;
-            A.grad_inputs = F.grad_inputs;
+            A.grad_inputs = F.rows;
             A.chunk = T;
             A.nchunks = 1;
-            assemble_frames<R, NP, 4>(P, W, A, 3, b, 0, (R *) F.tiles + (int64_t) b * 2 * N * N, S);
+            assemble_frames<R, NP, 4>(Q, W, A, 3, b, 0, (R *) F.tiles + (int64_t) b * 2 * N * N, S);
             for (int k = threadIdx.x; k < N * N; k += 256) ((R *) F.tiles)[((int64_t) b * 2 + 1) * N * N + k] = R(0);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             __syncthreads();
-            if (g != R(1)) {
-                R *gi = (R *) F.grad_inputs + (int64_t) b * N;
+            if (g != R(1) || P.in_bf16) {
+                R *gi = (R *) F.rows + (int64_t) b * N;
+                unsigned short *gh = (unsigned short *) F.grad_inputs + (int64_t) b * N;
                 const int total = T * N;
                 for (int k = threadIdx.x; k < total; k += 256) {
                     const int t = k / N, i = k - t * N;
-                    R *ptr = gi + (int64_t) t * B * N + i;
-                    *ptr = *ptr * g;
+                    const R v = gi[(int64_t) t * B * N + i] * g;
+                    if (P.in_bf16) gh[(int64_t) t * B * N + i] = float_to_bf16_bits(v);
+                    else gi[(int64_t) t * B * N + i] = v;
                 }
             }
             __syncthreads();
@@ -1476,8 +1528,9 @@ __global__ void __launch_bounds__(256) fused_bwd_kernel(Problem P, State W, Fuse
             if (lane >= ol) tgt = lane;
         }
         const unsigned rbS = (unsigned) Sx * sizeof(R);
-        __amdgpu_buffer_rsrc_t rg = make_rsrc((R *) F.grad_inputs + (int64_t) b * N,
+        __amdgpu_buffer_rsrc_t rg = make_rsrc((R *) F.rows + (int64_t) b * N,
                                               (unsigned) ((int64_t) (T - 1) * B * N + N) * (unsigned) sizeof(R));
+        unsigned short *gh = (unsigned short *) F.grad_inputs + (int64_t) b * N;       // bfloat16 emissions: the output
         const unsigned voff = lane < N ? (unsigned) lane * sizeof(R) : kOobOffset;          // out of range: loads 0, stores nothing
         const unsigned vQ = lane < Sx ? (unsigned) lane * 16u : kOobOffset;
         const unsigned grow_bytes = (unsigned) B * N * sizeof(R);
@@ -1526,7 +1579,11 @@ __global__ void __launch_bounds__(256) fused_bwd_kernel(Problem P, State W, Fuse
                     __builtin_amdgcn_wave_barrier();
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (r < cnt[u]) buf_store(g * (row[u][r] - gscale * FrameFix<R>::from(fv[r])), rg, voff, (unsigned) fr[u][r] * grow_bytes);
+                        if (r < cnt[u]) {
+                            const R v = g * (row[u][r] - gscale * FrameFix<R>::from(fv[r]));
+                            if (P.in_bf16) { if (lane < N) gh[(int64_t) fr[u][r] * B * N + lane] = float_to_bf16_bits(v); }
+                            else buf_store(v, rg, voff, (unsigned) fr[u][r] * grow_bytes);
+                        }
                 }
             }
         }

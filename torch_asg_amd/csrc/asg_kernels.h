@@ -18,6 +18,7 @@ struct Problem {
     const int64_t *in_len;       // [B] or nullptr (= T)
     const int64_t *tg_len;       // [B] or nullptr (= S)
     int T, B, N, S;
+    int in_bf16;                 // emissions are bfloat16 (fused training step only); strides stay in elements
 };
 
 // Saved lattice state (forward -> backward), all in log2 units and RELATIVE per frame.
@@ -81,6 +82,10 @@ struct FusedArgs {
     void *ascore;                // [B] double: aligned scores (log2 units)
     void *fscore;                // [B] double: full-lattice scores (log2 units), beta workgroup -> closing workgroup
     void *xstate;                // [B][2][xstate_blocks(T)][2][64][4] first-half states each full chain hands to the other
+    void *rows;                  // [T,B,N] fp32: where the forward launch leaves its rows -- grad_inputs itself, or (bfloat16
+                                 // emissions: grad_inputs is bfloat16) a work buffer
+    void *in32;                  // bfloat16 emissions only: [B][T][N] fp32 copies of the emissions of FLAGGED utterances, made by
+                                 // the forward launch for the exact stand-alone code (which reads fp32)
     void *aoff;                  // [B][2][T/16 + 2][2] double: per-block offsets of the stored aligned states
     unsigned *sync;              // caller-zeroed, returned zeroed: 64 words (word 0 = arrival ticket of the loss reduction)
                                  // + 16 words per utterance (UttSync in asg_fused.hip)
