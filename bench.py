@@ -464,7 +464,12 @@ def main():
                          "kernel_ms": kern_ms_med, "kernel_ms_avg": kern_ms_avg, "kernel_timing": kern_method,
                          "algorithmic_bytes_per_launch": a_alg,
                          "step_achieved": a_alg / (ms_per_step * 1e-3) / 1e9,
-                         "note": "serial-latency-bound scan: 400 dependent steps x 64 utterances; see DESIGN.md"},
+                         "note": "serial-latency-bound scan: 400 dependent steps x 64 utterances; see DESIGN.md",
+                         # what actually bounds the dominant kernel: T-1 dependent recursion steps at the LDS-broadcast floor of
+                         # this formulation (117 ns measured for the recursion wavefront alone)
+                         "latency_floor": {"dependent_steps": T - 1, "ns_per_step": 117.0,
+                                           "floor_ms": (T - 1) * 117.0e-6,
+                                           "frac_of_kernel": (T - 1) * 117.0e-6 / kern_ms_med} if fused_step else None},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
