@@ -294,9 +294,12 @@ def main():
                     one_step()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
+            sync_grads()                  # the communicator exists (and has run once) before anything is captured
+            torch.cuda.synchronize()
             def capture(with_collective):
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                # thread_local: RCCL's watchdog thread polls events while this thread captures
+                with torch.cuda.graph(g, capture_error_mode="thread_local" if with_collective else "global"):
                     for _ in range(gsteps):
                         one_step()
                         if with_collective:
