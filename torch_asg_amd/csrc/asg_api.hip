@@ -21,7 +21,7 @@ size_t bwd_scratch_bytes_small(int elem, int T, int B, int N, int S, int *chunk,
     if (nch < 1) nch = 1;
     int ch = (T + nch - 1) / nch;
     if (ch < 16) ch = 16;
-    ch = (ch + 3) / 4 * 4;
+    ch = (ch + 15) / 16 * 16;      // whole 16-frame blocks (bwd_mfma_kernel)
     nch = (T + ch - 1) / ch;
     if (nch < 1) nch = 1;
     if (chunk) *chunk = ch;

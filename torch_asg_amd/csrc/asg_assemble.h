@@ -281,6 +281,428 @@ __global__ void __launch_bounds__(256) bwd_small_kernel(Problem P, State W, BwdA
     assemble_frames<R, NP, 4>(P, W, A, parts, b, chunk, tile_out, S);
 }
 
+// ------------------------------------------------------------------ the same assembly on the matrix cores (fp32)
+// The per-frame code above spends its time in two N x N VALU products per frame (row sums, outer product) whose operand
+// is broadcast through LDS.  Over a BLOCK of 16 frames both are dense contractions:
+//   S^T[f][i] = sum_j P[f][j] Ehat[i][j]          (K = labels)   -> row sums of all 16 frames
+//   G[i][j]  += sum_f U[f][i] P[f][j]             (K = frames)   -> the outer products, U = posterior / S
+// so they go to v_mfma_f32_16x16x4_f32 (exact fp32, k-ordered).  Element layout of a block ("natural"): lane l = 16 g + m
+// holds label 16 r + m of frame tb + 4 g + q in register (r, q) -- which is at once the A and B operand layout of the
+// second product (k-slot g of k-step q) and the accumulator layout of the first, so the only data movement is ONE
+// transpose of P through LDS (the A operand of the first product wants frames along the lanes).  Everything per element
+// (posterior, reciprocal, stores) is done with all 64 lanes busy; the per-frame reductions are 16-lane DPP rows.
+// Rows whose sum leaves the safe range flag the workgroup, which then redoes its frames with the per-frame code.
+// Four independent 16-lane row reductions interleaved (every DPP source is four instructions old: no wait states).
+#define ASG_ROW4(op, ctl) \
+    op " %0, %0, %0 " ctl " row_mask:0xf bank_mask:0xf\n" op " %1, %1, %1 " ctl " row_mask:0xf bank_mask:0xf\n" \
+    op " %2, %2, %2 " ctl " row_mask:0xf bank_mask:0xf\n" op " %3, %3, %3 " ctl " row_mask:0xf bank_mask:0xf\n"
+__device__ __forceinline__ void row16_allmax4(float (&x)[4]) {
+    asm volatile("s_nop 1\n"
+                 ASG_ROW4("v_max_f32_dpp", "quad_perm:[1,0,3,2]") ASG_ROW4("v_max_f32_dpp", "quad_perm:[2,3,0,1]")
+                 ASG_ROW4("v_max_f32_dpp", "row_half_mirror") ASG_ROW4("v_max_f32_dpp", "row_mirror")
+                 "s_nop 1\n"
+                 : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
+}
+__device__ __forceinline__ void row16_allsum4(float (&x)[4]) {
+    asm volatile("s_nop 1\n"
+                 ASG_ROW4("v_add_f32_dpp", "quad_perm:[1,0,3,2]") ASG_ROW4("v_add_f32_dpp", "quad_perm:[2,3,0,1]")
+                 ASG_ROW4("v_add_f32_dpp", "row_half_mirror") ASG_ROW4("v_add_f32_dpp", "row_mirror")
+                 "s_nop 1\n"
+                 : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
+}
+#undef ASG_ROW4
+// Bitwise selects: no control flow (hipcc turns `c ? exp2(x) : 0` into an EXEC-masked branch per element) and NaN-proof
+// (frames past an utterance's length hold whatever the allocation held).
+__device__ __forceinline__ unsigned bmask(bool c) { return c ? 0xffffffffu : 0u; }
+__device__ __forceinline__ float bsel(unsigned mk, float x, float other) {
+    return __uint_as_float((__float_as_uint(x) & mk) | (__float_as_uint(other) & ~mk));
+}
+__device__ __forceinline__ float band(unsigned mk, float x) { return __uint_as_float(__float_as_uint(x) & mk); }
+
+// The aligned lattice's share of the same frames is batched the same way: lane 16 g + m holds target position 16 r + m of
+// frame tb + 4 g + q, the per-frame softmax is a 16-lane DPP row reduction, the scatter back to labels goes through a
+// per-wavefront fixed-point LDS frame buffer (integer adds commute: deterministic) that is read back in the natural
+// layout, so every grad_inputs row is written once, complete.
+template <int NP> struct MfmaLds {
+    static constexpr int NT = (NP + 15) / 16, KS = (NP + 3) / 4, STR = 16 * NT + 4;
+    union {
+        struct {
+            float pt[4][16 * STR];               // per wavefront: P of the block's frames, [frame][label]
+            unsigned fxI[4][16][16 * NT];        // per wavefront: aligned state posteriors of the block, scattered to labels
+        } blk;
+        float tileF[NP <= 48 ? 4 : 2][NP * NP + 1];   // after the frame loop: the wavefronts' tiles (+1: dump slot of padding)
+    };
+    float eb[NT * KS][64];                       // B operand of the row-sum product (Ehat in k-step order)
+    unsigned long long fxT[NP * NP];             // aligned edge posteriors (unscaled, fixed point)
+};
+
+template <int NP, int ST>
+__global__ void __launch_bounds__(256, ST <= 2 ? 2 : 1) bwd_mfma_kernel(Problem P, State W, BwdArgs A, int parts) {
+    typedef float R;
+    constexpr int NT = (NP + 15) / 16, KS = (NP + 3) / 4, STR = 16 * NT + 4;
+    union Lds {
+        AssembleLds<float, NP, 4> S;             // the per-frame code (exact redo of a flagged workgroup)
+        MfmaLds<NP> M;
+    };
+    __shared__ Lds L;
+    __shared__ int s_bad;
+    MfmaLds<NP> &M = L.M;
+#if defined(ASG_X_EXIT) && ASG_X_EXIT == 1
+    if (P.T > 0) return;
+#endif
+    const int b = blockIdx.x, chunk = blockIdx.y;
+    R *tile_out = (R *) A.scratch + ((int64_t) b * A.nchunks + chunk) * P.N * P.N;
+    const bool do_ali = (parts & 2) && P.targets;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, m = lane & 15;
+    const int N = P.N, T = P.T, S = P.S;
+    const R NINF = Num<R>::ninf(), LZ = Num<R>::logzero();
+    const int len = P.in_len ? clampi(P.in_len[b], 0, T) : T;
+    const int ol = do_ali ? (P.tg_len ? clampi(P.tg_len[b], 0, S) : S) : 0;
+    const int t0 = chunk * A.chunk, t1 = min(T, t0 + A.chunk), lim = min(t1, len);
+    const R g0 = A.unit_grad ? (R) A.gscale
+                             : (A.grad_full ? (R) ((double) ((const R *) A.grad_full)[(int64_t) b * A.gstride] * A.gscale) : R(0));
+    const R gf = g0;
+    const R ga = (parts & 2) ? (A.neg_aligned ? -g0 : (R) ((double) ((const R *) A.grad_aligned)[(int64_t) b * A.gstride] * A.gscale))
+                             : R(0);
+    const R *ehat = (const R *) W.ehat;
+    {   // every load in flight before the first LDS write (a rolled loop pays the L2 latency once per trip)
+        constexpr int CNT = (NT * KS * 64 + 255) / 256;
+        R ev[CNT];
+#pragma unroll
+        for (int n = 0; n < CNT; ++n) {
+            const int idx = threadIdx.x + 256 * n;
+            const int l = idx & 63, rk = idx >> 6, r = rk / KS, kk = rk - r * KS;
+            const int i = 16 * r + (l & 15), j = 4 * kk + (l >> 4);
+            const R v = ehat[(int64_t) min(i, N - 1) * W.npad + min(j, N - 1)];
+            ev[n] = (i < N && j < N) ? v : R(0);
+        }
+#pragma unroll
+        for (int n = 0; n < CNT; ++n) {
+            const int idx = threadIdx.x + 256 * n;
+            if (idx < NT * KS * 64) (&M.eb[0][0])[idx] = ev[n];
+        }
+    }
+    for (int k = threadIdx.x; k < N * N; k += 256) M.fxT[k] = 0;
+    for (int k = lane; k < 16 * 16 * NT; k += 64) (&M.blk.fxI[wave][0][0])[k] = 0;
+    if (threadIdx.x == 0) s_bad = 0;
+
+    bool lv[NT];
+#pragma unroll
+    for (int r = 0; r < NT; ++r) lv[r] = 16 * r + m < N;
+    // aligned lattice: this lane's target positions
+    bool sv[ST];
+    int sc[ST], sm1[ST], tgt[ST], prv[ST];
+    R H2[ST], Dp[ST], accH[ST], accD[ST];
+#pragma unroll
+    for (int r = 0; r < ST; ++r) {
+        const int s = 16 * r + m;
+        sv[r] = do_ali && s < S;
+        sc[r] = sv[r] ? s : 0;
+        sm1[r] = (sv[r] && s >= 1) ? s - 1 : 0;
+        V2<R> hd = {0, 0};
+        int2 tp = {0, 0};
+        if (do_ali) {
+            hd = reinterpret_cast<const V2<R> *>(W.asu)[(int64_t) b * S + sc[r]];
+            tp = reinterpret_cast<const int2 *>(W.asi)[(int64_t) b * S + sc[r]];
+        }
+        H2[r] = hd.x; Dp[r] = hd.y; tgt[r] = tp.x; prv[r] = tp.y;
+        accH[r] = 0; accD[r] = 0;
+    }
+    // states through raw buffer loads: lane offset = (clamped frame row) * row bytes + 4 m, the label / position tile is
+    // the instruction's immediate offset; elements past a row's end are masked below, past the buffer's end read 0
+    __amdgpu_buffer_rsrc_t r_ah = make_rsrc((R *) W.ah + (int64_t) b * T * N, (unsigned) T * (unsigned) N * 4u);
+    __amdgpu_buffer_rsrc_t r_bh = make_rsrc((R *) W.bh + (int64_t) b * T * N, (unsigned) T * (unsigned) N * 4u);
+    __amdgpu_buffer_rsrc_t r_ab = make_rsrc((R *) W.ab + (int64_t) b * T * S, (unsigned) T * (unsigned) S * 4u);
+    __amdgpu_buffer_rsrc_t r_bb = make_rsrc((R *) W.bb + (int64_t) b * T * S, (unsigned) T * (unsigned) S * 4u);
+    __amdgpu_buffer_rsrc_t rs_g = make_rsrc((R *) A.grad_inputs + (int64_t) b * N,
+                                            (unsigned) ((int64_t) (T - 1) * P.B * N + N) * 4u);
+    const unsigned rbN = (unsigned) N * 4u, rbS = (unsigned) S * 4u, rbG = (unsigned) P.B * (unsigned) N * 4u;
+    const unsigned m4 = (unsigned) m * 4u;
+    // position s - 1 of the previous frame: one element to the left (position 0 has no left neighbour: masked by Dp = logzero)
+    const unsigned m4l = m4 >= 4u ? m4 - 4u : 0u;
+    V4<R> acc[NT * NT];
+#pragma unroll
+    for (int q = 0; q < NT * NT; ++q) acc[q] = V4<R>{0, 0, 0, 0};
+    bool bad = false;
+    float *ptw = M.blk.pt[wave];
+    __syncthreads();
+#if defined(ASG_X_EXIT) && ASG_X_EXIT == 2
+    if (P.T > 0) return;
+#endif
+
+    struct BlockRegs {
+        R a[NT][4], bh[NT][4], ap0[NT];
+    };
+    struct AlignedRegs {
+        R xa[ST][4], xb[ST][4], xm[ST][4], xp0[ST];
+    };
+    auto issue_aligned = [&](AlignedRegs &X, int tb) {
+        const int tf = tb + 4 * g;
+        unsigned row[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) row[q] = (unsigned) min(tf + q, T - 1);
+        const unsigned rowp = (unsigned) clampi(tf - 1, 0, T - 1);
+#pragma unroll
+        for (int r = 0; r < ST; ++r) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                X.xa[r][q] = buf_load<R>(r_ab, row[q] * rbS + m4 + 64u * r, 0u);
+                X.xb[r][q] = buf_load<R>(r_bb, row[q] * rbS + m4 + 64u * r, 0u);
+                const unsigned rp = q == 0 ? rowp : row[q - 1];
+                X.xm[r][q] = buf_load<R>(r_ab, rp * rbS + (r == 0 ? m4l : m4 + 64u * r - 4u), 0u);
+            }
+            X.xp0[r] = buf_load<R>(r_ab, rowp * rbS + m4 + 64u * r, 0u);
+        }
+    };
+    auto issue_loads = [&](BlockRegs &X, int tb) {
+        const int tf = tb + 4 * g;
+        unsigned row[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) row[q] = (unsigned) min(tf + q, T - 1);
+        const unsigned rowp = (unsigned) clampi(tf - 1, 0, T - 1);
+#pragma unroll
+        for (int r = 0; r < NT; ++r) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                X.a[r][q] = buf_load<R>(r_ah, row[q] * rbN + m4 + 64u * r, 0u);
+                X.bh[r][q] = buf_load<R>(r_bh, row[q] * rbN + m4 + 64u * r, 0u);
+            }
+            X.ap0[r] = buf_load<R>(r_ah, rowp * rbN + m4 + 64u * r, 0u);
+        }
+    };
+    unsigned lvm[NT], lvo[NT], svm[ST], s1m[ST];
+#pragma unroll
+    for (int r = 0; r < NT; ++r) { lvm[r] = bmask(lv[r]); lvo[r] = lv[r] ? 0u : kOobOffset; }
+#pragma unroll
+    for (int r = 0; r < ST; ++r) { svm[r] = bmask(sv[r]); s1m[r] = bmask(16 * r + m >= 1); }
+    const R LZ2 = LZ + LZ;
+
+    auto process = [&](BlockRegs &C, int tb) {
+        const int tf = tb + 4 * g;               // first of this lane group's four frames
+        if (tb >= len) {                          // beyond the utterance: zero rows
+#pragma unroll
+            for (int r = 0; r < NT; ++r)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    buf_store(R(0), rs_g, (lv[r] && tf + q < t1) ? (unsigned) (tf + q) * rbG + m4 + 64u * r : kOobOffset, 0u);
+            return;
+        }
+        unsigned fvm[4], t1m[4];                  // frame inside the utterance / has a predecessor
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { fvm[q] = bmask(tf + q < lim); t1m[q] = fvm[q] & bmask(tf + q >= 1); }
+        AlignedRegs Q;
+        if (do_ali) issue_aligned(Q, tb);       // consumed after the full-lattice part of the block
+        // ---- full lattice
+        R w[NT][4], p[NT][4];
+        R mg[4], Z[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            R mx = NINF;
+#pragma unroll
+            for (int r = 0; r < NT; ++r) {
+                const R prev = q == 0 ? C.ap0[r] : C.a[r][q - 1];
+                p[r][q] = Num<R>::exp2(bsel(t1m[q] & lvm[r], prev, NINF));
+                w[r][q] = bsel(fvm[q] & lvm[r], C.a[r][q] + C.bh[r][q], NINF);
+                mx = fmaxf(mx, w[r][q]);
+            }
+            mg[q] = fmaxf(mx, LZ);
+        }
+        row16_allmax4(mg);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            R z = 0;
+#pragma unroll
+            for (int r = 0; r < NT; ++r) {
+                w[r][q] = Num<R>::exp2(w[r][q] - mg[q]);
+                z += w[r][q];
+            }
+            Z[q] = z;
+        }
+        row16_allsum4(Z);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Z[q] = band(bmask(Z[q] > 0), gf * Num<R>::rcp(Z[q]));
+        // P transposed through LDS: written [frame][label], read with the frame along the lanes
+#pragma unroll
+        for (int r = 0; r < NT; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ptw[(4 * g + q) * STR + 16 * r + m] = p[r][q];
+        __builtin_amdgcn_wave_barrier();
+        V4<R> sd[NT];
+#pragma unroll
+        for (int r = 0; r < NT; ++r) sd[r] = V4<R>{0, 0, 0, 0};
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            const R pa = ptw[m * STR + 4 * kk + g];
+#pragma unroll
+            for (int r = 0; r < NT; ++r)
+                sd[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa, M.eb[r * KS + kk][lane], sd[r], 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+        R u[NT][4];
+        unsigned badm = 0;
+#pragma unroll
+        for (int r = 0; r < NT; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const R post = w[r][q] * Z[q];
+                const unsigned sb = Rng<R>::bits(sd[r][q]);
+                const unsigned okm = bmask(sb - Rng<R>::lo <= Rng<R>::hi - Rng<R>::lo);      // lo <= sb <= hi
+                const unsigned live = t1m[q] & bmask(post != R(0));
+                badm |= live & ~okm;
+                u[r][q] = band(live & okm, post * Num<R>::rcp(sd[r][q]));
+                w[r][q] = post;
+            }
+        bad |= badm != 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int ri = 0; ri < NT; ++ri)
+#pragma unroll
+                for (int rj = 0; rj < NT; ++rj)
+                    acc[ri * NT + rj] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[ri][q], p[rj][q], acc[ri * NT + rj], 0, 0, 0);
+        // ---- aligned lattice: state posteriors -> label frame buffer, edge posteriors -> accH / accD
+        if (do_ali) {
+            R gm[ST][4], mg2[4], Z2[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                R mx = LZ2;
+#pragma unroll
+                for (int r = 0; r < ST; ++r) {
+                    gm[r][q] = bsel(fvm[q] & svm[r], Q.xa[r][q] + Q.xb[r][q], LZ2);
+                    mx = fmaxf(mx, gm[r][q]);
+                }
+                mg2[q] = mx;
+            }
+            row16_allmax4(mg2);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                R z = 0;
+#pragma unroll
+                for (int r = 0; r < ST; ++r) {
+                    gm[r][q] = Num<R>::exp2(gm[r][q] - mg2[q]);
+                    z += gm[r][q];
+                }
+                Z2[q] = z;
+            }
+            row16_allsum4(Z2);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)      // an infeasible alignment (all states at log zero) has no posterior
+                Z2[q] = band(bmask(mg2[q] > R(-1e29)) & bmask(Z2[q] > 0), Num<R>::rcp(Z2[q]));
+#pragma unroll
+            for (int r = 0; r < ST; ++r)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const R post2 = gm[r][q] * Z2[q];
+                    atomicAdd(&M.blk.fxI[wave][4 * g + q][tgt[r]], FrameFix<R>::to(post2));
+                    const R pc0 = (q == 0 ? Q.xp0[r] : Q.xa[r][q - 1]) + H2[r];
+                    const R pc1 = band(s1m[r], Q.xm[r][q]) + Dp[r];
+                    const R l = lse2<R>(pc0, pc1);
+                    const unsigned em = t1m[q] & bmask(post2 != R(0));
+                    accH[r] += band(em, post2 * Num<R>::exp2(pc0 - l));
+                    accD[r] += band(em, post2 * Num<R>::exp2(pc1 - l));
+                }
+        }
+        // ---- rows: full posterior + the aligned posteriors scattered to this label
+        unsigned so[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) so[q] = tf + q < t1 ? (unsigned) (tf + q) * rbG + m4 : kOobOffset;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < NT; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                R v = w[r][q];
+                if (do_ali) {
+                    unsigned *fp = &M.blk.fxI[wave][4 * g + q][16 * r + m];
+                    v += ga * FrameFix<R>::from(*fp);
+                    *fp = 0;
+                }
+                buf_store(v, rs_g, max(so[q] + 64u * r, lvo[r]), 0u);
+            }
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    // two register sets alternate: the next block's states travel while the current one is processed
+    {
+        BlockRegs X0, X1;
+        int tb = t0 + 16 * wave;
+        if (tb < t1) issue_loads(X0, tb);
+        for (; tb < t1; tb += 128) {
+#ifdef ASG_X_MAXBLK
+            if (tb >= t0 + 64 * ASG_X_MAXBLK) break;
+#endif
+            if (tb + 64 < lim) issue_loads(X1, tb + 64);
+            process(X0, tb);
+            if (tb + 64 >= t1) break;
+            if (tb + 128 < lim) issue_loads(X0, tb + 128);
+            process(X1, tb + 64);
+        }
+    }
+    if (do_ali) {
+#pragma unroll
+        for (int r = 0; r < ST; ++r) {
+            const int s = 16 * r + m;
+            if (s < ol) {
+                if (accH[r] != R(0)) atomicAdd(&M.fxT[tgt[r] * N + tgt[r]], to_fix<R>(accH[r]));
+                if (s >= 1 && accD[r] != R(0)) atomicAdd(&M.fxT[tgt[r] * N + prv[r]], to_fix<R>(accD[r]));
+            }
+        }
+    }
+#if defined(ASG_X_EXIT) && ASG_X_EXIT == 3
+    if (P.T > 0) return;
+#endif
+    if (__any(bad) && lane == 0) s_bad = 1;
+    __syncthreads();
+    if (s_bad) {         // rare: the per-frame code owns the exact treatment of unusable row sums
+        assemble_frames<float, NP, 4>(P, W, A, parts, b, chunk, tile_out, L.S);
+        return;
+    }
+    // one partial tile per workgroup: the four wavefronts' accumulators in a fixed order, scaled by Ehat
+    constexpr int CT = (NP * NP + 255) / 256;
+    R eh[CT];
+#pragma unroll
+    for (int n = 0; n < CT; ++n) {           // in flight during the combine below
+        const int k = min((int) threadIdx.x + 256 * n, N * N - 1), i = k / N, j = k - i * N;
+        eh[n] = ehat[(int64_t) i * W.npad + j];
+    }
+    // every wavefront stores its accumulators to its own slot (plain pipelined LDS writes; a read-modify-write per
+    // element pays the LDS latency per element); alphabets too large for four slots take two rounds
+    constexpr int TW = NP <= 48 ? 4 : 2;
+    for (int ph = 0; ph < 4 / TW; ++ph) {
+        if (wave / TW == ph) {
+            float *slot = M.tileF[wave % TW];
+#pragma unroll
+            for (int ri = 0; ri < NT; ++ri)
+#pragma unroll
+                for (int rj = 0; rj < NT; ++rj)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int i = 16 * ri + 4 * g + q, j = 16 * rj + m;
+                        const int at = (i < N && j < N) ? i * NP + j : NP * NP;
+                        slot[at] = (ph == 0 ? 0.f : slot[at]) + acc[ri * NT + rj][q];
+                    }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int n = 0; n < CT; ++n) {
+        const int k = threadIdx.x + 256 * n;
+        if (k < N * N) {
+            const int i = k / N, j = k - i * N;
+            R t = M.tileF[0][i * NP + j];
+#pragma unroll
+            for (int w2 = 1; w2 < TW; ++w2) t += M.tileF[w2][i * NP + j];      // fixed order
+            R v = t * eh[n];
+            const unsigned long long fv = M.fxT[k];
+            if (fv != 0) v += ga * from_fix<R>(fv);
+            tile_out[k] = v;
+        }
+    }
+}
+
 // Sum G partial tiles in a fixed order -> deterministic grad_transition.
 // block = 1024 threads = 32 elements x 32 tile-groups; thread (e, grp) sums tiles grp, grp+32, ... with 16
 // independent accumulators (16 loads in flight: the kernel is pure L2 latency, so the 512 tiles of cfg 3 take ONE
