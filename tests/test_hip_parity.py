@@ -182,8 +182,9 @@ def test_alpha_and_beta_scores_agree_and_matvec_variants():
     util.assert_close(outs[0][0], outs[1][0], 1e-6, "matvec variants")
 
 
+@pytest.mark.parametrize("launch_mode", ["single", "serial"])
 @pytest.mark.parametrize("case", ["wide_transitions", "neginf_transitions", "huge_emission_range", "logit_scale"])
-def test_exact_fallback_paths(case):
+def test_exact_fallback_paths(case, launch_mode):
     """Inputs that push row sums of the exp-domain mat-vec out of fp32 range, so the kernels must take their
     exact log-sum-exp path (forward) / exact softmax path (backward); checked against the fp64 oracle."""
     g = torch.Generator().manual_seed(42)
@@ -207,9 +208,10 @@ def test_exact_fallback_paths(case):
     tl = torch.tensor([6, 4, 5])
     o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il.numpy(), tl.numpy(), "none")
     assert np.isfinite(o["loss"]).all()
-    r = run_hip(x, tg, tr, il, tl, "none")
+    # 'serial' = the stand-alone kernels (the MFMA assembly flags a workgroup and redoes it with the per-frame code)
+    r = run_hip(x, tg, tr, il, tl, "none", launch_mode=launch_mode)
     for k in ("loss", "grad_inputs", "grad_transition"):
-        util.assert_close(r[k], o[k], 1e-4, "%s/%s" % (case, k))
+        util.assert_close(r[k], o[k], 1e-4, "%s/%s/%s" % (case, launch_mode, k))
 
 
 # ------------------------------------------------------------------ generic path (N > 64 and / or S > 64)
@@ -757,6 +759,21 @@ def test_large_batch_routes_to_standalone_kernels_and_agrees():
         o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il.numpy(), tl.numpy(), "sum")
         for k in ("loss", "grad_inputs", "grad_transition"):
             util.assert_close(r[k], o[k], 1e-4, "B=%d %s" % (B, k))
+
+
+@pytest.mark.parametrize("T,B,N,L", [(70, 5, 40, 30), (33, 3, 63, 50), (16, 2, 5, 3), (129, 2, 17, 33), (47, 4, 64, 64),
+                                     (401, 3, 40, 30), (15, 3, 33, 15), (64, 2, 48, 32)])
+def test_standalone_assembly_blocks(T, B, N, L):
+    """The stand-alone route's gradient assembly works on 16-frame blocks (full lattice on the matrix cores, aligned
+    lattice batched in the same layout): block tails, every label / target-position tile count, variable lengths."""
+    tr, x, tg, il, tl = util.synth(T, B, N, L, T + N, True)
+    o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il.numpy(), tl.numpy(), "none")
+    r = run_hip(x, tg, tr, il, tl, "none", launch_mode="serial")
+    for k in ("loss", "grad_inputs", "grad_transition"):
+        util.assert_close(r[k], o[k], 1e-4, "T%d B%d N%d L%d %s" % (T, B, N, L, k))
+    r2 = run_hip(x, tg, tr, il, tl, "none", launch_mode="serial")
+    for k in ("loss", "grad_inputs", "grad_transition"):
+        assert np.array_equal(r[k], r2[k]), "not deterministic: " + k
 
 
 def test_fused_step_long_utterances():

@@ -14,7 +14,7 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 d = collections.OrderedDict()
 for r in rows:
     n = r["Kernel_Name"]
-    if "bwd_" not in n and "fwd_small" not in n: continue
+    if "bwd_" not in n and "fwd_" not in n: continue
     k = (n.split("(")[0].split("::")[-1][:28], r["Grid_Size_X"] if "Grid_Size_X" in r else r.get("Grid_Size"))
     d.setdefault(k, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 # per (kernel, grid): the sequence is FCC x6, FAC x6, ASG x6 launches -> print min of each third

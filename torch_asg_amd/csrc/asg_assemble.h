@@ -347,9 +347,6 @@ __global__ void __launch_bounds__(256, ST <= 2 ? 2 : 1) bwd_mfma_kernel(Problem 
     __shared__ Lds L;
     __shared__ int s_bad;
     MfmaLds<NP> &M = L.M;
-#if defined(ASG_X_EXIT) && ASG_X_EXIT == 1
-    if (P.T > 0) return;
-#endif
     const int b = blockIdx.x, chunk = blockIdx.y;
     R *tile_out = (R *) A.scratch + ((int64_t) b * A.nchunks + chunk) * P.N * P.N;
     const bool do_ali = (parts & 2) && P.targets;
@@ -429,9 +426,6 @@ __global__ void __launch_bounds__(256, ST <= 2 ? 2 : 1) bwd_mfma_kernel(Problem 
     bool bad = false;
     float *ptw = M.blk.pt[wave];
     __syncthreads();
-#if defined(ASG_X_EXIT) && ASG_X_EXIT == 2
-    if (P.T > 0) return;
-#endif
 
     struct BlockRegs {
         R a[NT][4], bh[NT][4], ap0[NT];
@@ -631,9 +625,6 @@ __global__ void __launch_bounds__(256, ST <= 2 ? 2 : 1) bwd_mfma_kernel(Problem 
         int tb = t0 + 16 * wave;
         if (tb < t1) issue_loads(X0, tb);
         for (; tb < t1; tb += 128) {
-#ifdef ASG_X_MAXBLK
-            if (tb >= t0 + 64 * ASG_X_MAXBLK) break;
-#endif
             if (tb + 64 < lim) issue_loads(X1, tb + 64);
             process(X0, tb);
             if (tb + 64 >= t1) break;
@@ -651,9 +642,6 @@ __global__ void __launch_bounds__(256, ST <= 2 ? 2 : 1) bwd_mfma_kernel(Problem 
             }
         }
     }
-#if defined(ASG_X_EXIT) && ASG_X_EXIT == 3
-    if (P.T > 0) return;
-#endif
     if (__any(bad) && lane == 0) s_bad = 1;
     __syncthreads();
     if (s_bad) {         // rare: the per-frame code owns the exact treatment of unusable row sums
