@@ -185,7 +185,8 @@ def run_cfg5(args, real_stdout):
                      "algorithmic_bytes_per_launch": a_alg_step,
                      "step_algorithmic_bytes": a_alg, "step_achieved": a_alg / (ms_per_step * 1e-3) / 1e9,
                      "note": "A_alg(step) = 3 (T-1) N^2 w + 2 T B N w (SURVEY.md 8d: alpha, beta, gradient passes over Tr; the "
-                             "gradient products here are two tiled contractions, compute-bound on the VALU)"},
+                             "gradient pass here is ONE tiled contraction on the matrix cores that reads Tr once: this formulation "
+                             "moves 2 (T-1) N^2 w + N^2 w + 2 T B N w)"},
         "cpu_baseline": None,
         "cpu_baseline_note": "the reference cannot run cfg 5 (fully_connected_lattice.cpp:77: 25.6 TB of path_contrib)",
         "loss": float(loss),

@@ -96,6 +96,7 @@ struct StepBuf {
     const R *ehat;    // [N][npad] (alpha: rows, beta: columns)
     const R *etile;   // fp32: the same matrix in the MFMA step's operand order (tile_kernel)
     const R *hmax;    // [N]
+    R *mulog;         // alpha only, [T][B]: the normaliser each frame's state was stored against (read by the gradient pass)
     int npad;
 };
 
@@ -252,6 +253,7 @@ __device__ __forceinline__ void fwd_step_body(const Problem &P, const StepBuf<R>
             if (i == 0) {
                 S.off[b] += (double) muprev + (double) emw;
                 S.mu[((n + 2) % 3) * B + b] = fkey(-__builtin_inff());
+                if (!BETA && S.mulog) S.mulog[(int64_t) tw * B + b] = muprev;
             }
         }
         // one atomic per half-wave and utterance (max is order-independent: deterministic).  The two halves of a
@@ -459,6 +461,7 @@ __device__ __forceinline__ void fwd_step_mfma(const Problem &P, const StepBuf<fl
         if (i == 0) {
             S.off[b] += (double) muprev + (double) emw;
             S.mu[((n + 2) % 3) * B + b] = fkey(-__builtin_inff());
+            if (!BETA && S.mulog) S.mulog[(int64_t) tw * B + b] = muprev;
         }
     }
     // one atomic per utterance and workgroup at most (max is order-independent: deterministic), and only if it can
@@ -634,8 +637,14 @@ __global__ void __launch_bounds__(1024) aligned_wide_kernel(Problem P, State W, 
 // per (b,t) posterior + exp-domain previous frame.  grid = (T, B), block = 256.
 //   grad_inputs[t][b][:] = g_b * softmax(ah+bh)      (zeros for t >= len; the aligned part is added later)
 //   Pm[(b,t)][:] = exp2(ah[t-1] - max)  (t>=1, else 0)     Gm[(b,t)][:] = g_b * softmax   (t>=1 rows used)
-template <typename R>
-__global__ void __launch_bounds__(256) bwd_post_kernel(Problem P, State W, BwdArgs A, R *Pm, R *Gm, int npad) {
+// DIRECT (fp32): Gm receives U = g * softmax / (row sum) at once, WITHOUT the row-sum product.  The forward pass stored
+//   ah[t][i] = x2[t][i] - emax[t] + hmax[i] + log2(sum_j Ehat[i][j] exp2(ah[t-1][j])) - mu[t]
+// so the row sum against Pm = exp2(ah[t-1] - mp) is  exp2(lambda),  lambda = ah[t][i] - x2[t][i] + emax[t] + mu[t] - hmax[i] - mp:
+// five loads and an exp2 per element instead of a [N x N] x [N x BT] contraction (102 ms of cfg 5's 507).  Rows whose
+// sum is outside 2^+-100 are marked for bwd_fix_kernel exactly as the contraction's epilogue marked them.
+template <typename R, bool DIRECT>
+__global__ void __launch_bounds__(256) bwd_post_kernel(Problem P, State W, BwdArgs A, R *Pm, R *Gm, int npad, const R *emax,
+                                                       const R *mulog, int *anybad) {
     __shared__ R red[4];
     const int t = blockIdx.x, b = blockIdx.y, N = P.N, T = P.T;
     const int len = P.in_len ? gclampi(P.in_len[b], 0, T) : T;
@@ -669,7 +678,19 @@ __global__ void __launch_bounds__(256) bwd_post_kernel(Problem P, State W, BwdAr
             if (t >= 1) pv = Num<R>::exp2(ah[i - N] - mp);
         }
         pm[i] = pv;
-        gm[i] = (t >= 1) ? g : R(0);
+        if (DIRECT) {
+            R u = 0;
+            if (t >= 1 && i < N && g != R(0)) {
+                const R x2 = ((const R *) P.inputs)[(int64_t) t * P.is0 + (int64_t) b * P.is1 + (int64_t) i * P.is2] * Num<R>::log2e();
+                const R lam = ah[i] - x2 + emax[(int64_t) t * P.B + b] + mulog[(int64_t) t * P.B + b] - ((const R *) W.rmax)[i] - mp;
+                const bool ok = fabs(lam) < Num<R>::lg_limit();
+                u = ok ? g * Num<R>::exp2(-lam) : Num<R>::ninf();
+                if (!ok) *anybad = 1;
+            }
+            gm[i] = u;
+        } else {
+            gm[i] = (t >= 1) ? g : R(0);
+        }
     }
 }
 
@@ -1067,6 +1088,11 @@ size_t step_tile_bytes_generic(int elem, int N) {
 // forward work buffers live behind the saved state (see fwd_work_bytes_generic): emax, pbuf x2 dirs, mu, off
 size_t fwd_work_bytes_generic(int elem, int T, int B, int N) {
     const size_t npad = (size_t) (N + 3) / 4 * 4;
+    return au((size_t) T * B * elem) + 2 * au(2 * (size_t) B * npad * elem) + 2 * au(3 * (size_t) B * 4) + 2 * au((size_t) B * 8) +
+           au((size_t) T * B * elem);
+}
+// offset of the alpha pass's per-frame normaliser log inside the work area (its last member)
+static size_t work_mulog_offset(size_t elem, int T, int B, int npad) {
     return au((size_t) T * B * elem) + 2 * au(2 * (size_t) B * npad * elem) + 2 * au(3 * (size_t) B * 4) + 2 * au((size_t) B * 8);
 }
 
@@ -1103,6 +1129,7 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
             S.ehat = (const R *) (beta ? W.fhat : W.ehat);
             S.etile = (const R *) (beta ? W.ftile : W.etile);
             S.hmax = (const R *) (beta ? W.cmax : W.rmax);
+            S.mulog = beta ? nullptr : (R *) ((char *) W.work + work_mulog_offset(e, P.T, P.B, W.npad));
             Sd[dir] = S;
         }
         const bool do_a = full_mask & kFullAlpha, do_b = full_mask & kFullBeta;
@@ -1156,10 +1183,16 @@ hipError_t launch_bwd_generic(const Problem &P, const State &W, const BwdArgs &A
         if (P.N <= 64) return hipErrorInvalidValue;      // the small kernel owns this case
         const int K = P.B * P.T;
         (void) hipMemsetAsync(anybad, 0, sizeof(int), stream);
-        hipLaunchKernelGGL((bwd_post_kernel<R>), dim3(P.T, P.B), dim3(256), 0, stream, P, W, A, Pm, Gm, npad);
+        const R *emax = (const R *) W.work;
+        const R *mulog = (const R *) ((const char *) W.work + work_mulog_offset(e, P.T, P.B, npad));
         if constexpr (StepUsesMfma<R>::v) {
-            hipLaunchKernelGGL((bwd_gemm_mfma<0>), dim3((P.N + 127) / 128, (K + 127) / 128), dim3(256), 0, stream,
-                               (const float *) W.ehat, (const float *) Pm, (float *) Gm, (float *) gtr, P.N, npad, K, anybad);
+            if (!W.work) return hipErrorInvalidValue;
+            hipLaunchKernelGGL((bwd_post_kernel<R, true>), dim3(P.T, P.B), dim3(256), 0, stream, P, W, A, Pm, Gm, npad, emax, mulog, anybad);
+        } else {
+            hipLaunchKernelGGL((bwd_post_kernel<R, false>), dim3(P.T, P.B), dim3(256), 0, stream, P, W, A, Pm, Gm, npad, emax, mulog, anybad);
+        }
+        if constexpr (StepUsesMfma<R>::v) {
+            // (no row-sum contraction: bwd_post_kernel<.., true> derived the row sums from the stored state)
             hipLaunchKernelGGL((bwd_gemm_mfma<1>), dim3((P.N + 127) / 128, (P.N + 127) / 128), dim3(256), 0, stream,
                                (const float *) W.ehat, (const float *) Pm, (float *) Gm, (float *) gtr, P.N, npad, K, anybad);
         } else {
