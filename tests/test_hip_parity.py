@@ -683,6 +683,14 @@ def test_random_shapes_plain_gate_and_determinism(seed):
     print("plain-gate battery: %d cases, worst scaled error %.2e" % (n, worst))
 
 
+@pytest.mark.parametrize("seed", [2, 5])
+def test_random_shapes_standalone_route(seed):
+    """The same random shapes through launch_mode='serial': the stand-alone recursion kernels and the block-wise
+    (matrix-core) gradient assembly, plain parity rule, bit-identical repeats."""
+    n, worst, _ = _stress().run(seed, 60, regime="plain", mode="serial")
+    assert n == 60 and worst <= 1e-4
+
+
 @pytest.mark.parametrize("seed", [2, 4, 11])
 def test_random_shapes_extended_range_report(seed):
     """REPORTED SEPARATELY from the 1e-4 gate: emissions offset by -40 / +60 and/or spread over 30 nats, where absolute

@@ -9,7 +9,7 @@ from oracle import asg_oracle as orc
 dev = "cuda:0"
 
 
-def run(seed=0, ncase=150, dtype=torch.float32, generic=False, regime="all", only=None):
+def run(seed=0, ncase=150, dtype=torch.float32, generic=False, regime="all", only=None, mode=None):
     """regime: "plain" = emission spread <= 5 nats and no common offset, judged by the plain parity rule;
     "extended" = the rest (offsets -40/+60, spread 30), judged by the documented extended rule; "all" = both, each
     case by the rule of its own regime."""
@@ -40,7 +40,7 @@ def run(seed=0, ncase=150, dtype=torch.float32, generic=False, regime="all", onl
         if only is not None and case != only:
             continue
         o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il.numpy(), tl.numpy(), "none")
-        m = torch_asg_amd.ASGLoss(N, reduction="none").to(dev).to(dtype)
+        m = torch_asg_amd.ASGLoss(N, reduction="none", launch_mode=mode or os.environ.get("ASG_STRESS_MODE", "single")).to(dev).to(dtype)
         with torch.no_grad(): m.transition.copy_(tr)
         outs = []
         for rep in range(2):
