@@ -784,6 +784,31 @@ def test_standalone_assembly_blocks(T, B, N, L):
         assert np.array_equal(r[k], r2[k]), "not deterministic: " + k
 
 
+def test_very_large_batch_equals_its_chunks():
+    """B = 2100 through the stand-alone route (one workgroup per utterance in the assembly, 2100 x 4 recursion chains)
+    against the same utterances in chunks of 64 through the fused step: per-utterance losses and input gradients must
+    agree, the transition gradient must be the chunks' sum."""
+    A = _asg()
+    T, B, N, L = 37, 2100, 40, 10
+    tr, x, tg, il, tl = util.synth(T, B, N, L, 5, True)
+
+    def run(sl):
+        m = A.ASGLoss(N, reduction="none").to(DEV)
+        with torch.no_grad():
+            m.transition.copy_(tr)
+        xd = x[:, sl].contiguous().to(DEV).requires_grad_(True)
+        loss = m(xd, tg[sl].to(DEV), il[sl].to(DEV), tl[sl].to(DEV))
+        loss.sum().backward()
+        return loss.detach().cpu(), xd.grad.cpu(), m.transition.grad.cpu()
+
+    whole = run(slice(0, B))
+    parts = [run(slice(s0, min(s0 + 64, B))) for s0 in range(0, B, 64)]
+    ref = (torch.cat([p_[0] for p_ in parts]), torch.cat([p_[1] for p_ in parts], 1), sum(p_[2] for p_ in parts))
+    for name, u, v in zip(("loss", "grad_inputs", "grad_transition"), whole, ref):
+        assert torch.isfinite(u).all(), name
+        util.assert_close(u.numpy(), v.numpy(), 1e-5, "B=2100 " + name)
+
+
 def test_fused_step_long_utterances():
     """The fused training step near the top of its supported length (T <= 4000: per-block offset tables of the aligned
     finishers), variable lengths, against the fp64 oracle."""
