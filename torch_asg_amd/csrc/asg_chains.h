@@ -371,7 +371,7 @@ __device__ void full_alpha_chain(const Problem &P, const State &W, const FwdOut 
     R Ri;
     load_norm_row<R, NP>(trow, P.ts1, N, act, e2, Ri);
     const R RiX = act ? Ri : NINF;
-    if (STORE && b == 0 && act) {
+    if (STORE && !O.no_store && b == 0 && act) {
         // publish the normalised transition rows once per forward: the gradient-assembly kernel reads them
         // instead of redoing N loads + N exp2 in every one of its wavefronts
         V2<R> *erow = reinterpret_cast<V2<R> *>((R *) W.ehat + (int64_t) lane * W.npad);
@@ -391,7 +391,7 @@ __device__ void full_alpha_chain(const Problem &P, const State &W, const FwdOut 
     const unsigned vin = (unsigned) (lc * (int) P.is2) * (unsigned) sizeof(R);
     const unsigned fstride = (unsigned) P.is0 * (unsigned) sizeof(R);
     const unsigned row_bytes = (unsigned) N * sizeof(R);
-    __amdgpu_buffer_rsrc_t rs = make_rsrc((R *) W.ah + (int64_t) b * T * N, STORE ? (unsigned) T * row_bytes : 0u);
+    __amdgpu_buffer_rsrc_t rs = make_rsrc((R *) W.ah + (int64_t) b * T * N, (STORE && !O.no_store) ? (unsigned) T * row_bytes : 0u);
     const unsigned voff = act ? (unsigned) lane * sizeof(R) : kOobOffset;
 
     double C = 0.0;
@@ -442,7 +442,7 @@ __device__ void full_alpha_chain(const Problem &P, const State &W, const FwdOut 
                 for (int k = 0; k < kPF; ++k) cur[k] = nxt[k];
                 if (redo) {
                     ChainState<R> r = slow_full_steps<R, false>(in, P.is0, trow, P.ts1, N, lane, 1 + done, kPF, ah0, C0,
-                                                                (R *) W.ah + (int64_t) b * T * N + lc, N, STORE);
+                                                                (R *) W.ah + (int64_t) b * T * N + lc, N, STORE && !O.no_store);
                     ah = r.v;
                     C = r.C;
                     p = Num<R>::exp2(ah);
@@ -461,7 +461,7 @@ __device__ void full_alpha_chain(const Problem &P, const State &W, const FwdOut 
             if (full_alpha_block<R, NP, MV, STORE, true>(cur, nst - done, (unsigned) (1 + done) * row_bytes, row_bytes, e2,
                                                          RiX, actmask, N, lds, lane, rs, voff, p, ah, C ASG_PRB)) {
                 ChainState<R> r = slow_full_steps<R, false>(in, P.is0, trow, P.ts1, N, lane, 1 + done, nst - done, ah0,
-                                                            C0, (R *) W.ah + (int64_t) b * T * N + lc, N, STORE);
+                                                            C0, (R *) W.ah + (int64_t) b * T * N + lc, N, STORE && !O.no_store);
                 ah = r.v;
                 C = r.C;
             }
@@ -559,7 +559,7 @@ __device__ void full_beta_chain(const Problem &P, const State &W, const FwdOut &
     const unsigned vin = (unsigned) (lc * (int) P.is2) * (unsigned) sizeof(R);
     const unsigned fstride = (unsigned) P.is0 * (unsigned) sizeof(R);
     const unsigned row_bytes = (unsigned) N * sizeof(R);
-    __amdgpu_buffer_rsrc_t rs = make_rsrc((R *) W.bh + (int64_t) b * T * N, STORE ? (unsigned) T * row_bytes : 0u);
+    __amdgpu_buffer_rsrc_t rs = make_rsrc((R *) W.bh + (int64_t) b * T * N, (STORE && !O.no_store) ? (unsigned) T * row_bytes : 0u);
     const unsigned voff = act ? (unsigned) lane * sizeof(R) : kOobOffset;
 
     if (len < 1) {
@@ -593,7 +593,7 @@ __device__ void full_beta_chain(const Problem &P, const State &W, const FwdOut &
             for (int k = 0; k < kPF; ++k) cur[k] = nxt[k];
             if (redo) {
                 ChainState<R> r = slow_full_steps<R, true>(in, P.is0, tcol, P.ts0, N, lane, len - 1 - done, kPF, bh0, C0,
-                                                           (R *) W.bh + (int64_t) b * T * N + lc, N, STORE);
+                                                           (R *) W.bh + (int64_t) b * T * N + lc, N, STORE && !O.no_store);
                 bh = r.v;
                 C = r.C;
                 q = act ? Num<R>::exp2(bh - Ci) : R(0);
@@ -608,7 +608,7 @@ __device__ void full_beta_chain(const Problem &P, const State &W, const FwdOut &
             if (full_beta_block<R, NP, MV, STORE, true>(cur, nst - done, (unsigned) (len - 2 - done) * row_bytes, row_bytes,
                                                         f2, CiX, actmask, N, lds, lane, rs, voff, q, bh, C)) {
                 ChainState<R> r = slow_full_steps<R, true>(in, P.is0, tcol, P.ts0, N, lane, len - 1 - done, nst - done, bh0,
-                                                           C0, (R *) W.bh + (int64_t) b * T * N + lc, N, STORE);
+                                                           C0, (R *) W.bh + (int64_t) b * T * N + lc, N, STORE && !O.no_store);
                 bh = r.v;
                 C = r.C;
             }
@@ -727,10 +727,10 @@ __device__ void aligned_alpha_chain(const Problem &P, const State &W, const FwdO
     const AlignedSetup<R> A = aligned_setup<R>(P, b, lane);
     const int len = A.len;
     const unsigned row_bytes = (unsigned) S * sizeof(R);
-    __amdgpu_buffer_rsrc_t rs = make_rsrc((R *) W.ab + (int64_t) b * T * S, STORE ? (unsigned) T * row_bytes : 0u);
+    __amdgpu_buffer_rsrc_t rs = make_rsrc((R *) W.ab + (int64_t) b * T * S, (STORE && !O.no_store) ? (unsigned) T * row_bytes : 0u);
     const unsigned voff = lane < S ? (unsigned) lane * sizeof(R) : kOobOffset;
 
-    if (STORE && lane < S) {
+    if (STORE && !O.no_store && lane < S) {
         V2<R> u = {A.H2, A.Dprev};
         reinterpret_cast<V2<R> *>(W.asu)[(int64_t) b * S + lane] = u;
         int2 ii = {A.tgt, A.prv};
@@ -797,7 +797,7 @@ __device__ void aligned_beta_chain(const Problem &P, const State &W, const FwdOu
     const AlignedSetup<R> A = aligned_setup<R>(P, b, lane);
     const int len = A.len;
     const unsigned row_bytes = (unsigned) S * sizeof(R);
-    __amdgpu_buffer_rsrc_t rs = make_rsrc((R *) W.bb + (int64_t) b * T * S, STORE ? (unsigned) T * row_bytes : 0u);
+    __amdgpu_buffer_rsrc_t rs = make_rsrc((R *) W.bb + (int64_t) b * T * S, (STORE && !O.no_store) ? (unsigned) T * row_bytes : 0u);
     const unsigned voff = lane < S ? (unsigned) lane * sizeof(R) : kOobOffset;
     if (len < 1 || A.ol < 1) {
         publish_score<R>(O, (R *) O.aligned_scores, b, P.B, NINF, lane);
@@ -972,7 +972,7 @@ __device__ __forceinline__ void duo_main(const Problem &P, const State &W, const
     V2<R> e2[NP / 2];
     R X;
     load_norm_row<R, NP>(tline, BETA ? P.ts0 : P.ts1, N, act, e2, X);
-    if (!BETA && STORE && b == 0 && act) {
+    if (!BETA && STORE && !O.no_store && b == 0 && act) {
         V2<R> *erow = reinterpret_cast<V2<R> *>((R *) W.ehat + (int64_t) lane * W.npad);
 #pragma unroll
         for (int j = 0; j < NP / 2; ++j) erow[j] = e2[j];
@@ -1180,7 +1180,7 @@ __device__ __forceinline__ void duo_consumer(const Problem &P, const State &W, c
         return;
     }
     const unsigned row_bytes = (unsigned) N * sizeof(R);
-    __amdgpu_buffer_rsrc_t rs = make_rsrc((R *) (BETA ? W.bh : W.ah) + (int64_t) b * T * N, STORE ? (unsigned) T * row_bytes : 0u);
+    __amdgpu_buffer_rsrc_t rs = make_rsrc((R *) (BETA ? W.bh : W.ah) + (int64_t) b * T * N, (STORE && !O.no_store) ? (unsigned) T * row_bytes : 0u);
     const unsigned voff = act ? (unsigned) lane * sizeof(R) : kOobOffset;
     auto frame = [&](int n) { return BETA ? len - 1 - n : n; };
     bool bad = false;

@@ -51,6 +51,8 @@ struct FwdOut {
     void *loss;
     unsigned *counter;           // State::ticket of this call (zeroed on the stream before the launch)
     int reduction, expected;
+    int no_store;                // 1: scores only (eval / forward-only route): no lattice state is written.  A run-time
+                                 // flag (stores are dropped by a zero-sized buffer resource), not a second set of kernels
 };
 
 struct BwdArgs {
