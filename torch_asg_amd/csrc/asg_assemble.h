@@ -364,6 +364,62 @@ __global__ void __launch_bounds__(256, ST <= 2 ? 2 : 1) bwd_mfma_kernel(Problem 
     const R gf = g0;
     const R ga = (parts & 2) ? (A.neg_aligned ? -g0 : (R) ((double) ((const R *) A.grad_aligned)[(int64_t) b * A.gstride] * A.gscale))
                              : R(0);
+    // states through raw buffer loads: lane offset = (clamped frame row) * row bytes + 4 m, the label / position tile is
+    // the instruction's immediate offset; elements past a row's end are masked below, past the buffer's end read 0
+    __amdgpu_buffer_rsrc_t r_ah = make_rsrc((R *) W.ah + (int64_t) b * T * N, (unsigned) T * (unsigned) N * 4u);
+    __amdgpu_buffer_rsrc_t r_bh = make_rsrc((R *) W.bh + (int64_t) b * T * N, (unsigned) T * (unsigned) N * 4u);
+    __amdgpu_buffer_rsrc_t r_ab = make_rsrc((R *) W.ab + (int64_t) b * T * S, (unsigned) T * (unsigned) S * 4u);
+    __amdgpu_buffer_rsrc_t r_bb = make_rsrc((R *) W.bb + (int64_t) b * T * S, (unsigned) T * (unsigned) S * 4u);
+    __amdgpu_buffer_rsrc_t rs_g = make_rsrc((R *) A.grad_inputs + (int64_t) b * N,
+                                            (unsigned) ((int64_t) (T - 1) * P.B * N + N) * 4u);
+    const unsigned rbN = (unsigned) N * 4u, rbS = (unsigned) S * 4u, rbG = (unsigned) P.B * (unsigned) N * 4u;
+    const unsigned m4 = (unsigned) m * 4u;
+    // position s - 1 of the previous frame: one element to the left (position 0 has no left neighbour: masked by Dp = logzero)
+    const unsigned m4l = m4 >= 4u ? m4 - 4u : 0u;
+    struct BlockRegs {
+        R a[NT][4], bh[NT][4], ap0[NT];
+    };
+    struct AlignedRegs {
+        R xa[ST][4], xb[ST][4], xm[ST][4], xp0[ST];
+    };
+    auto issue_aligned = [&](AlignedRegs &X, int tb) {
+        const int tf = tb + 4 * g;
+        unsigned row[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) row[q] = (unsigned) min(tf + q, T - 1);
+        const unsigned rowp = (unsigned) clampi(tf - 1, 0, T - 1);
+#pragma unroll
+        for (int r = 0; r < ST; ++r) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                X.xa[r][q] = buf_load<R>(r_ab, row[q] * rbS + m4 + 64u * r, 0u);
+                X.xb[r][q] = buf_load<R>(r_bb, row[q] * rbS + m4 + 64u * r, 0u);
+                const unsigned rp = q == 0 ? rowp : row[q - 1];
+                X.xm[r][q] = buf_load<R>(r_ab, rp * rbS + (r == 0 ? m4l : m4 + 64u * r - 4u), 0u);
+            }
+            X.xp0[r] = buf_load<R>(r_ab, rowp * rbS + m4 + 64u * r, 0u);
+        }
+    };
+    auto issue_loads = [&](BlockRegs &X, int tb) {
+        const int tf = tb + 4 * g;
+        unsigned row[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) row[q] = (unsigned) min(tf + q, T - 1);
+        const unsigned rowp = (unsigned) clampi(tf - 1, 0, T - 1);
+#pragma unroll
+        for (int r = 0; r < NT; ++r) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                X.a[r][q] = buf_load<R>(r_ah, row[q] * rbN + m4 + 64u * r, 0u);
+                X.bh[r][q] = buf_load<R>(r_bh, row[q] * rbN + m4 + 64u * r, 0u);
+            }
+            X.ap0[r] = buf_load<R>(r_ah, rowp * rbN + m4 + 64u * r, 0u);
+        }
+    };
+    // the first block's states are requested before anything else: the prologue below (Ehat into LDS, target tables)
+    // then runs inside their latency instead of in front of it
+    BlockRegs X0;
+    if (t0 + 16 * wave < t1) issue_loads(X0, t0 + 16 * wave);
     const R *ehat = (const R *) W.ehat;
     {   // every load in flight before the first LDS write (a rolled loop pays the L2 latency once per trip)
         constexpr int CNT = (NT * KS * 64 + 255) / 256;
@@ -408,18 +464,6 @@ __global__ void __launch_bounds__(256, ST <= 2 ? 2 : 1) bwd_mfma_kernel(Problem 
         H2[r] = hd.x; Dp[r] = hd.y; tgt[r] = tp.x; prv[r] = tp.y;
         accH[r] = 0; accD[r] = 0;
     }
-    // states through raw buffer loads: lane offset = (clamped frame row) * row bytes + 4 m, the label / position tile is
-    // the instruction's immediate offset; elements past a row's end are masked below, past the buffer's end read 0
-    __amdgpu_buffer_rsrc_t r_ah = make_rsrc((R *) W.ah + (int64_t) b * T * N, (unsigned) T * (unsigned) N * 4u);
-    __amdgpu_buffer_rsrc_t r_bh = make_rsrc((R *) W.bh + (int64_t) b * T * N, (unsigned) T * (unsigned) N * 4u);
-    __amdgpu_buffer_rsrc_t r_ab = make_rsrc((R *) W.ab + (int64_t) b * T * S, (unsigned) T * (unsigned) S * 4u);
-    __amdgpu_buffer_rsrc_t r_bb = make_rsrc((R *) W.bb + (int64_t) b * T * S, (unsigned) T * (unsigned) S * 4u);
-    __amdgpu_buffer_rsrc_t rs_g = make_rsrc((R *) A.grad_inputs + (int64_t) b * N,
-                                            (unsigned) ((int64_t) (T - 1) * P.B * N + N) * 4u);
-    const unsigned rbN = (unsigned) N * 4u, rbS = (unsigned) S * 4u, rbG = (unsigned) P.B * (unsigned) N * 4u;
-    const unsigned m4 = (unsigned) m * 4u;
-    // position s - 1 of the previous frame: one element to the left (position 0 has no left neighbour: masked by Dp = logzero)
-    const unsigned m4l = m4 >= 4u ? m4 - 4u : 0u;
     V4<R> acc[NT * NT];
 #pragma unroll
     for (int q = 0; q < NT * NT; ++q) acc[q] = V4<R>{0, 0, 0, 0};
@@ -427,46 +471,6 @@ __global__ void __launch_bounds__(256, ST <= 2 ? 2 : 1) bwd_mfma_kernel(Problem 
     float *ptw = M.blk.pt[wave];
     __syncthreads();
 
-    struct BlockRegs {
-        R a[NT][4], bh[NT][4], ap0[NT];
-    };
-    struct AlignedRegs {
-        R xa[ST][4], xb[ST][4], xm[ST][4], xp0[ST];
-    };
-    auto issue_aligned = [&](AlignedRegs &X, int tb) {
-        const int tf = tb + 4 * g;
-        unsigned row[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) row[q] = (unsigned) min(tf + q, T - 1);
-        const unsigned rowp = (unsigned) clampi(tf - 1, 0, T - 1);
-#pragma unroll
-        for (int r = 0; r < ST; ++r) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                X.xa[r][q] = buf_load<R>(r_ab, row[q] * rbS + m4 + 64u * r, 0u);
-                X.xb[r][q] = buf_load<R>(r_bb, row[q] * rbS + m4 + 64u * r, 0u);
-                const unsigned rp = q == 0 ? rowp : row[q - 1];
-                X.xm[r][q] = buf_load<R>(r_ab, rp * rbS + (r == 0 ? m4l : m4 + 64u * r - 4u), 0u);
-            }
-            X.xp0[r] = buf_load<R>(r_ab, rowp * rbS + m4 + 64u * r, 0u);
-        }
-    };
-    auto issue_loads = [&](BlockRegs &X, int tb) {
-        const int tf = tb + 4 * g;
-        unsigned row[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) row[q] = (unsigned) min(tf + q, T - 1);
-        const unsigned rowp = (unsigned) clampi(tf - 1, 0, T - 1);
-#pragma unroll
-        for (int r = 0; r < NT; ++r) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                X.a[r][q] = buf_load<R>(r_ah, row[q] * rbN + m4 + 64u * r, 0u);
-                X.bh[r][q] = buf_load<R>(r_bh, row[q] * rbN + m4 + 64u * r, 0u);
-            }
-            X.ap0[r] = buf_load<R>(r_ah, rowp * rbN + m4 + 64u * r, 0u);
-        }
-    };
     unsigned lvm[NT], lvo[NT], svm[ST], s1m[ST];
 #pragma unroll
     for (int r = 0; r < NT; ++r) { lvm[r] = bmask(lv[r]); lvo[r] = lv[r] ? 0u : kOobOffset; }
@@ -622,12 +626,7 @@ __global__ void __launch_bounds__(256, ST <= 2 ? 2 : 1) bwd_mfma_kernel(Problem 
         __builtin_amdgcn_wave_barrier();
     };
 
-    {
-        BlockRegs X0;
-        int tb = t0 + 16 * wave;
-        if (tb < t1) issue_loads(X0, tb);
-        for (; tb < t1; tb += 64) process(X0, tb);
-    }
+    for (int tb = t0 + 16 * wave; tb < t1; tb += 64) process(X0, tb);
     if (do_ali) {
 #pragma unroll
         for (int r = 0; r < ST; ++r) {
