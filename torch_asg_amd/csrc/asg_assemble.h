@@ -598,12 +598,16 @@ __global__ void __launch_bounds__(256, ST <= 2 ? 2 : 1) bwd_mfma_kernel(Problem 
                 for (int q = 0; q < 4; ++q) {
                     const R post2 = gm[r][q] * Z2[q];
                     atomicAdd(&M.blk.fxI[wave][4 * g + q][tgt[r]], FrameFix<R>::to(post2));
+                    // stay / arrive shares of the state posterior: softmax over the two incoming edges,
+                    // 1 / (1 + 2^-|d|) and its complement (one exp2 and one rcp instead of a log-sum-exp and two exp2)
                     const R pc0 = (q == 0 ? Q.xp0[r] : Q.xa[r][q - 1]) + H2[r];
                     const R pc1 = band(s1m[r], Q.xm[r][q]) + Dp[r];
-                    const R l = lse2<R>(pc0, pc1);
+                    const R d = pc1 - pc0;
+                    const R tt = Num<R>::exp2(-fabsf(d));
+                    const R big = Num<R>::rcp(R(1) + tt), small = tt * big;
                     const unsigned em = t1m[q] & bmask(post2 != R(0));
-                    accH[r] += band(em, post2 * Num<R>::exp2(pc0 - l));
-                    accD[r] += band(em, post2 * Num<R>::exp2(pc1 - l));
+                    accH[r] += band(em, post2 * (d <= R(0) ? big : small));
+                    accD[r] += band(em, post2 * (d <= R(0) ? small : big));
                 }
         }
         // ---- rows: full posterior + the aligned posteriors scattered to this label
