@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Developer probe: fwd+bwd GPU time vs batch size at T=400 N=40 L=30 (graph replay of the fused loss step)."""
+"""Developer probe: fwd+bwd GPU time vs batch size at T=400 N=40 L=30 (graph replay of 10 consecutive steps)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, torch_asg_amd
@@ -23,11 +23,11 @@ for B, mode in [(B, m) for B in (16, 32, 64, 80, 96, 128, 192, 256, 512, 1024, 2
         torch.cuda.synchronize()
         gr = torch.cuda.CUDAGraph()
         with torch.cuda.graph(gr):
-            for _ in range(5): step()
+            for _ in range(10): step()
     for _ in range(3): gr.replay()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     K = 10
     for _ in range(K): gr.replay()
-    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K / 5
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K / 10
     abytes = 2 * T * B * N * 4 + 2 * N * N * 4 + B * (8 * L + 20)
     print("%-8s B=%5d  %8.1f us/step  %9.0f utt/s  algorithmic %.1f GB/s (%.2f%% of 8 TB/s)" % (mode, B, dt * 1e6, B / dt, abytes / dt / 1e9, abytes / dt / 8e12 * 100))
