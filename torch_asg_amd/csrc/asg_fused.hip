@@ -1133,7 +1133,6 @@ __device__ __forceinline__ void aligned_workgroup(int b, FusedShared<NP> &SH) {
 template <int NP, bool BETA>
 __device__ __forceinline__ void full_workgroup(int b, FusedShared<NP> &SH) {
     typedef float R;
-    constexpr int NT = (NP + 15) / 16;
     constexpr int kNC = Consumers<NP>::n;
     const Problem P = ld_problem(kernarg_params());
     const FusedArgs F = ld_fargs(kernarg_params());
