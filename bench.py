@@ -168,6 +168,14 @@ def run_cfg5(args, real_stdout):
     a_alg = 3 * (T5 - 1) * N5 * N5 * w + 2 * T5 * B5 * N5 * w      # alpha, beta and gradient passes over Tr
     ms_per_step = dt / args.steps * 1e3
     achieved = a_alg_step / (kern_ms * 1e-3) / 1e9
+    traffic5, traffic5_src = None, None
+    try:                                  # HBM bytes per launch of the dominant kernel, from the committed PMC passes
+        pj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_cfg5.json")
+        with open(pj) as f:
+            traffic5 = float(json.load(f)["dominant_kernel_hbm_bytes_per_launch"])
+        traffic5_src = "profiles/r02_pmc_cfg5.json"
+    except Exception:
+        pass
     out = {
         "metric": "utterances/sec fwd+bwd, T=2000 B=32 N=10000 (cfg 5, large alphabet); achieved HBM GB/s vs roofline",
         "value": B5 * args.steps / dt, "unit": "utterances/s", "n_gpus": 1, "steps": args.steps, "warmup": max(args.warmup, 1),
@@ -177,7 +185,7 @@ def run_cfg5(args, real_stdout):
                                "forward+backward on the generic (large-alphabet) kernels" % (T5, B5, N5, L5),
                    "global_batch": B5, "T": T5, "N": N5, "L": L5, "step_mode": "eager", "parallelism": "single GPU"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None,
+                     "traffic": traffic5, "traffic_source": traffic5_src,
                      "kernel": "fwd_step_kernel (one frame of the full-lattice alpha AND beta recursions for the whole batch: "
                                "the row- and column-normalised transition matrices streamed once each)",
                      "kernel_ms": kern_ms, "kernel_timing": "HIP events around the forward launch sequence / (T-1) step launches "

@@ -73,6 +73,57 @@ __global__ void __launch_bounds__(256) prep_kernel(const R *tr, int64_t ts0, int
     if (threadIdx.x == 0) mx[i] = m;
 }
 
+// The column-normalised twin without strided reads (prep_kernel<R, true> walks a column per workgroup: 16-32x read
+// amplification, 18 GB fetched for a 400 MB matrix at N = 10^4).  Two passes over 64 x 64 tiles read along the rows:
+//   colmax_kernel:    partial column maxima of a 64-column x 256-row slab -> atomicMax on an order-preserving key
+//                     (max is order-independent: deterministic);  keys[] starts at key(-inf)
+//   colnorm_kernel:   out[i][j] = exp2(Tr2[j][i] - colmax_i), the tile transposed through LDS so that reads follow
+//                     the matrix rows and writes follow the output rows; also writes mx[i] (block row 0)
+// grid colmax = (ceil(N/64), ceil(N/256)), colnorm = (ceil(npad/64) over j, ceil(N/64) over i); block = 256.
+__device__ __forceinline__ unsigned long long dkey(double f) {
+    unsigned long long b = (unsigned long long) __double_as_longlong(f);
+    return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double dunkey(unsigned long long k) {
+    unsigned long long b = (k & 0x8000000000000000ull) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long) b);
+}
+template <typename R>
+__global__ void __launch_bounds__(256) colmax_kernel(const R *tr, int64_t ts0, int64_t ts1, int N, unsigned long long *keys) {
+    __shared__ R part[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rq = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * 256;
+    R m = Num<R>::ninf();
+    if (c < N)
+        for (int r = r0 + rq; r < min(r0 + 256, N); r += 4) m = fmax(m, tr[(int64_t) r * ts0 + (int64_t) c * ts1] * Num<R>::log2e());
+    part[rq][threadIdx.x & 63] = m;
+    __syncthreads();
+    if (rq == 0 && c < N) {
+        m = fmax(fmax(part[0][threadIdx.x], part[1][threadIdx.x]), fmax(part[2][threadIdx.x], part[3][threadIdx.x]));
+        if (m == m) atomicMax(&keys[c], dkey((double) m));
+    }
+}
+template <typename R>
+__global__ void __launch_bounds__(256) colnorm_kernel(const R *tr, int64_t ts0, int64_t ts1, int N, int npad,
+                                                      const unsigned long long *keys, R *out, R *mx) {
+    __shared__ R tile[64][65];
+    const int j0 = blockIdx.x * 64, i0 = blockIdx.y * 64;          // out rows i0.., out columns j0.. (= matrix rows)
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int q = ty; q < 64; q += 4) {                             // matrix row j0 + q, columns i0 + tx: along the rows
+        const int j = j0 + q, i = i0 + tx;
+        tile[q][tx] = (j < N && i < N) ? tr[(int64_t) j * ts0 + (int64_t) i * ts1] * Num<R>::log2e() : Num<R>::ninf();
+    }
+    __syncthreads();
+    for (int q = ty; q < 64; q += 4) {                             // out row i0 + q, columns j0 + tx
+        const int i = i0 + q, j = j0 + tx;
+        if (i >= N || j >= npad) continue;
+        R m = (R) dunkey(keys[i]);
+        if (!(m > Num<R>::ninf())) m = 0;                          // a column of -inf: as prep_kernel
+        out[(int64_t) i * npad + j] = j < N ? Num<R>::exp2(tile[tx][q] - m) : R(0);
+        if (blockIdx.x == 0 && tx == 0) mx[i] = m;
+    }
+}
+
 // per-frame emission maximum: emax[t][b] = max_i I2[t][b][i]   (grid = (T, B), block = 256)
 template <typename R>
 __global__ void __launch_bounds__(256) emax_kernel(Problem P, R *emax) {
@@ -1071,8 +1122,18 @@ template <typename R>
 hipError_t launch_prep_generic(const Problem &P, const State &W, hipStream_t stream) {
     hipLaunchKernelGGL((prep_kernel<R, false>), dim3(P.N), dim3(256), 0, stream, (const R *) P.transition, P.ts0, P.ts1,
                        P.N, W.npad, (R *) W.ehat, (R *) W.rmax);
-    hipLaunchKernelGGL((prep_kernel<R, true>), dim3(P.N), dim3(256), 0, stream, (const R *) P.transition, P.ts0, P.ts1,
-                       P.N, W.npad, (R *) W.fhat, (R *) W.cmax);
+    {
+        // column-normalised twin: column maxima first.  Their [N] 64-bit keys borrow the head of the forward work area,
+        // which nothing uses before the recursion's own set-up kernels run (later on this stream); it is >= 16 B npad bytes
+        unsigned long long *keys = (unsigned long long *) W.work;
+        if (!keys) return hipErrorInvalidValue;
+        hipError_t me = hipMemsetAsync(keys, 0, (size_t) P.N * sizeof(unsigned long long), stream);      // 0 < key(-inf)
+        if (me != hipSuccess) return me;
+        hipLaunchKernelGGL((colmax_kernel<R>), dim3((P.N + 63) / 64, (P.N + 255) / 256), dim3(256), 0, stream,
+                           (const R *) P.transition, P.ts0, P.ts1, P.N, keys);
+        hipLaunchKernelGGL((colnorm_kernel<R>), dim3((W.npad + 63) / 64, (P.N + 63) / 64), dim3(256), 0, stream,
+                           (const R *) P.transition, P.ts0, P.ts1, P.N, W.npad, keys, (R *) W.fhat, (R *) W.cmax);
+    }
     if constexpr (StepUsesMfma<R>::v) {
         if (!W.etile || !W.ftile) return hipErrorInvalidValue;
         hipLaunchKernelGGL(tile_kernel, dim3(4096), dim3(256), 0, stream, (const float *) W.ehat, P.N, W.npad, (float *) W.etile);
