@@ -2,7 +2,7 @@
 """bench.py -- utterances/s of the ASG forward+backward hot path on MI355X (BASELINE.json metric).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--mode graph|eager] [--launch single|streams|serial]
-                    [--graph-steps G]
+                    [--graph-steps G] [--no-extra] [--no-cpu-baseline] [--config cfg3|cfg5]
 
 One "step" = ASGLoss(inputs, targets, input_lengths, target_lengths) + loss.backward() on one batch of
 synthetic utterances already resident in HBM (SURVEY.md 8d inputs: cfg 3, T=400 B=64 N=40 L=30, fp32).
@@ -10,15 +10,19 @@ With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank owns
 B=64*N batch (= cfg 4 at N=8), and the step ends with the single RCCL all-reduce of transition.grad
 (SURVEY.md 8e): weak scaling, no other collective.
 
-In graph mode G consecutive steps (default: the largest divisor of K up to 10) are captured into ONE hipGraph and the
-timed region replays it K/G times: every step's kernels run in full, back to back on the stream, as they do inside a
-training loop whose host runs ahead of the GPU; with G = 1 every step also pays the ~8 us fixed latency of a graph
-launch that nothing overlaps in this loop (measured: rocprofv3 trace, profiles/r02_summary.md).  `config.step_mode`
-names G.
+Timing.  After W warm-up steps, a block of EXACTLY K steps is timed between barrier + synchronize fences -- and that
+block is repeated (each repetition fenced the same way) until ~0.25 s of steps have run, because K steps of this
+workload are a millisecond or two, too short for one wall-clock reading; `ms_per_step` is the MEDIAN block / K, every
+block is listed in `timing.block_ms`, `timing.first_block_ms` is the first one.  In graph mode G consecutive steps
+(default: the largest divisor of K up to 10) are captured into ONE hipGraph and a block replays it K/G times: every
+step's kernels run in full, back to back on the stream, as inside a training loop whose host runs ahead of the GPU.
 
 Rank 0 prints ONE JSON line.  Besides the driver's contract fields it carries
-  roofline     -- dominant kernel (the recursion kernel): algorithmic bytes / measured kernel time vs HBM peak
+  roofline     -- dominant kernel (the fused recursion + assembly kernel): algorithmic bytes / its measured duration
   cpu_baseline -- the reference's own compiled CPU path (oracle/_ref) timed on this box's host cores (N=1 only)
+  extra        -- (N=1 only) the other BASELINE.json configurations timed in the same process: cfg 2, cfg 4 on one GPU
+                  (B=512), the evaluation route, eager (no hipGraph) cfg 3, and cfg 5 (large alphabet) with its own
+                  roofline object measured live
 """
 import argparse
 import json
@@ -35,6 +39,7 @@ import torch.distributed as dist  # noqa: E402
 
 T, B, N, L = 400, 64, 40, 30          # BASELINE.json configs[2] ("cfg 3"), per GPU
 HBM_PEAK_GBS = 8000.0                 # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+TARGET_TIMED_S = 0.25                 # wall time the repeated K-step blocks should add up to
 
 
 def algorithmic_bytes(T, B, N, L, w=4):
@@ -42,13 +47,18 @@ def algorithmic_bytes(T, B, N, L, w=4):
     return 2 * T * B * N * w + 2 * N * N * w + B * (8 * L + 16 + w)
 
 
-def synth(seed, device):
+def synth(seed, device, T=T, B=B, N=N, L=L, variable=False):
+    """SURVEY.md 8(d) draw order (tests/util.py::synth): transition, inputs, targets, then the lengths."""
     g = torch.Generator().manual_seed(seed)
     transition = torch.rand(N, N, generator=g)
     inputs = torch.randn(T, B, N, generator=g)
     targets = torch.randint(0, N, (B, L), generator=g)
-    il = torch.full((B,), T, dtype=torch.int64)
-    tl = torch.full((B,), L, dtype=torch.int64)
+    if variable:
+        il = torch.randint(T // 2, T + 1, (B,), generator=g)
+        tl = torch.randint(max(1, L // 2), L + 1, (B,), generator=g)
+    else:
+        il = torch.full((B,), T, dtype=torch.int64)
+        tl = torch.full((B,), L, dtype=torch.int64)
     return [t.to(device) for t in (transition, inputs, targets, il, tl)]
 
 
@@ -112,18 +122,115 @@ def cpu_baseline(budget_s=24.0):
                          ", ".join("%d:%.0f" % (n, results[n][0] * 1e3) for n in cands), default_threads)}
 
 
+# ------------------------------------------------------------------------------------------------ timing helpers
+def graph_steps_for(steps, requested=0):
+    g = requested if requested > 0 else max(q for q in range(1, 11) if steps % q == 0)
+    return g if steps % g == 0 else 1
+
+
+def median(v):
+    s = sorted(v)
+    return s[len(s) // 2]
+
+
+def capture_steps(one_step, gsteps, after_step=None, relaxed=False):
+    """A hipGraph of `gsteps` consecutive steps (warmed up on a side stream first, replayed once)."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            one_step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode="thread_local" if relaxed else "global"):
+        for _ in range(gsteps):
+            one_step()
+            if after_step is not None:
+                after_step()
+    g.replay()
+    torch.cuda.synchronize()
+    return g
+
+
+def timed_blocks(step_group, groups_per_block, fence, agree=None, target_s=TARGET_TIMED_S, max_blocks=400):
+    """Blocks of groups_per_block step groups, each fenced on both sides; returns the list of block seconds.
+    `agree` (multi-rank runs) maps this rank's first block time to one value all ranks share, so that every rank runs
+    the same number of blocks (and of barriers)."""
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(groups_per_block):
+        step_group()
+    fence()
+    first = time.perf_counter() - t0
+    nblocks = int(min(max_blocks, max(3, target_s / max(agree(first) if agree else first, 1e-6))))
+    out = [first]
+    for _ in range(nblocks - 1):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(groups_per_block):
+            step_group()
+        fence()
+        out.append(time.perf_counter() - t0)
+    return out
+
+
+def time_small_config(name, T_, B_, N_, L_, variable, steps, eval_route=False, eager=False, launch="single"):
+    """One of the small-alphabet configurations on cuda:0: graph replay (or eager) of forward+backward, or of the
+    evaluation route (beta recursions only, no gradient).  Same block protocol as the headline."""
+    import torch_asg_amd
+    dev = torch.device("cuda", torch.cuda.current_device())
+    tr, x, tg, il, tl = synth(7, dev, T_, B_, N_, L_, variable)
+    m = torch_asg_amd.ASGLoss(N_, reduction="mean", launch_mode=launch).to(dev)
+    with torch.no_grad():
+        m.transition.copy_(tr)
+    if eval_route:
+        m.eval()
+
+        def one_step():
+            with torch.no_grad():
+                return m(x, tg, il, tl)
+    else:
+        x.requires_grad_(True)
+
+        def one_step():
+            m.transition.grad = None
+            x.grad = None
+            loss = m(x, tg, il, tl)
+            loss.backward()
+            return loss
+    gsteps = 1 if eager else graph_steps_for(steps)
+    if eager:
+        for _ in range(5):
+            one_step()
+        group = one_step
+    else:
+        g = capture_steps(one_step, gsteps)
+        group = g.replay
+    for _ in range(3):
+        group()
+    blocks = timed_blocks(group, steps // gsteps, torch.cuda.synchronize, target_s=0.12)
+    ms = median(blocks) / steps * 1e3
+    return {"workload": "%s: T=%d B=%d N=%d L=%d fp32%s, %s" % (
+                name, T_, B_, N_, L_, ", variable lengths" if variable else "",
+                "evaluation route (beta recursions, no gradient)" if eval_route else "forward+backward"),
+            "step_mode": "eager" if eager else "graph (%d steps per replay)" % gsteps,
+            "ms_per_step": ms, "utt_s": B_ / (ms * 1e-3), "steps": steps, "timed_blocks": len(blocks),
+            "algorithmic_bytes": algorithmic_bytes(T_, B_, N_, L_),
+            "step_achieved_gbs": algorithmic_bytes(T_, B_, N_, L_) / (ms * 1e-3) / 1e9}
+
+
 CFG5 = dict(T=2000, B=32, N=10000, L=60)      # BASELINE.json configs[4]: large alphabet, variable lengths
 
 
-def run_cfg5(args, real_stdout):
-    """`--config cfg5`: the large-alphabet workload on the generic kernels (csrc/asg_generic.hip), same JSON contract.
-    A step is ASGLoss forward + backward on one batch (eager: a step is ~1.5 s of GPU time, launch overhead is nothing).
+def measure_cfg5(steps, warmup):
+    """The large-alphabet workload on the generic kernels (csrc/asg_generic.hip).  A step is ASGLoss forward + backward
+    on one batch (eager: a step is ~0.4 s of GPU time, launch overhead is nothing).
     The reference cannot run this size at all: fully_connected_lattice.cpp:77 allocates a [T-1,B,N,N] tensor = 25.6 TB."""
     import torch_asg_amd
-    from torch_asg_amd import asg as asg_mod, _lib as lib_mod
+    from torch_asg_amd import asg as asg_mod
     T5, B5, N5, L5 = CFG5["T"], CFG5["B"], CFG5["N"], CFG5["L"]
-    dev = torch.device("cuda", 0)
-    torch.cuda.set_device(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
     g = torch.Generator(device=dev).manual_seed(0)     # drawn on the device: 2.6 GB of emissions
     tr = torch.rand(N5, N5, generator=g, device=dev)
     x = torch.randn(T5, B5, N5, generator=g, device=dev).requires_grad_(True)
@@ -141,16 +248,16 @@ def run_cfg5(args, real_stdout):
         loss.backward()
         return loss
 
-    for _ in range(max(args.warmup, 1)):
+    for _ in range(max(warmup, 1)):
         one_step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         loss = one_step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    # dominant kernel: fwd_step_kernel, one launch per frame (alpha of frame n and beta of frame len-1-n together):
-    # forward alone between HIP events / (T - 1) launches
+    # dominant kernel: the recursion over frames (alpha of frame n and beta of frame len-1-n together): forward alone
+    # between HIP events / (T - 1) frame steps
     be = asg_mod.native()
     xd, trd = x.detach(), m.transition.detach()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -161,46 +268,85 @@ def run_cfg5(args, real_stdout):
     e1.record()
     torch.cuda.synchronize()
     fwd_ms = e0.elapsed_time(e1)
-    step_launches = T5 - 1
-    kern_ms = fwd_ms / step_launches
+    frame_steps = T5 - 1
+    kern_ms = fwd_ms / frame_steps
     w = 4
     a_alg_step = 2 * N5 * N5 * w + 2 * 2 * B5 * N5 * w        # one frame, both directions: E and F once, vectors in/out
     a_alg = 3 * (T5 - 1) * N5 * N5 * w + 2 * T5 * B5 * N5 * w      # alpha, beta and gradient passes over Tr
-    ms_per_step = dt / args.steps * 1e3
+    ms_per_step = dt / steps * 1e3
     achieved = a_alg_step / (kern_ms * 1e-3) / 1e9
-    traffic5, traffic5_src = None, None
-    try:                                  # HBM bytes per launch of the dominant kernel, from the committed PMC passes
-        pj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_cfg5.json")
-        with open(pj) as f:
-            traffic5 = float(json.load(f)["dominant_kernel_hbm_bytes_per_launch"])
-        traffic5_src = "profiles/r02_pmc_cfg5.json"
-    except Exception:
-        pass
-    out = {
-        "metric": "utterances/sec fwd+bwd, T=2000 B=32 N=10000 (cfg 5, large alphabet); achieved HBM GB/s vs roofline",
-        "value": B5 * args.steps / dt, "unit": "utterances/s", "n_gpus": 1, "steps": args.steps, "warmup": max(args.warmup, 1),
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-        "data": "synthetic",
-        "config": {"workload": "cfg5: T=%d B=%d N=%d L=%d fp32, variable input/target lengths, ASGLoss(reduction=mean) "
-                               "forward+backward on the generic (large-alphabet) kernels" % (T5, B5, N5, L5),
-                   "global_batch": B5, "T": T5, "N": N5, "L": L5, "step_mode": "eager", "parallelism": "single GPU"},
+    traffic5, traffic5_src = committed_traffic(("r03_pmc_cfg5.json", "r02_pmc_cfg5.json"))
+    del x, tr, m
+    torch.cuda.empty_cache()
+    return {
+        "workload": "cfg5: T=%d B=%d N=%d L=%d fp32, variable input/target lengths, ASGLoss(reduction=mean) "
+                    "forward+backward on the generic (large-alphabet) kernels" % (T5, B5, N5, L5),
+        "step_mode": "eager", "steps": steps, "warmup": max(warmup, 1),
+        "ms_per_step": ms_per_step, "utt_s": B5 * steps / dt, "loss": float(loss),
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic5, "traffic_source": traffic5_src,
-                     "kernel": "fwd_step_kernel (one frame of the full-lattice alpha AND beta recursions for the whole batch: "
-                               "the row- and column-normalised transition matrices streamed once each)",
-                     "kernel_ms": kern_ms, "kernel_timing": "HIP events around the forward launch sequence / (T-1) step launches "
+                     "traffic": traffic5, "traffic_source": traffic5_src, "traffic_measured_in_run": False,
+                     "kernel": "the full-lattice recursion, one frame of alpha AND beta for the whole batch per step: the "
+                               "row- and column-normalised transition matrices streamed once each per frame",
+                     "kernel_ms": kern_ms, "kernel_timing": "HIP events around the forward launch sequence / (T-1) frame steps "
                                                             "(includes the aligned chains and the prologue: < 2 %)",
                      "algorithmic_bytes_per_launch": a_alg_step,
                      "step_algorithmic_bytes": a_alg, "step_achieved": a_alg / (ms_per_step * 1e-3) / 1e9,
                      "note": "A_alg(step) = 3 (T-1) N^2 w + 2 T B N w (SURVEY.md 8d: alpha, beta, gradient passes over Tr; the "
                              "gradient pass here is ONE tiled contraction on the matrix cores that reads Tr once: this formulation "
                              "moves 2 (T-1) N^2 w + N^2 w + 2 T B N w)"},
-        "cpu_baseline": None,
         "cpu_baseline_note": "the reference cannot run cfg 5 (fully_connected_lattice.cpp:77: 25.6 TB of path_contrib)",
-        "loss": float(loss),
+    }
+
+
+def committed_traffic(names, key="dominant_kernel_hbm_bytes_per_launch"):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc needs its own runs:
+    profiles/*_summary.md).  NOT measured in this run: the file is named so that a stale number is detectable."""
+    for name in names:
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            try:
+                with open(path) as f:
+                    return float(json.load(f)[key]), "profiles/" + name
+            except Exception:
+                pass
+    return None, None
+
+
+def run_cfg5(args, real_stdout):
+    """`--config cfg5`: the large-alphabet workload as the headline of the line (same JSON contract)."""
+    torch.cuda.set_device(0)
+    r = measure_cfg5(args.steps, args.warmup)
+    out = {
+        "metric": "utterances/sec fwd+bwd, T=2000 B=32 N=10000 (cfg 5, large alphabet); achieved HBM GB/s vs roofline",
+        "value": r["utt_s"], "unit": "utterances/s", "n_gpus": 1, "steps": args.steps, "warmup": r["warmup"],
+        "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": r["workload"], "global_batch": CFG5["B"], "T": CFG5["T"], "N": CFG5["N"], "L": CFG5["L"],
+                   "step_mode": "eager", "parallelism": "single GPU"},
+        "roofline": r["roofline"], "cpu_baseline": None, "cpu_baseline_note": r["cpu_baseline_note"], "loss": r["loss"],
     }
     sys.stdout.flush()
     os.write(real_stdout, (json.dumps(out) + "\n").encode())
+
+
+def extras(args):
+    """The other BASELINE.json configurations, timed in this process (N = 1 only)."""
+    ex = {}
+
+    def attempt(key, fn):
+        try:
+            ex[key] = fn()
+        except Exception as e:            # an extra must never cost the headline line
+            ex[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+        torch.cuda.synchronize()
+
+    attempt("cfg2", lambda: time_small_config("cfg2", 150, 16, 30, 20, False, 100))
+    attempt("cfg4_one_gpu", lambda: time_small_config("cfg4 on one GPU", 400, 512, 40, 30, False, 50))
+    attempt("cfg3_eval", lambda: time_small_config("cfg3", T, B, N, L, False, 100, eval_route=True))
+    attempt("cfg3_eager", lambda: time_small_config("cfg3", T, B, N, L, False, 100, eager=True))
+    attempt("cfg3_streams", lambda: time_small_config("cfg3, launch_mode=streams", T, B, N, L, False, 50, launch="streams"))
+    attempt("cfg5", lambda: measure_cfg5(3, 1))
+    return ex
 
 
 def main():
@@ -212,6 +358,7 @@ def main():
     ap.add_argument("--launch", choices=["single", "streams", "serial"], default="single")
     ap.add_argument("--graph-steps", type=int, default=0, help="steps per captured hipGraph (0 = largest divisor of --steps <= 10)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the `extra` object (the other configurations)")
     ap.add_argument("--force-dist", action="store_true", help="init the process group even with one rank (testing)")
     ap.add_argument("--dry-run", action="store_true",
                     help="parse the arguments and the launcher's environment, print the plan as JSON, touch no GPU (tests)")
@@ -237,11 +384,7 @@ def main():
         raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
                          "--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ..." % (args.gpus, args.gpus))
     if args.dry_run:
-        gs = 1
-        if args.mode == "graph":
-            gs = args.graph_steps if args.graph_steps > 0 else max(g for g in range(1, 11) if args.steps % g == 0)
-            if args.steps % gs:
-                gs = 1
+        gs = graph_steps_for(args.steps, args.graph_steps) if args.mode == "graph" else 1
         if rank == 0:
             os.write(real_stdout, (json.dumps({"dry_run": True, "world": world, "gpus": args.gpus, "steps": args.steps,
                                                "warmup": args.warmup, "mode": args.mode, "steps_per_graph": gs,
@@ -266,11 +409,9 @@ def main():
     x.requires_grad_(True)
     global_batch = B * world
 
-    # ---- kernel timing hook: HIP events around the recursion-kernel launch, on the launch stream
-    ev_pairs = []
     be = asg_mod.native()
     # local mean over B times 1/world == mean over the global batch (equal shards); the factor enters as the
-    # incoming gradient of backward(), i.e. inside the assembly kernel, not as extra elementwise launches
+    # incoming gradient of backward(), i.e. inside the kernels, not as extra elementwise launches
     gscale = torch.full((), 1.0 / world, device=dev)
 
     def one_step():
@@ -284,11 +425,7 @@ def main():
         if use_dist:
             dist.all_reduce(loss_mod.transition.grad, op=dist.ReduceOp.SUM)   # the one collective of the step
 
-    gsteps = 1
-    if args.mode == "graph":
-        gsteps = args.graph_steps if args.graph_steps > 0 else max(g for g in range(1, 11) if args.steps % g == 0)
-        if args.steps % gsteps:
-            gsteps = 1
+    gsteps = graph_steps_for(args.steps, args.graph_steps) if args.mode == "graph" else 1
 
     # ---- optional hipGraph capture of the compute part of the step (static shapes)
     graph = None
@@ -296,36 +433,22 @@ def main():
     mode = args.mode
     if mode == "graph":
         try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(3):
-                    one_step()
-            torch.cuda.current_stream().wait_stream(side)
+            for _ in range(2):
+                one_step()
             torch.cuda.synchronize()
             sync_grads()                  # the communicator exists (and has run once) before anything is captured
             torch.cuda.synchronize()
-            def capture(with_collective):
-                g = torch.cuda.CUDAGraph()
-                # thread_local: RCCL's watchdog thread polls events while this thread captures
-                with torch.cuda.graph(g, capture_error_mode="thread_local" if with_collective else "global"):
-                    for _ in range(gsteps):
-                        one_step()
-                        if with_collective:
-                            sync_grads()
-                g.replay()
-                torch.cuda.synchronize()
-                return g
             if use_dist and gsteps > 1:
                 try:                     # the all-reduce inside the graph, so that G steps stay one replay
-                    graph = capture(True)
+                    # thread_local: RCCL's watchdog thread polls events while this thread captures
+                    graph = capture_steps(one_step, gsteps, after_step=sync_grads, relaxed=True)
                     graph_has_collective = True
                 except Exception as e:
                     sys.stderr.write("[bench] could not capture the all-reduce (%s); one step per graph\n" % (e,))
                     gsteps = 1
                     graph = None
             if graph is None:
-                graph = capture(False)
+                graph = capture_steps(one_step, gsteps)
         except Exception as e:           # capture unsupported in this environment: fall back, say so
             sys.stderr.write("[bench] hipGraph capture failed (%s); running eager\n" % (e,))
             graph = None
@@ -351,22 +474,23 @@ def main():
     for _ in range(args.warmup % gsteps):      # the rest of the W warm-up steps, one at a time
         one_step()
         sync_grads()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps // gsteps):
-        step_group()
-    fence()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    def agree(v):
+        if not use_dist:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
-    # ---- dominant-kernel duration, measured live with HIP events on the launch stream.
-    # The recursion kernel is launched on its own here (same entry point, inputs and launch flags as inside the
-    # step: asg_forward is what asg_loss_forward calls first) so the event pair brackets exactly that kernel; a
-    # ~0.2 ms spin kernel queued ahead of each launch lets the host run ahead, so the events measure kernel
-    # time, not host enqueue time.
+    blocks = timed_blocks(step_group, args.steps // gsteps, fence, agree)
+    if use_dist:
+        tb = torch.tensor(blocks, dtype=torch.float64, device=dev)
+        dist.all_reduce(tb, op=dist.ReduceOp.MAX)          # every block: the slowest rank's time
+        blocks = [float(v) for v in tb.tolist()]
+    dt = median(blocks)
+
+    # ---- dominant-kernel duration, measured live with HIP events on the launch stream: a hipGraph holding ONLY that
+    # kernel launch, replayed back to back between one pair of HIP events (launch gaps inside a graph are ~1 us); this is
+    # the number that tracks rocprofv3's kernel time.  Fallback: event pairs around single eager launches.
     from torch_asg_amd import _lib as lib_mod
     lflags = {"streams": lib_mod.FLAG_STREAMS, "single": lib_mod.FLAG_SINGLE_LAUNCH, "serial": 0}[args.launch]
     xd = x.detach()
@@ -383,70 +507,45 @@ def main():
         dominant_launch()
     torch.cuda.synchronize()
     nk = min(max(args.steps, 20), 200)
-    for _ in range(nk):
-        torch.cuda._sleep(400000)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        dominant_launch()
-        e1.record()
-        ev_pairs.append((e0, e1))
-    torch.cuda.synchronize()
-    kern_ms = sorted(e0.elapsed_time(e1) for e0, e1 in ev_pairs)
-    kern_ms_avg = sum(kern_ms) / len(kern_ms)
-    kern_ms_med = kern_ms[len(kern_ms) // 2]
-    kern_method = "HIP events around single eager launches (includes ~3 us of dispatch)"
-    # Tighter: a hipGraph holding ONLY that kernel launch, replayed back to back between one pair of HIP events
-    # (launch gaps inside a graph are ~1 us); this is the number that tracks rocprofv3's kernel time.
     try:
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        kg = torch.cuda.CUDAGraph()
-        with torch.cuda.stream(side):
-            dominant_launch()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
         per_graph = 25
-        with torch.cuda.graph(kg):
-            for _ in range(per_graph):
-                dominant_launch()
+        kg = capture_steps(dominant_launch, per_graph)
         for _ in range(3):
             kg.replay()
         torch.cuda.synchronize()
         reps = []
-        for _ in range(max(nk // per_graph, 4)):
+        for _ in range(max(nk // per_graph, 8)):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             kg.replay()
             e1.record()
             torch.cuda.synchronize()
             reps.append(e0.elapsed_time(e1) / per_graph)
-        reps.sort()
-        kern_ms_eager = kern_ms_med
-        kern_ms_med = reps[len(reps) // 2]
+        kern_ms_med = median(reps)
         kern_ms_avg = sum(reps) / len(reps)
-        kern_method = ("HIP events around a hipGraph of %d consecutive launches of this kernel only, per launch "
-                       "(single eager launches: %.4f ms incl. ~3 us dispatch)" % (per_graph, kern_ms_eager))
+        kern_method = "HIP events around a hipGraph of %d consecutive launches of this kernel only, per launch" % per_graph
     except Exception as e:
-        sys.stderr.write("[bench] single-kernel graph timing failed (%s); keeping eager event pairs\n" % (e,))
+        sys.stderr.write("[bench] single-kernel graph timing failed (%s); eager event pairs\n" % (e,))
+        ev_pairs = []
+        for _ in range(nk):
+            torch.cuda._sleep(400000)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            dominant_launch()
+            e1.record()
+            ev_pairs.append((e0, e1))
+        torch.cuda.synchronize()
+        kern_ms = sorted(e0.elapsed_time(e1) for e0, e1 in ev_pairs)
+        kern_ms_avg = sum(kern_ms) / len(kern_ms)
+        kern_ms_med = kern_ms[len(kern_ms) // 2]
+        kern_method = "HIP events around single eager launches (includes ~3 us of dispatch)"
 
     if rank == 0:
         a_alg = algorithmic_bytes(T, B, N, L)
         ms_per_step = dt / args.steps * 1e3
         value = global_batch * args.steps / dt
         achieved = a_alg / (kern_ms_med * 1e-3) / 1e9
-        traffic = None
-        # HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc, separate runs:
-        # profiles/r02_summary.md); the file is named in the line so that a stale number is detectable
-        traffic_source = None
-        for name, key in (("r02_pmc_cfg3.json", "dominant_kernel_hbm_bytes_per_launch"),):
-            pmc_path = os.path.join(ROOT, "profiles", name)
-            if fused_step and os.path.exists(pmc_path):
-                try:
-                    with open(pmc_path) as f:
-                        traffic = json.load(f).get(key)
-                    traffic_source = "profiles/" + name
-                except Exception:
-                    traffic = None
+        traffic, traffic_source = committed_traffic(("r03_pmc_cfg3.json", "r02_pmc_cfg3.json")) if fused_step else (None, None)
         out = {
             "metric": "utterances/sec fwd+bwd, T=400 B=64 N=40; achieved HBM GB/s vs roofline",
             "value": value,
@@ -468,8 +567,14 @@ def main():
                        "step_mode": mode if mode != "graph" else "graph (%d consecutive steps per hipGraph replay)" % gsteps,
                        "launch_mode": args.launch,
                        "parallelism": "batch-sharded x%d" % world},
+            "timing": {"protocol": "blocks of exactly `steps` steps, each between barrier + synchronize fences; "
+                                   "ms_per_step and value come from the MEDIAN block",
+                       "timed_blocks": len(blocks), "first_block_ms": blocks[0] * 1e3,
+                       "min_block_ms": min(blocks) * 1e3, "median_block_ms": dt * 1e3, "max_block_ms": max(blocks) * 1e3,
+                       "total_timed_s": sum(blocks)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "traffic_measured_in_run": False,
                          "kernel": "fused_fwd_kernel (all four recursions of every utterance AND the gradient assembly in "
                                    "one launch: three workgroups per utterance)"
                                    if fused_step else "asg_forward launches (recursion kernels)",
@@ -483,6 +588,8 @@ def main():
                                            "floor_ms": (T - 1) * 117.0e-6,
                                            "frac_of_kernel": (T - 1) * 117.0e-6 / kern_ms_med} if fused_step else None},
         }
+        if world == 1 and not args.no_extra:
+            out["extra"] = extras(args)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         sys.stdout.flush()

@@ -45,7 +45,6 @@ extern "C" {
                                        without it everything is issued on `stream` in order
                                        (= ASGLoss(gpu_no_stream_impl=True), asg.py:124) */
 #define ASG_FLAG_SINGLE_LAUNCH 2    /* all four recursions in ONE kernel launch (blockIdx.y = pass) */
-#define ASG_FLAG_MATVEC_READLANE 4  /* accepted and ignored (a tuning variant of round 1 that lost every measurement) */
 #define ASG_FLAG_ALPHA_SCORES 8     /* debugging: forward also writes the scores obtained from the alpha passes
                                        into full_scores[B..2B) / aligned_scores[B..2B) */
 
@@ -78,6 +77,10 @@ const char *asg_hip_strerror(int status);
 
 int asg_ctx_create(asg_ctx **out);
 int asg_ctx_destroy(asg_ctx *ctx);
+
+/* *id = the identifier of the hipGraph capture `stream` is recording into, 0 when it is not capturing.  Host bindings
+ * use it to give every capture its own `sync` region (asg_loss_fused_forward) without allocating under capture. */
+int asg_stream_capture_id(void *stream, unsigned long long *id);
 
 /* Bytes of saved lattice state (forward -> backward) and of backward scratch for a problem shape.
  * Only T,B,N,S,dtype of `p` are read. */

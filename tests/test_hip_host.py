@@ -1,0 +1,232 @@
+"""GPU tests (-m gpu) of the host side of the binding: what the autograd Functions keep alive, hipGraph capture of the
+fused step, retained graphs, saved-tensor hooks, batch splitting at the 32-bit offset limit, documented exceptions.
+Everything is checked against the CPU oracle (tests only) or against another route of the same library."""
+import numpy as np
+import pytest
+import torch
+
+import util
+from oracle import asg_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _asg():
+    import torch_asg_amd
+    return torch_asg_amd
+
+
+def _module(N, tr, **kw):
+    m = _asg().ASGLoss(N, **kw).to(DEV)
+    with torch.no_grad():
+        m.transition.copy_(tr)
+    return m
+
+
+@pytest.mark.parametrize("mode", ["single", "serial"])
+def test_cpu_lengths_on_the_training_route_survive_allocator_churn(mode):
+    """The reference takes CPU lengths on its GPU route (streamlined_fast_gpu.cpp:40).  The device copies made for the
+    kernels must live until backward: allocate and overwrite a lot of memory between forward and backward."""
+    tr, x, tg, il, tl = util.synth(120, 12, 28, 9, 3, True)
+    o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il.numpy(), tl.numpy(), "mean")
+    m = _module(28, tr, launch_mode=mode)
+    xd = x.to(DEV).requires_grad_(True)
+    loss = m(xd, tg, il[::1].clone(), tl)                        # targets and lengths stay on the CPU
+    junk = [torch.full((1 << 16,), 7, dtype=torch.int64, device=DEV) for _ in range(64)]   # reuse freed small blocks
+    del junk
+    junk = [torch.full((n,), 9, dtype=torch.int64, device=DEV) for n in (12, 12, 64, 128, 12, 12, 256, 12)]
+    loss.backward()
+    torch.cuda.synchronize()
+    del junk
+    util.assert_close(loss.item(), o["loss"], 1e-4, "loss")
+    util.assert_close(xd.grad.cpu().numpy(), o["grad_inputs"], 1e-4, "grad_inputs")
+    util.assert_close(m.transition.grad.cpu().numpy(), o["grad_transition"], 1e-4, "grad_transition")
+
+
+def test_noncontiguous_lengths():
+    tr, x, tg, il, tl = util.synth(60, 6, 20, 7, 4, True)
+    o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il.numpy(), tl.numpy(), "sum")
+    m = _module(20, tr, reduction="sum")
+    il2 = torch.stack([il, il], 1).to(DEV)[:, 0]
+    tl2 = torch.stack([tl, tl], 1).to(DEV)[:, 1]
+    assert not il2.is_contiguous()
+    xd = x.to(DEV).requires_grad_(True)
+    m(xd, tg.to(DEV), il2, tl2).backward()
+    util.assert_close(xd.grad.cpu().numpy(), o["grad_inputs"], 1e-4, "grad_inputs")
+    util.assert_close(m.transition.grad.cpu().numpy(), o["grad_transition"], 1e-4, "grad_transition")
+
+
+def test_fused_step_captured_in_a_graph_replays_with_fresh_inputs():
+    """hipGraph capture of the fused step (what bench.py times): several steps per graph, replayed with new emissions;
+    every replay must equal the eager result on the same values, and eager calls in between must not disturb it."""
+    A = _asg()
+    T, B, N, L = 200, 24, 40, 14
+    tr, x, tg, il, tl = util.synth(T, B, N, L, 5, True)
+    m = _module(N, tr)
+    static_x = x.to(DEV).clone().requires_grad_(True)
+    tgd, ild, tld = tg.to(DEV), il.to(DEV), tl.to(DEV)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):                                         # warm-up (creates the sync pool eagerly)
+            m.transition.grad = None
+            static_x.grad = None
+            m(static_x, tgd, ild, tld).backward()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    m.transition.grad = None
+    static_x.grad = None
+    with torch.cuda.graph(g):
+        losses = []
+        for _ in range(3):
+            loss = m(static_x, tgd, ild, tld)
+            loss.backward()
+            losses.append(loss)
+    for seed in (11, 12, 13):
+        _, x2, _, _, _ = util.synth(T, B, N, L, seed, True)
+        with torch.no_grad():
+            static_x.copy_(x2)
+        static_x.grad.zero_()
+        m.transition.grad.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        got = (losses[-1].item(), static_x.grad.clone(), m.transition.grad.clone())
+        # an eager call between replays, on the same stream and on another one
+        m2 = _module(N, tr)
+        xe = x2.to(DEV).requires_grad_(True)
+        le = m2(xe, tgd, ild, tld)
+        le.backward()
+        with torch.cuda.stream(side):
+            m3 = _module(N, tr)
+            xs = x2.to(DEV).requires_grad_(True)
+            m3(xs, tgd, ild, tld).backward()
+        torch.cuda.synchronize()
+        assert got[0] == le.item()
+        assert torch.equal(got[1], 3 * xe.grad), "3 captured steps accumulate 3x the eager gradient"
+        assert torch.allclose(got[2], 3 * m2.transition.grad, rtol=1e-6, atol=1e-7)
+        assert torch.equal(xs.grad, xe.grad)
+
+
+def test_first_fused_call_inside_a_capture_is_refused_or_served_from_a_reserved_pool():
+    A = _asg()
+    be = A.asg.HipBackend()                    # a fresh backend: no pool yet
+    old = A.asg._backend
+    A.asg._backend = be
+    try:
+        tr, x, tg, il, tl = util.synth(50, 4, 12, 5, 6, True)
+        m = _module(12, tr)
+        xd = x.to(DEV).requires_grad_(True)
+        tgd, ild, tld = tg.to(DEV), il.to(DEV), tl.to(DEV)
+        # (the kernels of this alphabet tile have run before: module loading is not part of what is tested)
+        old_be = A.asg._backend
+        A.asg._backend = old
+        m(xd, tgd, ild, tld)
+        torch.cuda.synchronize()
+        A.asg._backend = old_be
+        g = torch.cuda.CUDAGraph()
+        with pytest.raises(RuntimeError, match="warm-up"):
+            with torch.cuda.graph(g):
+                m(xd, tgd, ild, tld)
+        torch.cuda.synchronize()
+        be.reserve(DEV)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            loss = m(xd, tgd, ild, tld)
+        g.replay()
+        torch.cuda.synchronize()
+        o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il.numpy(), tl.numpy(), "mean", need_grad=False)
+        util.assert_close(loss.item(), o["loss"], 1e-4, "loss from a replay")
+    finally:
+        A.asg._backend = old
+
+
+@pytest.mark.parametrize("mode", ["single", "serial"])
+def test_second_backward_through_a_retained_graph(mode):
+    """Fused route: the buffers of the first backward were handed to autograd, the step is recomputed; both passes
+    must give the gradients of the split route."""
+    tr, x, tg, il, tl = util.synth(90, 10, 25, 8, 7, True)
+    o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il.numpy(), tl.numpy(), "mean")
+    m = _module(25, tr, launch_mode=mode)
+    xd = x.to(DEV).requires_grad_(True)
+    loss = m(xd, tg.to(DEV), il.to(DEV), tl.to(DEV))
+    loss.backward(retain_graph=True)
+    g1 = (xd.grad.clone(), m.transition.grad.clone())
+    xd.grad = None
+    m.transition.grad = None
+    (2.0 * loss).backward()
+    for got, scale in ((g1, 1.0), ((xd.grad, m.transition.grad), 2.0)):
+        util.assert_close(got[0].cpu().numpy(), scale * o["grad_inputs"], 1e-4, "grad_inputs x%g" % scale)
+        util.assert_close(got[1].cpu().numpy(), scale * o["grad_transition"], 1e-4, "grad_transition x%g" % scale)
+
+
+@pytest.mark.parametrize("mode", ["single", "serial"])
+def test_saved_tensor_hooks_move_the_saved_buffers(mode):
+    """torch.autograd.graph.save_on_cpu: everything saved comes back at other addresses; the problem block is rebuilt."""
+    tr, x, tg, il, tl = util.synth(70, 6, 22, 7, 8, True)
+    o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il.numpy(), tl.numpy(), "mean")
+    m = _module(22, tr, launch_mode=mode)
+    xd = x.to(DEV).requires_grad_(True)
+    with torch.autograd.graph.save_on_cpu():
+        loss = m(xd, tg.to(DEV), il.to(DEV), tl.to(DEV))
+    junk = torch.full((1 << 20,), 3.0, device=DEV)
+    loss.backward()
+    del junk
+    util.assert_close(xd.grad.cpu().numpy(), o["grad_inputs"], 1e-4, "grad_inputs")
+    util.assert_close(m.transition.grad.cpu().numpy(), o["grad_transition"], 1e-4, "grad_transition")
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(launch_mode="serial"), dict(gpu_no_stream_impl=True),
+                                dict(scale_mode="target_size_sqrt"), dict(reduction="none")])
+def test_batches_beyond_the_32bit_offset_limit_are_split(kw):
+    """asg_api.hip:check_problem refuses T*B*max(N,S)*w >= 4 GiB on the small-alphabet path; ASGLoss splits such a batch
+    along B.  The limit is lowered here so that the split route runs at test size: 3 + 3 + 1 utterances."""
+    A = _asg()
+    T, B, N, L = 40, 7, 18, 6
+    tr, x, tg, il, tl = util.synth(T, B, N, L, 9, True)
+    red = kw.get("reduction", "mean")
+    m = _module(N, tr, **kw)
+    whole = _module(N, tr, **kw)
+    m.OFFSET_LIMIT = T * N * 4 * 3 + 1
+    assert m._batch_chunk(x, tg) == 3 and whole._batch_chunk(x, tg) == 0
+    res = []
+    for mod in (m, whole):
+        xd = x.to(DEV).requires_grad_(True)
+        loss = mod(xd, tg.to(DEV), il.to(DEV), tl.to(DEV))
+        loss.sum().backward()
+        res.append((loss.detach().cpu().numpy(), xd.grad.cpu().numpy(), mod.transition.grad.cpu().numpy()))
+    for a, b_, what in zip(res[0], res[1], ("loss", "grad_inputs", "grad_transition")):
+        util.assert_close(a, b_, 1e-5, what + " split vs whole")
+    if not kw.get("scale_mode"):
+        o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il.numpy(), tl.numpy(), red)
+        util.assert_close(res[0][0], o["loss"], 1e-4, "loss vs oracle")
+        util.assert_close(res[0][1], o["grad_inputs"], 1e-4, "grad_inputs vs oracle")
+
+
+def test_input_is_logits_exception_for_infeasible_utterances():
+    """Documented exception of ASGLoss(input_is_logits=True): an utterance with target_length > input_length has
+    loss = +inf and, as in the reference, grad_inputs rows that hold only the full-lattice
+    posterior -- they sum to g, not to 0 -- so for THAT utterance d loss / d logits differs from d loss / d log-probs
+    by softmax * g.  Feasible utterances of the same batch are unaffected."""
+    A = _asg()
+    T, B, N, L = 12, 3, 9, 8
+    tr, x, tg, _, _ = util.synth(T, B, N, L, 10, False, torch.float64)
+    il = torch.tensor([12, 5, 12])
+    tl = torch.tensor([6, 8, 8])                                   # utterance 1: 8 targets in 5 frames
+    m = _module(N, tr.float(), input_is_logits=True, reduction="none")
+    ref = _module(N, tr.float(), reduction="none")
+    xa = x.float().to(DEV).requires_grad_(True)
+    xb = x.float().to(DEV).requires_grad_(True)
+    la = m(xa, tg.to(DEV), il.to(DEV), tl.to(DEV))
+    lb = ref(torch.log_softmax(xb, 2), tg.to(DEV), il.to(DEV), tl.to(DEV))
+    assert torch.isinf(la[1]) and torch.isinf(lb[1]) and torch.isfinite(la[[0, 2]]).all()
+    la.sum().backward()
+    lb.sum().backward()
+    ga, gb = xa.grad.cpu(), xb.grad.cpu()
+    assert torch.isfinite(ga).all() and torch.isfinite(gb).all()
+    assert torch.allclose(ga[:, [0, 2]], gb[:, [0, 2]], atol=1e-5), "feasible utterances: identical"
+    # the infeasible one: rows of the flag route sum to g = 1 over the labels (frames < input_length), and the
+    # difference to the composition is exactly softmax * 1
+    sm = torch.softmax(x.float(), 2)
+    assert torch.allclose(ga[:5, 1].sum(-1), torch.ones(5), atol=1e-5)
+    assert torch.allclose(ga[:5, 1] - gb[:5, 1], sm[:5, 1], atol=1e-5)

@@ -161,25 +161,22 @@ def test_every_alphabet_tile(N):
         util.assert_close(r[k], o[k], 1e-4, "N%d/%s" % (N, k))
 
 
-def test_alpha_and_beta_scores_agree_and_matvec_variants():
+def test_alpha_and_beta_scores_agree():
+    """The score read off the end of the alpha pass equals the one read off the end of the beta pass (two independent
+    recursions over the same lattice), and both equal the oracle's."""
     A = _asg()
     from torch_asg_amd import _lib
     tr, x, tg, il, tl = util.synth(150, 16, 30, 20, 0, True)
     o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il.numpy(), tl.numpy(), "none",
                      need_grad=False)
     be = A.asg.native()
-    outs = []
-    for extra in (0, _lib.FLAG_MATVEC_READLANE):
-        full, ali, _ = be.forward(x.to(DEV), tg.to(DEV), tr.to(DEV), il.to(DEV), tl.to(DEV),
-                                  _lib.FLAG_ALPHA_SCORES | extra)
-        full, ali = full.cpu().numpy(), ali.cpu().numpy()
-        B = 16
-        util.assert_close(full[:B], o["full_scores"], 1e-5, "full beta")
-        util.assert_close(full[B:], o["full_scores"], 1e-5, "full alpha")
-        util.assert_close(ali[:B], o["aligned_scores"], 1e-5, "aligned beta")
-        util.assert_close(ali[B:], o["aligned_scores"], 1e-5, "aligned alpha")
-        outs.append((full, ali))
-    util.assert_close(outs[0][0], outs[1][0], 1e-6, "matvec variants")
+    full, ali, _ = be.forward(x.to(DEV), tg.to(DEV), tr.to(DEV), il.to(DEV), tl.to(DEV), _lib.FLAG_ALPHA_SCORES)
+    full, ali = full.cpu().numpy(), ali.cpu().numpy()
+    B = 16
+    util.assert_close(full[:B], o["full_scores"], 1e-5, "full beta")
+    util.assert_close(full[B:], o["full_scores"], 1e-5, "full alpha")
+    util.assert_close(ali[:B], o["aligned_scores"], 1e-5, "aligned beta")
+    util.assert_close(ali[B:], o["aligned_scores"], 1e-5, "aligned alpha")
 
 
 @pytest.mark.parametrize("launch_mode", ["single", "serial"])

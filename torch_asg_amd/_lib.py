@@ -10,10 +10,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ASG_HIP_LIB") or os.path.join(_HERE, "csrc", "libasg_hip.so")
 
 ASG_DTYPE_F32, ASG_DTYPE_F64, ASG_DTYPE_BF16 = 0, 1, 2
-FLAG_STREAMS, FLAG_SINGLE_LAUNCH, FLAG_MATVEC_READLANE, FLAG_ALPHA_SCORES = 1, 2, 4, 8
+FLAG_STREAMS, FLAG_SINGLE_LAUNCH, FLAG_ALPHA_SCORES = 1, 2, 8
 
 # every symbol include/asg_hip.h declares
-SYMBOLS = ["asg_hip_version", "asg_hip_strerror", "asg_ctx_create", "asg_ctx_destroy", "asg_state_bytes",
+SYMBOLS = ["asg_hip_version", "asg_hip_strerror", "asg_ctx_create", "asg_ctx_destroy", "asg_stream_capture_id", "asg_state_bytes",
            "asg_scratch_bytes", "asg_full_forward", "asg_full_backward", "asg_aligned_forward",
            "asg_aligned_backward", "asg_forward", "asg_forward_only", "asg_backward", "asg_loss_forward",
            "asg_loss_backward", "asg_viterbi_work_bytes", "asg_viterbi", "asg_loss_fused_supported",
@@ -50,6 +50,7 @@ def lib():
     L.asg_hip_strerror.argtypes = [ci]
     L.asg_ctx_create.argtypes = [ctypes.POINTER(vp)]
     L.asg_ctx_destroy.argtypes = [vp]
+    L.asg_stream_capture_id.argtypes = [vp, ctypes.POINTER(ctypes.c_ulonglong)]
     L.asg_state_bytes.restype = sz
     L.asg_state_bytes.argtypes = [pp]
     L.asg_scratch_bytes.restype = sz

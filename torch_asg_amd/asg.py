@@ -80,6 +80,19 @@ class HipBackend:
             raise RuntimeError("torch_asg_amd: targets must be [B=%d, S>=1] but got %s" % (B, tuple(targets.shape)))
 
     @staticmethod
+    def device_args(dev, targets, input_lengths, target_lengths):
+        """targets / lengths as the kernels read them: on `dev`, lengths contiguous."""
+        def conv(t, contiguous):
+            if t is None:
+                return None
+            if t.device != dev:
+                t = t.to(dev, non_blocking=True)
+            if contiguous and not t.is_contiguous():
+                t = t.contiguous()
+            return t
+        return conv(targets, False), conv(input_lengths, True), conv(target_lengths, True)
+
+    @staticmethod
     def _problem(inputs, transition, targets, input_lengths, target_lengths):
         T, B, N = inputs.shape
         dev = inputs.device
@@ -118,6 +131,8 @@ class HipBackend:
             p.dtype = _lib.ASG_DTYPE_F32 if inputs.dtype == torch.float32 else _lib.ASG_DTYPE_F64
         return p, keep
 
+    MAX_CONTEXTS = 64
+
     def _context(self, device):
         """Side stream + fork/join events of the 'streams' launch mode, ONE SET PER CALLING STREAM: calls issued on
         different streams (other threads, other modules, a capture in progress) never share an event pair."""
@@ -129,6 +144,11 @@ class HipBackend:
                 h = self._ctx.get(key)
                 if h is None:
                     h = ctypes.c_void_p()
+                    if len(self._ctx) >= self.MAX_CONTEXTS:
+                        # streams come and go in long runs: drop the oldest handle (stream / event destruction is
+                        # deferred by the runtime until their pending work has finished)
+                        old = next(iter(self._ctx))
+                        _lib.lib().asg_ctx_destroy(self._ctx.pop(old))
                     with torch.cuda.device(idx):
                         _lib.check(_lib.lib().asg_ctx_create(ctypes.byref(h)), "asg_ctx_create")
                     self._ctx[key] = h
@@ -270,28 +290,64 @@ class HipBackend:
 
     def _sync(self, device, nbytes):
         """Zeroed device memory for the cross-workgroup words of a fused launch (include/asg_hip.h: zero on entry,
-        left zero).  One region per calling stream for eager calls (calls on one stream are ordered, they may share);
-        a fresh region for every call made while a hipGraph is being captured, so that graphs replayed concurrently
-        never share one.  Regions are carved from pools that are zeroed ONCE, outside the hot path."""
+        left zero).  Calls that are ordered on one stream may share a region, so there is one region per calling
+        stream for eager calls and one per (capture, stream) for calls recorded into a hipGraph -- graphs that may be
+        replayed concurrently never share one, and a capture of many steps consumes one region, not one per step.
+        Regions are carved from pools that are allocated and zeroed EAGERLY: never while a capture is in progress
+        (the pool would come out of the graph's private memory and its zero-fill would become a graph node)."""
         idx = device.index if device.index is not None else torch.cuda.current_device()
+        stream = torch.cuda.current_stream(idx).cuda_stream
         capturing = torch.cuda.is_current_stream_capturing()
-        key = (idx, torch.cuda.current_stream(idx).cuda_stream)
-        if not capturing:
-            t = self._tickets.get(key)
-            if t is not None and t.numel() >= nbytes:
-                return t
+        cap = 0
+        if capturing:
+            cid = ctypes.c_ulonglong(0)
+            _lib.check(_lib.lib().asg_stream_capture_id(ctypes.c_void_p(stream), ctypes.byref(cid)), "asg_stream_capture_id")
+            cap = int(cid.value) or -1
+        key = (idx, stream, cap)
+        t = self._tickets.get(key)
+        if t is not None and t.numel() >= nbytes:
+            return t
         nbytes = (int(nbytes) + 255) // 256 * 256
         with self._lock:
             pool = self._pools.get(idx)
             if pool is None or pool[1] + nbytes > pool[0].numel():
-                pool = [torch.zeros(max(1 << 20, 4 * nbytes), dtype=torch.uint8, device=device), 0]
+                if capturing:
+                    raise RuntimeError(
+                        "torch_asg_amd: the fused step needs a zeroed sync region and its pool cannot be created while "
+                        "a hipGraph is being captured -- run one warm-up step (or torch_asg_amd.reserve(device)) "
+                        "before the capture")
+                pool = [torch.zeros(max(self.POOL_BYTES, 4 * nbytes), dtype=torch.uint8, device=device), 0]
                 self._pools[idx] = pool
-                self._pool_keep.append(pool[0])
+                self._pool_keep.append(pool[0])       # regions handed to captured graphs must outlive the pool's turn
             t = pool[0][pool[1]: pool[1] + nbytes]
             pool[1] += nbytes
-            if not capturing:
-                self._tickets[key] = t
+            if len(self._tickets) > 4096:             # long runs that keep creating streams / captures
+                self._tickets.clear()
+            self._tickets[key] = t
         return t
+
+    POOL_BYTES = 1 << 20
+
+    def reserve(self, device, nbytes=0):
+        """Create the sync pool of `device` now (e.g. before a capture whose first fused call would need it)."""
+        device = torch.device(device)
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        with self._lock:
+            pool = self._pools.get(idx)
+            if pool is None or pool[1] + nbytes > pool[0].numel():
+                pool = [torch.zeros(max(self.POOL_BYTES, 4 * int(nbytes)), dtype=torch.uint8, device=torch.device("cuda", idx)), 0]
+                self._pools[idx] = pool
+                self._pool_keep.append(pool[0])
+
+    def release(self):
+        """Destroy the side-stream contexts and drop the sync pools (call when no launch of this process is in flight)."""
+        with self._lock:
+            for h in self._ctx.values():
+                _lib.lib().asg_ctx_destroy(h)
+            self._ctx.clear()
+            self._tickets.clear()
+            self._pools.clear()
+            self._pool_keep.clear()
 
     def fused_supported(self, p):
         return bool(_lib.lib().asg_loss_fused_supported(ctypes.byref(p)))
@@ -364,7 +420,9 @@ class HipBackend:
         dev = inputs.device
         with self._guard(dev):
             p = saved.problem
-            if p.inputs != inputs.data_ptr() or p.transition != transition.data_ptr() or p.targets != targets.data_ptr():
+            if (p.inputs != inputs.data_ptr() or p.transition != transition.data_ptr() or p.targets != targets.data_ptr()
+                    or (p.input_lengths or 0) != (input_lengths.data_ptr() if input_lengths is not None else 0)
+                    or (p.target_lengths or 0) != (target_lengths.data_ptr() if target_lengths is not None else 0)):
                 # the saved tensors came back at other addresses (saved-tensor hooks): rebuild the problem block
                 p, _ = self._problem(inputs, transition, targets, input_lengths, target_lengths)
             g = grad_loss
@@ -514,10 +572,14 @@ class ASGLossFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, inputs, transition, outputs, input_lengths, output_lengths, reduction, flags):
         be = native()
+        # The problem block built by loss_forward is reused by loss_backward: everything it points at must be one of the
+        # tensors autograd saves.  CPU (the reference accepts them on its GPU route, streamlined_fast_gpu.cpp:40) or
+        # strided lengths / targets are therefore converted HERE, and the converted tensors are the saved ones.
+        outputs, input_lengths, output_lengths = HipBackend.device_args(inputs.device, outputs, input_lengths, output_lengths)
         loss, saved = be.loss_forward(inputs, outputs, transition, input_lengths, output_lengths, reduction, flags)
         ctx.save_for_backward(inputs, outputs, input_lengths, output_lengths, transition, *saved.tensors)
         saved.tensors = None          # autograd owns them now (and frees them after backward)
-        saved.keep = None
+        saved.keep = None             # (every tensor the block points at is in ctx.saved_tensors)
         ctx.reduction = reduction
         ctx.flags = flags
         ctx.saved = saved
@@ -566,6 +628,10 @@ class ASGLoss(nn.Module):
                    d loss / d logits = d loss / d log-probs.  The flag records the caller's intent and is what the
                    parity test pins (tests/test_hip_parity.py::test_input_is_logits); the individual scores returned by
                    FCC / FAC are NOT shift-invariant and take log-probabilities as in the reference.
+                   EXCEPTION: an utterance with target_length > input_length has no alignment: its loss is +inf and, as
+                   in the reference, its `inputs.grad` rows hold only the full-lattice posterior (they sum to the
+                   upstream gradient g, not to 0), so for that utterance d loss / d logits differs from what autograd
+                   through log_softmax would give by softmax * g (tests/test_hip_host.py pins this).
     bfloat16 `inputs` (with the float32 `transition`): "bf16 in, fp32 accumulate"  -- the fused training step
     reads them as they are and returns a bfloat16 `inputs.grad`; every other route widens them first.  The loss and
     `transition.grad` are float32 and match a float32 run on the same (bf16-representable) values to 1e-4; `inputs.grad`
@@ -625,44 +691,75 @@ class ASGLoss(nn.Module):
 
     def _bf16_direct(self, inputs, targets):
         """bfloat16 emissions go to the kernels as they are (bf16 in, fp32 accumulate, bf16 gradient out: half the
-        compulsory read and write of SURVEY.md 8(d)) on the fused training route; everywhere else they are widened here."""
+        compulsory read and write of SURVEY.md 8(d)) on the fused training route; everywhere else they are widened here.
+        Whether the fused route takes the problem is asked of the library (asg_loss_fused_supported), not re-stated."""
         if (self.gpu_no_stream_impl or self.forward_only or not self.training or self.scale_mode != 'none'
                 or self.launch_mode != 'single' or self.reduction not in ('mean', 'sum', 'none')):
             return False
-        if not inputs.is_cuda or self.transition.dtype != torch.float32 or inputs.dim() != 3:
+        if not inputs.is_cuda or self.transition.dtype != torch.float32 or inputs.dim() != 3 or targets.dim() != 2:
             return False
-        T, B, N = inputs.shape
-        S = min(targets.shape[1], T)
+        be = native()
+        tg = targets[:, :inputs.shape[0]] if targets.shape[1] > inputs.shape[0] else targets
+        try:
+            p, _ = be._problem(inputs, self.transition, tg if tg.is_cuda else None, None, None)
+        except RuntimeError:
+            return False
+        if not tg.is_cuda:                       # only the shape of the targets matters to the check
+            p.targets, p.S = inputs.data_ptr(), tg.shape[1]
+        return be.fused_supported(p) and be.fused_preferred(p, inputs.device)
 
-        class _P:
-            pass
-        p = _P()
-        p.B = B
-        return N < 64 and S <= 64 and T <= 4000 and T * B * N * 4 < 2 ** 32 and native().fused_preferred(p, inputs.device)
+    # The small-alphabet kernels address state and gradient rows with 32-bit byte offsets (asg_api.hip:check_problem):
+    # T * B * max(N, S) * itemsize must stay below this.  Larger batches are split along B here.
+    OFFSET_LIMIT = 2 ** 32
+
+    def _batch_chunk(self, inputs, targets):
+        """Utterances per call so that the 32-bit offset limit of the small-alphabet kernels holds (0 = no split)."""
+        T, B, N = inputs.shape
+        if N > 64:
+            return 0
+        w = 8 if inputs.dtype == torch.float64 else 4
+        per_utt = T * max(N, min(targets.shape[1], T)) * w
+        if per_utt * B < self.OFFSET_LIMIT:
+            return 0
+        return max(1, (self.OFFSET_LIMIT - 1) // per_utt)
+
+    def _per_utterance(self, inputs, targets, input_lengths, target_lengths):
+        """[B] unreduced losses through the route the module's settings select."""
+        args = (targets, input_lengths, target_lengths)
+        if self.gpu_no_stream_impl:
+            # "serial" route: two independent Functions, difference taken by autograd (asg.py:124-128)
+            return FCC.apply(self.transition, inputs, *args) - FAC.apply(self.transition, inputs, *args)
+        if self.forward_only or not self.training:
+            # evaluation route: beta recursions only, nothing saved, no gradient (asg.py:129-131)
+            return ASGGPUFastForwardOnly.apply(inputs, targets, self.transition, input_lengths, target_lengths,
+                                               self._flags())
+        if self.reduction not in ('mean', 'sum', 'none'):
+            # an unknown reduction string behaves like the reference: the unreduced loss falls through (asg.py:141-142)
+            full, aligned = ASGGPUFast.apply(inputs, self.transition, *args, self._flags())
+            return full - aligned
+        return ASGLossFunction.apply(inputs, self.transition, *args, 'none', self._flags())
 
     def forward(self, inputs, targets, input_lengths=None, target_lengths=None):
         if inputs.dtype == torch.bfloat16 and not self._bf16_direct(inputs, targets):
             inputs = inputs.to(self.transition.dtype)
         targets, input_lengths, target_lengths = self._canonical(inputs, targets, input_lengths, target_lengths)
         weights = self._utterance_weights(inputs, input_lengths, target_lengths)
-        args = (targets, input_lengths, target_lengths)
+        chunk = self._batch_chunk(inputs, targets) if inputs.dim() == 3 else 0
 
-        if self.gpu_no_stream_impl:
-            # "serial" route: two independent Functions, difference taken by autograd (asg.py:124-128)
-            per_utt = (FCC.apply(self.transition, inputs, *args) - FAC.apply(self.transition, inputs, *args))
-        elif self.forward_only or not self.training:
-            # evaluation route: beta recursions only, nothing saved, no gradient (asg.py:129-131)
-            per_utt = ASGGPUFastForwardOnly.apply(inputs, targets, self.transition, input_lengths, target_lengths,
-                                                  self._flags())
-        elif self.reduction not in ('mean', 'sum', 'none'):
-            # an unknown reduction string behaves like the reference: the unreduced loss falls through (asg.py:141-142)
-            full, aligned = ASGGPUFast.apply(inputs, self.transition, *args, self._flags())
-            per_utt = full - aligned
-        elif weights is None:
+        if chunk:
+            # the batch exceeds what one launch can address: the same routes on slices of it (views: no copy of the
+            # emissions; transition.grad accumulates over the slices through autograd)
+            B = inputs.shape[1]
+            per_utt = torch.cat([self._per_utterance(inputs[:, b0:b0 + chunk], targets[b0:b0 + chunk],
+                                                     input_lengths[b0:b0 + chunk], target_lengths[b0:b0 + chunk])
+                                 for b0 in range(0, B, chunk)])
+        elif (weights is None and self.reduction in ('mean', 'sum', 'none') and self.training
+              and not (self.gpu_no_stream_impl or self.forward_only)):
             # training route: subtraction, reduction and their gradients are inside the kernels
-            return ASGLossFunction.apply(inputs, self.transition, *args, self.reduction, self._flags())
+            return ASGLossFunction.apply(inputs, self.transition, targets, input_lengths, target_lengths,
+                                         self.reduction, self._flags())
         else:
-            per_utt = ASGLossFunction.apply(inputs, self.transition, *args, 'none', self._flags())
+            per_utt = self._per_utterance(inputs, targets, input_lengths, target_lengths)
 
         if weights is not None:
             per_utt = per_utt * weights

@@ -153,7 +153,6 @@ int run_forward(asg_ctx *ctx, const asg_problem *p, void *state, void *full_scor
         if (full_scores) O.full_scores_alpha = (R *) full_scores + p->B;
         if (aligned_scores) O.aligned_scores_alpha = (R *) aligned_scores + p->B;
     }
-    const int mv = (flags & ASG_FLAG_MATVEC_READLANE) ? 1 : 0;
 #ifdef ASG_DEV_PROBES
     if (const char *dm = getenv("ASG_DEBUG_MASK")) mask &= atoi(dm);      // developer probe: time single passes
 #endif
@@ -174,12 +173,12 @@ int run_forward(asg_ctx *ctx, const asg_problem *p, void *state, void *full_scor
             if ((e = hipStreamWaitEvent(s2, ctx->fork, 0)) != hipSuccess) return hip_status(e);
         }
         if (full_mask) {
-            e = sf ? launch_fwd_small<R>(P, W, O, full_mask, store, mv, stream)
+            e = sf ? launch_fwd_small<R>(P, W, O, full_mask, store, stream)
                    : launch_fwd_generic<R>(P, W, O, full_mask, store, stream);
             if (e != hipSuccess) return hip_status(e);
         }
         if (ali_mask) {
-            e = sa ? launch_fwd_small<R>(P, W, O, ali_mask, store, mv, s2)
+            e = sa ? launch_fwd_small<R>(P, W, O, ali_mask, store, s2)
                    : launch_fwd_generic<R>(P, W, O, ali_mask, store, s2);
             if (e != hipSuccess) return hip_status(e);
         }
@@ -194,15 +193,15 @@ int run_forward(asg_ctx *ctx, const asg_problem *p, void *state, void *full_scor
         // fork: aligned passes on the side stream, full passes on the caller's stream; join back.
         if ((e = hipEventRecord(ctx->fork, stream)) != hipSuccess) return hip_status(e);
         if ((e = hipStreamWaitEvent(ctx->side, ctx->fork, 0)) != hipSuccess) return hip_status(e);
-        if ((e = launch_fwd_small<R>(P, W, O, full_mask, store, mv, stream)) != hipSuccess) return hip_status(e);
-        if ((e = launch_fwd_small<R>(P, W, O, ali_mask, store, mv, ctx->side)) != hipSuccess) return hip_status(e);
+        if ((e = launch_fwd_small<R>(P, W, O, full_mask, store, stream)) != hipSuccess) return hip_status(e);
+        if ((e = launch_fwd_small<R>(P, W, O, ali_mask, store, ctx->side)) != hipSuccess) return hip_status(e);
         if ((e = hipEventRecord(ctx->join, ctx->side)) != hipSuccess) return hip_status(e);
         if ((e = hipStreamWaitEvent(stream, ctx->join, 0)) != hipSuccess) return hip_status(e);
         return ASG_OK;
     }
-    if (flags & ASG_FLAG_SINGLE_LAUNCH) return hip_status(launch_fwd_small<R>(P, W, O, mask, store, mv, stream));
-    if (full_mask && (e = launch_fwd_small<R>(P, W, O, full_mask, store, mv, stream)) != hipSuccess) return hip_status(e);
-    if (ali_mask && (e = launch_fwd_small<R>(P, W, O, ali_mask, store, mv, stream)) != hipSuccess) return hip_status(e);
+    if (flags & ASG_FLAG_SINGLE_LAUNCH) return hip_status(launch_fwd_small<R>(P, W, O, mask, store, stream));
+    if (full_mask && (e = launch_fwd_small<R>(P, W, O, full_mask, store, stream)) != hipSuccess) return hip_status(e);
+    if (ali_mask && (e = launch_fwd_small<R>(P, W, O, ali_mask, store, stream)) != hipSuccess) return hip_status(e);
     return ASG_OK;
 }
 
@@ -268,6 +267,16 @@ int asg_ctx_create(asg_ctx **out) {
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->join, hipEventDisableTiming);
     if (e != hipSuccess) { delete c; return hip_status(e); }
     *out = c;
+    return ASG_OK;
+}
+
+int asg_stream_capture_id(void *stream, unsigned long long *id) {
+    if (!id) return ASG_ERR_INVALID;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    unsigned long long cid = 0;
+    hipError_t e = hipStreamGetCaptureInfo((hipStream_t) stream, &st, &cid);
+    if (e != hipSuccess) return hip_status(e);
+    *id = st == hipStreamCaptureStatusActive ? (cid ? cid : ~0ull) : 0;
     return ASG_OK;
 }
 

@@ -59,6 +59,19 @@ template <int NP> struct Consumers {          // each has a [16 NT][16 NT + 1] d
     static constexpr int fit = NP <= 48 ? 4 : 2;
     static constexpr int n = ASG_X_NC < fit ? ASG_X_NC : fit;
 };
+// Developer variants (tests/test_hip_variants.py builds them through build.py --define; the shipped library has neither):
+//   ASG_X_SPREAD_XCD     the three workgroups of an utterance on three DIFFERENT XCDs: every cross-workgroup hand-off
+//                        then crosses L2s, which the default placement (all behind one L2, speed only) never exercises
+//   ASG_X_TEST_DELAY     utterance 1's aligned workgroup and utterance 2's full-alpha workgroup start late, past every
+//                        bounded wait of their partners (caps divided by 2^ASG_X_CAPSHIFT so the test stays short)
+#ifndef ASG_X_CAPSHIFT
+#define ASG_X_CAPSHIFT 0
+#endif
+constexpr int kCapLds = kSpinCap >> ASG_X_CAPSHIFT;               // waits on a word of this workgroup's LDS
+constexpr int kCapGlobal = (kSpinCap >> 4) >> ASG_X_CAPSHIFT;     // waits on another workgroup's progress word
+constexpr int kCapVerdictEarly = (1 << 18) >> ASG_X_CAPSHIFT;     // the early look at the aligned workgroup's verdict
+constexpr int kCapVerdict = (1 << 24) >> ASG_X_CAPSHIFT;          // the epilogue's wait for it
+constexpr unsigned kClosedWithoutAligned = 3u;                    // UttSync::adone: the full workgroups gave up waiting
 constexpr int kFusedThreads = 512;   // 8 wavefronts: two per SIMD, 256 VGPRs each (the consumers keep 72 of double accumulators)
 constexpr unsigned kSc1 = 16;   // buffer load/store aux bit: agent scope (served by / written through to L2)
 
@@ -266,7 +279,7 @@ __device__ __forceinline__ bool wait_ge(int *p, int need, const Ctl &c) {
     int spins = 0;
     while (lds_load_rlx(p) < need) {
         if (c.stop()) return false;
-        if (++spins > kSpinCap) { c.abort(1); return false; }
+        if (++spins > kCapLds) { c.abort(1); return false; }
         __builtin_amdgcn_s_sleep(6);
     }
     asm volatile("" ::: "memory");
@@ -279,7 +292,7 @@ __device__ __forceinline__ bool wait_finished(int need, const Ctl &c) {
     int spins = 0;
     while (c.L->finished() < need) {
         if (c.stop()) return false;
-        if (++spins > kSpinCap) { c.abort(2); return false; }
+        if (++spins > kCapLds) { c.abort(2); return false; }
         __builtin_amdgcn_s_sleep(6);
     }
     asm volatile("" ::: "memory");
@@ -342,7 +355,7 @@ __device__ __forceinline__ bool wait_global_ge(unsigned *p, unsigned need, unsig
         if (seen >= need) break;
         if (c.stop()) return false;
         if (c.killed_elsewhere()) { c.abort(12); return false; }
-        if (++spins > (kSpinCap >> 4)) { c.abort(3); return false; }
+        if (++spins > kCapGlobal) { c.abort(3); return false; }
         __builtin_amdgcn_s_sleep(16);
     }
     return true;
@@ -366,7 +379,7 @@ __device__ __forceinline__ void fused_main(const Problem &P, int b, FusedSide &L
         int spins = 0;
         while (__hip_atomic_load(tr_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < tr_need) {
             if (L.stop()) return;
-            if (++spins > kSpinCap) { ctl.abort(14); return; }
+            if (++spins > kCapLds) { ctl.abort(14); return; }
             __builtin_amdgcn_s_sleep(1);
         }
         asm volatile("" ::: "memory");
@@ -396,7 +409,7 @@ __device__ __forceinline__ void fused_main(const Problem &P, int b, FusedSide &L
             asm volatile("" ::: "memory");
             if (kl) return;
             if (ep >= need) break;
-            if (++spins > kSpinCap) { ctl.abort(4); return; }
+            if (++spins > kCapLds) { ctl.abort(4); return; }
             __builtin_amdgcn_s_sleep(1);
         })
         const int need_next = min(n0 + 2 * kPF, len);
@@ -469,7 +482,7 @@ __device__ __forceinline__ void fused_consumer(const Problem &P, const State &W,
             const R v = lds_ldf(slot);
             if (__ballot(__float_as_uint(v) != kSentinel) == ~0ull) return true;
             if (L.stop()) return false;
-            if (++spins > kSpinCap) { ctl.abort(5); return false; }
+            if (++spins > kCapLds) { ctl.abort(5); return false; }
             __builtin_amdgcn_s_sleep(3);          // ~1 recursion step: every poll is an LDS access the recursion waits behind
         }
     };
@@ -564,7 +577,7 @@ __device__ __forceinline__ void fused_consumer(const Problem &P, const State &W,
             int spins = 0;
             while (__ballot(__float_as_uint(lds_ldf(first)) != kSentinel) != ~0ull) {
                 if (L.stop()) return;
-                if (++spins > kSpinCap) { ctl.abort(13); return; }
+                if (++spins > kCapLds) { ctl.abort(13); return; }
                 __builtin_amdgcn_s_sleep(10);
             }
             __builtin_amdgcn_s_sleep(2 * (kGS - 2));
@@ -698,7 +711,7 @@ __device__ __forceinline__ void fused_consumer(const Problem &P, const State &W,
         int spins = 0;
         while (!(lds_load_acq(&L.main_done) && lds_load_acq(&L.prod_done))) {
             if (L.stop()) return;
-            if (++spins > kSpinCap) { ctl.abort(10); return; }
+            if (++spins > kCapLds) { ctl.abort(10); return; }
             __builtin_amdgcn_s_sleep(1);
         }
     }
@@ -1122,7 +1135,15 @@ __device__ __forceinline__ void aligned_workgroup(int b, FusedShared<NP> &SH) {
         // this workgroup left dirty there: measured 5-6 us, on the path of the full workgroups' epilogue).
         __hip_atomic_store((double *) F.ascore + b, SH.score_ali, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(&us->adone, gave_up ? 2u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned expect = 0u;
+        if (!__hip_atomic_compare_exchange_strong(&us->adone, &expect, gave_up ? 2u : 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                  __HIP_MEMORY_SCOPE_AGENT)) {
+            // the full workgroups closed this utterance without us (kClosedWithoutAligned): whatever this workgroup left in
+            // the utterance's words goes back to zero, the claim last
+            unsigned *w = reinterpret_cast<unsigned *>(us);
+            for (int k = (int) (sizeof(UttSync) / sizeof(unsigned)) - 1; k >= 0; --k)
+                __hip_atomic_store(w + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
 #ifdef ASG_PROBE
         if (b == 0) ((long long *) ld_state(kernarg_params()).dbg)[55] = clock64();
 #endif
@@ -1226,7 +1247,7 @@ __device__ __forceinline__ void full_workgroup(int b, FusedShared<NP> &SH) {
                 unsigned v = 0;
                 int spins = 0;
                 while ((v = __hip_atomic_load(&us->adone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
-                    if (L.stop() || ++spins > (1 << 18)) break;
+                    if (L.stop() || ++spins > kCapVerdictEarly) break;
                     __builtin_amdgcn_s_sleep(32);
                 }
                 v = __builtin_amdgcn_readfirstlane(v);
@@ -1275,7 +1296,18 @@ __device__ __forceinline__ void full_workgroup(int b, FusedShared<NP> &SH) {
             unsigned v = 0;
             int spins = 0;
             while ((v = __hip_atomic_load(&us->adone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
-                if (++spins > (1 << 24)) { v = 3; break; }       // cannot happen: that workgroup waits for nobody
+                if (++spins > kCapVerdict) {
+                    // The aligned workgroup has not reported (it waits for nobody, so it has not been scheduled yet: a grid
+                    // larger than the device, a co-running kernel).  Give up on it -- the utterance is flagged and redone
+                    // exactly by the backward launch -- but CLAIM the word first: if the claim fails the verdict arrived
+                    // after all; if it succeeds the aligned workgroup will find the claim when it finally runs and
+                    // clears it itself (it is then the last one to touch this utterance's words).
+                    unsigned expect = 0u;
+                    v = __hip_atomic_compare_exchange_strong(&us->adone, &expect, kClosedWithoutAligned, __ATOMIC_RELAXED,
+                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                            ? kClosedWithoutAligned : expect;
+                    break;
+                }
                 __builtin_amdgcn_s_sleep(4);
             }
             SH.adone = (int) v;
@@ -1377,8 +1409,9 @@ __device__ __forceinline__ void full_workgroup(int b, FusedShared<NP> &SH) {
             if (!flagged) ((R *) F.scores)[P.B + b] = ali;
             __hip_atomic_store(F.flags + b, flagged ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // the cross-workgroup words of this utterance go back to zero (all three workgroups are done with them)
+            // (word 0 = adone stays when it holds the claim of a time-out: the aligned workgroup clears it when it runs)
             unsigned *w = reinterpret_cast<unsigned *>(us);
-            for (int k = 0; k < (int) (sizeof(UttSync) / sizeof(unsigned)); ++k)
+            for (int k = SH.adone == (int) kClosedWithoutAligned ? 1 : 0; k < (int) (sizeof(UttSync) / sizeof(unsigned)); ++k)
                 __hip_atomic_store(w + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         // the last utterance to close (fixed order inside): reduces the loss over the batch and counts the flagged
@@ -1421,8 +1454,19 @@ __global__ void __launch_bounds__(kFusedThreads, 2) fused_fwd_kernel(FusedParams
     __shared__ FusedShared<NP> SH;
     const int B = kernarg_params()->P.B;
     const int G = (int) blockIdx.x / 48, w = (int) blockIdx.x - 48 * G;
-    const int j = w >= 24 ? 1 : 0, role = (w - 24 * j) >> 3, b = 16 * G + 2 * (w & 7) + j;
+    const int j = w >= 24 ? 1 : 0, role = (w - 24 * j) >> 3;
+#ifdef ASG_X_SPREAD_XCD
+    const int b = 16 * G + 2 * ((w - 3 * role) & 7) + j;      // roles 0, 1, 2 of an utterance on XCDs x, x + 3, x + 6 (mod 8)
+#else
+    const int b = 16 * G + 2 * (w & 7) + j;
+#endif
     if (b >= B) return;
+#ifdef ASG_X_TEST_DELAY
+    if ((b == 1 && role == 0) || (b == 2 && role == 1)) {
+        if (threadIdx.x == 0) for (int q = 0; q < ASG_X_TEST_DELAY; ++q) __builtin_amdgcn_s_sleep(127);
+        __syncthreads();
+    }
+#endif
 #ifdef ASG_PROBE_XCC
     if (threadIdx.x == 0 && b < 16) {
         unsigned xcc;

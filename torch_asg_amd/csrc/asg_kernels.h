@@ -104,7 +104,7 @@ enum ChainBits { kFullAlpha = 1, kFullBeta = 2, kAlignedAlpha = 4, kAlignedBeta 
 // chain_mask selects which of the four recursions this launch runs.
 template <typename R>
 hipError_t launch_fwd_small(const Problem &P, const State &W, const FwdOut &O, int chain_mask, bool store,
-                            int matvec_variant, hipStream_t stream);
+                            hipStream_t stream);
 template <typename R>
 hipError_t launch_bwd_small(const Problem &P, const State &W, const BwdArgs &A, int parts, hipStream_t stream);
 hipError_t launch_fused_forward(const Problem &P, const State &W, const FusedArgs &F, hipStream_t stream);

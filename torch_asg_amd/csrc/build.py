@@ -66,7 +66,47 @@ def build(force=False, verbose=False, defines=(), out=None):
     return OUT
 
 
+# Developer variants of the library that the GPU test-suite loads through ASG_HIP_LIB (tests/test_hip_variants.py):
+# only asg_fused.hip differs, every other object is the shipped one.
+VARIANTS = {
+    "spread": ["ASG_X_SPREAD_XCD"],
+    "delay": ["ASG_X_TEST_DELAY=60000", "ASG_X_CAPSHIFT=7"],
+}
+VAR_DIR = os.path.join(HERE, "var_libs")
+
+
+def build_variants(force=False, verbose=False):
+    """var_libs/libasg_hip_<name>.so for every entry of VARIANTS (git-ignored; they travel to the GPU box)."""
+    build(force=False, verbose=verbose)
+    os.makedirs(VAR_DIR, exist_ok=True)
+    src = os.path.join(HERE, "asg_fused.hip")
+    newest = max([_mtime(src), _mtime(__file__)] + [_mtime(os.path.join(HERE, h)) for h in HEADERS])
+    procs = []
+    for name, defs in VARIANTS.items():
+        obj = os.path.join(VAR_DIR, "asg_fused_%s.o" % name)
+        if force or _mtime(obj) < newest:
+            cmd = [HIPCC] + CFLAGS + ["-D" + d for d in defs] + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((name, subprocess.Popen(cmd, stderr=None if verbose else subprocess.DEVNULL)))
+    for name, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("hipcc failed on variant %s" % name)
+    outs = []
+    for name in VARIANTS:
+        out = os.path.join(VAR_DIR, "libasg_hip_%s.so" % name)
+        objs = [os.path.join(HERE, s_.replace(".hip", ".o")) for s_ in SOURCES if s_ != "asg_fused.hip"]
+        objs.append(os.path.join(VAR_DIR, "asg_fused_%s.o" % name))
+        if force or _mtime(out) < max(_mtime(o) for o in objs):
+            subprocess.check_call([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", out] + objs)
+        outs.append(out)
+    return outs
+
+
 if __name__ == "__main__":
+    if "--variants" in sys.argv:
+        print("\n".join(build_variants(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv)))
+        sys.exit(0)
     if "--define" in sys.argv:
         i = sys.argv.index("--define")
         defs = sys.argv[i + 1].split(",")
