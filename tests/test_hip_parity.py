@@ -870,3 +870,27 @@ def test_bf16_emissions_fp32_accumulate():
     assert xd.grad.dtype == torch.bfloat16
     util.assert_close(xd.grad.float().cpu().numpy(), o["grad_inputs"], 2.0 ** -8, "bf16 grad_inputs (widened route)")
     util.assert_close(m.transition.grad.cpu().numpy(), o["grad_transition"], 1e-4, "bf16 grad_transition (widened route)")
+
+
+@pytest.mark.gpu
+def test_generic_one_launch_forward_equals_per_frame_launches(monkeypatch):
+    """ASG_PERSIST=1 runs all T-1 frames of the large-alphabet recursion in ONE cooperative launch (a grid barrier per
+    direction between frames, write-through hand-offs); results must be bit-identical to the T-1 launches."""
+    T, B, N, L = 40, 5, 300, 9
+    tr, x, tg, il, tl = util.synth(T, B, N, L, 11, True)
+    outs = []
+    for env in ("0", "1"):
+        monkeypatch.setenv("ASG_PERSIST", env)
+        m = _asg().ASGLoss(N, reduction="sum").to(DEV)
+        with torch.no_grad():
+            m.transition.copy_(tr)
+        xd = x.to(DEV).requires_grad_(True)
+        loss = m(xd, tg.to(DEV), il.to(DEV), tl.to(DEV))
+        loss.backward()
+        torch.cuda.synchronize()
+        outs.append((loss.detach().cpu(), xd.grad.cpu(), m.transition.grad.cpu()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il.numpy(), tl.numpy(), "sum")
+    ok, e = util.tol_ok(outs[1][0].numpy(), o["loss"], 1e-4)
+    assert ok, e

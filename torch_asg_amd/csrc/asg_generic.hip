@@ -15,6 +15,8 @@
 //    neighbour exchange through LDS; gradient kernel per (utterance, frame-chunk).
 //
 // VALU only (no MFMA), fp32 or fp64.  Not tuned to the level of the small path; see DESIGN.md.
+#include <cstdio>
+#include <cstdlib>
 #include "asg_common.h"
 #include "asg_kernels.h"
 
@@ -369,7 +371,13 @@ __global__ void __launch_bounds__(256) tile_kernel(const float *src, int N, int 
     }
 }
 
-template <bool BETA>
+// PERSIST: the frame is one iteration of fwd_persist_kernel -- what another workgroup reads in the next frame (the
+// vectors, the log-domain state the rare exact path falls back on) is stored write-through (agent scope), so the grid
+// barrier between frames needs no L2 write-back.
+#ifndef ASG_X_PERSIST_SKEW
+#define ASG_X_PERSIST_SKEW 7000      // 100 MHz ticks the second direction starts late (about half a frame at cfg 5)
+#endif
+template <bool BETA, bool PERSIST>
 __device__ __forceinline__ void fwd_step_mfma(const Problem &P, const StepBuf<float> &S, int n) {
     typedef float R;
     constexpr int MB = kStepMB;
@@ -403,7 +411,11 @@ __device__ __forceinline__ void fwd_step_mfma(const Problem &P, const StepBuf<fl
                 st.a[h] = *reinterpret_cast<const V4f *>(va + 32 * c + 4 * h);
                 st.b[h] = *reinterpret_cast<const V4f *>(vb + 32 * c + 4 * h);
 #pragma unroll
-                for (int m = 0; m < MB; ++m) st.e[m][h] = et[((size_t) c * MB * 2 + m * 2 + h) * 64];
+                for (int m = 0; m < MB; ++m) {
+                    // (non-temporal: every element of the matrix is used once per frame, and the lines it would displace in
+                    // L2 are the batch's vectors that all workgroups of the XCD read: 144.4 -> 137.9 us per frame at cfg 5)
+                    st.e[m][h] = __builtin_nontemporal_load(&et[((size_t) c * MB * 2 + m * 2 + h) * 64]);
+                }
             }
         };
         auto multiply = [&](const Stage &st) {
@@ -506,13 +518,25 @@ __device__ __forceinline__ void fwd_step_mfma(const Problem &P, const StepBuf<fl
         R stv, q;
         if (BETA) { stv = rr - muprev; q = emis + stv; }
         else { stv = emis + rr - muprev; q = stv; }
-        S.state[((int64_t) b * T + tw) * N + i] = stv;
-        pnext[(int64_t) b * npad + i] = Num<R>::exp2(q);
+        if (PERSIST) {
+            __hip_atomic_store(&S.state[((int64_t) b * T + tw) * N + i], stv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&pnext[(int64_t) b * npad + i], Num<R>::exp2(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            S.state[((int64_t) b * T + tw) * N + i] = stv;
+            pnext[(int64_t) b * npad + i] = Num<R>::exp2(q);
+        }
         qkey = fmaxf(qkey, (float) q);
         if (i == 0) {
-            S.off[b] += (double) muprev + (double) emw;
-            S.mu[((n + 2) % 3) * B + b] = fkey(-__builtin_inff());
-            if (!BETA && S.mulog) S.mulog[(int64_t) tw * B + b] = muprev;
+            if (PERSIST) {
+                // (nothing stays dirty in this XCD's L2: the other workgroups' atomics on `mu` execute behind it)
+                __hip_atomic_store(&S.off[b], S.off[b] + ((double) muprev + (double) emw), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&S.mu[((n + 2) % 3) * B + b], fkey(-__builtin_inff()), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!BETA && S.mulog) __hip_atomic_store(&S.mulog[(int64_t) tw * B + b], muprev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                S.off[b] += (double) muprev + (double) emw;
+                S.mu[((n + 2) % 3) * B + b] = fkey(-__builtin_inff());
+                if (!BETA && S.mulog) S.mulog[(int64_t) tw * B + b] = muprev;
+            }
         }
     }
     // one atomic per utterance and workgroup at most (max is order-independent: deterministic), and only if it can
@@ -537,11 +561,73 @@ template <> struct StepUsesMfma<float> { static constexpr bool v = true; };
 template <typename R>
 __global__ void __launch_bounds__(256) fwd_step_kernel(Problem P, StepBuf<R> Sa, StepBuf<R> Sb, int n, int dir_base) {
     if constexpr (StepUsesMfma<R>::v) {
-        if ((int) blockIdx.z + dir_base == 0) fwd_step_mfma<false>(P, Sa, n);
-        else fwd_step_mfma<true>(P, Sb, n);
+        if ((int) blockIdx.z + dir_base == 0) fwd_step_mfma<false, false>(P, Sa, n);
+        else fwd_step_mfma<true, false>(P, Sb, n);
     } else {
         if ((int) blockIdx.z + dir_base == 0) fwd_step_body<R, false>(P, Sa, n);
         else fwd_step_body<R, true>(P, Sb, n);
+    }
+}
+
+// All T-1 frames in ONE cooperative launch (fp32): every workgroup keeps its tile of rows and walks the frames, with a
+// grid barrier PER DIRECTION between frames (the alpha and the beta recursion are independent chains: while the
+// workgroups of one direction finish a frame -- reduction, logarithms, stores, barrier -- those of the other keep the
+// transition-matrix stream running, where T-1 separate launches drained and refilled the whole memory pipeline 1999
+// times).  bar[16 dir]: arrival counter of the direction, zero on entry.  Cross-workgroup data of a frame is stored
+// write-through (fwd_step_mfma<.., true>), so the barrier is: stores drained (the workgroup barrier), one arrival
+// atomic, a spin on the counter, an L1 / L2 invalidate for the vectors the next frame reads.
+__global__ void __launch_bounds__(256) fwd_persist_kernel(Problem P, StepBuf<float> Sa, StepBuf<float> Sb, int dir_base, int nsteps,
+                                                          unsigned *bar) {
+    const int dir = (int) blockIdx.z + dir_base;
+    const unsigned nwg = gridDim.x * gridDim.y;
+    // Barrier of one direction, two levels: same-address atomics from different XCDs execute one after the other at the
+    // memory side (~50 ns each: 125 arrivals on one word cost more than the launch they replace), so a workgroup arrives
+    // at the word of its XCD (a cache line of its own) and the last one there arrives at the direction's word.
+    //   bar[(dir * 32 + k) * 16], k = 0: arrivals of whole XCDs; k = 1 + xcc: arrivals of the workgroups on that XCD;
+    //   k = 9 + xcc: how many workgroups of this direction the XCD got (counted once, before the first frame); k = 17: that count's barrier
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 7u;
+    unsigned *top = bar + (dir * 32) * 16, *mine = bar + (dir * 32 + 1 + xcc) * 16, *members = bar + (dir * 32 + 9 + xcc) * 16;
+    unsigned *flat = bar + (dir * 32 + 17) * 16;
+    constexpr int kSpinMax = 1 << 24;          // (a barrier that cannot complete gives up instead of hanging the device)
+    __shared__ unsigned sh_members, sh_groups;
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(members, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(flat, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int spins = 0; __hip_atomic_load(flat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nwg && spins < kSpinMax; ++spins)
+            __builtin_amdgcn_s_sleep(8);
+        unsigned groups = 0;
+        for (int k = 0; k < 8; ++k)
+            groups += __hip_atomic_load(bar + (dir * 32 + 9 + k) * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ? 1u : 0u;
+        sh_members = __hip_atomic_load(members, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sh_groups = groups;
+        // the two directions half a frame apart: one streams the matrix while the other is between frames
+        if (dir != dir_base) {
+            const unsigned long long t0 = wall_clock64();
+            while (wall_clock64() - t0 < (unsigned long long) ASG_X_PERSIST_SKEW) __builtin_amdgcn_s_sleep(64);
+        }
+    }
+    __syncthreads();
+    const unsigned msize = sh_members, ngroups = sh_groups;
+    for (int n = 0; n < nsteps; ++n) {
+        if (dir == 0) fwd_step_mfma<false, true>(P, Sa, n);
+        else fwd_step_mfma<true, true>(P, Sb, n);
+        if (n + 1 == nsteps) break;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wavefront's stores of the frame have been acknowledged
+        __syncthreads();
+#ifdef ASG_X_NOBARRIER
+        continue;       // (developer timing: how fast do the frames stream with nothing between them?  results are wrong)
+#endif
+        if (threadIdx.x == 0) {
+            const unsigned before = __hip_atomic_fetch_add(mine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (before + 1 == msize * (unsigned) (n + 1)) __hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned target = ngroups * (unsigned) (n + 1);
+            for (int spins = 0; __hip_atomic_load(top, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && spins < kSpinMax; ++spins)
+                __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
     }
 }
 
@@ -693,18 +779,23 @@ __global__ void __launch_bounds__(1024) aligned_wide_kernel(Problem P, State W, 
 // so the row sum against Pm = exp2(ah[t-1] - mp) is  exp2(lambda),  lambda = ah[t][i] - x2[t][i] + emax[t] + mu[t] - hmax[i] - mp:
 // five loads and an exp2 per element instead of a [N x N] x [N x BT] contraction (102 ms of cfg 5's 507).  Rows whose
 // sum is outside 2^+-100 are marked for bwd_fix_kernel exactly as the contraction's epilogue marked them.
+// rowoff (fp32 route): the rows of Pm / Gm are COMPACTED -- only frames 1 .. len-1 of every utterance carry a
+// transition (frame 0 has no predecessor, frames >= len are padding: both would be rows of zeros in the contraction over
+// the frame axis), row of (b, t) = rowoff[b] + t - 1, rowoff[B] = number of rows = the contraction's K (rowoff_kernel).
 template <typename R, bool DIRECT>
 __global__ void __launch_bounds__(256) bwd_post_kernel(Problem P, State W, BwdArgs A, R *Pm, R *Gm, int npad, const R *emax,
-                                                       const R *mulog, int *anybad) {
+                                                       const R *mulog, int *anybad, const int *rowoff) {
     __shared__ R red[4];
     const int t = blockIdx.x, b = blockIdx.y, N = P.N, T = P.T;
     const int len = P.in_len ? gclampi(P.in_len[b], 0, T) : T;
     const R LZ = Num<R>::logzero();
     R *gin = (R *) A.grad_inputs + ((int64_t) t * P.B + b) * N;
-    R *pm = Pm + ((int64_t) b * T + t) * npad, *gm = Gm + ((int64_t) b * T + t) * npad;
+    const int64_t row = rowoff ? (int64_t) rowoff[b] + t - 1 : (int64_t) b * T + t;
+    const bool has_row = !rowoff || (t >= 1 && t < len);
+    R *pm = Pm + row * npad, *gm = Gm + row * npad;
     if (t >= len) {
         for (int i = threadIdx.x; i < N; i += 256) gin[i] = 0;
-        for (int i = threadIdx.x; i < npad; i += 256) { pm[i] = 0; gm[i] = 0; }
+        if (has_row) for (int i = threadIdx.x; i < npad; i += 256) { pm[i] = 0; gm[i] = 0; }
         return;
     }
     const R gf = (R) ((double) ((const R *) A.grad_full)[(int64_t) b * A.gstride] * A.gscale);
@@ -728,6 +819,7 @@ __global__ void __launch_bounds__(256) bwd_post_kernel(Problem P, State W, BwdAr
             gin[i] = g;
             if (t >= 1) pv = Num<R>::exp2(ah[i - N] - mp);
         }
+        if (!has_row) continue;
         pm[i] = pv;
         if (DIRECT) {
             R u = 0;
@@ -743,6 +835,26 @@ __global__ void __launch_bounds__(256) bwd_post_kernel(Problem P, State W, BwdAr
             gm[i] = (t >= 1) ? g : R(0);
         }
     }
+}
+
+// rowoff[b] = sum over b' < b of max(len_b' - 1, 0), rowoff[B] = the total.  One wavefront, utterances in chunks of 64
+// (wave prefix sums by DPP-free shuffles: B is small next to T * N).
+__global__ void __launch_bounds__(64) rowoff_kernel(Problem P, int *rowoff) {
+    const int lane = threadIdx.x, T = P.T, B = P.B;
+    int base = 0;
+    for (int b0 = 0; b0 < B; b0 += 64) {
+        const int b = b0 + lane;
+        const int len = b < B ? (P.in_len ? gclampi(P.in_len[b], 0, T) : T) : 0;
+        int v = len > 1 ? len - 1 : 0;
+        int incl = v;
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        if (b < B) rowoff[b] = base + incl - v;
+        base += __shfl(incl, 63);
+    }
+    if (lane == 0) rowoff[B] = base;
 }
 
 // LDS-tiled product C[m][n] = sum_k A(m,k) * B(k,n), 64x64 tile, 4x4 per thread, BK = 16.
@@ -822,8 +934,9 @@ __global__ void __launch_bounds__(256) bwd_gemm_kernel(const R *ehat, const R *P
 // flight.  Operands come out of LDS in the MFMA's own order: A[m = l & 15][k = l >> 4] = As[k][m], B likewise.
 template <int MODE>
 __global__ void __launch_bounds__(256) bwd_gemm_mfma(const float *ehat, const float *Pm, float *Gm, float *out, int N, int npad,
-                                                     int K, int *anybad) {
+                                                     int K, int *anybad, const int *kdev) {
     typedef float R;
+    if (kdev) K = __builtin_amdgcn_readfirstlane(*kdev);        // compacted rows: their number is known on the device only
     constexpr int BK = 16, TS = 128, LD = TS + 4;
     __shared__ __attribute__((aligned(16))) R As[BK][LD];
     __shared__ __attribute__((aligned(16))) R Bs[BK][LD];
@@ -920,13 +1033,14 @@ __global__ void __launch_bounds__(256) bwd_gemm_mfma(const float *ehat, const fl
 // path uses a float atomicAdd: it only runs for degenerate inputs (transition spans > 69 nats) and is the one
 // place whose summation ORDER is not fixed.
 template <typename R>
-__global__ void __launch_bounds__(256) bwd_fix_kernel(Problem P, State W, BwdArgs A, R *Gm, R *out, int npad, const int *anybad) {
+__global__ void __launch_bounds__(256) bwd_fix_kernel(Problem P, State W, BwdArgs A, R *Gm, R *out, int npad, const int *anybad,
+                                                      const int *rowoff) {
     __shared__ R red[4];
     if (!*anybad) return;
     const int t = blockIdx.x, b = blockIdx.y, N = P.N, T = P.T;
     const int len = P.in_len ? gclampi(P.in_len[b], 0, T) : T;
     if (t < 1 || t >= len) return;
-    R *gm = Gm + ((int64_t) b * T + t) * npad;
+    R *gm = Gm + (rowoff ? (int64_t) rowoff[b] + t - 1 : (int64_t) b * T + t) * npad;
     const R *ah = (const R *) W.ah + ((int64_t) b * T + t) * N;
     const R *bh = (const R *) W.bh + ((int64_t) b * T + t) * N;
     const R *ahp = ah - N;
@@ -1150,7 +1264,7 @@ size_t step_tile_bytes_generic(int elem, int N) {
 size_t fwd_work_bytes_generic(int elem, int T, int B, int N) {
     const size_t npad = (size_t) (N + 3) / 4 * 4;
     return au((size_t) T * B * elem) + 2 * au(2 * (size_t) B * npad * elem) + 2 * au(3 * (size_t) B * 4) + 2 * au((size_t) B * 8) +
-           au((size_t) T * B * elem);
+           au((size_t) T * B * elem) + 4096;
 }
 // offset of the alpha pass's per-frame normaliser log inside the work area (its last member)
 static size_t work_mulog_offset(size_t elem, int T, int B, int npad) {
@@ -1176,7 +1290,10 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
         R *emax = (R *) wk; wk += au((size_t) P.T * P.B * e);
         hipLaunchKernelGGL((emax_kernel<R>), dim3(P.T, P.B), dim3(256), 0, stream, P, emax);
         // the p vectors are npad wide: their pad columns must be (and stay) zero
+        // (... and the arrival counters of the one-launch route, at the very end of the work area)
+        char *bar_area = (char *) W.work + fwd_work_bytes_generic((int) e, P.T, P.B, P.N) - 4096;
         (void) hipMemsetAsync(wk, 0, 2 * (au(2 * (size_t) P.B * W.npad * e) + au(3 * (size_t) P.B * 4) + au((size_t) P.B * 8)), stream);
+        (void) hipMemsetAsync(bar_area, 0, 4096, stream);
         StepBuf<R> Sd[2];
         for (int dir = 0; dir < 2; ++dir) {
             StepBuf<R> S{};
@@ -1198,8 +1315,32 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
         if (do_b) hipLaunchKernelGGL((fwd_init_kernel<R, true>), dim3(P.B), dim3(256), 0, stream, P, Sd[1]);
         const int srows = StepUsesMfma<R>::v ? 16 * kStepMB : 64;
         dim3 sgrid((P.N + srows - 1) / srows, (P.B + 31) / 32, (do_a && do_b) ? 2 : 1);
-        for (int n = 0; n + 1 < P.T; ++n)
-            hipLaunchKernelGGL((fwd_step_kernel<R>), sgrid, dim3(256), 0, stream, P, Sd[0], Sd[1], n, do_a ? 0 : 1);
+        bool stepped = false;
+        if constexpr (StepUsesMfma<R>::v) {
+            // ASG_PERSIST=1: one cooperative launch when every workgroup fits on the device at once (the runtime refuses
+            // otherwise) and the stream is not being captured.  Measured at cfg 5 (tools/run_cfg5_var.sh): 145.0-145.5 us per
+            // frame against 144.1 us with T-1 launches, whatever the barrier and the offset between the directions -- the
+            // frame is bound by the steady stream (5.5 TB/s = 88 % of what a copy kernel reaches), not by what happens between
+            // frames -- so the launches, which need no co-residency, stay the default.
+            const char *pe = getenv("ASG_PERSIST");
+            const bool persist = pe && atoi(pe) != 0;
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (persist) (void) hipStreamIsCapturing(stream, &cs);
+            if (persist && cs == hipStreamCaptureStatusNone && P.T >= 3) {
+                unsigned *bar = (unsigned *) bar_area;
+                Problem Pk = P;
+                StepBuf<float> A0 = Sd[0], B0 = Sd[1];
+                int dir_base = do_a ? 0 : 1, nsteps = P.T - 1;
+                void *args[] = {&Pk, &A0, &B0, &dir_base, &nsteps, &bar};
+                const hipError_t ce = hipLaunchCooperativeKernel((const void *) fwd_persist_kernel, sgrid, dim3(256), args, 0, stream);
+                if (ce == hipSuccess) stepped = true;
+                else (void) hipGetLastError();          // too large for one wave of workgroups: fall back
+                if (getenv("ASG_DBG_PERSIST")) fprintf(stderr, "[asg] cooperative forward launch: %s (grid %u x %u x %u)\n", hipGetErrorString(ce), sgrid.x, sgrid.y, sgrid.z);
+            }
+        }
+        if (!stepped)
+            for (int n = 0; n + 1 < P.T; ++n)
+                hipLaunchKernelGGL((fwd_step_kernel<R>), sgrid, dim3(256), 0, stream, P, Sd[0], Sd[1], n, do_a ? 0 : 1);
         if (do_b)
             hipLaunchKernelGGL((fwd_score_kernel<R, true>), dim3(P.B), dim3(256), 0, stream, P, Sd[1], (R *) O.full_scores);
         if (do_a && O.full_scores_alpha)
@@ -1224,7 +1365,7 @@ size_t bwd_scratch_bytes_generic(int elem, int T, int B, int N, int S) {
     const size_t npad = (size_t) (N + 3) / 4 * 4;
     int ch, nch;
     generic_chunks(T, B, &ch, &nch);
-    return 2 * au((size_t) B * T * npad * elem) + au((size_t) B * nch * 2 * S * elem) + 512;
+    return 2 * au((size_t) B * T * npad * elem) + au((size_t) B * nch * 2 * S * elem) + 512 + au(((size_t) B + 1) * 4);
 }
 
 template <typename R>
@@ -1237,7 +1378,8 @@ hipError_t launch_bwd_generic(const Problem &P, const State &W, const BwdArgs &A
     R *Pm = (R *) sc; sc += au((size_t) P.B * P.T * npad * e);
     R *Gm = (R *) sc; sc += au((size_t) P.B * P.T * npad * e);
     R *gHD = (R *) sc; sc += au((size_t) P.B * A.nchunks * 2 * P.S * e);
-    int *anybad = (int *) sc;
+    int *anybad = (int *) sc; sc += 512;
+    int *rowoff = (int *) sc;
     const bool do_full = parts & 1, do_ali = parts & 2, have_full = (parts & 5) != 0;
     R *gtr = (R *) A.grad_transition;
     if (do_full) {
@@ -1248,21 +1390,26 @@ hipError_t launch_bwd_generic(const Problem &P, const State &W, const BwdArgs &A
         const R *mulog = (const R *) ((const char *) W.work + work_mulog_offset(e, P.T, P.B, npad));
         if constexpr (StepUsesMfma<R>::v) {
             if (!W.work) return hipErrorInvalidValue;
-            hipLaunchKernelGGL((bwd_post_kernel<R, true>), dim3(P.T, P.B), dim3(256), 0, stream, P, W, A, Pm, Gm, npad, emax, mulog, anybad);
+            hipLaunchKernelGGL(rowoff_kernel, dim3(1), dim3(64), 0, stream, P, rowoff);
+            hipLaunchKernelGGL((bwd_post_kernel<R, true>), dim3(P.T, P.B), dim3(256), 0, stream, P, W, A, Pm, Gm, npad, emax, mulog, anybad,
+                               (const int *) rowoff);
         } else {
-            hipLaunchKernelGGL((bwd_post_kernel<R, false>), dim3(P.T, P.B), dim3(256), 0, stream, P, W, A, Pm, Gm, npad, emax, mulog, anybad);
+            hipLaunchKernelGGL((bwd_post_kernel<R, false>), dim3(P.T, P.B), dim3(256), 0, stream, P, W, A, Pm, Gm, npad, emax, mulog, anybad,
+                               (const int *) nullptr);
         }
         if constexpr (StepUsesMfma<R>::v) {
             // (no row-sum contraction: bwd_post_kernel<.., true> derived the row sums from the stored state)
             hipLaunchKernelGGL((bwd_gemm_mfma<1>), dim3((P.N + 127) / 128, (P.N + 127) / 128), dim3(256), 0, stream,
-                               (const float *) W.ehat, (const float *) Pm, (float *) Gm, (float *) gtr, P.N, npad, K, anybad);
+                               (const float *) W.ehat, (const float *) Pm, (float *) Gm, (float *) gtr, P.N, npad, K, anybad,
+                               (const int *) (rowoff + P.B));
         } else {
             hipLaunchKernelGGL((bwd_gemm_kernel<R, 0>), dim3((P.N + 63) / 64, (K + 63) / 64), dim3(256), 0, stream,
                                (const R *) W.ehat, Pm, Gm, gtr, P.N, npad, K, anybad);
             hipLaunchKernelGGL((bwd_gemm_kernel<R, 1>), dim3((P.N + 63) / 64, (P.N + 63) / 64), dim3(256), 0, stream,
                                (const R *) W.ehat, Pm, Gm, gtr, P.N, npad, K, anybad);
         }
-        hipLaunchKernelGGL((bwd_fix_kernel<R>), dim3(P.T, P.B), dim3(256), 0, stream, P, W, A, Gm, gtr, npad, anybad);
+        hipLaunchKernelGGL((bwd_fix_kernel<R>), dim3(P.T, P.B), dim3(256), 0, stream, P, W, A, Gm, gtr, npad, anybad,
+                           StepUsesMfma<R>::v ? (const int *) rowoff : (const int *) nullptr);
     }
     if (do_ali) {
         if (P.S > 1024) return hipErrorInvalidValue;
