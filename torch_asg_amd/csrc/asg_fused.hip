@@ -44,20 +44,11 @@ constexpr int kAR = 64;         // aligned chain -> finisher ring of aligned sta
 constexpr int kGS = 8;          // frames per poll of the consumers / finishers
 constexpr int kMinFused = 4;
 constexpr int kAF = 3;          // aligned finisher wavefronts per side (round-robin over 8-index groups)
-#ifndef ASG_X_ALIPRIO
-#define ASG_X_ALIPRIO 3
-#endif
-#ifndef ASG_X_P2_AUX
-#define ASG_X_P2_AUX 0
-#endif
-#ifndef ASG_X_NC
-#define ASG_X_NC 3
-#endif
 // consumer wavefronts per full workgroup (round-robin over 8-index groups of the second half): what the LDS holds
 constexpr int kMaxNC = 4;
 template <int NP> struct Consumers {          // each has a [16 NT][16 NT + 1] double tile beside the 64 KB of rings
     static constexpr int fit = NP <= 48 ? 4 : 2;
-    static constexpr int n = ASG_X_NC < fit ? ASG_X_NC : fit;
+    static constexpr int n = 3 < fit ? 3 : fit;
 };
 // Developer variants (tests/test_hip_variants.py builds them through build.py --define; the shipped library has neither):
 //   ASG_X_SPREAD_XCD     the three workgroups of an utterance on three DIFFERENT XCDs: every cross-workgroup hand-off
@@ -568,7 +559,6 @@ __device__ __forceinline__ void fused_consumer(const Problem &P, const State &W,
 #ifdef ASG_PROBE_TAIL
         long long tl[8]; tl[0] = clock64();
 #endif
-#ifndef ASG_X_FINEPOLL
         // every poll is an LDS access the recursion wavefront's broadcast reads queue behind, and kNC - 1 consumers are
         // waiting at any time: sleep in long steps until the group's FIRST row sum is there, then through most of the
         // seven recursion steps that follow, and only then poll closely
@@ -582,7 +572,6 @@ __device__ __forceinline__ void fused_consumer(const Problem &P, const State &W,
             }
             __builtin_amdgcn_s_sleep(2 * (kGS - 2));
         }
-#endif
         if (!wait_slot(n + g - 2)) return;
 #ifdef ASG_PROBE_TAIL
         tl[1] = clock64();
@@ -610,9 +599,6 @@ __device__ __forceinline__ void fused_consumer(const Problem &P, const State &W,
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the values are in registers before the producer may refill
         lds_store_rlx(&L.cd[cw], n + g - 1 + (kNC - 1) * kGS);
         if ((__ballot(lo < Rng<R>::lo || hi > Rng<R>::hi) & actmask) != 0) { ctl.abort(7); return; }
-#ifdef ASG_X_NOCONSUME
-        sv = sg[kGS - 1]; n += kNC * kGS; continue;      // developer experiment: how fast is the recursion left alone?
-#endif
         // a short last group re-processes its last frame in the unused positions (the block holds nothing there)
 #pragma unroll
         for (int q = 1; q < kGS; ++q) oth[q] = (q < g) ? oth[q] : oth[q - 1];
@@ -639,9 +625,7 @@ __device__ __forceinline__ void fused_consumer(const Problem &P, const State &W,
         R u[kGS];
         auto half_group = [&](const int q0) -> bool {
             R z0 = w[q0], z1 = w[q0 + 1], z2 = w[q0 + 2], z3 = w[q0 + 3];
-#ifndef ASG_X_NOSUM
             wave_allsum4(z0, z1, z2, z3);
-#endif
             const R Z[4] = {z0, z1, z2, z3};
             unsigned zlo = 0xffffffffu, zhi = 0;
 #pragma unroll
@@ -665,11 +649,7 @@ __device__ __forceinline__ void fused_consumer(const Problem &P, const State &W,
                 pg[q0 + q] = act ? pg[q0 + q] : R(0);
             }
             float ua[4] = {u[q0], u[q0 + 1], u[q0 + 2], u[q0 + 3]}, va[4] = {pg[q0], pg[q0 + 1], pg[q0 + 2], pg[q0 + 3]};
-#ifndef ASG_X_NOMFMA
             outer4_accumulate_f64<NT>(ua, va, acc);
-#else
-            acc[0][0] += (double) (ua[0] + va[1]);
-#endif
             return true;
         };
         if (!half_group(0)) { ctl.abort(8); return; }
@@ -817,9 +797,7 @@ __device__ __forceinline__ void fused_aligned(const Problem &P, const State &W, 
         // index m0-kAR+16
         const int m0 = 1 + done;
         ok = true;
-#ifndef ASG_X_NOFIN
         PRB_WAIT(0, ok = wait_finished(m0 + 17 - kAR, ctl);)
-#endif
         {
             const R m = wave_allmax((R) st);
             if (m > R(-1e29)) { st = fmax(st - (double) m, kLZd); C += (double) m; }
@@ -990,7 +968,6 @@ __device__ __forceinline__ void fused_afin(const Problem &P, const State &W, con
         // hundreds of frames of a lattice whose edge posteriors must cancel against the full lattice's (tiny alphabets)
         // that shows.  Renormalise every frame over the positions, as the reference's softmax does
         // (force_aligned_lattice.cpp:164-166); a sum far from 1 can only be an infeasible or underflowed frame: left alone.
-#ifndef ASG_X_NORENORM
         {
             R z0 = p2v[0], z1 = p2v[1], z2 = p2v[2], z3 = p2v[3];
             wave_allsum4(z0, z1, z2, z3);
@@ -1000,15 +977,14 @@ __device__ __forceinline__ void fused_afin(const Problem &P, const State &W, con
 #pragma unroll
             for (int q = 0; q < kGS; ++q) p2v[q] *= (Z[q] > R(0.99) && Z[q] < R(1.01)) ? R(2) - Z[q] : R(1);    // 1/Z to 1e-8
         }
-#endif
         {
             typedef unsigned u4 __attribute__((ext_vector_type(4)));
             const unsigned qoff = (unsigned) ((n - h) >> 2) * (unsigned) S * 16u;
             u4 a = {__float_as_uint(p2v[0]), __float_as_uint(p2v[1]), __float_as_uint(p2v[2]), __float_as_uint(p2v[3])};
             u4 c = {__float_as_uint(p2v[4]), __float_as_uint(p2v[5]), __float_as_uint(p2v[6]), __float_as_uint(p2v[7])};
             // (plain stores: nothing in THIS launch reads them)
-            __builtin_amdgcn_raw_buffer_store_b128(a, rp, vQ, qoff, ASG_X_P2_AUX);
-            if (g > 4) __builtin_amdgcn_raw_buffer_store_b128(c, rp, vQ, qoff + (unsigned) S * 16u, ASG_X_P2_AUX);
+            __builtin_amdgcn_raw_buffer_store_b128(a, rp, vQ, qoff, 0);
+            if (g > 4) __builtin_amdgcn_raw_buffer_store_b128(c, rp, vQ, qoff + (unsigned) S * 16u, 0);
         }
 #pragma unroll
         for (int q = 0; q < kGS; ++q) {
@@ -1091,22 +1067,20 @@ __device__ __forceinline__ void aligned_workgroup(int b, FusedShared<NP> &SH) {
         const FusedArgs F = ld_fargs(kernarg_params());
         switch (wave) {
             case 0:
-                __builtin_amdgcn_s_setprio(ASG_X_ALIPRIO);
+                __builtin_amdgcn_s_setprio(3);
                 if (P.in_bf16) fused_aligned<false, true>(P, W, b, LA, LB, len, mid, sc2, (double *) F.aoff + ((int64_t) b * 2 + 0) * ((T + kPF - 1) / kPF + 1) * 2, us);
                 else fused_aligned<false, false>(P, W, b, LA, LB, len, mid, sc2, (double *) F.aoff + ((int64_t) b * 2 + 0) * ((T + kPF - 1) / kPF + 1) * 2, us);
                 break;
             case 1:
-                __builtin_amdgcn_s_setprio(ASG_X_ALIPRIO);
+                __builtin_amdgcn_s_setprio(3);
                 if (P.in_bf16) fused_aligned<true, true>(P, W, b, LB, LA, len, len - mid, sc2, (double *) F.aoff + ((int64_t) b * 2 + 1) * ((T + kPF - 1) / kPF + 1) * 2, us);
                 else fused_aligned<true, false>(P, W, b, LB, LA, len, len - mid, sc2, (double *) F.aoff + ((int64_t) b * 2 + 1) * ((T + kPF - 1) / kPF + 1) * 2, us);
                 break;
-#ifndef ASG_X_NOFIN
             // two finishers of a side on a SIMD of their own pair, the third beside the OTHER side's chain (which has priority)
             case 2: case 6: fused_afin<false>(P, W, F, b, LA, LB, len, mid, us, (wave - 2) >> 2); break;
             case 3: case 7: fused_afin<true>(P, W, F, b, LB, LA, len, len - mid, us, (wave - 3) >> 2); break;
             case 5: fused_afin<false>(P, W, F, b, LA, LB, len, mid, us, 2); break;
             case 4: fused_afin<true>(P, W, F, b, LB, LA, len, len - mid, us, 2); break;
-#endif
             default: break;
         }
         if (wave == 1 && lane == 0) SH.score_ali = sc2;
@@ -1232,16 +1206,8 @@ __device__ __forceinline__ void full_workgroup(int b, FusedShared<NP> &SH) {
             case 3: fused_consumer<NP, BETA>(P, W, F, b, L, us, len, h, TL.sx[1], sc2, 1); break;
             // (consumers on three SIMDs: the third beside the producer, which is light)
             case 5: if (kNC > 2) fused_consumer<NP, BETA>(P, W, F, b, L, us, len, h, TL.sx[2 % kNC], sc2, 2); break;
-#ifdef ASG_X_C4_ON_SIMD0
-            case 4: if (kNC > 3) fused_consumer<NP, BETA>(P, W, F, b, L, us, len, h, TL.sx[3 % kNC], sc2, 3); break;
-#else
             case 6: if (kNC > 3) fused_consumer<NP, BETA>(P, W, F, b, L, us, len, h, TL.sx[3 % kNC], sc2, 3); break;
-#endif
-#ifdef ASG_X_C4_ON_SIMD0
-            case 6: {
-#else
             case 4: {
-#endif
                 // the aligned workgroup's verdict and the edge posteriors of THIS side's frames (it finishes a little
                 // before the recursion does; slow polls beside the recursion wavefront)
                 unsigned v = 0;
@@ -1279,11 +1245,7 @@ __device__ __forceinline__ void full_workgroup(int b, FusedShared<NP> &SH) {
 #endif
     // LDS-only barrier: what the epilogue reads from the roles is in LDS; the consumers' last row stores (a microsecond or
     // two from acknowledgement) need not have landed -- nothing in this launch reads them
-#ifdef ASG_X_FULLBARRIER
-    __syncthreads();
-#else
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
 #ifdef ASG_PROBE
     if (b == 0 && !BETA && threadIdx.x == 0) ((long long *) ld_state(kernarg_params()).dbg)[52] = clock64();
 #endif
@@ -1332,11 +1294,7 @@ __device__ __forceinline__ void full_workgroup(int b, FusedShared<NP> &SH) {
         EdgeLds<NP> &EL = SH.u.e;
         for (int k = threadIdx.x; k < NP * NP; k += kFusedThreads) EL.fxT[k] = 0;
         __syncthreads();
-#ifdef ASG_X_C4_ON_SIMD0
-        if (wave == 6) {
-#else
         if (wave == 4) {
-#endif
             // aligned edge posteriors of THIS side's frames, scattered to [to][from]: with them the tile is a small
             // residual (full-lattice and aligned edge posteriors of the same frames nearly cancel for peaked lattices),
             // so the sum over tiles in the backward launch does not lose what the cancellation leaves
@@ -1488,14 +1446,8 @@ __global__ void __launch_bounds__(kFusedThreads, 2) fused_fwd_kernel(FusedParams
 //   workgroup kCH B + r:  once the redos have arrived, grad_transition[slice r] = sum_b g_b * (tile[b][alpha] + tile[b][beta])[slice r],
 //                      tiles in ascending order.
 constexpr int kBwdSlice = 64;
-#ifndef ASG_X_KCH
-#define ASG_X_KCH 8
-#endif
-#ifndef ASG_X_KQB
-#define ASG_X_KQB 4
-#endif
-constexpr int kCH = ASG_X_KCH;  // workgroups per utterance in the row pass
-constexpr int kQB = ASG_X_KQB;  // quads a wavefront has in flight
+constexpr int kCH = 8;     // workgroups per utterance in the row pass
+constexpr int kQB = 4;     // quads a wavefront has in flight
 template <int NP>
 __global__ void __launch_bounds__(256) fused_bwd_kernel(Problem P, State W, FusedArgs F) {
     typedef float R;
@@ -1646,14 +1598,16 @@ __global__ void __launch_bounds__(256) fused_bwd_kernel(Problem P, State W, Fuse
     const int k = min(r * kBwdSlice + lane, n2 - 1);
     const R *tiles = (const R *) F.tiles;
     const R *gl = (const R *) F.grad_loss;
-    // wave w sums tiles w, w+4, ... (two per utterance; 16 loads in flight), then a fixed-order combine over the four waves
-    R a[16];
+    // wave w sums tiles w, w+4, ... (two per utterance; 32 loads in flight: ONE memory round trip up to 64 utterances),
+    // then a fixed-order combine over the four waves
+    constexpr int kIF = 32;
+    R a[kIF];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) a[q] = 0;
+    for (int q = 0; q < kIF; ++q) a[q] = 0;
     const int NTILE = 2 * B;
-    for (int b0 = wave; b0 < NTILE; b0 += 64) {
+    for (int b0 = wave; b0 < NTILE; b0 += 4 * kIF) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
+        for (int q = 0; q < kIF; ++q) {
             const int bb = b0 + 4 * q;
             const int bc = min(bb, NTILE - 1);
             const R v = __hip_atomic_load(tiles + (int64_t) bc * n2 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1663,7 +1617,7 @@ __global__ void __launch_bounds__(256) fused_bwd_kernel(Problem P, State W, Fuse
     }
     R s = 0;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) s += a[q];
+    for (int q = 0; q < kIF; ++q) s += a[q];
     part[wave][lane] = s;
     __syncthreads();
     if (wave == 0 && r * kBwdSlice + lane < n2)
