@@ -345,6 +345,9 @@ def extras(args):
     attempt("cfg3_eval", lambda: time_small_config("cfg3", T, B, N, L, False, 100, eval_route=True))
     attempt("cfg3_eager", lambda: time_small_config("cfg3", T, B, N, L, False, 100, eager=True))
     attempt("cfg3_streams", lambda: time_small_config("cfg3, launch_mode=streams", T, B, N, L, False, 50, launch="streams"))
+    # not a BASELINE config: the shape letter-based speech models give the criterion (a few dozen labels, targets of
+    # hundreds of positions, ~10 s of frames) -- S > 64 leaves the fused step for the long-target kernels
+    attempt("long_targets", lambda: time_small_config("long targets (not a BASELINE config)", 1000, 64, 40, 200, True, 20))
     attempt("cfg5", lambda: measure_cfg5(3, 1))
     return ex
 

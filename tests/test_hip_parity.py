@@ -894,3 +894,36 @@ def test_generic_one_launch_forward_equals_per_frame_launches(monkeypatch):
     o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il.numpy(), tl.numpy(), "sum")
     ok, e = util.tol_ok(outs[1][0].numpy(), o["loss"], 1e-4)
     assert ok, e
+
+
+# ------------------------------------------------------------------ long targets over a small alphabet (letter models)
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,B,N,L", [(90, 3, 29, 65), (140, 2, 40, 128), (150, 3, 40, 129), (300, 2, 31, 200),
+                                       (280, 2, 64, 256), (330, 2, 8, 300), (520, 2, 40, 512), (600, 1, 5, 513)])
+@pytest.mark.parametrize("dtype,rtol", [(torch.float32, 1e-4), (torch.float64, 1e-9)])
+def test_long_targets_small_alphabet(T, B, N, L, dtype, rtol):
+    """64 < S <= 512 with N <= 64: one wavefront per aligned chain, 2 / 4 / 8 target positions per lane
+    (aligned_long_kernel), label scatter through fixed-point LDS rows (bwd_aligned_long_kernel); S = 513 takes the
+    one-position-per-thread kernels.  Small alphabets repeat labels all the time, lengths vary, one utterance is
+    infeasible when B >= 3."""
+    rng = np.random.default_rng(T + 7 * L)
+    tr, x, tg, _, _ = util.synth(T, B, N, L, L + N)
+    il = rng.integers(max(L, T // 2), T + 1, B)
+    tl = rng.integers(max(1, L - 70), L + 1, B)
+    tl[0] = L
+    if B >= 3:
+        il[2], tl[2] = 20, 40                       # target longer than the input: +inf loss, NaN-free gradients
+    red = ["mean", "sum", "none"][(T + N) % 3]
+    o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il, tl, "none")
+    r = run_hip(x, tg, tr, il, tl, "none", dtype)
+    for k in ("loss", "grad_inputs", "grad_transition"):
+        util.assert_close(r[k], o[k], rtol, "long targets T%d B%d N%d L%d %s" % (T, B, N, L, k))
+    assert not np.isnan(r["grad_inputs"]).any() and not np.isnan(r["grad_transition"]).any()
+    if B < 3:                                        # (a reduced loss of a batch with an infeasible utterance is +inf)
+        o2 = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il, tl, red)
+        r2 = run_hip(x, tg, tr, il, tl, red, dtype, gpu_no_stream_impl=True)     # FCC / FAC separately (asg.py:124-128)
+        for k in ("loss", "grad_inputs", "grad_transition"):
+            util.assert_close(r2[k], o2[k], rtol, "long targets serial T%d L%d %s" % (T, L, k))
+    # run-to-run determinism (integer scatter)
+    r3 = run_hip(x, tg, tr, il, tl, "none", dtype)
+    assert np.array_equal(r["grad_inputs"], r3["grad_inputs"]) and np.array_equal(r["grad_transition"], r3["grad_transition"])

@@ -660,6 +660,181 @@ __global__ void __launch_bounds__(256) fwd_score_kernel(Problem P, StepBuf<R> S,
     }
 }
 
+
+// ------------------------------------------------------------------ aligned lattice, long targets (64 < S <= 512)
+// grid = (B, 2), block = 64: ONE wavefront per chain, lane l owns the K CONSECUTIVE target positions K l .. K l + K - 1
+// (K = 2, 4, 8), so all but one neighbour of a frame's update sit in the lane's own registers and the last one comes
+// from the lane next door by DPP -- no LDS, no barrier (aligned_wide_kernel below pays one workgroup barrier per frame:
+// 428 ns per frame at S = 200 against ~120 here).  Same stored states, scores and side tables as aligned_wide_kernel;
+// force_aligned_lattice.cpp:84-154 is what both restate.
+template <typename R, int K, bool STORE>
+__global__ void __launch_bounds__(64) aligned_long_kernel(Problem P, State W, FwdOut O, int mask) {
+    constexpr int PF = K <= 4 ? 4 : 2;          // frames of emissions in flight ahead of the recursion
+    const int b = blockIdx.x;
+    const bool beta = (mask == kAlignedBeta) || (mask == (kAlignedAlpha | kAlignedBeta) && blockIdx.y == 1);
+    const int lane = threadIdx.x, S = P.S, T = P.T, N = P.N;
+    const R L2E = Num<R>::log2e(), LZ = Num<R>::logzero();
+    const int len = P.in_len ? gclampi(P.in_len[b], 0, T) : T;
+    const int ol = P.tg_len ? gclampi(P.tg_len[b], 0, S) : S;
+    const int64_t *tg = P.targets + (int64_t) b * P.gs0;
+    const R *tr = (const R *) P.transition;
+    const R *inb = (const R *) P.inputs + (int64_t) b * P.is1;
+    bool act[K];
+    unsigned eoff[K], soffv[K];                 // byte offsets: the label's emission inside a frame row; the position inside a state row
+    double H2[K], Dx[K];                        // stay edge; alpha: edge from the previous position, beta: edge to the next
+    // frames through buffer accesses: lane offset in a VGPR, frame offset in an SGPR (launch_fwd_generic checks that both
+    // fit 32 bits); stores of positions >= S go out of bounds = nowhere (no EXEC juggling per position)
+    __amdgpu_buffer_rsrc_t rin = make_rsrc((R *) inb, 0xffffffffu);
+    __amdgpu_buffer_rsrc_t rout = make_rsrc((R *) (beta ? W.bb : W.ab) + (int64_t) b * T * S, STORE ? (unsigned) ((int64_t) T * S * sizeof(R)) : 0u);
+    const unsigned frame_bytes = (unsigned) P.is0 * (unsigned) sizeof(R), row_bytes = (unsigned) S * (unsigned) sizeof(R);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int p = lane * K + k;
+        act[k] = p < ol;
+        const int cur = act[k] ? gclampi(tg[(int64_t) p * P.gs1], 0, N - 1) : 0;
+        const int prv = (act[k] && p >= 1) ? gclampi(tg[(int64_t) (p - 1) * P.gs1], 0, N - 1) : 0;
+        const int nxt = (p + 1 < ol) ? gclampi(tg[(int64_t) (p + 1) * P.gs1], 0, N - 1) : 0;
+        const R h2 = act[k] ? fmax(tr[(int64_t) cur * P.ts0 + (int64_t) cur * P.ts1] * L2E, LZ) : R(0);
+        const R dp = (act[k] && p >= 1) ? fmax(tr[(int64_t) cur * P.ts0 + (int64_t) prv * P.ts1] * L2E, LZ) : LZ;
+        const R dn = (p + 1 < ol) ? fmax(tr[(int64_t) nxt * P.ts0 + (int64_t) cur * P.ts1] * L2E, LZ) : LZ;
+        H2[k] = (double) h2;
+        Dx[k] = (double) (beta ? dn : dp);
+        eoff[k] = (unsigned) (cur * (int) P.is2) * (unsigned) sizeof(R);
+        soffv[k] = p < S ? (unsigned) p * (unsigned) sizeof(R) : kOobOffset;
+        if (STORE && !beta && p < S) {
+            V2<R> u = {h2, dp};
+            reinterpret_cast<V2<R> *>(W.asu)[(int64_t) b * S + p] = u;
+            int2 ii = {cur, prv};
+            reinterpret_cast<int2 *>(W.asi)[(int64_t) b * S + p] = ii;
+        }
+    }
+    R *score_out = (R *) (beta ? O.aligned_scores : O.aligned_scores_alpha);
+    if (len < 1 || ol < 1) {
+        if (lane == 0 && score_out) score_out[b] = Num<R>::ninf();
+        return;
+    }
+    const double kZ = -1e30, L2Ed = 1.4426950408889634;
+    auto lse2d = [&](double x, double y) {
+        const double m = fmax(x, y);
+        const R d = (R) (fmin(x, y) - m);
+        return m + (double) Num<R>::log2(R(1) + Num<R>::exp2(d));
+    };
+    auto st = [&](double x) { return (R) fmax(x, kZ); };
+    auto store_row = [&](int t, const double (&v)[K]) {
+        if (!STORE) return;
+        const unsigned so = (unsigned) __builtin_amdgcn_readfirstlane(t) * row_bytes;
+#pragma unroll
+        for (int k = 0; k < K; ++k) buf_store(st(v[k]), rout, soffv[k], so);
+    };
+    // frame f's emissions of this lane's labels (clamped frame index: the surplus loads of the last block are never used)
+    auto fetch = [&](int f, R (&e)[K]) {
+        const unsigned so = (unsigned) __builtin_amdgcn_readfirstlane(gclampi(f, 0, len - 1)) * frame_bytes;
+#pragma unroll
+        for (int k = 0; k < K; ++k) e[k] = buf_load<R>(rin, eoff[k], so);
+    };
+    double C = 0.0, v[K];
+    auto renorm = [&]() {
+        double mx = v[0];
+#pragma unroll
+        for (int k = 1; k < K; ++k) mx = fmax(mx, v[k]);
+        const R m = wave_allmax((R) mx);
+        if (m > R(-1e29)) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) v[k] = fmax(v[k] - (double) m, kZ);
+            C += (double) m;
+        }
+    };
+    R cur[PF][K], nxt[PF][K];
+    if (!beta) {
+        {
+            R e0[K];
+            fetch(0, e0);
+#pragma unroll
+            for (int k = 0; k < K; ++k) v[k] = (lane == 0 && k == 0 && act[0]) ? fmax((double) e0[0] * L2Ed, kZ) : kZ;
+        }
+        store_row(0, v);
+#pragma unroll
+        for (int u = 0; u < PF; ++u) fetch(1 + u, cur[u]);
+        for (int t0 = 1; t0 < len; t0 += PF) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) fetch(t0 + PF + u, nxt[u]);
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int t = t0 + u;
+                if (t < len) {
+                    const double left = prev_lane_or_zero<double>(v[K - 1]);
+                    const double lft = lane == 0 ? kZ : left;
+#pragma unroll
+                    for (int k = K - 1; k >= 0; --k) {
+                        const double em = act[k] ? (double) cur[u][k] * L2Ed : kZ;
+                        const double from = k == 0 ? lft : v[k - 1];
+                        v[k] = fmax(em + lse2d(v[k] + H2[k], from + Dx[k]), kZ);
+                    }
+                    if ((t & 15) == 0) renorm();
+                    store_row(t, v);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < PF; ++u)
+#pragma unroll
+                for (int k = 0; k < K; ++k) cur[u][k] = nxt[u][k];
+        }
+        if (score_out) {
+            const int pl = ol - 1;
+            double mine = v[0];
+#pragma unroll
+            for (int k = 1; k < K; ++k) mine = (pl % K == k) ? v[k] : mine;
+            const double last = __shfl(mine, pl / K);
+            if (lane == 0) {
+                const double sc = C + last;
+                score_out[b] = (sc < -1e29) ? Num<R>::ninf() : (R) (sc * kLn2);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < K; ++k) v[k] = (lane * K + k == ol - 1) ? 0.0 : kZ;
+        store_row(len - 1, v);
+        // step u of a block that starts at frame t0 consumes the emissions of frame t0 - u and writes frame t0 - u - 1
+#pragma unroll
+        for (int u = 0; u < PF; ++u) fetch(len - 1 - u, cur[u]);
+        for (int t0 = len - 1; t0 >= 1; t0 -= PF) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) fetch(t0 - PF - u, nxt[u]);
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int t = t0 - u;
+                if (t >= 1) {
+                    double y[K];
+#pragma unroll
+                    for (int k = 0; k < K; ++k) y[k] = fmax((act[k] ? (double) cur[u][k] * L2Ed : kZ) + v[k], kZ);
+                    const double right = next_lane_or_zero<double>(y[0]);
+                    const double rgt = lane == 63 ? kZ : right;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        const double to = k == K - 1 ? rgt : y[k + 1];
+                        v[k] = fmax(lse2d(y[k] + H2[k], to + Dx[k]), kZ);
+                    }
+                    if ((t & 15) == 0) renorm();
+                    store_row(t - 1, v);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < PF; ++u)
+#pragma unroll
+                for (int k = 0; k < K; ++k) cur[u][k] = nxt[u][k];
+        }
+        if (score_out) {
+            R e0[K];
+            fetch(0, e0);
+            if (lane == 0) {
+                const double em = act[0] ? (double) e0[0] * L2Ed : kZ;
+                const double sc = C + (em + v[0]);
+                score_out[b] = (sc < -1e29) ? Num<R>::ninf() : (R) (sc * kLn2);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ aligned lattice, wide targets
 // grid = (B, 2), block = 64 * ceil(S/64) (<= 1024).  blockIdx.y: 0 = alpha, 1 = beta.  Thread s owns target
 // position s; the neighbour's value travels through a double-buffered LDS row (one barrier per frame).
@@ -932,12 +1107,17 @@ __global__ void __launch_bounds__(256) bwd_gemm_kernel(const R *ehat, const R *P
 // The same two products on the matrix cores (fp32 only): 128 x 128 tile per workgroup, 64 x 64 per wavefront (4 x 4
 // blocks of v_mfma_f32_16x16x4_f32: exact fp32), BK = 16 staged global -> registers -> LDS with the next tile's loads in
 // flight.  Operands come out of LDS in the MFMA's own order: A[m = l & 15][k = l >> 4] = As[k][m], B likewise.
+#ifndef ASG_X_GEMM_BK
+#define ASG_X_GEMM_BK 32
+#endif
 template <int MODE>
 __global__ void __launch_bounds__(256) bwd_gemm_mfma(const float *ehat, const float *Pm, float *Gm, float *out, int N, int npad,
                                                      int K, int *anybad, const int *kdev) {
     typedef float R;
     if (kdev) K = __builtin_amdgcn_readfirstlane(*kdev);        // compacted rows: their number is known on the device only
-    constexpr int BK = 16, TS = 128, LD = TS + 4;
+    // BK = 32: one stage of global -> register -> LDS staging (and its two workgroup barriers) per 128 MFMAs of a
+    // wavefront; at BK = 16 the barriers and the LDS round trip took 29 % of the kernel (112 of 157 TFLOP/s)
+    constexpr int BK = ASG_X_GEMM_BK, TS = 128, LD = TS + 4, NST = BK * TS / 4 / 256;      // NST float4 per thread and operand
     __shared__ __attribute__((aligned(16))) R As[BK][LD];
     __shared__ __attribute__((aligned(16))) R Bs[BK][LD];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -955,7 +1135,7 @@ __global__ void __launch_bounds__(256) bwd_gemm_mfma(const float *ehat, const fl
     //   MODE 1: rows of Gm / Pm (m / n contiguous): element e -> k row e >> 5, column quad e & 31
     auto fetchA = [&](int k0, int e) -> V4f {
         if (MODE == 0) {
-            const int mm = m0 + (e >> 2), kk = k0 + 4 * (e & 3);
+            const int mm = m0 + e / (BK / 4), kk = k0 + 4 * (e % (BK / 4));
             return (mm < Mdim && kk < Kdim) ? *reinterpret_cast<const V4f *>(ehat + (int64_t) mm * npad + kk) : zero4;
         } else {
             const int kk = k0 + (e >> 5), mm = m0 + 4 * (e & 31);
@@ -967,7 +1147,7 @@ __global__ void __launch_bounds__(256) bwd_gemm_mfma(const float *ehat, const fl
     };
     auto fetchB = [&](int k0, int e) -> V4f {
         if (MODE == 0) {
-            const int nn = n0 + (e >> 2), kk = k0 + 4 * (e & 3);
+            const int nn = n0 + e / (BK / 4), kk = k0 + 4 * (e % (BK / 4));
             return (nn < Ndim && kk < Kdim) ? *reinterpret_cast<const V4f *>(Pm + (int64_t) nn * npad + kk) : zero4;
         } else {
             const int kk = k0 + (e >> 5), nn = n0 + 4 * (e & 31);
@@ -976,19 +1156,24 @@ __global__ void __launch_bounds__(256) bwd_gemm_mfma(const float *ehat, const fl
     };
     auto put = [&](R (*dst)[LD], int e, const V4f &v) {
         if (MODE == 0) {
-            const int mm = e >> 2, kq = 4 * (e & 3);
+            const int mm = e / (BK / 4), kq = 4 * (e % (BK / 4));
             dst[kq + 0][mm] = v.x; dst[kq + 1][mm] = v.y; dst[kq + 2][mm] = v.z; dst[kq + 3][mm] = v.w;
         } else {
             *reinterpret_cast<V4f *>(&dst[e >> 5][4 * (e & 31)]) = v;
         }
     };
-    const int e0 = threadIdx.x, e1 = threadIdx.x + 256;
-    V4f a0 = fetchA(0, e0), a1 = fetchA(0, e1), b0 = fetchB(0, e0), b1 = fetchB(0, e1);
+    V4f sa[NST], sb[NST];
+#pragma unroll
+    for (int r = 0; r < NST; ++r) { sa[r] = fetchA(0, (int) threadIdx.x + 256 * r); sb[r] = fetchB(0, (int) threadIdx.x + 256 * r); }
     for (int k0 = 0; k0 < Kdim; k0 += BK) {
         __syncthreads();
-        put(As, e0, a0); put(As, e1, a1); put(Bs, e0, b0); put(Bs, e1, b1);
+#pragma unroll
+        for (int r = 0; r < NST; ++r) { put(As, (int) threadIdx.x + 256 * r, sa[r]); put(Bs, (int) threadIdx.x + 256 * r, sb[r]); }
         __syncthreads();
-        if (k0 + BK < Kdim) { a0 = fetchA(k0 + BK, e0); a1 = fetchA(k0 + BK, e1); b0 = fetchB(k0 + BK, e0); b1 = fetchB(k0 + BK, e1); }
+        if (k0 + BK < Kdim) {
+#pragma unroll
+            for (int r = 0; r < NST; ++r) { sa[r] = fetchA(k0 + BK, (int) threadIdx.x + 256 * r); sb[r] = fetchB(k0 + BK, (int) threadIdx.x + 256 * r); }
+        }
 #pragma unroll
         for (int ks = 0; ks < BK; ks += 4) {
             float av[4], bv[4];
@@ -1074,6 +1259,143 @@ __global__ void __launch_bounds__(256) bwd_fix_kernel(Problem P, State W, BwdArg
             R x = (v == v) ? g * Num<R>::exp2(v - mx) / sm : R(0);
             if (x != R(0)) atomicAdd(&out[(int64_t) i * N + j], x);
         }
+    }
+}
+
+
+// ------------------------------------------------------------------ gradient: aligned lattice, small alphabet + long targets
+// N <= 64, 64 < S <= 512 (the lattices of letter-based models: a few dozen labels, targets of hundreds of positions).
+// grid = (B, nchunks), block = 256.  Wave w handles frames t0+w, t0+w+4, ...; lane l owns the K consecutive positions
+// K l .. K l + K - 1 (as aligned_long_kernel).  The aligned posteriors of a frame are scattered to the N labels with
+// fixed-point LDS adds (integer adds commute: repeated labels give bit-identical sums, no O(S^2) de-duplication as in
+// bwd_aligned_kernel below, which has to serve N = 10^4) and added to the frame's grad_inputs row; the stay / arrive
+// edge posteriors go the same way into ONE [N][N] fixed-point tile per workgroup, written out as a float tile that
+// add_tiles_kernel sums over (b, chunk) in a fixed order -- no single-workgroup scatter over the whole batch
+// (aligned_tr_scatter_kernel: 2.5 ms at T = 1000 B = 64 S = 200).  Restates force_aligned_lattice.cpp:156-264.
+template <typename R, int K>
+__global__ void __launch_bounds__(256) bwd_aligned_long_kernel(Problem P, State W, BwdArgs A, R *tiles, int add_to_inputs) {
+    typedef typename FrameFix<R>::T FX;
+    __shared__ FX fxI[4][64];
+    __shared__ unsigned long long fxT[64 * 64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.x, chunk = blockIdx.y;
+    const int S = P.S, T = P.T, N = P.N;
+    const R LZ = Num<R>::logzero();
+    const int len = P.in_len ? gclampi(P.in_len[b], 0, T) : T;
+    const int ol = P.tg_len ? gclampi(P.tg_len[b], 0, S) : S;
+    const R g0 = (R) ((double) ((const R *) (A.grad_aligned ? A.grad_aligned : A.grad_full))[(int64_t) b * A.gstride] * A.gscale);
+    const R ga = (A.grad_aligned || !A.neg_aligned) ? g0 : -g0;
+    const int2 *asi = reinterpret_cast<const int2 *>(W.asi) + (int64_t) b * S;
+    const V2<R> *asu = reinterpret_cast<const V2<R> *>(W.asu) + (int64_t) b * S;
+    for (int q = threadIdx.x; q < N * N; q += 256) fxT[q] = 0;
+    fxI[wave][lane] = 0;
+    R H2[K], Dp[K];
+    double accH[K], accD[K];
+    int tgt[K], prv[K];
+    bool act[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int p = lane * K + k;
+        act[k] = p < ol;
+        const V2<R> u = p < S ? asu[p] : V2<R>{0, LZ};
+        const int2 ii = p < S ? asi[p] : int2{0, 0};
+        H2[k] = u.x; Dp[k] = u.y;
+        tgt[k] = act[k] ? ii.x : lane;           // (positions past the target add 0: each lane to a word of its own)
+        prv[k] = ii.y;
+        accH[k] = 0; accD[k] = 0;
+    }
+    __syncthreads();
+    const R *abp = (const R *) W.ab + (int64_t) b * T * S;
+    const R *bbp = (const R *) W.bb + (int64_t) b * T * S;
+    const int t0 = chunk * A.chunk, t1 = min(min(T, t0 + A.chunk), len);
+    for (int t = t0 + wave; t < t1; t += 4) {
+        R gam[K], m = LZ;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int p = lane * K + k;
+            gam[k] = p < S ? abp[(int64_t) t * S + p] + bbp[(int64_t) t * S + p] : LZ;
+            m = fmax(m, gam[k]);
+        }
+        m = wave_allmax(m);
+        R z = 0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            gam[k] = (m > R(-1e29)) ? Num<R>::exp2(gam[k] - m) : R(0);
+            z += gam[k];
+        }
+        z = wave_allsum(z);
+        R apl = LZ;                              // alpha-bar of the previous frame at the position left of this lane's first
+        R ap[K];
+        if (t >= 1) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) ap[k] = act[k] ? abp[(int64_t) (t - 1) * S + lane * K + k] : LZ;
+            apl = prev_lane_or_zero<R>(ap[K - 1]);
+            if (lane == 0) apl = R(0);           // (position 0 has no arrive edge: Dp is log-zero there)
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const R post = (z > 0 && act[k]) ? gam[k] / z : R(0);
+            atomicAdd(&fxI[wave][tgt[k]], FrameFix<R>::to(post));
+            if (t >= 1 && act[k]) {
+                const R al = k == 0 ? apl : ap[k - 1];
+                const R pc0 = ap[k] + H2[k], pc1 = al + Dp[k];
+                const R l = lse2<R>(pc0, pc1);
+                accH[k] += (double) (post * Num<R>::exp2(pc0 - l));
+                accD[k] += (double) (post * Num<R>::exp2(pc1 - l));
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        const FX fv = fxI[wave][lane];
+        __builtin_amdgcn_wave_barrier();
+        fxI[wave][lane] = 0;
+        __builtin_amdgcn_wave_barrier();
+        if (lane < N) {
+            R *gin = (R *) A.grad_inputs + ((int64_t) t * P.B + b) * N + lane;
+            const R add = ga * FrameFix<R>::from(fv);
+            *gin = add_to_inputs ? *gin + add : add;
+        }
+    }
+    // this workgroup's edge posteriors -> one [N][N] tile: stay (O_s, O_s), arrive (O_s, O_{s-1})   (force_aligned_lattice.cpp:204-231)
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        if (act[k]) {
+            if (accH[k] != 0.0) atomicAdd(&fxT[tgt[k] * N + tgt[k]], (unsigned long long) __double2ll_rn(accH[k] * Num<R>::kFix));
+            if (lane * K + k >= 1 && accD[k] != 0.0)
+                atomicAdd(&fxT[tgt[k] * N + prv[k]], (unsigned long long) __double2ll_rn(accD[k] * Num<R>::kFix));
+        }
+    }
+    __syncthreads();
+    R *tile = tiles + ((int64_t) b * A.nchunks + chunk) * N * N;
+    for (int q = threadIdx.x; q < N * N; q += 256)
+        tile[q] = (R) ((double) ga * ((double) (long long) fxT[q] * (1.0 / Num<R>::kFix)));
+}
+
+// out[k] (+)= sum over the G tiles in a fixed order (deterministic).  grid = ceil(n / 32), block = 1024 = 32 elements x
+// 32 tile groups: thread (e, grp) sums tiles grp, grp + 32, ... (8 loads in flight), then a fixed-order combine in LDS.
+template <typename R>
+__global__ void __launch_bounds__(1024) add_tiles_kernel(const R *tiles, int G, int n, R *out, int accumulate) {
+    __shared__ R part[32][33];
+    const int e = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int k = min((int) blockIdx.x * 32 + e, n - 1);
+    R a[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) a[q] = 0;
+    for (int g = grp; g < G; g += 32 * 8) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int gg = g + 32 * q;
+            const R v = tiles[(int64_t) min(gg, G - 1) * n + k];
+            a[q] += gg < G ? v : R(0);
+        }
+    }
+    part[grp][e] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    __syncthreads();
+    if (grp == 0 && (int) blockIdx.x * 32 + e < n) {
+        R t = part[0][e];
+#pragma unroll
+        for (int q = 1; q < 32; ++q) t += part[q][e];
+        out[k] = accumulate ? out[k] + t : t;
     }
 }
 
@@ -1280,8 +1602,24 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
         const int threads = ((P.S + 63) / 64) * 64;
         if (threads > 1024) return hipErrorInvalidValue;
         dim3 grid(P.B, __builtin_popcount(ali_mask));
-        if (store) hipLaunchKernelGGL((aligned_wide_kernel<R, true>), grid, dim3(threads), 0, stream, P, W, O, ali_mask);
-        else hipLaunchKernelGGL((aligned_wide_kernel<R, false>), grid, dim3(threads), 0, stream, P, W, O, ali_mask);
+        // up to 512 target positions: one wavefront per chain, 2 / 4 / 8 positions per lane; beyond: one position per
+        // thread and a workgroup barrier per frame
+        const double fr = (double) (P.T - 1) * (double) P.is0 * sizeof(R), ln = (double) (P.N - 1) * (double) P.is2 * sizeof(R);
+        const bool off32 = P.is0 >= 0 && P.is2 >= 0 && fr < 4294967296.0 && ln < 2147483648.0 &&
+                           (double) P.T * P.S * sizeof(R) < 4294967296.0;
+        if (!off32 || P.S > 512) {
+            if (store) hipLaunchKernelGGL((aligned_wide_kernel<R, true>), grid, dim3(threads), 0, stream, P, W, O, ali_mask);
+            else hipLaunchKernelGGL((aligned_wide_kernel<R, false>), grid, dim3(threads), 0, stream, P, W, O, ali_mask);
+        } else if (P.S <= 128) {
+            if (store) hipLaunchKernelGGL((aligned_long_kernel<R, 2, true>), grid, dim3(64), 0, stream, P, W, O, ali_mask);
+            else hipLaunchKernelGGL((aligned_long_kernel<R, 2, false>), grid, dim3(64), 0, stream, P, W, O, ali_mask);
+        } else if (P.S <= 256) {
+            if (store) hipLaunchKernelGGL((aligned_long_kernel<R, 4, true>), grid, dim3(64), 0, stream, P, W, O, ali_mask);
+            else hipLaunchKernelGGL((aligned_long_kernel<R, 4, false>), grid, dim3(64), 0, stream, P, W, O, ali_mask);
+        } else {
+            if (store) hipLaunchKernelGGL((aligned_long_kernel<R, 8, true>), grid, dim3(64), 0, stream, P, W, O, ali_mask);
+            else hipLaunchKernelGGL((aligned_long_kernel<R, 8, false>), grid, dim3(64), 0, stream, P, W, O, ali_mask);
+        }
     }
     if (full_mask) {
         if (!W.work) return hipErrorInvalidValue;
@@ -1365,7 +1703,8 @@ size_t bwd_scratch_bytes_generic(int elem, int T, int B, int N, int S) {
     const size_t npad = (size_t) (N + 3) / 4 * 4;
     int ch, nch;
     generic_chunks(T, B, &ch, &nch);
-    return 2 * au((size_t) B * T * npad * elem) + au((size_t) B * nch * 2 * S * elem) + 512 + au(((size_t) B + 1) * 4);
+    const size_t tiles = N <= 64 ? au((size_t) B * nch * N * N * elem) : 0;       // bwd_aligned_long_kernel
+    return 2 * au((size_t) B * T * npad * elem) + au((size_t) B * nch * 2 * S * elem) + 512 + au(((size_t) B + 1) * 4) + tiles;
 }
 
 template <typename R>
@@ -1379,7 +1718,8 @@ hipError_t launch_bwd_generic(const Problem &P, const State &W, const BwdArgs &A
     R *Gm = (R *) sc; sc += au((size_t) P.B * P.T * npad * e);
     R *gHD = (R *) sc; sc += au((size_t) P.B * A.nchunks * 2 * P.S * e);
     int *anybad = (int *) sc; sc += 512;
-    int *rowoff = (int *) sc;
+    int *rowoff = (int *) sc; sc += au(((size_t) P.B + 1) * 4);
+    R *atiles = (R *) sc;
     const bool do_full = parts & 1, do_ali = parts & 2, have_full = (parts & 5) != 0;
     R *gtr = (R *) A.grad_transition;
     if (do_full) {
@@ -1414,9 +1754,19 @@ hipError_t launch_bwd_generic(const Problem &P, const State &W, const BwdArgs &A
     if (do_ali) {
         if (P.S > 1024) return hipErrorInvalidValue;
         if (!have_full) (void) hipMemsetAsync(A.grad_inputs, 0, (size_t) P.T * P.B * P.N * e, stream);
-        hipLaunchKernelGGL((bwd_aligned_kernel<R>), dim3(P.B, A.nchunks), dim3(256), 0, stream, P, W, A, gHD, 1);
-        hipLaunchKernelGGL((aligned_tr_scatter_kernel<R>), dim3(1), dim3(1024), 0, stream, P, W, A, gHD, gtr,
-                           have_full ? 1 : 0);
+        if (P.N <= 64 && P.S <= 512) {
+            dim3 grid(P.B, A.nchunks);
+            if (P.S <= 128) hipLaunchKernelGGL((bwd_aligned_long_kernel<R, 2>), grid, dim3(256), 0, stream, P, W, A, atiles, 1);
+            else if (P.S <= 256) hipLaunchKernelGGL((bwd_aligned_long_kernel<R, 4>), grid, dim3(256), 0, stream, P, W, A, atiles, 1);
+            else hipLaunchKernelGGL((bwd_aligned_long_kernel<R, 8>), grid, dim3(256), 0, stream, P, W, A, atiles, 1);
+            const int n2 = P.N * P.N;
+            hipLaunchKernelGGL((add_tiles_kernel<R>), dim3((n2 + 31) / 32), dim3(1024), 0, stream, (const R *) atiles,
+                               P.B * A.nchunks, n2, gtr, have_full ? 1 : 0);
+        } else {
+            hipLaunchKernelGGL((bwd_aligned_kernel<R>), dim3(P.B, A.nchunks), dim3(256), 0, stream, P, W, A, gHD, 1);
+            hipLaunchKernelGGL((aligned_tr_scatter_kernel<R>), dim3(1), dim3(1024), 0, stream, P, W, A, gHD, gtr,
+                               have_full ? 1 : 0);
+        }
     }
     return hipGetLastError();
 }
