@@ -631,6 +631,199 @@ __global__ void __launch_bounds__(256) fwd_persist_kernel(Problem P, StepBuf<flo
     }
 }
 
+
+// ------------------------------------------------------------------ full lattice, medium alphabets (64 < N <= 256, fp32)
+// One workgroup per chain (utterance x direction), NW = ceil(N / 64) wavefronts, thread i = label i.  The thread keeps
+// its normalised transition row (alpha) / column (beta) in REGISTERS (up to 256 floats: one wavefront per SIMD has the
+// whole register file) and the frame's exp-domain vector travels through LDS -- the recursion of the small path
+// (asg_chains.h) widened over several wavefronts, two workgroup barriers per frame, ALL frames in one launch.  The
+// per-frame step launches of fwd_step_kernel are built for N = 10^4 (a 400 MB matrix per frame); at N = 128 every one of
+// them is a 10 us round of dependent memory accesses for 4 workgroups of work: 399 launches = 4 ms per cfg-3-sized step.
+//   alpha: a_t[i] = x2_t[i] + hmax_i + log2 sum_j Ehat[i][j] p_{t-1}[j],   p = exp2(a - max_i a)      (fully_connected_lattice.cpp:9-29)
+//   beta:  y_t = x2_t + b_t,  p = exp2(y - max y),  b_{t-1}[i] = cmax_i + log2 sum_j Fhat[j][i] p[j]  (:32-47)
+// Stored states are relative to a per-frame offset (max = 0): the gradient pass (bwd_post_kernel<.., false> + both
+// contractions) is offset-free per frame.  A row sum outside [2^-100, 2^100] is redone as an exact log-sum-exp.
+template <int NW>
+__global__ void __launch_bounds__(64 * NW) fwd_mid_kernel(Problem P, State W, FwdOut O, int mask) {
+    typedef float R;
+    constexpr int NP = 64 * NW;
+    __shared__ __attribute__((aligned(16))) float pbuf[NP];      // exp-domain vector of the frame being consumed
+    __shared__ float qbuf[NP];                                   // its log-domain twin (exact path)
+    __shared__ float red[8];
+    const int b = blockIdx.x;
+    const bool beta = (mask == kFullBeta) || (mask == (kFullAlpha | kFullBeta) && blockIdx.y == 1);
+    const int i = threadIdx.x, lane = i & 63, wave = i >> 6;
+    const int N = P.N, T = P.T;
+    const int len = P.in_len ? gclampi(P.in_len[b], 0, T) : T;
+    const R L2E = Num<R>::log2e(), LZ = Num<R>::logzero(), NINF = Num<R>::ninf();
+    const bool act = i < N;
+    const int ic = act ? i : 0;
+    const R *tr = (const R *) P.transition;
+    R *score_out = (R *) (beta ? O.full_scores : O.full_scores_alpha);
+    if (len < 1) {
+        if (i == 0 && score_out) score_out[b] = NINF;
+        return;
+    }
+    // this label's row (alpha: Tr[i][.], scores of arriving at i) / column (beta: Tr[.][i], of leaving i), normalised
+    const int64_t tbase = beta ? (int64_t) ic * P.ts1 : (int64_t) ic * P.ts0, tstep = beta ? P.ts0 : P.ts1;
+    R hmax = NINF;
+    for (int j = 0; j < N; ++j) hmax = fmax(hmax, tr[tbase + (int64_t) j * tstep] * L2E);
+    hmax = fmax(hmax, LZ);
+    V2<R> e2[NP / 2];
+#pragma unroll
+    for (int j = 0; j < NP / 2; ++j) {
+        const R ea = (act && 2 * j < N) ? Num<R>::exp2(tr[tbase + (int64_t) min(2 * j, N - 1) * tstep] * L2E - hmax) : R(0);
+        const R eb = (act && 2 * j + 1 < N) ? Num<R>::exp2(tr[tbase + (int64_t) min(2 * j + 1, N - 1) * tstep] * L2E - hmax) : R(0);
+        e2[j] = V2<R>{ea, eb};
+    }
+    // emissions of this label: frame offset in an SGPR, label offset in a VGPR (32-bit: checked by the launcher)
+    __amdgpu_buffer_rsrc_t rin = make_rsrc((R *) P.inputs + (int64_t) b * P.is1, 0xffffffffu);
+    const unsigned eoff = (unsigned) (ic * (int) P.is2) * 4u, frame_bytes = (unsigned) P.is0 * 4u;
+    auto emis = [&](int f) -> R {
+        return buf_load<R>(rin, eoff, (unsigned) __builtin_amdgcn_readfirstlane(gclampi(f, 0, len - 1)) * frame_bytes);
+    };
+    R *st = (R *) (beta ? W.bh : W.ah) + (int64_t) b * T * N + ic;
+    auto wg_max = [&](R v) -> R {              // max over the workgroup (one barrier); every thread gets it
+        const R m = wave_allmax(v);
+        if (lane == 0) red[wave] = m;
+        __syncthreads();
+        R r = red[0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) r = fmax(r, red[w]);
+        return r;
+    };
+    auto matvec = [&]() -> R {                 // sum_j e[j] p[j], the vector broadcast from LDS
+        V2<R> a0 = {0, 0}, a1 = {0, 0};
+#pragma unroll
+        for (int q = 0; q < NP / 4; ++q) {
+            const V4<R> pv = *reinterpret_cast<const V4<R> *>(&pbuf[4 * q]);
+            if constexpr (NW <= 3) {
+                a0 = __builtin_elementwise_fma(e2[2 * q], V2<R>{pv.x, pv.y}, a0);          // v_pk_fma_f32
+                a1 = __builtin_elementwise_fma(e2[2 * q + 1], V2<R>{pv.z, pv.w}, a1);
+            } else {
+                // 256 row elements do not fit the 256 architectural registers: part of them lives in accumulation registers,
+                // and moving a PAIR back for a packed FMA costs more than it saves (679 vs 1007 us at N = 256, T = 400)
+                a0 = V2<R>{fmaf(e2[2 * q].x, pv.x, a0.x), fmaf(e2[2 * q].y, pv.y, a0.y)};
+                a1 = V2<R>{fmaf(e2[2 * q + 1].x, pv.z, a1.x), fmaf(e2[2 * q + 1].y, pv.w, a1.y)};
+            }
+        }
+        const V2<R> a = a0 + a1;
+        return a.x + a.y;
+    };
+    auto exact = [&]() -> R {                  // log2 sum_j 2^(Tr2 + q_j) for this label, from the log-domain vector
+        R mx = NINF;
+        for (int j = 0; j < N; ++j) { const R v = tr[tbase + (int64_t) j * tstep] * L2E + qbuf[j]; mx = (v == v) ? fmax(mx, v) : mx; }
+        if (mx == NINF) return NINF;
+        R sm = 0;
+        for (int j = 0; j < N; ++j) { const R v = tr[tbase + (int64_t) j * tstep] * L2E + qbuf[j]; sm += (v == v) ? Num<R>::exp2(v - mx) : R(0); }
+        return mx + Num<R>::log2(sm);
+    };
+    constexpr int PF = 4;
+    double M = 0.0;
+    R x2[PF];
+    if (!beta) {
+        // frame 0
+        R a = act ? emis(0) * L2E : NINF;
+        R m = fmax(wg_max(a), LZ);
+        R ah = a - m;
+        M = (double) m;
+        if (act) st[0] = ah;
+        pbuf[i] = act ? Num<R>::exp2(ah) : R(0);
+        qbuf[i] = act ? ah : NINF;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < PF; ++u) x2[u] = emis(1 + u) * L2E;
+        for (int t0 = 1; t0 < len; t0 += PF) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int t = t0 + u;
+                if (t < len) {
+                    const R xe = x2[u];
+                    x2[u] = emis(t + PF) * L2E;
+                    const R s = matvec();
+                    const R lg = Num<R>::log2(s);
+                    R rr = hmax + lg;
+                    if (act && !(fabs(lg) < Num<R>::lg_limit())) rr = exact();      // (rare)
+                    a = act ? xe + rr : NINF;
+                    m = fmax(wg_max(a), LZ);           // (barrier: every thread has read the old vector)
+                    ah = a - m;
+                    M += (double) m;
+                    if (act) st[(int64_t) t * N] = ah;
+                    pbuf[i] = act ? Num<R>::exp2(ah) : R(0);
+                    qbuf[i] = act ? ah : NINF;
+                    __syncthreads();
+                }
+            }
+        }
+        if (score_out) {
+            const R sm = wave_allsum(act ? Num<R>::exp2(ah) : R(0));
+            __syncthreads();
+            if (lane == 0) red[wave] = sm;
+            __syncthreads();
+            if (i == 0) {
+                R tot = red[0];
+#pragma unroll
+                for (int w = 1; w < NW; ++w) tot += red[w];
+                const double sc = M + (double) Num<R>::log2(tot);
+                score_out[b] = (sc < -1e29) ? NINF : (R) (sc * kLn2);
+            }
+        }
+    } else {
+        R bh = act ? R(0) : NINF;                     // beta at the last frame
+        if (act) st[(int64_t) (len - 1) * N] = R(0);
+#pragma unroll
+        for (int u = 0; u < PF; ++u) x2[u] = emis(len - 1 - u) * L2E;
+        for (int t0 = len - 1; t0 >= 1; t0 -= PF) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int t = t0 - u;
+                if (t >= 1) {
+                    const R xe = x2[u];
+                    x2[u] = emis(t - PF) * L2E;
+                    const R y = act ? xe + bh : NINF;
+                    const R my = fmax(wg_max(y), LZ);
+                    M += (double) my;
+                    pbuf[i] = act ? Num<R>::exp2(y - my) : R(0);
+                    qbuf[i] = act ? y - my : NINF;
+                    __syncthreads();
+                    const R s = matvec();
+                    const R lg = Num<R>::log2(s);
+                    R rr = hmax + lg;
+                    if (act && !(fabs(lg) < Num<R>::lg_limit())) rr = exact();      // (rare)
+                    bh = act ? rr : NINF;
+                    if (act) st[(int64_t) (t - 1) * N] = bh;
+                    __syncthreads();                   // (the vector is rewritten in the next frame)
+                }
+            }
+        }
+        if (score_out) {
+            // S_full = LSE_i(I_0[i] + beta_0[i])   (fully_connected_lattice.cpp:89)
+            const R y = act ? emis(0) * L2E + bh : NINF;
+            const R my = fmax(wg_max(y), LZ);
+            const R sm = wave_allsum(act ? Num<R>::exp2(y - my) : R(0));
+            __syncthreads();
+            if (lane == 0) red[wave] = sm;
+            __syncthreads();
+            if (i == 0) {
+                R tot = red[0];
+#pragma unroll
+                for (int w = 1; w < NW; ++w) tot += red[w];
+                const double sc = M + (double) my + (double) Num<R>::log2(tot);
+                score_out[b] = (sc < -1e29) ? NINF : (R) (sc * kLn2);
+            }
+        }
+    }
+}
+
+// the medium-alphabet route: fp32, 64 < N <= 256, 32-bit emission offsets (ASG_NO_MID=1: the per-frame launches instead)
+static bool mid_alphabet(const Problem &P, size_t elem) {
+    if (elem != 4 || P.N <= 64 || P.N > 256) return false;
+    const char *ev = getenv("ASG_NO_MID");
+    if (ev && atoi(ev) != 0) return false;
+    const double fr = (double) (P.T - 1) * (double) P.is0 * 4.0, ln = (double) (P.N - 1) * (double) P.is2 * 4.0;
+    return P.is0 >= 0 && P.is2 >= 0 && fr < 4294967296.0 && ln < 2147483648.0;
+}
+
 // scores: grid = B, block = 256.  alpha: A + LSE_i(ah[len-1]);  beta: C_0 + LSE_i(q_0), q_0 = I2[0]-emax[0]+bh[0]
 template <typename R, bool BETA>
 __global__ void __launch_bounds__(256) fwd_score_kernel(Problem P, StepBuf<R> S, R *scores) {
@@ -1112,9 +1305,12 @@ __global__ void __launch_bounds__(256) bwd_gemm_kernel(const R *ehat, const R *P
 #endif
 template <int MODE>
 __global__ void __launch_bounds__(256) bwd_gemm_mfma(const float *ehat, const float *Pm, float *Gm, float *out, int N, int npad,
-                                                     int K, int *anybad, const int *kdev) {
+                                                     int K, int *anybad, const int *kdev, int kslice, float *partial) {
     typedef float R;
     if (kdev) K = __builtin_amdgcn_readfirstlane(*kdev);        // compacted rows: their number is known on the device only
+    // MODE 1, small alphabets: the contraction axis is split over blockIdx.z (a 128 x 128 output has ONE tile: the whole
+    // product would run on one compute unit, 1.7 ms at N = 128 B T = 25 600); slice z leaves its raw sums in partial[z],
+    // gemm_combine_kernel adds the slices in order and applies the E factor
     // BK = 32: one stage of global -> register -> LDS staging (and its two workgroup barriers) per 128 MFMAs of a
     // wavefront; at BK = 16 the barriers and the LDS round trip took 29 % of the kernel (112 of 157 TFLOP/s)
     constexpr int BK = ASG_X_GEMM_BK, TS = 128, LD = TS + 4, NST = BK * TS / 4 / 256;      // NST float4 per thread and operand
@@ -1123,7 +1319,9 @@ __global__ void __launch_bounds__(256) bwd_gemm_mfma(const float *ehat, const fl
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64;
     const int m0 = blockIdx.x * TS, n0 = blockIdx.y * TS;
-    const int Mdim = N, Ndim = MODE == 0 ? K : N, Kdim = MODE == 0 ? npad : K;
+    const int Mdim = N, Ndim = MODE == 0 ? K : N;
+    const int kbeg = (MODE == 1 && partial) ? (int) blockIdx.z * kslice : 0;
+    const int Kdim = (MODE == 1 && partial) ? min(K, kbeg + kslice) : (MODE == 0 ? npad : K);
     const V4f zero4 = {0, 0, 0, 0};
     V4f acc[4][4];
 #pragma unroll
@@ -1164,8 +1362,8 @@ __global__ void __launch_bounds__(256) bwd_gemm_mfma(const float *ehat, const fl
     };
     V4f sa[NST], sb[NST];
 #pragma unroll
-    for (int r = 0; r < NST; ++r) { sa[r] = fetchA(0, (int) threadIdx.x + 256 * r); sb[r] = fetchB(0, (int) threadIdx.x + 256 * r); }
-    for (int k0 = 0; k0 < Kdim; k0 += BK) {
+    for (int r = 0; r < NST; ++r) { sa[r] = fetchA(kbeg, (int) threadIdx.x + 256 * r); sb[r] = fetchB(kbeg, (int) threadIdx.x + 256 * r); }
+    for (int k0 = kbeg; k0 < Kdim; k0 += BK) {
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < NST; ++r) { put(As, (int) threadIdx.x + 256 * r, sa[r]); put(Bs, (int) threadIdx.x + 256 * r, sb[r]); }
@@ -1205,11 +1403,28 @@ __global__ void __launch_bounds__(256) bwd_gemm_mfma(const float *ehat, const fl
                     const bool mark = !ok && g != R(0);
                     Gm[(int64_t) gn * npad + gm_] = ok ? g / sden : (mark ? Num<R>::ninf() : R(0));
                     if (mark) *anybad = 1;
+                } else if (partial) {
+                    partial[((int64_t) blockIdx.z * N + gm_) * N + gn] = acc[a][c][q];
                 } else {
                     out[(int64_t) gm_ * N + gn] = acc[a][c][q] * ehat[(int64_t) gm_ * npad + gn];
                 }
             }
         }
+}
+
+// out[m][n] = ehat[m][n] * sum over the slices of partial[z][m][n], slices in ascending order.  grid = ceil(N^2 / 256).
+__global__ void __launch_bounds__(256) gemm_combine_kernel(const float *partial, int nslices, const float *ehat, int N, int npad, float *out) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= N * N) return;
+    const int m = k / N, n = k - m * N;
+    float a[4] = {0, 0, 0, 0};
+    int z = 0;
+    for (; z + 4 <= nslices; z += 4) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[q] += partial[(int64_t) (z + q) * N * N + k];
+    }
+    for (; z < nslices; ++z) a[0] += partial[(int64_t) z * N * N + k];
+    out[k] = ((a[0] + a[1]) + (a[2] + a[3])) * ehat[(int64_t) m * npad + n];
 }
 
 // exact fix-up of marked rows (rare; exits at once unless the row-sum pass raised `anybad`).
@@ -1507,6 +1722,36 @@ __global__ void __launch_bounds__(256) bwd_aligned_kernel(Problem P, State W, Bw
     }
 }
 
+// Medium alphabets (64 < N <= 2048): the same scatter with one workgroup PER UTTERANCE and 64-bit fixed-point atomic adds
+// into an [N][N] accumulator in memory (integer adds commute: deterministic; the float result is formed once, by
+// fx_to_grad_kernel) -- the single workgroup below walks the batch utterance by utterance (713 us at B = 64, S = 30).
+template <typename R> struct GlobalFix { static constexpr double scale = sizeof(R) == 4 ? 68719476736.0 : 1099511627776.0; };   // 2^36 / 2^40
+template <typename R>
+__global__ void __launch_bounds__(256) aligned_tr_scatter_fx_kernel(Problem P, State W, BwdArgs A, const R *gHD, unsigned long long *fx) {
+    const int S = P.S, N = P.N, b = blockIdx.x;
+    const int ol = P.tg_len ? gclampi(P.tg_len[b], 0, S) : S;
+    const R g0 = (R) ((double) ((const R *) (A.grad_aligned ? A.grad_aligned : A.grad_full))[(int64_t) b * A.gstride] * A.gscale);
+    const R ga = (A.grad_aligned || !A.neg_aligned) ? g0 : -g0;
+    const int2 *asi = reinterpret_cast<const int2 *>(W.asi) + (int64_t) b * S;
+    for (int e = threadIdx.x; e < 2 * S; e += 256) {
+        const int pass = e / S, s = e - pass * S;
+        const bool valid = pass == 0 ? (s < ol) : (s >= 1 && s < ol);
+        if (!valid) continue;
+        R v = 0;
+        for (int c = 0; c < A.nchunks; ++c) v += gHD[(((int64_t) b * A.nchunks + c) * 2 + pass) * S + s];
+        const int2 ii = asi[s];
+        const long long q = __double2ll_rn((double) ga * (double) v * GlobalFix<R>::scale);
+        if (q != 0) atomicAdd(&fx[(int64_t) ii.x * N + (pass == 0 ? ii.x : ii.y)], (unsigned long long) q);
+    }
+}
+template <typename R>
+__global__ void __launch_bounds__(256) fx_to_grad_kernel(const unsigned long long *fx, int64_t n, R *out, int accumulate) {
+    const int64_t k = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const R v = (R) ((double) (long long) fx[k] * (1.0 / GlobalFix<R>::scale));
+    out[k] = accumulate ? out[k] + v : v;
+}
+
 // scatter the aligned edge posteriors into grad_transition: ONE workgroup, utterances in order, duplicates
 // of an (i,j) key inside an utterance folded onto the first occurrence -> deterministic, no atomics.
 // keys: stay  (O_s, O_s)      <- gH[s]   for s < ol
@@ -1621,7 +1866,15 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
             else hipLaunchKernelGGL((aligned_long_kernel<R, 8, false>), grid, dim3(64), 0, stream, P, W, O, ali_mask);
         }
     }
-    if (full_mask) {
+    if (full_mask && mid_alphabet(P, sizeof(R))) {
+        if constexpr (sizeof(R) == 4) {
+            dim3 grid(P.B, __builtin_popcount(full_mask));
+            const int nw = (P.N + 63) / 64;
+            if (nw <= 2) hipLaunchKernelGGL((fwd_mid_kernel<2>), grid, dim3(128), 0, stream, P, W, O, full_mask);
+            else if (nw == 3) hipLaunchKernelGGL((fwd_mid_kernel<3>), grid, dim3(192), 0, stream, P, W, O, full_mask);
+            else hipLaunchKernelGGL((fwd_mid_kernel<4>), grid, dim3(256), 0, stream, P, W, O, full_mask);
+        }
+    } else if (full_mask) {
         if (!W.work) return hipErrorInvalidValue;
         char *wk = (char *) W.work;
         const size_t e = sizeof(R);
@@ -1689,6 +1942,16 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
     return hipGetLastError();
 }
 
+// slices of the frame axis for the outer-product contraction: enough workgroups to fill the device when the output
+// has only a few 128 x 128 tiles (N <= 1024), each slice at least 256 rows long
+static int gemm_slices(int N, int K) {
+    const int tiles = ((N + 127) / 128) * ((N + 127) / 128);
+    if (tiles >= 64) return 1;
+    int n = (512 + tiles - 1) / tiles;
+    if (n > K / 256) n = K / 256;
+    return n < 1 ? 1 : n;
+}
+
 static void generic_chunks(int T, int B, int *chunk, int *nchunks) {
     int nch = (512 + B - 1) / B;
     if (nch < 1) nch = 1;
@@ -1703,7 +1966,9 @@ size_t bwd_scratch_bytes_generic(int elem, int T, int B, int N, int S) {
     const size_t npad = (size_t) (N + 3) / 4 * 4;
     int ch, nch;
     generic_chunks(T, B, &ch, &nch);
-    const size_t tiles = N <= 64 ? au((size_t) B * nch * N * N * elem) : 0;       // bwd_aligned_long_kernel
+    size_t tiles = N <= 64 ? au((size_t) B * nch * N * N * elem) : 0;             // bwd_aligned_long_kernel
+    if (N > 64 && N <= 2048) tiles = au((size_t) N * N * 8);                      // aligned_tr_scatter_fx_kernel
+    if (elem == 4 && N > 64) tiles += au((size_t) gemm_slices(N, B * T) * N * N * 4);       // split contraction: partial sums
     return 2 * au((size_t) B * T * npad * elem) + au((size_t) B * nch * 2 * S * elem) + 512 + au(((size_t) B + 1) * 4) + tiles;
 }
 
@@ -1720,6 +1985,9 @@ hipError_t launch_bwd_generic(const Problem &P, const State &W, const BwdArgs &A
     int *anybad = (int *) sc; sc += 512;
     int *rowoff = (int *) sc; sc += au(((size_t) P.B + 1) * 4);
     R *atiles = (R *) sc;
+    if (P.N <= 64) sc += au((size_t) P.B * A.nchunks * P.N * P.N * e);
+    else if (P.N <= 2048) sc += au((size_t) P.N * P.N * 8);
+    R *gpart = (R *) sc;
     const bool do_full = parts & 1, do_ali = parts & 2, have_full = (parts & 5) != 0;
     R *gtr = (R *) A.grad_transition;
     if (do_full) {
@@ -1728,6 +1996,28 @@ hipError_t launch_bwd_generic(const Problem &P, const State &W, const BwdArgs &A
         (void) hipMemsetAsync(anybad, 0, sizeof(int), stream);
         const R *emax = (const R *) W.work;
         const R *mulog = (const R *) ((const char *) W.work + work_mulog_offset(e, P.T, P.B, npad));
+        const bool mid = mid_alphabet(P, e);
+        if (mid) {
+            if constexpr (StepUsesMfma<R>::v) {
+                // medium alphabets: the forward pass (fwd_mid_kernel) stores per-frame-normalised states, so the row sums
+                // come from the contraction (MODE 0), then the outer product, its frame axis split over workgroups
+                hipLaunchKernelGGL((bwd_post_kernel<R, false>), dim3(P.T, P.B), dim3(256), 0, stream, P, W, A, Pm, Gm, npad, emax, mulog, anybad,
+                                   (const int *) nullptr);
+                hipLaunchKernelGGL((bwd_gemm_mfma<0>), dim3((P.N + 127) / 128, (K + 127) / 128), dim3(256), 0, stream,
+                                   (const float *) W.ehat, (const float *) Pm, (float *) Gm, (float *) gtr, P.N, npad, K, anybad,
+                                   (const int *) nullptr, 0, (float *) nullptr);
+                const int nsl = gemm_slices(P.N, K);
+                const int kslice = ((K + nsl - 1) / nsl + ASG_X_GEMM_BK - 1) / ASG_X_GEMM_BK * ASG_X_GEMM_BK;
+                hipLaunchKernelGGL((bwd_gemm_mfma<1>), dim3((P.N + 127) / 128, (P.N + 127) / 128, nsl), dim3(256), 0, stream,
+                                   (const float *) W.ehat, (const float *) Pm, (float *) Gm, (float *) gtr, P.N, npad, K, anybad,
+                                   (const int *) nullptr, kslice, nsl > 1 ? (float *) gpart : (float *) nullptr);
+                if (nsl > 1)
+                    hipLaunchKernelGGL(gemm_combine_kernel, dim3((P.N * P.N + 255) / 256), dim3(256), 0, stream, (const float *) gpart,
+                                       nsl, (const float *) W.ehat, P.N, npad, (float *) gtr);
+            }
+            hipLaunchKernelGGL((bwd_fix_kernel<R>), dim3(P.T, P.B), dim3(256), 0, stream, P, W, A, Gm, gtr, npad, anybad,
+                               (const int *) nullptr);
+        } else {
         if constexpr (StepUsesMfma<R>::v) {
             if (!W.work) return hipErrorInvalidValue;
             hipLaunchKernelGGL(rowoff_kernel, dim3(1), dim3(64), 0, stream, P, rowoff);
@@ -1739,9 +2029,21 @@ hipError_t launch_bwd_generic(const Problem &P, const State &W, const BwdArgs &A
         }
         if constexpr (StepUsesMfma<R>::v) {
             // (no row-sum contraction: bwd_post_kernel<.., true> derived the row sums from the stored state)
-            hipLaunchKernelGGL((bwd_gemm_mfma<1>), dim3((P.N + 127) / 128, (P.N + 127) / 128), dim3(256), 0, stream,
-                               (const float *) W.ehat, (const float *) Pm, (float *) Gm, (float *) gtr, P.N, npad, K, anybad,
-                               (const int *) (rowoff + P.B));
+            const int tiles1 = ((P.N + 127) / 128) * ((P.N + 127) / 128);
+            const int nsl = gemm_slices(P.N, K);
+            if (nsl > 1) {
+                const int kslice = ((K + nsl - 1) / nsl + ASG_X_GEMM_BK - 1) / ASG_X_GEMM_BK * ASG_X_GEMM_BK;
+                hipLaunchKernelGGL((bwd_gemm_mfma<1>), dim3((P.N + 127) / 128, (P.N + 127) / 128, nsl), dim3(256), 0, stream,
+                                   (const float *) W.ehat, (const float *) Pm, (float *) Gm, (float *) gtr, P.N, npad, K, anybad,
+                                   (const int *) (rowoff + P.B), kslice, (float *) gpart);
+                hipLaunchKernelGGL(gemm_combine_kernel, dim3((P.N * P.N + 255) / 256), dim3(256), 0, stream, (const float *) gpart,
+                                   nsl, (const float *) W.ehat, P.N, npad, (float *) gtr);
+            } else {
+                hipLaunchKernelGGL((bwd_gemm_mfma<1>), dim3((P.N + 127) / 128, (P.N + 127) / 128), dim3(256), 0, stream,
+                                   (const float *) W.ehat, (const float *) Pm, (float *) Gm, (float *) gtr, P.N, npad, K, anybad,
+                                   (const int *) (rowoff + P.B), 0, (float *) nullptr);
+            }
+            (void) tiles1;
         } else {
             hipLaunchKernelGGL((bwd_gemm_kernel<R, 0>), dim3((P.N + 63) / 64, (K + 63) / 64), dim3(256), 0, stream,
                                (const R *) W.ehat, Pm, Gm, gtr, P.N, npad, K, anybad);
@@ -1750,6 +2052,7 @@ hipError_t launch_bwd_generic(const Problem &P, const State &W, const BwdArgs &A
         }
         hipLaunchKernelGGL((bwd_fix_kernel<R>), dim3(P.T, P.B), dim3(256), 0, stream, P, W, A, Gm, gtr, npad, anybad,
                            StepUsesMfma<R>::v ? (const int *) rowoff : (const int *) nullptr);
+        }
     }
     if (do_ali) {
         if (P.S > 1024) return hipErrorInvalidValue;
@@ -1764,8 +2067,17 @@ hipError_t launch_bwd_generic(const Problem &P, const State &W, const BwdArgs &A
                                P.B * A.nchunks, n2, gtr, have_full ? 1 : 0);
         } else {
             hipLaunchKernelGGL((bwd_aligned_kernel<R>), dim3(P.B, A.nchunks), dim3(256), 0, stream, P, W, A, gHD, 1);
-            hipLaunchKernelGGL((aligned_tr_scatter_kernel<R>), dim3(1), dim3(1024), 0, stream, P, W, A, gHD, gtr,
-                               have_full ? 1 : 0);
+            if (P.N > 64 && P.N <= 2048) {
+                unsigned long long *fx = (unsigned long long *) atiles;
+                const int64_t n2 = (int64_t) P.N * P.N;
+                (void) hipMemsetAsync(fx, 0, (size_t) n2 * 8, stream);
+                hipLaunchKernelGGL((aligned_tr_scatter_fx_kernel<R>), dim3(P.B), dim3(256), 0, stream, P, W, A, (const R *) gHD, fx);
+                hipLaunchKernelGGL((fx_to_grad_kernel<R>), dim3((unsigned) ((n2 + 255) / 256)), dim3(256), 0, stream,
+                                   (const unsigned long long *) fx, n2, gtr, have_full ? 1 : 0);
+            } else {
+                hipLaunchKernelGGL((aligned_tr_scatter_kernel<R>), dim3(1), dim3(1024), 0, stream, P, W, A, gHD, gtr,
+                                   have_full ? 1 : 0);
+            }
         }
     }
     return hipGetLastError();
