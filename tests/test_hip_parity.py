@@ -932,7 +932,7 @@ def test_long_targets_small_alphabet(T, B, N, L, dtype, rtol):
 # ------------------------------------------------------------------ medium alphabets (64 < N <= 256): one launch per pass
 @pytest.mark.gpu
 @pytest.mark.parametrize("T,B,N,L", [(60, 3, 65, 9), (120, 2, 128, 20), (45, 4, 129, 7), (80, 2, 192, 30), (70, 3, 200, 70),
-                                       (50, 2, 256, 11)])
+                                       (50, 2, 256, 11), (260, 2, 130, 200), (300, 2, 66, 290)])
 def test_medium_alphabets(T, B, N, L):
     """fp32, 64 < N <= 256: the full-lattice recursions run as ONE launch (fwd_mid_kernel: a workgroup of ceil(N / 64)
     wavefronts per chain, transition row in registers), the gradient through the row-sum and outer-product contractions

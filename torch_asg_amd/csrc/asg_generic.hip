@@ -1478,6 +1478,9 @@ __global__ void __launch_bounds__(256) bwd_fix_kernel(Problem P, State W, BwdArg
 }
 
 
+// scale of the 64-bit fixed-point accumulators in memory (sums over the whole batch): 2^36 (fp32) / 2^40 (fp64)
+template <typename R> struct GlobalFix { static constexpr double scale = sizeof(R) == 4 ? 68719476736.0 : 1099511627776.0; };   // 2^36 / 2^40
+
 // ------------------------------------------------------------------ gradient: aligned lattice, small alphabet + long targets
 // N <= 64, 64 < S <= 512 (the lattices of letter-based models: a few dozen labels, targets of hundreds of positions).
 // grid = (B, nchunks), block = 256.  Wave w handles frames t0+w, t0+w+4, ...; lane l owns the K consecutive positions
@@ -1487,11 +1490,14 @@ __global__ void __launch_bounds__(256) bwd_fix_kernel(Problem P, State W, BwdArg
 // edge posteriors go the same way into ONE [N][N] fixed-point tile per workgroup, written out as a float tile that
 // add_tiles_kernel sums over (b, chunk) in a fixed order -- no single-workgroup scatter over the whole batch
 // (aligned_tr_scatter_kernel: 2.5 ms at T = 1000 B = 64 S = 200).  Restates force_aligned_lattice.cpp:156-264.
-template <typename R, int K>
-__global__ void __launch_bounds__(256) bwd_aligned_long_kernel(Problem P, State W, BwdArgs A, R *tiles, int add_to_inputs) {
+// NL = 256 (64 < N <= 256): label rows of 256 words; the edge posteriors go straight into the [N][N] 64-bit fixed-point
+// accumulator in memory (`gfx`, as aligned_tr_scatter_fx_kernel) instead of an LDS tile.
+template <typename R, int K, int NL>
+__global__ void __launch_bounds__(256) bwd_aligned_long_kernel(Problem P, State W, BwdArgs A, R *tiles, int add_to_inputs,
+                                                               unsigned long long *gfx) {
     typedef typename FrameFix<R>::T FX;
-    __shared__ FX fxI[4][64];
-    __shared__ unsigned long long fxT[64 * 64];
+    __shared__ FX fxI[4][NL];
+    __shared__ unsigned long long fxT[NL == 64 ? 64 * 64 : 1];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.x, chunk = blockIdx.y;
@@ -1503,8 +1509,8 @@ __global__ void __launch_bounds__(256) bwd_aligned_long_kernel(Problem P, State 
     const R ga = (A.grad_aligned || !A.neg_aligned) ? g0 : -g0;
     const int2 *asi = reinterpret_cast<const int2 *>(W.asi) + (int64_t) b * S;
     const V2<R> *asu = reinterpret_cast<const V2<R> *>(W.asu) + (int64_t) b * S;
-    for (int q = threadIdx.x; q < N * N; q += 256) fxT[q] = 0;
-    fxI[wave][lane] = 0;
+    if (NL == 64) for (int q = threadIdx.x; q < N * N; q += 256) fxT[q] = 0;
+    for (int q = lane; q < NL; q += 64) fxI[wave][q] = 0;
     R H2[K], Dp[K];
     double accH[K], accD[K];
     int tgt[K], prv[K];
@@ -1561,29 +1567,44 @@ __global__ void __launch_bounds__(256) bwd_aligned_long_kernel(Problem P, State 
             }
         }
         __builtin_amdgcn_wave_barrier();
-        const FX fv = fxI[wave][lane];
-        __builtin_amdgcn_wave_barrier();
-        fxI[wave][lane] = 0;
-        __builtin_amdgcn_wave_barrier();
-        if (lane < N) {
-            R *gin = (R *) A.grad_inputs + ((int64_t) t * P.B + b) * N + lane;
-            const R add = ga * FrameFix<R>::from(fv);
-            *gin = add_to_inputs ? *gin + add : add;
+#pragma unroll
+        for (int q = 0; q < NL / 64; ++q) {
+            const int lab = lane + 64 * q;
+            const FX fv = fxI[wave][lab];
+            fxI[wave][lab] = 0;
+            if (lab < N && (NL == 64 || fv != 0)) {
+                R *gin = (R *) A.grad_inputs + ((int64_t) t * P.B + b) * N + lab;
+                const R add = ga * FrameFix<R>::from(fv);
+                *gin = add_to_inputs ? *gin + add : add;
+            }
         }
+        __builtin_amdgcn_wave_barrier();
     }
     // this workgroup's edge posteriors -> one [N][N] tile: stay (O_s, O_s), arrive (O_s, O_{s-1})   (force_aligned_lattice.cpp:204-231)
+    if constexpr (NL == 64) {
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        if (act[k]) {
-            if (accH[k] != 0.0) atomicAdd(&fxT[tgt[k] * N + tgt[k]], (unsigned long long) __double2ll_rn(accH[k] * Num<R>::kFix));
-            if (lane * K + k >= 1 && accD[k] != 0.0)
-                atomicAdd(&fxT[tgt[k] * N + prv[k]], (unsigned long long) __double2ll_rn(accD[k] * Num<R>::kFix));
+        for (int k = 0; k < K; ++k) {
+            if (act[k]) {
+                if (accH[k] != 0.0) atomicAdd(&fxT[tgt[k] * N + tgt[k]], (unsigned long long) __double2ll_rn(accH[k] * Num<R>::kFix));
+                if (lane * K + k >= 1 && accD[k] != 0.0)
+                    atomicAdd(&fxT[tgt[k] * N + prv[k]], (unsigned long long) __double2ll_rn(accD[k] * Num<R>::kFix));
+            }
+        }
+        __syncthreads();
+        R *tile = tiles + ((int64_t) b * A.nchunks + chunk) * N * N;
+        for (int q = threadIdx.x; q < N * N; q += 256)
+            tile[q] = (R) ((double) ga * ((double) (long long) fxT[q] * (1.0 / Num<R>::kFix)));
+    } else {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            if (act[k]) {
+                const long long qh = __double2ll_rn((double) ga * accH[k] * GlobalFix<R>::scale);
+                const long long qd = __double2ll_rn((double) ga * accD[k] * GlobalFix<R>::scale);
+                if (qh != 0) atomicAdd(&gfx[(int64_t) tgt[k] * N + tgt[k]], (unsigned long long) qh);
+                if (lane * K + k >= 1 && qd != 0) atomicAdd(&gfx[(int64_t) tgt[k] * N + prv[k]], (unsigned long long) qd);
+            }
         }
     }
-    __syncthreads();
-    R *tile = tiles + ((int64_t) b * A.nchunks + chunk) * N * N;
-    for (int q = threadIdx.x; q < N * N; q += 256)
-        tile[q] = (R) ((double) ga * ((double) (long long) fxT[q] * (1.0 / Num<R>::kFix)));
 }
 
 // out[k] (+)= sum over the G tiles in a fixed order (deterministic).  grid = ceil(n / 32), block = 1024 = 32 elements x
@@ -1725,7 +1746,6 @@ __global__ void __launch_bounds__(256) bwd_aligned_kernel(Problem P, State W, Bw
 // Medium alphabets (64 < N <= 2048): the same scatter with one workgroup PER UTTERANCE and 64-bit fixed-point atomic adds
 // into an [N][N] accumulator in memory (integer adds commute: deterministic; the float result is formed once, by
 // fx_to_grad_kernel) -- the single workgroup below walks the batch utterance by utterance (713 us at B = 64, S = 30).
-template <typename R> struct GlobalFix { static constexpr double scale = sizeof(R) == 4 ? 68719476736.0 : 1099511627776.0; };   // 2^36 / 2^40
 template <typename R>
 __global__ void __launch_bounds__(256) aligned_tr_scatter_fx_kernel(Problem P, State W, BwdArgs A, const R *gHD, unsigned long long *fx) {
     const int S = P.S, N = P.N, b = blockIdx.x;
@@ -2057,14 +2077,26 @@ hipError_t launch_bwd_generic(const Problem &P, const State &W, const BwdArgs &A
     if (do_ali) {
         if (P.S > 1024) return hipErrorInvalidValue;
         if (!have_full) (void) hipMemsetAsync(A.grad_inputs, 0, (size_t) P.T * P.B * P.N * e, stream);
-        if (P.N <= 64 && P.S <= 512) {
+        unsigned long long *nofx = nullptr;
+        if (P.N <= 64 && P.S > 64 && P.S <= 512) {
             dim3 grid(P.B, A.nchunks);
-            if (P.S <= 128) hipLaunchKernelGGL((bwd_aligned_long_kernel<R, 2>), grid, dim3(256), 0, stream, P, W, A, atiles, 1);
-            else if (P.S <= 256) hipLaunchKernelGGL((bwd_aligned_long_kernel<R, 4>), grid, dim3(256), 0, stream, P, W, A, atiles, 1);
-            else hipLaunchKernelGGL((bwd_aligned_long_kernel<R, 8>), grid, dim3(256), 0, stream, P, W, A, atiles, 1);
+            if (P.S <= 128) hipLaunchKernelGGL((bwd_aligned_long_kernel<R, 2, 64>), grid, dim3(256), 0, stream, P, W, A, atiles, 1, nofx);
+            else if (P.S <= 256) hipLaunchKernelGGL((bwd_aligned_long_kernel<R, 4, 64>), grid, dim3(256), 0, stream, P, W, A, atiles, 1, nofx);
+            else hipLaunchKernelGGL((bwd_aligned_long_kernel<R, 8, 64>), grid, dim3(256), 0, stream, P, W, A, atiles, 1, nofx);
             const int n2 = P.N * P.N;
             hipLaunchKernelGGL((add_tiles_kernel<R>), dim3((n2 + 31) / 32), dim3(1024), 0, stream, (const R *) atiles,
                                P.B * A.nchunks, n2, gtr, have_full ? 1 : 0);
+        } else if (P.N > 64 && P.N <= 256 && P.S > 64 && P.S <= 512) {
+            // medium alphabet AND long targets
+            dim3 grid(P.B, A.nchunks);
+            unsigned long long *fx = (unsigned long long *) atiles;
+            const int64_t n2 = (int64_t) P.N * P.N;
+            (void) hipMemsetAsync(fx, 0, (size_t) n2 * 8, stream);
+            if (P.S <= 128) hipLaunchKernelGGL((bwd_aligned_long_kernel<R, 2, 256>), grid, dim3(256), 0, stream, P, W, A, (R *) nullptr, 1, fx);
+            else if (P.S <= 256) hipLaunchKernelGGL((bwd_aligned_long_kernel<R, 4, 256>), grid, dim3(256), 0, stream, P, W, A, (R *) nullptr, 1, fx);
+            else hipLaunchKernelGGL((bwd_aligned_long_kernel<R, 8, 256>), grid, dim3(256), 0, stream, P, W, A, (R *) nullptr, 1, fx);
+            hipLaunchKernelGGL((fx_to_grad_kernel<R>), dim3((unsigned) ((n2 + 255) / 256)), dim3(256), 0, stream,
+                               (const unsigned long long *) fx, n2, gtr, have_full ? 1 : 0);
         } else {
             hipLaunchKernelGGL((bwd_aligned_kernel<R>), dim3(P.B, A.nchunks), dim3(256), 0, stream, P, W, A, gHD, 1);
             if (P.N > 64 && P.N <= 2048) {
