@@ -161,11 +161,15 @@ int asg_loss_backward(asg_ctx *ctx, const asg_problem *p, const void *state, siz
  * reached second), and leaves the aligned posteriors beside them; asg_loss_fused_backward finishes the grad_inputs rows
  * (minus the aligned posteriors scattered to labels, times the actual upstream gradient), reduces the tiles in a fixed
  * order into grad_transition and redoes, exactly, any utterance the fused path declined (row sums outside the
- * fp32-safe range, fewer than 4 frames).  Results are bit-deterministic.  Only half of the lattice state ever goes to
- * device memory.
+ * fp32-safe range, fewer than 4 frames, a bounded wait on another workgroup that ran out).  Results are
+ * bit-deterministic as long as no wait runs out, i.e. while the three workgroups of every utterance are co-resident
+ * (an utterance redone by the exact code differs from the fused result in summation order, within the 1e-4 contract).
+ * Only half of the lattice state ever goes to device memory.
  *   supported: float32, N < 64, S <= 64, T <= 4000 (asg_loss_fused_supported returns 1); otherwise use
- *              asg_loss_forward/backward.  The launch gives every utterance three compute units of its own: it is the
- *              fast route while B <= 80 on 256 compute units (every XCD must hold three workgroups per utterance) (the Python binding routes larger batches to asg_loss_forward).
+ *              asg_loss_forward/backward.
+ *   fast while: B <= 80 on 256 compute units -- the launch gives every utterance three compute units of its own and
+ *              every XCD must hold three workgroups for each of its utterances; above that it still works (in rounds)
+ *              but asg_loss_forward is faster, and the Python binding routes larger batches there.
  *   state:     asg_state_bytes(p) bytes, as for asg_loss_forward; the SAME buffer must be passed to backward.
  *   scratch:   asg_loss_fused_scratch_bytes(p) bytes; the SAME buffer must be passed to backward.
  *   grad_inputs [T,B,N] contiguous: partly written by forward, completed in place by backward.
