@@ -31,6 +31,16 @@ class _NullGuard:
 
 _NULL_GUARD = _NullGuard()
 
+# torch.cuda.current_stream() builds a Stream object (4 us per call on the training path); the raw handle is a C call away
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_is_capturing = getattr(torch._C, "_cuda_isCurrentStreamCapturing", None)
+
+
+def _current_stream_handle(idx):
+    if _raw_stream is not None:
+        return int(_raw_stream(idx))
+    return int(torch.cuda.current_stream(idx).cuda_stream)
+
 
 class HipBackend:
     """Thin tensor <-> C-ABI adapter.  Every method launches HIP kernels on the current stream."""
@@ -98,15 +108,21 @@ class HipBackend:
         dev = inputs.device
         p = _lib.AsgProblem()
         p.inputs = inputs.data_ptr()
-        p.inputs_strides[:] = list(inputs.stride())
+        st = inputs.stride()
+        ps = p.inputs_strides
+        ps[0], ps[1], ps[2] = st[0], st[1], st[2]
         p.transition = transition.data_ptr()
-        p.transition_strides[:] = list(transition.stride())
+        st = transition.stride()
+        ps = p.transition_strides
+        ps[0], ps[1] = st[0], st[1]
         keep = [inputs, transition]
         if targets is not None:
             if targets.device != dev:
                 targets = targets.to(dev, non_blocking=True)
             p.targets = targets.data_ptr()
-            p.targets_strides[:] = list(targets.stride())
+            st = targets.stride()
+            ps = p.targets_strides
+            ps[0], ps[1] = st[0], st[1]
             p.S = targets.shape[1]
             keep.append(targets)
         else:
@@ -137,7 +153,7 @@ class HipBackend:
         """Side stream + fork/join events of the 'streams' launch mode, ONE SET PER CALLING STREAM: calls issued on
         different streams (other threads, other modules, a capture in progress) never share an event pair."""
         idx = device.index if device.index is not None else torch.cuda.current_device()
-        key = (idx, torch.cuda.current_stream(idx).cuda_stream)
+        key = (idx, _current_stream_handle(idx))
         h = self._ctx.get(key)
         if h is None:
             with self._lock:
@@ -164,7 +180,8 @@ class HipBackend:
 
     @staticmethod
     def _stream(device):
-        return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        return ctypes.c_void_p(_current_stream_handle(idx))
 
     @staticmethod
     def _buf(nbytes, device):
@@ -296,8 +313,8 @@ class HipBackend:
         Regions are carved from pools that are allocated and zeroed EAGERLY: never while a capture is in progress
         (the pool would come out of the graph's private memory and its zero-fill would become a graph node)."""
         idx = device.index if device.index is not None else torch.cuda.current_device()
-        stream = torch.cuda.current_stream(idx).cuda_stream
-        capturing = torch.cuda.is_current_stream_capturing()
+        stream = _current_stream_handle(idx)
+        capturing = bool(_is_capturing()) if _is_capturing is not None else torch.cuda.is_current_stream_capturing()
         cap = 0
         if capturing:
             cid = ctypes.c_ulonglong(0)
