@@ -9,7 +9,7 @@ dev = "cuda:0"
 shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]] or [(1000, 64, 40, 64), (1000, 64, 40, 100), (1000, 64, 40, 200)]
 for T, B, N, L in shapes:
     tr, x, tg, il, tl = util.synth(T, B, N, L, 0, True)
-    m = torch_asg_amd.ASGLoss(N).to(dev)
+    m = torch_asg_amd.ASGLoss(N, launch_mode=os.environ.get("ASG_MODE", "single")).to(dev)
     with torch.no_grad(): m.transition.copy_(tr)
     xd = x.to(dev).requires_grad_(True); tgd, ild, tld = tg.to(dev), il.to(dev), tl.to(dev)
     one = torch.ones((), device=dev)
