@@ -899,12 +899,12 @@ def test_generic_one_launch_forward_equals_per_frame_launches(monkeypatch):
 # ------------------------------------------------------------------ long targets over a small alphabet (letter models)
 @pytest.mark.gpu
 @pytest.mark.parametrize("T,B,N,L", [(90, 3, 29, 65), (140, 2, 40, 128), (150, 3, 40, 129), (300, 2, 31, 200),
-                                       (280, 2, 64, 256), (330, 2, 8, 300), (520, 2, 40, 512), (600, 1, 5, 513)])
+                                       (280, 2, 64, 256), (330, 2, 8, 300), (520, 2, 40, 512), (600, 1, 5, 513), (1030, 1, 30, 1024)])
 @pytest.mark.parametrize("dtype,rtol", [(torch.float32, 1e-4), (torch.float64, 1e-9)])
 def test_long_targets_small_alphabet(T, B, N, L, dtype, rtol):
-    """64 < S <= 512 with N <= 64: one wavefront per aligned chain, 2 / 4 / 8 target positions per lane
-    (aligned_long_kernel), label scatter through fixed-point LDS rows (bwd_aligned_long_kernel); S = 513 takes the
-    one-position-per-thread kernels.  Small alphabets repeat labels all the time, lengths vary, one utterance is
+    """64 < S <= 1024 with N <= 64: up to S = 256 one wavefront per aligned chain with 2 / 4 target positions per lane
+    (aligned_long_kernel), beyond that a pipeline of wavefronts, one position per thread (aligned_pipe_kernel); label
+    scatter through fixed-point LDS rows (bwd_aligned_long_kernel, 2 .. 16 positions per lane).  Small alphabets repeat labels all the time, lengths vary, one utterance is
     infeasible when B >= 3."""
     rng = np.random.default_rng(T + 7 * L)
     tr, x, tg, _, _ = util.synth(T, B, N, L, L + N)

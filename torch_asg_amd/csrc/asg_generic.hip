@@ -873,6 +873,7 @@ __global__ void __launch_bounds__(64) aligned_long_kernel(Problem P, State W, Fw
     const R *tr = (const R *) P.transition;
     const R *inb = (const R *) P.inputs + (int64_t) b * P.is1;
     bool act[K];
+    double ebias[K];                            // 0 on positions inside the target, log-zero otherwise: em = raw * log2 e + ebias
     unsigned eoff[K], soffv[K];                 // byte offsets: the label's emission inside a frame row; the position inside a state row
     double H2[K], Dx[K];                        // stay edge; alpha: edge from the previous position, beta: edge to the next
     // frames through buffer accesses: lane offset in a VGPR, frame offset in an SGPR (launch_fwd_generic checks that both
@@ -892,6 +893,7 @@ __global__ void __launch_bounds__(64) aligned_long_kernel(Problem P, State W, Fw
         const R dn = (p + 1 < ol) ? fmax(tr[(int64_t) nxt * P.ts0 + (int64_t) cur * P.ts1] * L2E, LZ) : LZ;
         H2[k] = (double) h2;
         Dx[k] = (double) (beta ? dn : dp);
+        ebias[k] = act[k] ? 0.0 : -1e30;
         eoff[k] = (unsigned) (cur * (int) P.is2) * (unsigned) sizeof(R);
         soffv[k] = p < S ? (unsigned) p * (unsigned) sizeof(R) : kOobOffset;
         if (STORE && !beta && p < S) {
@@ -938,6 +940,11 @@ __global__ void __launch_bounds__(64) aligned_long_kernel(Problem P, State W, Fw
         }
     };
     R cur[PF][K], nxt[PF][K];
+    // the PF K emission loads of the NEXT block are issued before this block's PF K state stores: "at most PF K memory
+    // operations outstanding" = they have landed.  Said explicitly (left alone hipcc drains the store queue, vmcnt(0), at
+    // every use of a loaded value: the previous frame's stores, every frame)
+    constexpr int kOut = PF * K;
+    constexpr int kWaitLoads = STORE ? (((kOut >> 4) << 14) | 0x0F70 | (kOut & 15)) : 0x0F70;
     if (!beta) {
         {
             R e0[K];
@@ -948,6 +955,7 @@ __global__ void __launch_bounds__(64) aligned_long_kernel(Problem P, State W, Fw
         store_row(0, v);
 #pragma unroll
         for (int u = 0; u < PF; ++u) fetch(1 + u, cur[u]);
+        __builtin_amdgcn_s_waitcnt(0x0F70);
         for (int t0 = 1; t0 < len; t0 += PF) {
 #pragma unroll
             for (int u = 0; u < PF; ++u) fetch(t0 + PF + u, nxt[u]);
@@ -955,18 +963,21 @@ __global__ void __launch_bounds__(64) aligned_long_kernel(Problem P, State W, Fw
             for (int u = 0; u < PF; ++u) {
                 const int t = t0 + u;
                 if (t < len) {
+                    // (everything below is branch-free: an `act ? .. : ..` around the transcendentals becomes an EXEC-masked
+                    // branch per position, which also keeps the K independent updates from overlapping.  Lane 0's left
+                    // neighbour reads 0, and position 0 has a log-zero arrive edge: no select needed)
                     const double left = prev_lane_or_zero<double>(v[K - 1]);
-                    const double lft = lane == 0 ? kZ : left;
 #pragma unroll
                     for (int k = K - 1; k >= 0; --k) {
-                        const double em = act[k] ? (double) cur[u][k] * L2Ed : kZ;
-                        const double from = k == 0 ? lft : v[k - 1];
+                        const double em = fma((double) cur[u][k], L2Ed, ebias[k]);
+                        const double from = k == 0 ? left : v[k - 1];
                         v[k] = fmax(em + lse2d(v[k] + H2[k], from + Dx[k]), kZ);
                     }
                     if ((t & 15) == 0) renorm();
                     store_row(t, v);
                 }
             }
+            __builtin_amdgcn_s_waitcnt(kWaitLoads);
 #pragma unroll
             for (int u = 0; u < PF; ++u)
 #pragma unroll
@@ -990,6 +1001,7 @@ __global__ void __launch_bounds__(64) aligned_long_kernel(Problem P, State W, Fw
         // step u of a block that starts at frame t0 consumes the emissions of frame t0 - u and writes frame t0 - u - 1
 #pragma unroll
         for (int u = 0; u < PF; ++u) fetch(len - 1 - u, cur[u]);
+        __builtin_amdgcn_s_waitcnt(0x0F70);
         for (int t0 = len - 1; t0 >= 1; t0 -= PF) {
 #pragma unroll
             for (int u = 0; u < PF; ++u) fetch(t0 - PF - u, nxt[u]);
@@ -999,18 +1011,18 @@ __global__ void __launch_bounds__(64) aligned_long_kernel(Problem P, State W, Fw
                 if (t >= 1) {
                     double y[K];
 #pragma unroll
-                    for (int k = 0; k < K; ++k) y[k] = fmax((act[k] ? (double) cur[u][k] * L2Ed : kZ) + v[k], kZ);
-                    const double right = next_lane_or_zero<double>(y[0]);
-                    const double rgt = lane == 63 ? kZ : right;
+                    for (int k = 0; k < K; ++k) y[k] = fmax(fma((double) cur[u][k], L2Ed, ebias[k]) + v[k], kZ);
+                    const double right = next_lane_or_zero<double>(y[0]);      // (lane 63 reads 0; its last position has a log-zero leave edge)
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
-                        const double to = k == K - 1 ? rgt : y[k + 1];
+                        const double to = k == K - 1 ? right : y[k + 1];
                         v[k] = fmax(lse2d(y[k] + H2[k], to + Dx[k]), kZ);
                     }
                     if ((t & 15) == 0) renorm();
                     store_row(t - 1, v);
                 }
             }
+            __builtin_amdgcn_s_waitcnt(kWaitLoads);
 #pragma unroll
             for (int u = 0; u < PF; ++u)
 #pragma unroll
@@ -1022,6 +1034,201 @@ __global__ void __launch_bounds__(64) aligned_long_kernel(Problem P, State W, Fw
             if (lane == 0) {
                 const double em = act[0] ? (double) e0[0] * L2Ed : kZ;
                 const double sc = C + (em + v[0]);
+                score_out[b] = (sc < -1e29) ? Num<R>::ninf() : (R) (sc * kLn2);
+            }
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------ aligned lattice, long targets, pipelined wavefronts
+// grid = (B, 2), block = 64 * ceil(S / 64) (<= 1024): thread p owns target position p (one position per lane: the
+// per-position work of a frame is a dozen double-precision / transcendental instructions, and one SIMD retires them at
+// ~8 cycles apiece -- K positions per lane cost K times that, aligned_long_kernel: 276 us at S = 200, T = 1000).  The
+// wavefronts of a chain form a PIPELINE instead of meeting at a workgroup barrier every frame (aligned_wide_kernel):
+// the only value that crosses a wavefront boundary per frame (alpha: the state of position 64 w - 1, beta: y of position
+// 64 (w + 1)) travels through a 64-slot LDS ring as a (value, frame) pair, the consumer polls the frame tag.  All
+// wavefronts of a workgroup are co-resident, the dependency runs one way, so nothing can dead-lock.
+// States are kept ABSOLUTE in double (no renormalisation inside the recursion); what is stored for the gradient pass is
+// float(v - Cref), Cref = the largest state two 16-frame blocks ago, gathered once per block through LDS -- the same
+// per-frame offset for every position of a frame, which is all the gradient pass needs.  Waiting for that gather also
+// bounds the skew between the fastest and the slowest wavefront to two blocks, which is what makes 64 ring slots enough.
+template <typename R, bool STORE>
+__global__ void __launch_bounds__(1024) aligned_pipe_kernel(Problem P, State W, FwdOut O, int mask) {
+    constexpr int D = 64;
+    __shared__ double ring_v[16][D];
+    __shared__ int ring_t[16][D];
+    __shared__ float blk_m[4][16];
+    __shared__ int blk_t[4][16];
+    const int b = blockIdx.x;
+    const bool beta = (mask == kAlignedBeta) || (mask == (kAlignedAlpha | kAlignedBeta) && blockIdx.y == 1);
+    const int s = threadIdx.x, lane = s & 63, wave = __builtin_amdgcn_readfirstlane(s >> 6), NW = (int) (blockDim.x >> 6);
+    const int S = P.S, T = P.T, N = P.N;
+    const R L2E = Num<R>::log2e(), LZ = Num<R>::logzero();
+    const int len = P.in_len ? gclampi(P.in_len[b], 0, T) : T;
+    const int ol = P.tg_len ? gclampi(P.tg_len[b], 0, S) : S;
+    const bool act = s < ol;
+    const int64_t *tg = P.targets + (int64_t) b * P.gs0;
+    const int cur = act ? gclampi(tg[(int64_t) s * P.gs1], 0, N - 1) : 0;
+    const int prv = (act && s >= 1) ? gclampi(tg[(int64_t) (s - 1) * P.gs1], 0, N - 1) : 0;
+    const int nxt = (s + 1 < ol) ? gclampi(tg[(int64_t) (s + 1) * P.gs1], 0, N - 1) : 0;
+    const R *tr = (const R *) P.transition;
+    const R H2f = act ? fmax(tr[(int64_t) cur * P.ts0 + (int64_t) cur * P.ts1] * L2E, LZ) : R(0);
+    const R Dprev = (act && s >= 1) ? fmax(tr[(int64_t) cur * P.ts0 + (int64_t) prv * P.ts1] * L2E, LZ) : LZ;
+    const R Dnext = (s + 1 < ol) ? fmax(tr[(int64_t) nxt * P.ts0 + (int64_t) cur * P.ts1] * L2E, LZ) : LZ;
+    if (STORE && !beta && s < S) {
+        V2<R> u = {H2f, Dprev};
+        reinterpret_cast<V2<R> *>(W.asu)[(int64_t) b * S + s] = u;
+        int2 ii = {cur, prv};
+        reinterpret_cast<int2 *>(W.asi)[(int64_t) b * S + s] = ii;
+    }
+    R *score_out = (R *) (beta ? O.aligned_scores : O.aligned_scores_alpha);
+    if (len < 1 || ol < 1) {
+        if (s == 0 && score_out) score_out[b] = Num<R>::ninf();
+        return;
+    }
+    for (int q = s; q < 16 * D; q += (int) blockDim.x) (&ring_t[0][0])[q] = -1;
+    if (s < 64) (&blk_t[0][0])[s] = -1;
+    __syncthreads();
+    const double kZ = -1e30, L2Ed = 1.4426950408889634;
+    const double H2 = (double) H2f, Dx = (double) (beta ? Dnext : Dprev), ebias = act ? 0.0 : -1e30;
+    auto lse2d = [&](double x, double y) {
+        const double m = fmax(x, y);
+        const R d = (R) (fmin(x, y) - m);
+        return m + (double) Num<R>::log2(R(1) + Num<R>::exp2(d));
+    };
+    // emissions of this position's label: frame offset in an SGPR (32-bit offsets checked by the launcher)
+    __amdgpu_buffer_rsrc_t rin = make_rsrc((R *) P.inputs + (int64_t) b * P.is1, 0xffffffffu);
+    const unsigned eoff = (unsigned) (cur * (int) P.is2) * (unsigned) sizeof(R), frame_bytes = (unsigned) P.is0 * (unsigned) sizeof(R);
+    auto emis = [&](int f) -> R {
+        return buf_load<R>(rin, eoff, (unsigned) __builtin_amdgcn_readfirstlane(gclampi(f, 0, len - 1)) * frame_bytes);
+    };
+    __amdgpu_buffer_rsrc_t rout = make_rsrc((R *) (beta ? W.bb : W.ab) + (int64_t) b * T * S, STORE ? (unsigned) ((int64_t) T * S * sizeof(R)) : 0u);
+    const unsigned soff = s < S ? (unsigned) s * (unsigned) sizeof(R) : kOobOffset, row_bytes = (unsigned) S * (unsigned) sizeof(R);
+    // reference offset of the stored states: frame-0 emission of the first target label to start with (every thread can
+    // compute it), then the block maxima
+    double Cref;
+    {
+        const int c0 = gclampi(tg[0], 0, N - 1);
+        const R e0 = ((const R *) P.inputs)[(int64_t) b * P.is1 + (int64_t) (beta ? len - 1 : 0) * P.is0 + (int64_t) c0 * P.is2];
+        Cref = beta ? 0.0 : (double) e0 * L2Ed;
+    }
+    auto store = [&](int t, double v) {
+        if (STORE) buf_store((R) fmax(v - Cref, kZ), rout, soff, (unsigned) __builtin_amdgcn_readfirstlane(t) * row_bytes);
+    };
+    // step n = 1, 2, ...: block boundary bookkeeping.  End of block k (n & 15 == 15): publish this wavefront's largest
+    // state; start of block k >= 2: Cref = max over the wavefronts of their block k - 2 maxima.
+    auto block_end = [&](int n, double v) {
+        const float m = wave_allmax((float) fmax(v, kZ));
+        if (lane == 0) {
+            const int k = n >> 4;
+            // (LDS executes one wavefront's accesses in order: value first, tag second is all the ordering a reader of the
+            // tag needs.  A RELEASE store would also wait for this wavefront's pending global stores -- the frame's
+            // state -- every frame: 700+ cycles per step instead of ~250)
+            blk_m[k & 3][wave] = m;
+            asm volatile("" ::: "memory");
+            __hip_atomic_store(&blk_t[k & 3][wave], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
+    auto block_begin = [&](int n) {
+        const int k = (n >> 4) - 2;
+        if (k < 0) return;
+        float m = -3e38f;
+        for (int w = 0; w < NW; ++w) {
+            while (__hip_atomic_load(&blk_t[k & 3][w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != k) __builtin_amdgcn_s_sleep(2);
+            asm volatile("" ::: "memory");
+            m = fmaxf(m, __hip_atomic_load(&blk_m[k & 3][w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        }
+        if (m > -1e29f) Cref = (double) m;
+    };
+    // the value wavefront `w` published for step `n`
+    auto take = [&](int w, int n) -> double {
+        const int slot = n & (D - 1);
+        while (__hip_atomic_load(&ring_t[w][slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != n) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+        return __hip_atomic_load(&ring_v[w][slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto give = [&](int n, double v) {             // (by ONE lane of this wavefront)
+        const int slot = n & (D - 1);
+        __hip_atomic_store(&ring_v[wave][slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        asm volatile("" ::: "memory");
+        __hip_atomic_store(&ring_t[wave][slot], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    // Emissions are fetched a 16-frame block ahead: the loads of the next block are issued before this block's 16 state
+    // stores, so "at most 16 memory operations outstanding" means they have all landed -- said explicitly below; left to
+    // itself hipcc waits for vmcnt(0) at every use of a loaded value, i.e. for the previous frame's store, every frame
+    // (700 cycles per frame instead of ~250).
+    constexpr int PF = 16;
+    R ecur[PF], enxt[PF];
+    double v;
+    if (!beta) {
+        v = (s == 0) ? fma((double) emis(0), L2Ed, ebias) : kZ;
+        store(0, v);
+        if (wave < NW - 1 && lane == 63) give(0, v);
+#pragma unroll
+        for (int u = 0; u < PF; ++u) ecur[u] = emis(1 + u);
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        for (int t0 = 1; t0 < len; t0 += PF) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) enxt[u] = emis(t0 + PF + u);
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int t = t0 + u;                       // step n = t
+                if (t < len) {
+                    if ((t & 15) == 0) block_begin(t);
+                    double left = prev_lane_or_zero<double>(v);
+                    if (wave > 0) {
+                        const double nb = take(wave - 1, t - 1);
+                        left = lane == 0 ? nb : left;
+                    }
+                    const double em = fma((double) ecur[u], L2Ed, ebias);
+                    v = em + lse2d(v + H2, left + Dx);
+                    if (wave < NW - 1 && lane == 63) give(t, v);
+                    store(t, v);
+                    if ((t & 15) == 15) block_end(t, v);
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(STORE ? 0x4F70 : 0x0F70);
+#pragma unroll
+            for (int u = 0; u < PF; ++u) ecur[u] = enxt[u];
+        }
+        if (score_out) {
+            if (s == ol - 1) score_out[b] = (v < -1e29) ? Num<R>::ninf() : (R) (v * kLn2);
+        }
+    } else {
+        v = (s == ol - 1) ? 0.0 : kZ;
+        store(len - 1, v);
+#pragma unroll
+        for (int u = 0; u < PF; ++u) ecur[u] = emis(len - 1 - u);
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        // step n = len - t (1, 2, ...) consumes the emissions of frame t and writes frame t - 1
+        for (int t0 = len - 1; t0 >= 1; t0 -= PF) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) enxt[u] = emis(t0 - PF - u);
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int t = t0 - u, n = len - t;
+                if (t >= 1) {
+                    if ((n & 15) == 0) block_begin(n);
+                    const double y = fma((double) ecur[u], L2Ed, ebias) + v;
+                    if (wave > 0 && lane == 0) give(n, y);
+                    double right = next_lane_or_zero<double>(y);
+                    if (wave < NW - 1) {
+                        const double nb = take(wave + 1, n);
+                        right = lane == 63 ? nb : right;
+                    }
+                    v = lse2d(y + H2, right + Dx);
+                    store(t - 1, v);
+                    if ((n & 15) == 15) block_end(n, v);
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(STORE ? 0x4F70 : 0x0F70);
+#pragma unroll
+            for (int u = 0; u < PF; ++u) ecur[u] = enxt[u];
+        }
+        if (score_out) {
+            if (s == 0) {
+                const double sc = fma((double) emis(0), L2Ed, ebias) + v;
                 score_out[b] = (sc < -1e29) ? Num<R>::ninf() : (R) (sc * kLn2);
             }
         }
@@ -1872,7 +2079,12 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
         const double fr = (double) (P.T - 1) * (double) P.is0 * sizeof(R), ln = (double) (P.N - 1) * (double) P.is2 * sizeof(R);
         const bool off32 = P.is0 >= 0 && P.is2 >= 0 && fr < 4294967296.0 && ln < 2147483648.0 &&
                            (double) P.T * P.S * sizeof(R) < 4294967296.0;
-        if (!off32 || P.S > 512) {
+        const char *ak = getenv("ASG_ALIGNED_KERNEL");        // developer A/B: "long" (K positions per lane), "wide" (barrier per frame)
+        const bool use_pipe = off32 && ((P.S > 256 && !(ak && (ak[0] == 'l' || ak[0] == 'w'))) || (ak && ak[0] == 'p'));
+        if (use_pipe) {
+            if (store) hipLaunchKernelGGL((aligned_pipe_kernel<R, true>), grid, dim3(threads), 0, stream, P, W, O, ali_mask);
+            else hipLaunchKernelGGL((aligned_pipe_kernel<R, false>), grid, dim3(threads), 0, stream, P, W, O, ali_mask);
+        } else if (!off32 || P.S > 512 || (ak && ak[0] == 'w')) {
             if (store) hipLaunchKernelGGL((aligned_wide_kernel<R, true>), grid, dim3(threads), 0, stream, P, W, O, ali_mask);
             else hipLaunchKernelGGL((aligned_wide_kernel<R, false>), grid, dim3(threads), 0, stream, P, W, O, ali_mask);
         } else if (P.S <= 128) {
@@ -2078,15 +2290,16 @@ hipError_t launch_bwd_generic(const Problem &P, const State &W, const BwdArgs &A
         if (P.S > 1024) return hipErrorInvalidValue;
         if (!have_full) (void) hipMemsetAsync(A.grad_inputs, 0, (size_t) P.T * P.B * P.N * e, stream);
         unsigned long long *nofx = nullptr;
-        if (P.N <= 64 && P.S > 64 && P.S <= 512) {
+        if (P.N <= 64 && P.S > 64 && P.S <= 1024) {
             dim3 grid(P.B, A.nchunks);
             if (P.S <= 128) hipLaunchKernelGGL((bwd_aligned_long_kernel<R, 2, 64>), grid, dim3(256), 0, stream, P, W, A, atiles, 1, nofx);
             else if (P.S <= 256) hipLaunchKernelGGL((bwd_aligned_long_kernel<R, 4, 64>), grid, dim3(256), 0, stream, P, W, A, atiles, 1, nofx);
-            else hipLaunchKernelGGL((bwd_aligned_long_kernel<R, 8, 64>), grid, dim3(256), 0, stream, P, W, A, atiles, 1, nofx);
+            else if (P.S <= 512) hipLaunchKernelGGL((bwd_aligned_long_kernel<R, 8, 64>), grid, dim3(256), 0, stream, P, W, A, atiles, 1, nofx);
+            else hipLaunchKernelGGL((bwd_aligned_long_kernel<R, 16, 64>), grid, dim3(256), 0, stream, P, W, A, atiles, 1, nofx);
             const int n2 = P.N * P.N;
             hipLaunchKernelGGL((add_tiles_kernel<R>), dim3((n2 + 31) / 32), dim3(1024), 0, stream, (const R *) atiles,
                                P.B * A.nchunks, n2, gtr, have_full ? 1 : 0);
-        } else if (P.N > 64 && P.N <= 256 && P.S > 64 && P.S <= 512) {
+        } else if (P.N > 64 && P.N <= 256 && P.S > 64 && P.S <= 1024) {
             // medium alphabet AND long targets
             dim3 grid(P.B, A.nchunks);
             unsigned long long *fx = (unsigned long long *) atiles;
@@ -2094,7 +2307,8 @@ hipError_t launch_bwd_generic(const Problem &P, const State &W, const BwdArgs &A
             (void) hipMemsetAsync(fx, 0, (size_t) n2 * 8, stream);
             if (P.S <= 128) hipLaunchKernelGGL((bwd_aligned_long_kernel<R, 2, 256>), grid, dim3(256), 0, stream, P, W, A, (R *) nullptr, 1, fx);
             else if (P.S <= 256) hipLaunchKernelGGL((bwd_aligned_long_kernel<R, 4, 256>), grid, dim3(256), 0, stream, P, W, A, (R *) nullptr, 1, fx);
-            else hipLaunchKernelGGL((bwd_aligned_long_kernel<R, 8, 256>), grid, dim3(256), 0, stream, P, W, A, (R *) nullptr, 1, fx);
+            else if (P.S <= 512) hipLaunchKernelGGL((bwd_aligned_long_kernel<R, 8, 256>), grid, dim3(256), 0, stream, P, W, A, (R *) nullptr, 1, fx);
+            else hipLaunchKernelGGL((bwd_aligned_long_kernel<R, 16, 256>), grid, dim3(256), 0, stream, P, W, A, (R *) nullptr, 1, fx);
             hipLaunchKernelGGL((fx_to_grad_kernel<R>), dim3((unsigned) ((n2 + 255) / 256)), dim3(256), 0, stream,
                                (const unsigned long long *) fx, n2, gtr, have_full ? 1 : 0);
         } else {
