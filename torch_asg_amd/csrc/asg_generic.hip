@@ -1056,8 +1056,10 @@ __global__ void __launch_bounds__(64) aligned_long_kernel(Problem P, State W, Fw
 template <typename R, bool STORE>
 __global__ void __launch_bounds__(1024) aligned_pipe_kernel(Problem P, State W, FwdOut O, int mask) {
     constexpr int D = 64;
-    __shared__ double ring_v[16][D];
-    __shared__ int ring_t[16][D];
+    typedef int I4 __attribute__((ext_vector_type(4)));
+    // one 16-byte slot per (wavefront, frame mod D): {value lo, frame, value hi, frame} -- written with ONE ds_write_b128 and
+    // read with one ds_read_b128; the frame tag sits in both 8-byte halves, so a reader that finds it in both has the value
+    __shared__ __attribute__((aligned(16))) I4 ring[16][D];
     __shared__ float blk_m[4][16];
     __shared__ int blk_t[4][16];
     const int b = blockIdx.x;
@@ -1087,7 +1089,7 @@ __global__ void __launch_bounds__(1024) aligned_pipe_kernel(Problem P, State W, 
         if (s == 0 && score_out) score_out[b] = Num<R>::ninf();
         return;
     }
-    for (int q = s; q < 16 * D; q += (int) blockDim.x) (&ring_t[0][0])[q] = -1;
+    for (int q = s; q < 16 * D; q += (int) blockDim.x) (&ring[0][0])[q] = I4{0, -1, 0, -1};
     if (s < 64) (&blk_t[0][0])[s] = -1;
     __syncthreads();
     const double kZ = -1e30, L2Ed = 1.4426950408889634;
@@ -1141,18 +1143,29 @@ __global__ void __launch_bounds__(1024) aligned_pipe_kernel(Problem P, State W, 
         }
         if (m > -1e29f) Cref = (double) m;
     };
-    // the value wavefront `w` published for step `n`
-    auto take = [&](int w, int n) -> double {
-        const int slot = n & (D - 1);
-        while (__hip_atomic_load(&ring_t[w][slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != n) __builtin_amdgcn_s_sleep(1);
+    // the slot wavefront `w` uses for step `n` (16 bytes, one LDS read; valid when both tags say n)
+    auto peek = [&](int w, int n) -> I4 {
+        // (not `volatile`: address-space inference skips volatile accesses and this would become a flat load; the empty asm
+        // keeps the compiler from caching or hoisting the read)
         asm volatile("" ::: "memory");
-        return __hip_atomic_load(&ring_v[w][slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const I4 r = ring[w][n & (D - 1)];
+        asm volatile("" ::: "memory");
+        return r;
+    };
+    // the value of step `n` from a slot read earlier (`raw`: normally the look-ahead read of the previous frame, long landed);
+    // re-read until the producer has written it
+    auto take = [&](int w, int n, I4 raw) -> double {
+        while (raw.y != n || raw.w != n) {
+            __builtin_amdgcn_s_sleep(1);
+            raw = peek(w, n);
+        }
+        return __hiloint2double(raw.z, raw.x);
     };
     auto give = [&](int n, double v) {             // (by ONE lane of this wavefront)
-        const int slot = n & (D - 1);
-        __hip_atomic_store(&ring_v[wave][slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const I4 pk = {__double2loint(v), n, __double2hiint(v), n};
         asm volatile("" ::: "memory");
-        __hip_atomic_store(&ring_t[wave][slot], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        ring[wave][n & (D - 1)] = pk;
+        asm volatile("" ::: "memory");
     };
     // Emissions are fetched a 16-frame block ahead: the loads of the next block are issued before this block's 16 state
     // stores, so "at most 16 memory operations outstanding" means they have all landed -- said explicitly below; left to
@@ -1168,6 +1181,8 @@ __global__ void __launch_bounds__(1024) aligned_pipe_kernel(Problem P, State W, 
 #pragma unroll
         for (int u = 0; u < PF; ++u) ecur[u] = emis(1 + u);
         __builtin_amdgcn_s_waitcnt(0x0F70);
+        I4 ahead = {0, -1, 0, -1};                   // the neighbour's slot of the NEXT frame, read one frame early
+        if (wave > 0) ahead = peek(wave - 1, 0);
         for (int t0 = 1; t0 < len; t0 += PF) {
 #pragma unroll
             for (int u = 0; u < PF; ++u) enxt[u] = emis(t0 + PF + u);
@@ -1178,7 +1193,8 @@ __global__ void __launch_bounds__(1024) aligned_pipe_kernel(Problem P, State W, 
                     if ((t & 15) == 0) block_begin(t);
                     double left = prev_lane_or_zero<double>(v);
                     if (wave > 0) {
-                        const double nb = take(wave - 1, t - 1);
+                        const double nb = take(wave - 1, t - 1, ahead);
+                        ahead = peek(wave - 1, t);
                         left = lane == 0 ? nb : left;
                     }
                     const double em = fma((double) ecur[u], L2Ed, ebias);
@@ -1202,6 +1218,8 @@ __global__ void __launch_bounds__(1024) aligned_pipe_kernel(Problem P, State W, 
         for (int u = 0; u < PF; ++u) ecur[u] = emis(len - 1 - u);
         __builtin_amdgcn_s_waitcnt(0x0F70);
         // step n = len - t (1, 2, ...) consumes the emissions of frame t and writes frame t - 1
+        I4 ahead = {0, -1, 0, -1};
+        if (wave < NW - 1) ahead = peek(wave + 1, 1);
         for (int t0 = len - 1; t0 >= 1; t0 -= PF) {
 #pragma unroll
             for (int u = 0; u < PF; ++u) enxt[u] = emis(t0 - PF - u);
@@ -1214,7 +1232,8 @@ __global__ void __launch_bounds__(1024) aligned_pipe_kernel(Problem P, State W, 
                     if (wave > 0 && lane == 0) give(n, y);
                     double right = next_lane_or_zero<double>(y);
                     if (wave < NW - 1) {
-                        const double nb = take(wave + 1, n);
+                        const double nb = take(wave + 1, n, ahead);
+                        ahead = peek(wave + 1, n + 1);
                         right = lane == 63 ? nb : right;
                     }
                     v = lse2d(y + H2, right + Dx);
