@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Developer fuzz (GPU): random shapes through the long-target / medium-alphabet routes against the fp64 oracle.
+   fuzz_routes.py [cases] [seed]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np, torch
+import torch_asg_amd, util
+from oracle import asg_oracle as orc
+dev = "cuda:0"
+ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 120
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+bad = 0
+t_start = time.time()
+for c in range(ncases):
+    kind = rng.integers(0, 4)
+    if kind == 0:      # long targets, small alphabet
+        N = int(rng.integers(2, 65)); S = int(rng.integers(65, 1025)); T = int(rng.integers(1, 700))
+    elif kind == 1:    # medium alphabet, short targets
+        N = int(rng.integers(65, 257)); S = int(rng.integers(1, 65)); T = int(rng.integers(1, 300))
+    elif kind == 2:    # both
+        N = int(rng.integers(65, 257)); S = int(rng.integers(65, 600)); T = int(rng.integers(1, 400))
+    else:              # boundaries
+        N = int(rng.choice([64, 65, 128, 129, 192, 193, 256, 257])); S = int(rng.choice([64, 65, 128, 129, 256, 257, 512, 513])); T = int(rng.integers(2, 200))
+    B = int(rng.integers(1, 5))
+    dtype = torch.float32 if rng.random() < 0.8 else torch.float64
+    tr, x, tg, _, _ = util.synth(T, B, N, S, int(rng.integers(0, 1 << 30)))
+    scaled = rng.random() < 0.3
+    if scaled:
+        tr = tr * float(rng.choice([5.0, 40.0])) - 2.0
+    il = rng.integers(1, T + 1, B); tl = rng.integers(1, S + 1, B)
+    if rng.random() < 0.5: il[0] = T
+    if rng.random() < 0.5: tl[0] = S
+    red = ["mean", "sum", "none"][int(rng.integers(0, 3))]
+    if (tl > il).any() and red != "none":
+        red = "none"
+    o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il, tl, red)
+    m = torch_asg_amd.ASGLoss(N, reduction=red).to(dev).to(dtype)
+    with torch.no_grad(): m.transition.copy_(tr.to(dtype))
+    xd = x.to(dev, dtype).requires_grad_(True)
+    loss = m(xd, tg.to(dev), torch.from_numpy(il).to(dev), torch.from_numpy(tl).to(dev))
+    fin = torch.isfinite(loss)
+    (loss[fin].sum() if red == "none" else loss).backward() if fin.any() else None
+    torch.cuda.synchronize()
+    # fp32 states of long targets are stored relative to the frame's largest state: with transition scores of tens of nats
+    # the state ON the forced path can sit ~1000 log2 units below that maximum (the other direction compensates), which is
+    # 1e-4 of a float.  Seen only with such transitions and near-forced alignments (tl ~ il); bound: 3e-4.  DESIGN.md 5c.
+    tol = (3e-4 if scaled else 1e-4) if dtype == torch.float32 else 1e-9
+    res = {"loss": loss.detach().cpu().numpy()}
+    if fin.any():
+        go = None
+        if red == "none":
+            go = fin.cpu().numpy().astype(np.float64)
+            o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il, tl, red, grad_out=go)
+        res["grad_inputs"] = xd.grad.cpu().numpy(); res["grad_transition"] = m.transition.grad.cpu().numpy()
+    msg = []
+    for k, v in res.items():
+        ok, e = util.tol_ok(v, o[k], tol)
+        if not ok or np.isnan(v).any(): msg.append("%s %.2e" % (k, e))
+    if msg:
+        bad += 1
+        if "grad_inputs" in res:
+            d = np.abs(res["grad_inputs"].astype(np.float64) - o["grad_inputs"])
+            print("   per-utterance max |d grad_inputs|:", ["%.1e" % d[:, bb, :].max() for bb in range(B)],
+                  " worst frame of the worst utterance:", int(np.unravel_index(d.argmax(), d.shape)[0]), " max |ref| %.3f" % np.abs(o["grad_inputs"]).max())
+        print("FAIL T=%d B=%d N=%d S=%d %s red=%s il=%s tl=%s: %s" % (T, B, N, S, dtype, red, il.tolist(), tl.tolist(), "; ".join(msg)))
+print("%d cases, %d failures, %.0f s" % (ncases, bad, time.time() - t_start))
+sys.exit(1 if bad else 0)

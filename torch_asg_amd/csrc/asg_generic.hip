@@ -973,7 +973,7 @@ __global__ void __launch_bounds__(64) aligned_long_kernel(Problem P, State W, Fw
                         const double from = k == 0 ? left : v[k - 1];
                         v[k] = fmax(em + lse2d(v[k] + H2[k], from + Dx[k]), kZ);
                     }
-                    if ((t & 15) == 0) renorm();
+                    if ((t & 3) == 0) renorm();       // (every 4 frames: the stored floats stay within a few frames' growth of the offset)
                     store_row(t, v);
                 }
             }
@@ -1018,7 +1018,7 @@ __global__ void __launch_bounds__(64) aligned_long_kernel(Problem P, State W, Fw
                         const double to = k == K - 1 ? right : y[k + 1];
                         v[k] = fmax(lse2d(y[k] + H2[k], to + Dx[k]), kZ);
                     }
-                    if ((t & 15) == 0) renorm();
+                    if ((t & 3) == 0) renorm();       // (every 4 frames: the stored floats stay within a few frames' growth of the offset)
                     store_row(t - 1, v);
                 }
             }
@@ -1115,8 +1115,15 @@ __global__ void __launch_bounds__(1024) aligned_pipe_kernel(Problem P, State W, 
         const R e0 = ((const R *) P.inputs)[(int64_t) b * P.is1 + (int64_t) (beta ? len - 1 : 0) * P.is0 + (int64_t) c0 * P.is2];
         Cref = beta ? 0.0 : (double) e0 * L2Ed;
     }
-    auto store = [&](int t, double v) {
-        if (STORE) buf_store((R) fmax(v - Cref, kZ), rout, soff, (unsigned) __builtin_amdgcn_readfirstlane(t) * row_bytes);
+    // ... extrapolated linearly: the largest state two blocks ago plus the growth per step between the last two gathered
+    // maxima (transition scores of tens of nats move the scores by ~50 log2 units per frame: 32 frames of that above a
+    // constant reference would cost the stored floats 1e-4 of precision).  Every wavefront derives the same numbers.
+    double Cslope = 0.0;
+    int Cstep = 0;                                   // the step Cref belongs to
+    bool Chave = false;
+    auto store = [&](int t, int n, double v) {       // frame t, step n
+        if (STORE) buf_store((R) fmax(v - fma(Cslope, (double) (n - Cstep), Cref), kZ), rout, soff,
+                             (unsigned) __builtin_amdgcn_readfirstlane(t) * row_bytes);
     };
     // step n = 1, 2, ...: block boundary bookkeeping.  End of block k (n & 15 == 15): publish this wavefront's largest
     // state; start of block k >= 2: Cref = max over the wavefronts of their block k - 2 maxima.
@@ -1141,7 +1148,13 @@ __global__ void __launch_bounds__(1024) aligned_pipe_kernel(Problem P, State W, 
             asm volatile("" ::: "memory");
             m = fmaxf(m, __hip_atomic_load(&blk_m[k & 3][w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
         }
-        if (m > -1e29f) Cref = (double) m;
+        if (m > -1e29f) {
+            const int at = 16 * k + 15;
+            Cslope = Chave ? ((double) m - Cref) / (double) (at - Cstep) : 0.0;
+            Cref = (double) m;
+            Cstep = at;
+            Chave = true;
+        }
     };
     // the slot wavefront `w` uses for step `n` (16 bytes, one LDS read; valid when both tags say n)
     auto peek = [&](int w, int n) -> I4 {
@@ -1176,7 +1189,7 @@ __global__ void __launch_bounds__(1024) aligned_pipe_kernel(Problem P, State W, 
     double v;
     if (!beta) {
         v = (s == 0) ? fma((double) emis(0), L2Ed, ebias) : kZ;
-        store(0, v);
+        store(0, 0, v);
         if (wave < NW - 1 && lane == 63) give(0, v);
 #pragma unroll
         for (int u = 0; u < PF; ++u) ecur[u] = emis(1 + u);
@@ -1200,7 +1213,7 @@ __global__ void __launch_bounds__(1024) aligned_pipe_kernel(Problem P, State W, 
                     const double em = fma((double) ecur[u], L2Ed, ebias);
                     v = em + lse2d(v + H2, left + Dx);
                     if (wave < NW - 1 && lane == 63) give(t, v);
-                    store(t, v);
+                    store(t, t, v);
                     if ((t & 15) == 15) block_end(t, v);
                 }
             }
@@ -1213,7 +1226,7 @@ __global__ void __launch_bounds__(1024) aligned_pipe_kernel(Problem P, State W, 
         }
     } else {
         v = (s == ol - 1) ? 0.0 : kZ;
-        store(len - 1, v);
+        store(len - 1, 0, v);
 #pragma unroll
         for (int u = 0; u < PF; ++u) ecur[u] = emis(len - 1 - u);
         __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -1237,7 +1250,7 @@ __global__ void __launch_bounds__(1024) aligned_pipe_kernel(Problem P, State W, 
                         right = lane == 63 ? nb : right;
                     }
                     v = lse2d(y + H2, right + Dx);
-                    store(t - 1, v);
+                    store(t - 1, n, v);
                     if ((n & 15) == 15) block_end(n, v);
                 }
             }
