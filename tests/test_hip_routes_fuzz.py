@@ -1,0 +1,63 @@
+"""Random shapes through the routes between the fused step and the large-alphabet kernels (long targets over small
+alphabets, medium alphabets, both, and the boundaries N = 64/65/256/257, S = 64/65/256/257/512/513) against the fp64
+oracle: lengths of every kind (infeasible included), all reductions, fp32 and fp64.  tools/fuzz_routes.py is the long form."""
+import numpy as np
+import pytest
+import torch
+
+import util
+from oracle import asg_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _case(rng):
+    kind = int(rng.integers(0, 4))
+    if kind == 0:
+        N, S, T = int(rng.integers(2, 65)), int(rng.integers(65, 1025)), int(rng.integers(1, 500))
+    elif kind == 1:
+        N, S, T = int(rng.integers(65, 257)), int(rng.integers(1, 65)), int(rng.integers(1, 250))
+    elif kind == 2:
+        N, S, T = int(rng.integers(65, 257)), int(rng.integers(65, 500)), int(rng.integers(1, 300))
+    else:
+        N = int(rng.choice([64, 65, 128, 129, 192, 193, 256, 257]))
+        S = int(rng.choice([64, 65, 128, 129, 256, 257, 512, 513]))
+        T = int(rng.integers(2, 160))
+    return T, int(rng.integers(1, 4)), N, S
+
+
+@pytest.mark.parametrize("seed", [3, 17, 29, 41])
+def test_random_shapes_between_the_paths(seed):
+    import torch_asg_amd
+    rng = np.random.default_rng(seed)
+    for _ in range(22):
+        T, B, N, S = _case(rng)
+        dtype = torch.float32 if rng.random() < 0.8 else torch.float64
+        tr, x, tg, _, _ = util.synth(T, B, N, S, int(rng.integers(0, 1 << 30)))
+        il = rng.integers(1, T + 1, B)
+        tl = rng.integers(1, S + 1, B)
+        if rng.random() < 0.5:
+            il[0] = T
+        if rng.random() < 0.5:
+            tl[0] = S
+        red = ["mean", "sum", "none"][int(rng.integers(0, 3))]
+        if (tl > il).any():
+            red = "none"                                  # (a reduced loss with an infeasible utterance is +inf)
+        m = torch_asg_amd.ASGLoss(N, reduction=red).to(DEV).to(dtype)
+        with torch.no_grad():
+            m.transition.copy_(tr.to(dtype))
+        xd = x.to(DEV, dtype).requires_grad_(True)
+        loss = m(xd, tg.to(DEV), torch.from_numpy(il).to(DEV), torch.from_numpy(tl).to(DEV))
+        fin = torch.isfinite(loss)
+        go = fin.cpu().numpy().astype(np.float64) if red == "none" else None
+        o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il, tl, red, grad_out=go)
+        tol = 1e-4 if dtype == torch.float32 else 1e-9
+        what = "T%d B%d N%d S%d %s %s il=%s tl=%s" % (T, B, N, S, dtype, red, il.tolist(), tl.tolist())
+        util.assert_close(loss.detach().cpu().numpy(), o["loss"], tol, what + " loss")
+        if fin.any():
+            (loss[fin].sum() if red == "none" else loss).backward()
+            torch.cuda.synchronize()
+            util.assert_close(xd.grad.cpu().numpy(), o["grad_inputs"], tol, what + " grad_inputs")
+            util.assert_close(m.transition.grad.cpu().numpy(), o["grad_transition"], tol, what + " grad_transition")
+            assert not torch.isnan(xd.grad).any()
