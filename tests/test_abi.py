@@ -73,3 +73,27 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         _lib.lib()
+
+
+def test_cpp_fast_path_loads_and_declines_cpu_tensors():
+    """torch_asg_amd/_binding.so (csrc/binding.cpp) is host plumbing above the C ABI: it must import without a GPU,
+    take the entry points by address, and hand anything that is not the plain device case back to the Python path
+    (None) -- where CPU tensors raise, there being no CPU implementation."""
+    import torch
+    from torch_asg_amd import _lib
+    from torch_asg_amd import asg as A
+    assert os.path.exists(_lib.BINDING_PATH), "build with python torch_asg_amd/csrc/build.py"
+    be = A.HipBackend()
+    assert be.binding is not None
+    x = torch.zeros(5, 2, 4)
+    tr = torch.zeros(4, 4)
+    tg = torch.zeros(2, 3, dtype=torch.int64)
+    assert be.binding.try_loss_forward(x, tr, tg, None, None, 2, 2) is None
+    with pytest.raises(RuntimeError, match="no CPU implementation"):
+        A.ASGLossFunction.apply(x, tr, tg, None, None, "mean", 2)
+
+
+def test_cpp_fast_path_can_be_switched_off(monkeypatch):
+    from torch_asg_amd import asg as A
+    monkeypatch.setenv("ASG_NO_BINDING", "1")
+    assert A.HipBackend().binding is None

@@ -84,3 +84,21 @@ def check(status, what):
     if status != 0:
         msg = lib().asg_hip_strerror(int(status)).decode()
         raise RuntimeError("torch_asg_amd: %s failed: %s (status %d)" % (what, msg, status))
+
+
+# what the C++ fast path of ASGLossFunction (csrc/binding.cpp) calls, in the order its init() expects
+BINDING_SYMBOLS = ["asg_state_bytes", "asg_scratch_bytes", "asg_loss_fused_scratch_bytes", "asg_loss_fused_sync_bytes",
+                   "asg_loss_fused_supported", "asg_stream_capture_id", "asg_hip_strerror", "asg_loss_forward",
+                   "asg_loss_backward", "asg_loss_fused_forward", "asg_loss_fused_backward"]
+BINDING_PATH = os.path.join(_HERE, "_binding.so")
+
+
+def binding(backend):
+    """The C++ host fast path (torch_asg_amd/_binding.so), one object per backend, initialised with the entry points of the library that
+    `lib()` loaded (so ASG_HIP_LIB variants are honoured), or None when it has not been built or ASG_NO_BINDING=1 --
+    the Python statements in asg.py then do the same work, only slower (host time)."""
+    if os.environ.get("ASG_NO_BINDING", "0") not in ("", "0") or not os.path.exists(BINDING_PATH):
+        return None
+    from . import _binding
+    L = lib()
+    return _binding.Fast([ctypes.cast(getattr(L, n), ctypes.c_void_p).value for n in BINDING_SYMBOLS], backend)

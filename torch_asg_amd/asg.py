@@ -53,6 +53,13 @@ class HipBackend:
         self._tickets = {}
         self._pools = {}
         self._pool_keep = []
+        self.binding = _lib.binding(self)        # C++ fast path of ASGLossFunction, or None (csrc/binding.cpp)
+
+    def _cu_count(self, idx):
+        cus = self._cus.get(idx)
+        if cus is None:
+            cus = self._cus[idx] = int(torch.cuda.get_device_properties(idx).multi_processor_count)
+        return cus
 
     def _bytes(self, p):
         """(state_bytes, scratch_bytes) of a problem shape, cached per (dtype, T, B, N, S)."""
@@ -165,6 +172,8 @@ class HipBackend:
                         # deferred by the runtime until their pending work has finished)
                         old = next(iter(self._ctx))
                         _lib.lib().asg_ctx_destroy(self._ctx.pop(old))
+                        if self.binding is not None:
+                            self.binding.reset()
                     with torch.cuda.device(idx):
                         _lib.check(_lib.lib().asg_ctx_create(ctypes.byref(h)), "asg_ctx_create")
                     self._ctx[key] = h
@@ -365,6 +374,8 @@ class HipBackend:
             self._tickets.clear()
             self._pools.clear()
             self._pool_keep.clear()
+            if self.binding is not None:
+                self.binding.reset()
 
     def fused_supported(self, p):
         return bool(_lib.lib().asg_loss_fused_supported(ctypes.byref(p)))
@@ -375,9 +386,7 @@ class HipBackend:
         which pack one chain per wavefront, are faster (measured on MI355X, 256 CUs, T=400 N=40: B=80 68 us fused;
         B=96 117 us fused vs ~85 stand-alone; B=128 125 vs ~90; tools/batch_sweep.py)."""
         idx = device.index if device.index is not None else torch.cuda.current_device()
-        cus = self._cus.get(idx)
-        if cus is None:
-            cus = self._cus[idx] = int(torch.cuda.get_device_properties(idx).multi_processor_count)
+        cus = self._cu_count(idx)
         # the launch places utterances 2x, 2x+1 on XCD x mod 8 (asg_fused.hip): the fullest XCD must hold its workgroups
         pairs = (int(p.B) + 1) // 2
         return ((pairs + 7) // 8) * 2 * 3 <= cus // 8
@@ -437,7 +446,7 @@ class HipBackend:
         dev = inputs.device
         with self._guard(dev):
             p = saved.problem
-            if (p.inputs != inputs.data_ptr() or p.transition != transition.data_ptr() or p.targets != targets.data_ptr()
+            if (p is None or p.inputs != inputs.data_ptr() or p.transition != transition.data_ptr() or p.targets != targets.data_ptr()
                     or (p.input_lengths or 0) != (input_lengths.data_ptr() if input_lengths is not None else 0)
                     or (p.target_lengths or 0) != (target_lengths.data_ptr() if target_lengths is not None else 0)):
                 # the saved tensors came back at other addresses (saved-tensor hooks): rebuild the problem block
@@ -468,11 +477,12 @@ class HipBackend:
 
 class _Saved:
     """Host-side record of one loss_forward call: which route ran, the device buffers it filled, the C problem block."""
-    __slots__ = ("mode", "tensors", "problem", "keep", "sizes", "consumed")
+    __slots__ = ("mode", "tensors", "problem", "keep", "sizes", "consumed", "rec")
 
     def __init__(self, mode, tensors, problem, keep, sizes):
         self.mode, self.tensors, self.problem, self.keep, self.sizes = mode, tensors, problem, keep, sizes
         self.consumed = False
+        self.rec = None               # (mode, sc_bytes, state_bytes, scratch_bytes, reduction) when csrc/binding.cpp ran the forward
 
 
 _backend = None
@@ -589,11 +599,23 @@ class ASGLossFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, inputs, transition, outputs, input_lengths, output_lengths, reduction, flags):
         be = native()
-        # The problem block built by loss_forward is reused by loss_backward: everything it points at must be one of the
-        # tensors autograd saves.  CPU (the reference accepts them on its GPU route, streamlined_fast_gpu.cpp:40) or
-        # strided lengths / targets are therefore converted HERE, and the converted tensors are the saved ones.
-        outputs, input_lengths, output_lengths = HipBackend.device_args(inputs.device, outputs, input_lengths, output_lengths)
-        loss, saved = be.loss_forward(inputs, outputs, transition, input_lengths, output_lengths, reduction, flags)
+        r = None
+        bd = getattr(be, "binding", None)
+        if bd is not None:
+            # the plain case (everything on the device, contiguous lengths) entirely in C++; None = not that case
+            r = bd.try_loss_forward(inputs, transition, outputs, input_lengths, output_lengths,
+                                    HipBackend._RED[reduction], flags)
+        if r is not None:
+            loss, mode, buf0, buf1, sc_bytes, state_bytes, fs = r
+            saved = _Saved("fused" if mode else "split", (buf0, buf1) if mode else (buf0,), None, None,
+                           (sc_bytes, state_bytes, fs))
+            saved.rec = (mode, sc_bytes, state_bytes, fs, HipBackend._RED[reduction])
+        else:
+            # The problem block built by loss_forward is reused by loss_backward: everything it points at must be one of
+            # the tensors autograd saves.  CPU (the reference accepts them on its GPU route, streamlined_fast_gpu.cpp:40)
+            # or strided lengths / targets are therefore converted HERE, and the converted tensors are the saved ones.
+            outputs, input_lengths, output_lengths = HipBackend.device_args(inputs.device, outputs, input_lengths, output_lengths)
+            loss, saved = be.loss_forward(inputs, outputs, transition, input_lengths, output_lengths, reduction, flags)
         ctx.save_for_backward(inputs, outputs, input_lengths, output_lengths, transition, *saved.tensors)
         saved.tensors = None          # autograd owns them now (and frees them after backward)
         saved.keep = None             # (every tensor the block points at is in ctx.saved_tensors)
@@ -614,8 +636,19 @@ class ASGLossFunction(torch.autograd.Function):
                 _, saved = be.loss_forward(inputs, outputs, transition, input_lengths, output_lengths, ctx.reduction,
                                            ctx.flags)
             tensors = saved.tensors
-        grad_transition, grad_inputs = be.loss_backward(saved, tensors, grad_loss, inputs, outputs, transition,
-                                                        input_lengths, output_lengths, ctx.reduction)
+        r = None
+        bd = getattr(be, "binding", None)
+        if bd is not None:
+            rec = saved.rec
+            if rec is None:             # the forward ran in Python: same buffers, same sizes
+                rec = (1,) + saved.sizes if saved.mode == "fused" else (0, 0, 0, 0)
+                rec += (HipBackend._RED[ctx.reduction],)
+            r = bd.try_loss_backward(rec, tensors[0], tensors[1] if rec[0] else None, grad_loss, inputs, transition,
+                                     outputs, input_lengths, output_lengths)
+        if r is None:
+            r = be.loss_backward(saved, tensors, grad_loss, inputs, outputs, transition, input_lengths, output_lengths,
+                                 ctx.reduction)
+        grad_transition, grad_inputs = r
         ctx.saved.consumed = True
         return grad_inputs, grad_transition, None, None, None, None, None
 

@@ -103,7 +103,35 @@ def build_variants(force=False, verbose=False):
     return outs
 
 
+BINDING_SRC = os.path.join(HERE, "binding.cpp")
+BINDING_OUT = os.path.join(HERE, "..", "_binding.so")
+
+
+def build_binding(force=False, verbose=False):
+    """torch_asg_amd/_binding.so: the C++ host fast path of ASGLossFunction (binding.cpp) -- g++ against the torch
+    headers of the running interpreter; reaches libasg_hip.so only through addresses handed over at init()."""
+    hdr = os.path.join(HERE, "..", "..", "include", "asg_hip.h")
+    if not force and _mtime(BINDING_OUT) > max(_mtime(BINDING_SRC), _mtime(hdr), _mtime(__file__)):
+        return BINDING_OUT
+    import sysconfig
+    import torch
+    from torch.utils import cpp_extension as ce
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-shared", "-fPIC", "-w", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           "-DTORCH_EXTENSION_NAME=_binding", "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch.compiled_with_cxx11_abi())]
+    cmd += ["-I" + d for d in ce.include_paths()] + ["-I/opt/rocm/include", "-I" + sysconfig.get_paths()["include"]]
+    cmd += [BINDING_SRC, "-o", BINDING_OUT, "-L" + tlib, "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch_hip", "-ltorch",
+            "-ltorch_python", "-Wl,-rpath," + tlib]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return BINDING_OUT
+
+
 if __name__ == "__main__":
+    if "--binding" in sys.argv:
+        print(build_binding(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv))
+        sys.exit(0)
     if "--variants" in sys.argv:
         print("\n".join(build_variants(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv)))
         sys.exit(0)
@@ -113,3 +141,4 @@ if __name__ == "__main__":
         print(build(defines=[d for d in defs if d], out=sys.argv[sys.argv.index("--out") + 1]))
         sys.exit(0)
     print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv))
+    print(build_binding(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv))
