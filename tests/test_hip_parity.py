@@ -929,6 +929,60 @@ def test_long_targets_small_alphabet(T, B, N, L, dtype, rtol):
     assert np.array_equal(r["grad_inputs"], r3["grad_inputs"]) and np.array_equal(r["grad_transition"], r3["grad_transition"])
 
 
+# ------------------------------------------------------------------ 256 < N <= 1024: the matrix resident in a cluster of workgroups
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,B,N,L", [(60, 5, 257, 7), (50, 3, 300, 20), (45, 4, 512, 9), (40, 20, 700, 6), (30, 2, 1024, 5),
+                                       (12, 70, 1024, 3), (35, 3, 390, 30), (2, 3, 300, 1), (3, 2, 513, 2)])
+def test_resident_slice_alphabets(T, B, N, L, monkeypatch):
+    """fp32, 256 < N <= 1024: all frames of the full-lattice recursions in ONE launch (fwd_cluster_kernel: the matrix
+    stays in the registers of a cluster of workgroups that exchange the frame's vectors through write-through stores
+    and one progress word each).  Stored states, normaliser log and offsets are the per-frame step kernel's, so the
+    same gradient pass follows; ASG_NO_CLUSTER=1 (a launch per frame) must agree to rounding, and the route is deterministic.  Variable lengths, an
+    infeasible utterance, more chains than one batch of a cluster holds (B = 70 at N = 1024: two rounds)."""
+    rng = np.random.default_rng(T + N)
+    tr, x, tg, _, _ = util.synth(T, B, N, L, N)
+    il = rng.integers(max(L, T // 2), T + 1, B)
+    tl = rng.integers(1, L + 1, B)
+    if B >= 3 and T > 4:
+        il[1], tl[1] = 3, min(L, 5)                  # infeasible when L >= 4; a 3-frame utterance otherwise
+    o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il, tl, "none")
+    outs = []
+    for env in ("0", "1"):
+        monkeypatch.setenv("ASG_NO_CLUSTER", env)
+        r = run_hip(x, tg, tr, il, tl, "none")
+        for k in ("loss", "grad_inputs", "grad_transition"):
+            util.assert_close(r[k], o[k], 1e-4, "resident slices T%d B%d N%d L%d no_cluster=%s/%s" % (T, B, N, L, env, k))
+        assert not np.isnan(r["grad_inputs"]).any() and not np.isnan(r["grad_transition"]).any()
+        outs.append(r)
+    for k in ("loss", "grad_inputs", "grad_transition"):       # (different summation orders: VALU quarters vs MFMA k-steps)
+        util.assert_close(outs[0][k], outs[1][k], 3e-5, "cluster vs per-frame launches: %s" % k)
+    monkeypatch.setenv("ASG_NO_CLUSTER", "0")
+    again = run_hip(x, tg, tr, il, tl, "none")
+    assert np.array_equal(again["grad_inputs"], outs[0]["grad_inputs"]) and np.array_equal(again["loss"], outs[0]["loss"], equal_nan=True)
+
+
+@pytest.mark.gpu
+def test_resident_slice_exact_path_and_eval_route():
+    """Transitions spanning hundreds of nats push row sums out of the fp32 exp-domain range inside the cluster kernel:
+    the exact log-sum-exp over the other workgroups' stored states takes over; eval route (beta only: one direction)."""
+    T, B, N, L = 30, 3, 320, 6
+    tr, x, tg, il, tl = util.synth(T, B, N, L, 5, True)
+    tr = tr * 600.0 - 300.0
+    tr[3, :] = float("-inf")
+    tr[3, 3] = 0.0
+    tr[:, 7] = -250.0
+    o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il.numpy(), tl.numpy(), "none")
+    r = run_hip(x, tg, tr, il, tl, "none")
+    for k in ("loss", "grad_inputs", "grad_transition"):
+        util.assert_close(r[k], o[k], 1e-4, "resident slices exact path %s" % k)
+    A = _asg()
+    m = A.ASGLoss(N, reduction="none").to(DEV).eval()
+    with torch.no_grad():
+        m.transition.copy_(tr)
+        ev = m(x.to(DEV), tg.to(DEV), il.to(DEV), tl.to(DEV)).cpu().numpy()
+    util.assert_close(ev, o["loss"], 1e-4, "resident slices eval route")
+
+
 # ------------------------------------------------------------------ medium alphabets (64 < N <= 256): one launch per pass
 @pytest.mark.gpu
 @pytest.mark.parametrize("T,B,N,L", [(60, 3, 65, 9), (120, 2, 128, 20), (45, 4, 129, 7), (80, 2, 192, 30), (70, 3, 200, 70),

@@ -815,6 +815,237 @@ __global__ void __launch_bounds__(64 * NW) fwd_mid_kernel(Problem P, State W, Fw
     }
 }
 
+// ------------------------------------------------------------------ full lattice, 256 < N <= 1024 (fp32): resident slices
+// Between the one-workgroup-per-chain kernel above (the row of a label fits its thread's registers up to N = 256) and
+// the streamed step (N ~ 10^4: 400 MB per frame) the matrix is 0.25 - 4 MB: too large for one compute unit, far too
+// small to be worth a launch per frame (fwd_step_kernel: 14 / 27 us per frame at N = 512 / 1024, a round of dependent
+// memory accesses for 14 - 52 workgroups of work).  Here a CLUSTER of G workgroups keeps the whole matrix in registers
+// for all frames -- workgroup g the rows i0 = g RW .. + RW - 1, thread (r, kq) the 128 columns 128 kq .. of row i0 + r --
+// and takes a batch of up to 16 chains of one direction through the frames together:
+//   product   s[u][i] = sum_k E[i][k] p_u[k]: the batch's vectors sit in LDS ([u][k], broadcast reads), the K quarters
+//             meet in LDS;
+//   epilogue  the streamed step's, element for element (same stored state, normaliser log and offsets: the gradient
+//             pass and fwd_score_kernel do not know which of the two ran): q = x2 + hmax + log2 s - max of the previous
+//             frame; exact log-sum-exp from the stored log-domain state when s leaves [2^-100, 2^100];
+//   hand-off  the workgroup's RW new elements per chain and its local maximum go to the cluster's exchange buffer
+//             write-through, then ONE word says "frame n published"; every workgroup polls its G peers' words and
+//             copies the frame's vectors (nb N floats) into its LDS.  Double buffered by frame parity: a workgroup
+//             can be at most one frame ahead of the slowest reader.
+// Clusters are placed with the workgroup index as the slow coordinate (block = g * ncl + c), so a cluster's workgroups
+// land on ONE XCD whenever the cluster count is a multiple of 8 and the exchange stays in that XCD's L2.
+// All workgroups must be co-resident (they wait for each other): the launcher sizes the grid to the device's compute
+// units; a wait that runs out (2^25 polls) poisons the scores with NaN instead of hanging the device.
+constexpr int kClNB = 16, kClKPT = 128;
+constexpr unsigned kClSc1 = 16;   // buffer load aux bit: agent scope
+typedef unsigned ClU4 __attribute__((ext_vector_type(4)));
+struct ClusterArgs {
+    float *xbuf;        // [ncl][2][kClNB][npadL]   exp-domain vectors of the frame just produced (pad columns stay zero)
+    unsigned *xmax;     // [ncl][2][G][kClNB]       key(max q) of each workgroup's rows
+    unsigned *flags;    // [ncl][G]                 frames published so far (zero on entry)
+    int G, RW, nkq, npadL, ncd, cpc, ndirs;
+};
+static __host__ __device__ inline size_t cluster_xbuf_floats(int ncl, int npadL) { return (size_t) ncl * 2 * kClNB * npadL; }
+
+__global__ void __launch_bounds__(256) fwd_cluster_kernel(Problem P, StepBuf<float> Sa, StepBuf<float> Sb, ClusterArgs C, int dir_base) {
+    typedef float R;
+    extern __shared__ __attribute__((aligned(16))) float cl_lds[];
+    __shared__ unsigned lmax[kClNB];
+    __shared__ float mus[kClNB];
+    __shared__ int lens[kClNB];
+    __shared__ double offs[kClNB];
+    __shared__ int sfail, smaxlen;
+    const int ncl = C.ndirs * C.ncd;
+    const int c = (int) blockIdx.x % ncl, g = (int) blockIdx.x / ncl;
+    const int dir = dir_base + c / C.ncd, cd = c % C.ncd;
+    const bool BETA = dir == 1;
+    const StepBuf<float> &S = BETA ? Sb : Sa;
+    const int N = P.N, T = P.T, B = P.B, npad = S.npad, G = C.G, RW = C.RW, nkq = C.nkq, npadL = C.npadL;
+    const int tid = threadIdx.x;
+    float *pl = cl_lds;                          // [kClNB][npadL]
+    float *red = cl_lds + kClNB * npadL;         // [nkq][kClNB][RW]
+    const R L2E = Num<R>::log2e(), LZ = Num<R>::logzero(), NINF = Num<R>::ninf();
+    const int kq = tid / RW, r = tid - kq * RW;
+    const bool mv = kq < nkq;
+    const int i0 = g * RW;
+    // ---- this thread's 128 elements of the (normalised) matrix
+    V2<R> e2[kClKPT / 2];
+    {
+        const int irow = i0 + r;
+        const bool rowok = mv && irow < N;
+        const R *src = S.ehat + (int64_t) min(irow, N - 1) * npad + min(kq, nkq - 1) * kClKPT;
+#pragma unroll
+        for (int j = 0; j < kClKPT / 4; ++j) {
+            const int k = kq * kClKPT + 4 * j;
+            V4<R> v = {0, 0, 0, 0};
+            if (rowok && k < npad) v = *reinterpret_cast<const V4<R> *>(src + 4 * j);
+            e2[2 * j] = V2<R>{v.x, v.y};
+            e2[2 * j + 1] = V2<R>{v.z, v.w};
+        }
+    }
+    float *xb = C.xbuf + (size_t) c * 2 * kClNB * npadL;
+    __amdgpu_buffer_rsrc_t rxb = make_rsrc(xb, (unsigned) (2 * kClNB * npadL * 4));
+    unsigned *xm = C.xmax + (size_t) c * 2 * G * kClNB;
+    unsigned *fl = C.flags + (size_t) c * G;
+    const R *tr = (const R *) P.transition;
+    if (tid == 0) sfail = 0;
+    unsigned pub = 0;                             // frames this cluster has published (uniform over its workgroups)
+    constexpr int kSpinMax = 1 << 25;
+    const int cb0 = cd * C.cpc, cb1 = min(B, cb0 + C.cpc);
+    constexpr int IT = 4;                         // epilogue elements per thread: RW * kClNB <= 64 * 16 = 4 * 256
+    for (int rb = cb0; rb < cb1; rb += kClNB) {
+        const int nb = min(kClNB, cb1 - rb);
+        __syncthreads();
+        if (tid < kClNB) {
+            const int b = min(rb + tid, B - 1);
+            const int len = tid < nb ? (P.in_len ? gclampi(P.in_len[b], 0, T) : T) : 0;
+            lens[tid] = len;
+            mus[tid] = 0.0f;                      // the first frame's maximum is exactly 0 (fwd_init_kernel)
+            offs[tid] = (tid < nb && len >= 1) ? S.off[b] : 0.0;
+        }
+        if (tid == 0) smaxlen = 0;
+        __syncthreads();
+        if (tid < nb) atomicMax(&smaxlen, lens[tid]);
+        // the vectors of the first frame (fwd_init_kernel wrote them to pbuf[0]); pad columns of the LDS copy are zero
+        for (int idx = tid; idx < nb * npadL; idx += 256) {
+            const int u = idx / npadL, k = idx - u * npadL;
+            pl[idx] = k < npad ? S.pbuf[(int64_t) (rb + u) * npad + k] : 0.0f;
+        }
+        __syncthreads();
+        const int nsteps = smaxlen - 1;
+        for (int n = 0; n < nsteps; ++n) {
+            const unsigned par = pub & 1u;
+            // ---- this frame's emissions for the elements this thread finishes (in flight under the product)
+            R xe[IT], xw[IT];
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const int idx = tid + 256 * it, u = idx / RW, rr_ = idx - u * RW, i = i0 + rr_;
+                xe[it] = 0; xw[it] = 0;
+                if (u < nb && i < N) {
+                    const int len = lens[u], b = rb + u;
+                    if (n < len - 1) {
+                        const int tw = BETA ? len - 2 - n : n + 1;
+                        xe[it] = ((const R *) P.inputs)[(int64_t) tw * P.is0 + (int64_t) b * P.is1 + (int64_t) i * P.is2];
+                        xw[it] = S.emax[(int64_t) tw * B + b];
+                    }
+                }
+            }
+            if (tid < kClNB) lmax[tid] = fkey(-__builtin_inff());
+            // ---- product: every chain of the batch against the resident slice
+            for (int u = 0; u < nb; ++u) {
+                if (n >= lens[u] - 1) continue;                  // (uniform: this chain has ended)
+                const R *pv = pl + u * npadL + min(kq, nkq - 1) * kClKPT;
+                V2<R> a0 = {0, 0}, a1 = {0, 0};
+#pragma unroll
+                for (int j = 0; j < kClKPT / 4; ++j) {
+                    const V4<R> v = *reinterpret_cast<const V4<R> *>(pv + 4 * j);
+                    a0 = __builtin_elementwise_fma(e2[2 * j], V2<R>{v.x, v.y}, a0);
+                    a1 = __builtin_elementwise_fma(e2[2 * j + 1], V2<R>{v.z, v.w}, a1);
+                }
+                const V2<R> a = a0 + a1;
+                if (mv) red[(kq * kClNB + u) * RW + r] = a.x + a.y;
+            }
+            __syncthreads();
+            // ---- epilogue (fwd_step_mfma's, element for element)
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const int idx = tid + 256 * it, u = idx / RW, rr_ = idx - u * RW, i = i0 + rr_;
+                if (!(u < nb && i < N)) continue;
+                const int len = lens[u], b = rb + u;
+                if (!(n < len - 1)) continue;
+                const int t = BETA ? len - 1 - n : n + 1, tw = BETA ? t - 1 : t;
+                R a = 0;
+                for (int q = 0; q < nkq; ++q) a += red[(q * kClNB + u) * RW + rr_];
+                const R muprev = fmax(mus[u], LZ);
+                const R lg = Num<R>::log2(a);
+                R rr = S.hmax[i] + lg;
+                if (!(fabs(lg) < Num<R>::lg_limit())) {
+                    // exact rare path: log2-sum-exp2 over j of (Tr2[.][.] + q_j) from the log-domain state (other
+                    // workgroups' write-through stores of the previous frame: agent-scope loads)
+                    const int tq = BETA ? t : t - 1;
+                    const R *stq = S.state + ((int64_t) b * T + tq) * N;
+                    const R *inq = (const R *) P.inputs + (int64_t) tq * P.is0 + (int64_t) b * P.is1;
+                    const R emq = S.emax[(int64_t) tq * B + b];
+                    R mx = NINF;
+                    for (int j = 0; j < N; ++j) {
+                        const R sj = __hip_atomic_load(&stq[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const R qj = BETA ? inq[(int64_t) j * P.is2] * L2E - emq + sj : sj;
+                        const R trv = BETA ? tr[(int64_t) j * P.ts0 + (int64_t) i * P.ts1] : tr[(int64_t) i * P.ts0 + (int64_t) j * P.ts1];
+                        const R v = trv * L2E + qj;
+                        mx = (v == v) ? fmax(mx, v) : mx;
+                    }
+                    R sm = 0;
+                    for (int j = 0; j < N; ++j) {
+                        const R sj = __hip_atomic_load(&stq[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const R qj = BETA ? inq[(int64_t) j * P.is2] * L2E - emq + sj : sj;
+                        const R trv = BETA ? tr[(int64_t) j * P.ts0 + (int64_t) i * P.ts1] : tr[(int64_t) i * P.ts0 + (int64_t) j * P.ts1];
+                        const R v = trv * L2E + qj;
+                        sm += (v == v && mx != NINF) ? Num<R>::exp2(v - mx) : R(0);
+                    }
+                    rr = (mx == NINF) ? mx : mx + Num<R>::log2(sm);
+                }
+                const R emw = xw[it];
+                const R emis = xe[it] * L2E - emw;
+                R stv, q;
+                if (BETA) { stv = rr - muprev; q = emis + stv; }
+                else { stv = emis + rr - muprev; q = stv; }
+                __hip_atomic_store(&S.state[((int64_t) b * T + tw) * N + i], stv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&xb[((size_t) par * kClNB + u) * npadL + i], Num<R>::exp2(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                atomicMax(&lmax[u], fkey((float) q));
+                if (i == 0) {
+                    offs[u] += (double) muprev + (double) emw;
+                    if (!BETA && S.mulog) S.mulog[(int64_t) tw * B + b] = muprev;
+                }
+            }
+            __syncthreads();
+            if (tid < nb)
+                __hip_atomic_store(&xm[((size_t) par * G + g) * kClNB + tid], lmax[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wavefront's stores of the frame have been acknowledged
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(&fl[g], pub + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // ---- wait for the G workgroups of the cluster, then take the frame
+            if (tid < G) {
+                int spins = 0;
+                while (__hip_atomic_load(&fl[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < pub + 1u && spins < kSpinMax) {
+                    __builtin_amdgcn_s_sleep(1);
+                    ++spins;
+                }
+                if (spins >= kSpinMax) sfail = 1;
+            }
+            __syncthreads();
+            if (sfail) break;
+            if (tid < nb && n < lens[tid] - 1) {
+                float m = -__builtin_inff();
+                for (int gg = 0; gg < G; ++gg)
+                    m = fmaxf(m, funkey(__hip_atomic_load(&xm[((size_t) par * G + gg) * kClNB + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+                mus[tid] = m;
+            }
+            const int n4 = npad / 4;
+            for (int idx = tid; idx < nb * n4; idx += 256) {
+                const int u = idx / n4, k4 = idx - u * n4;
+                if (n < lens[u] - 1) {
+                    // (agent-scope load: the line may sit, two frames old, in this XCD's L2)
+                    const ClU4 w = __builtin_amdgcn_raw_buffer_load_b128(rxb, (unsigned) ((((size_t) par * kClNB + u) * npadL + 4 * k4) * 4), 0u, kClSc1);
+                    *reinterpret_cast<ClU4 *>(pl + u * npadL + 4 * k4) = w;
+                }
+            }
+            __syncthreads();
+            ++pub;
+        }
+        if (sfail) break;
+        if (g == 0 && tid < nb && lens[tid] >= 1) S.off[rb + tid] = offs[tid];
+    }
+    if (sfail && g == 0 && tid < kClNB)
+        for (int b = cb0 + tid; b < cb1; b += kClNB) S.off[b] = __builtin_nan("");      // (never hang, never return a wrong number quietly)
+}
+
+// the resident-slice route: fp32, 256 < N <= 1024 (ASG_NO_CLUSTER=1: the per-frame launches instead)
+static bool cluster_alphabet(const Problem &P, size_t elem) {
+    if (elem != 4 || P.N <= 256 || P.N > 1024) return false;
+    const char *ev = getenv("ASG_NO_CLUSTER");
+    return !(ev && atoi(ev) != 0);
+}
+constexpr size_t kClusterBytes = 8u << 20;       // exchange vectors + maxima + flags of every cluster (cluster_layout)
+
 // the medium-alphabet route: fp32, 64 < N <= 256, 32-bit emission offsets (ASG_NO_MID=1: the per-frame launches instead)
 static bool mid_alphabet(const Problem &P, size_t elem) {
     if (elem != 4 || P.N <= 64 || P.N > 256) return false;
@@ -2090,7 +2321,7 @@ size_t step_tile_bytes_generic(int elem, int N) {
 size_t fwd_work_bytes_generic(int elem, int T, int B, int N) {
     const size_t npad = (size_t) (N + 3) / 4 * 4;
     return au((size_t) T * B * elem) + 2 * au(2 * (size_t) B * npad * elem) + 2 * au(3 * (size_t) B * 4) + 2 * au((size_t) B * 8) +
-           au((size_t) T * B * elem) + 4096;
+           au((size_t) T * B * elem) + ((elem == 4 && N > 256 && N <= 1024) ? kClusterBytes : 0) + 4096;
 }
 // offset of the alpha pass's per-frame normaliser log inside the work area (its last member)
 static size_t work_mulog_offset(size_t elem, int T, int B, int npad) {
@@ -2171,6 +2402,42 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
         const int srows = StepUsesMfma<R>::v ? 16 * kStepMB : 64;
         dim3 sgrid((P.N + srows - 1) / srows, (P.B + 31) / 32, (do_a && do_b) ? 2 : 1);
         bool stepped = false;
+        if constexpr (sizeof(R) == 4) {
+            if (cluster_alphabet(P, e) && P.T >= 2) {
+                int dev = 0, cus = 0;
+                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+                    cus = 256;
+                ClusterArgs C{};
+                C.nkq = (W.npad + kClKPT - 1) / kClKPT;
+                C.RW = C.nkq <= 4 ? 64 : 32;
+                C.G = (P.N + C.RW - 1) / C.RW;
+                C.npadL = C.nkq * kClKPT;
+                C.ndirs = (do_a && do_b) ? 2 : 1;
+                int ncd = cus / C.G / C.ndirs;
+                if (ncd < 1) ncd = 1;
+                if (ncd > P.B) ncd = P.B;
+                C.cpc = (P.B + ncd - 1) / ncd;
+                C.ncd = (P.B + C.cpc - 1) / C.cpc;
+                const int ncl = C.ndirs * C.ncd;
+                char *ca = bar_area - kClusterBytes;
+                const size_t xb = au(cluster_xbuf_floats(ncl, C.npadL) * 4), xmb = au((size_t) ncl * 2 * C.G * kClNB * 4), flb = au((size_t) ncl * C.G * 4);
+                if (ncl * C.G <= cus && xb + xmb + flb <= kClusterBytes) {
+                    C.xbuf = (float *) ca;
+                    C.xmax = (unsigned *) (ca + xb);
+                    C.flags = (unsigned *) (ca + xb + xmb);
+                    (void) hipMemsetAsync(ca, 0, xb + xmb + flb, stream);
+                    const size_t lds = ((size_t) kClNB * C.npadL + (size_t) C.nkq * kClNB * C.RW) * 4;
+                    static bool attr_set = false;
+                    if (!attr_set) {
+                        (void) hipFuncSetAttribute((const void *) fwd_cluster_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+                        attr_set = true;
+                    }
+                    StepBuf<float> A0 = Sd[0], B0 = Sd[1];
+                    hipLaunchKernelGGL(fwd_cluster_kernel, dim3(ncl * C.G), dim3(256), lds, stream, P, A0, B0, C, do_a ? 0 : 1);
+                    stepped = true;
+                }
+            }
+        }
         if constexpr (StepUsesMfma<R>::v) {
             // ASG_PERSIST=1: one cooperative launch when every workgroup fits on the device at once (the runtime refuses
             // otherwise) and the stream is not being captured.  Measured at cfg 5 (tools/run_cfg5_var.sh): 145.0-145.5 us per
@@ -2178,7 +2445,7 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
             // frame is bound by the steady stream (5.5 TB/s = 88 % of what a copy kernel reaches), not by what happens between
             // frames -- so the launches, which need no co-residency, stay the default.
             const char *pe = getenv("ASG_PERSIST");
-            const bool persist = pe && atoi(pe) != 0;
+            const bool persist = !stepped && pe && atoi(pe) != 0;
             hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
             if (persist) (void) hipStreamIsCapturing(stream, &cs);
             if (persist && cs == hipStreamCaptureStatusNone && P.T >= 3) {
