@@ -820,36 +820,40 @@ __global__ void __launch_bounds__(64 * NW) fwd_mid_kernel(Problem P, State W, Fw
 // the streamed step (N ~ 10^4: 400 MB per frame) the matrix is 0.25 - 4 MB: too large for one compute unit, far too
 // small to be worth a launch per frame (fwd_step_kernel: 14 / 27 us per frame at N = 512 / 1024, a round of dependent
 // memory accesses for 14 - 52 workgroups of work).  Here a CLUSTER of G workgroups keeps the whole matrix in registers
-// for all frames -- workgroup g the rows i0 = g RW .. + RW - 1, thread (r, kq) the 128 columns 128 kq .. of row i0 + r --
-// and takes a batch of up to 16 chains of one direction through the frames together:
-//   product   s[u][i] = sum_k E[i][k] p_u[k]: the batch's vectors sit in LDS ([u][k], broadcast reads), the K quarters
-//             meet in LDS;
+// for all frames -- workgroup g the RW = 64 (N <= 512) or 32 rows from i0 = g RW, as the A operand of
+// v_mfma_f32_16x16x4_f32 (exact fp32, as in the streamed step): wavefront w the 16-row block w % (RW / 16) and, for
+// RW = 32, the K half w / 2 -- and takes a batch of up to 16 chains of one direction through the frames together:
+//   product   s[i][u] = sum_k E[i][k] p_u[k]: the batch's vectors sit in LDS as the B operand ([k / 4][u][k % 4]: one
+//             conflict-free ds_read_b128 feeds four MFMAs), at most 128 MFMAs per wavefront and frame whatever the
+//             batch size; the K halves meet in LDS;
 //   epilogue  the streamed step's, element for element (same stored state, normaliser log and offsets: the gradient
 //             pass and fwd_score_kernel do not know which of the two ran): q = x2 + hmax + log2 s - max of the previous
 //             frame; exact log-sum-exp from the stored log-domain state when s leaves [2^-100, 2^100];
-//   hand-off  the workgroup's RW new elements per chain and its local maximum go to the cluster's exchange buffer
-//             write-through, then ONE word says "frame n published"; every workgroup polls its G peers' words and
-//             copies the frame's vectors (nb N floats) into its LDS.  Double buffered by frame parity: a workgroup
-//             can be at most one frame ahead of the slowest reader.
+//   hand-off  the workgroup's new elements p = 2^q go to the cluster's exchange buffer write-through, in the B-operand
+//             layout; once they are acknowledged ONE word says "frame n published"; every workgroup polls its G peers'
+//             words and copies the frame's vectors (nb N floats, agent-scope loads) into its LDS, together with
+//             the workgroups' maxima of q (the next frame's normaliser).  Double
+//             buffered by frame parity: a workgroup can be at most one frame ahead of the slowest reader.
+//             (Measured against polling the data itself for a tag in the sign bit: 2.3 vs 5.5 us per frame at N = 512.)
 // Clusters are placed with the workgroup index as the slow coordinate (block = g * ncl + c), so a cluster's workgroups
 // land on ONE XCD whenever the cluster count is a multiple of 8 and the exchange stays in that XCD's L2.
 // All workgroups must be co-resident (they wait for each other): the launcher sizes the grid to the device's compute
-// units; a wait that runs out (2^25 polls) poisons the scores with NaN instead of hanging the device.
-constexpr int kClNB = 16, kClKPT = 128;
+// units; a wait that runs out (2^26 polls) poisons the scores with NaN instead of hanging the device.
+constexpr int kClNB = 16;
 constexpr unsigned kClSc1 = 16;   // buffer load aux bit: agent scope
 typedef unsigned ClU4 __attribute__((ext_vector_type(4)));
 struct ClusterArgs {
-    float *xbuf;        // [ncl][2][kClNB][npadL]   exp-domain vectors of the frame just produced (pad columns stay zero)
-    unsigned *xmax;     // [ncl][2][G][kClNB]       key(max q) of each workgroup's rows
-    unsigned *flags;    // [ncl][G]                 frames published so far (zero on entry)
-    int G, RW, nkq, npadL, ncd, cpc, ndirs;
+    float *xbuf;        // [ncl][2][npadL / 4][kClNB][4]   exp-domain vectors of the frame just produced (pad columns stay zero)
+    unsigned *xmax;     // [ncl][2][G][kClNB]             key(max q) over each workgroup's rows
+    unsigned *flags;    // [ncl][G]                       frames published so far (zero on entry)
+    int G, RW, npadL, ncd, cpc, ndirs;
 };
 static __host__ __device__ inline size_t cluster_xbuf_floats(int ncl, int npadL) { return (size_t) ncl * 2 * kClNB * npadL; }
 
 __global__ void __launch_bounds__(256) fwd_cluster_kernel(Problem P, StepBuf<float> Sa, StepBuf<float> Sb, ClusterArgs C, int dir_base) {
     typedef float R;
     extern __shared__ __attribute__((aligned(16))) float cl_lds[];
-    __shared__ unsigned lmax[kClNB];
+    __shared__ unsigned pmax[kClNB], lmax[kClNB];
     __shared__ float mus[kClNB];
     __shared__ int lens[kClNB];
     __shared__ double offs[kClNB];
@@ -859,41 +863,50 @@ __global__ void __launch_bounds__(256) fwd_cluster_kernel(Problem P, StepBuf<flo
     const int dir = dir_base + c / C.ncd, cd = c % C.ncd;
     const bool BETA = dir == 1;
     const StepBuf<float> &S = BETA ? Sb : Sa;
-    const int N = P.N, T = P.T, B = P.B, npad = S.npad, G = C.G, RW = C.RW, nkq = C.nkq, npadL = C.npadL;
-    const int tid = threadIdx.x;
-    float *pl = cl_lds;                          // [kClNB][npadL]
-    float *red = cl_lds + kClNB * npadL;         // [nkq][kClNB][RW]
+    const int N = P.N, T = P.T, B = P.B, npad = S.npad, RW = C.RW, npadL = C.npadL;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float *pl = cl_lds;                          // [npadL / 4][kClNB][4]: the B operand
+    float *red = cl_lds + kClNB * npadL;         // [NKH][RW][kClNB]
     const R L2E = Num<R>::log2e(), LZ = Num<R>::logzero(), NINF = Num<R>::ninf();
-    const int kq = tid / RW, r = tid - kq * RW;
-    const bool mv = kq < nkq;
+    const int MBW = RW / 16, NKH = 4 / MBW;      // row blocks per workgroup, K parts
+    const int mb = wave % MBW, kh = wave / MBW;
+    const int kspan = npadL / NKH, kbase = kh * kspan, KS4 = kspan / 16;      // this wavefront's K range, in groups of 16
     const int i0 = g * RW;
-    // ---- this thread's 128 elements of the (normalised) matrix
-    V2<R> e2[kClKPT / 2];
+    // ---- this lane's elements of the (normalised) matrix: row i0 + 16 mb + (lane & 15), k = kbase + 16 s + 4 (lane >> 4) + c
+    V4<R> ea[32];
     {
-        const int irow = i0 + r;
-        const bool rowok = mv && irow < N;
-        const R *src = S.ehat + (int64_t) min(irow, N - 1) * npad + min(kq, nkq - 1) * kClKPT;
+        const int irow = i0 + 16 * mb + (lane & 15);
+        const R *src = S.ehat + (int64_t) min(irow, N - 1) * npad;
 #pragma unroll
-        for (int j = 0; j < kClKPT / 4; ++j) {
-            const int k = kq * kClKPT + 4 * j;
+        for (int s4 = 0; s4 < 32; ++s4) {
+            const int k = kbase + 16 * s4 + 4 * (lane >> 4);
             V4<R> v = {0, 0, 0, 0};
-            if (rowok && k < npad) v = *reinterpret_cast<const V4<R> *>(src + 4 * j);
-            e2[2 * j] = V2<R>{v.x, v.y};
-            e2[2 * j + 1] = V2<R>{v.z, v.w};
+            if (s4 < KS4 && irow < N && k < npad) v = *reinterpret_cast<const V4<R> *>(src + k);
+            ea[s4] = v;
         }
     }
     float *xb = C.xbuf + (size_t) c * 2 * kClNB * npadL;
     __amdgpu_buffer_rsrc_t rxb = make_rsrc(xb, (unsigned) (2 * kClNB * npadL * 4));
-    unsigned *xm = C.xmax + (size_t) c * 2 * G * kClNB;
-    unsigned *fl = C.flags + (size_t) c * G;
+    unsigned *fl = C.flags + (size_t) c * C.G;
+    unsigned *xm = C.xmax + (size_t) c * 2 * C.G * kClNB;
     const R *tr = (const R *) P.transition;
     if (tid == 0) sfail = 0;
+#ifdef ASG_X_CL_PROBE
+    unsigned long long pr[5] = {0, 0, 0, 0, 0};
+#endif
     unsigned pub = 0;                             // frames this cluster has published (uniform over its workgroups)
-    constexpr int kSpinMax = 1 << 25;
+    constexpr int kSpinMax = 1 << 26;
     const int cb0 = cd * C.cpc, cb1 = min(B, cb0 + C.cpc);
     constexpr int IT = 4;                         // epilogue elements per thread: RW * kClNB <= 64 * 16 = 4 * 256
+    const int n4 = npad / 4;
     for (int rb = cb0; rb < cb1; rb += kClNB) {
         const int nb = min(kClNB, cb1 - rb);
+        // epilogue elements: (chain u, row rr_) = (idx & nbm, idx >> nbs), the chain count rounded up to a power of two,
+        // so that small batches fill the threads of the first pass instead of a quarter of every pass
+        const int nbs = nb <= 1 ? 0 : nb <= 2 ? 1 : nb <= 4 ? 2 : nb <= 8 ? 3 : 4, nbm = (1 << nbs) - 1;
+        R hm[4];                                  // hmax of the rows this thread finishes
+#pragma unroll
+        for (int it = 0; it < 4; ++it) hm[it] = S.hmax[min(i0 + ((tid + 256 * it) >> nbs), N - 1)];
         __syncthreads();
         if (tid < kClNB) {
             const int b = min(rb + tid, B - 1);
@@ -905,59 +918,84 @@ __global__ void __launch_bounds__(256) fwd_cluster_kernel(Problem P, StepBuf<flo
         if (tid == 0) smaxlen = 0;
         __syncthreads();
         if (tid < nb) atomicMax(&smaxlen, lens[tid]);
-        // the vectors of the first frame (fwd_init_kernel wrote them to pbuf[0]); pad columns of the LDS copy are zero
-        for (int idx = tid; idx < nb * npadL; idx += 256) {
-            const int u = idx / npadL, k = idx - u * npadL;
-            pl[idx] = k < npad ? S.pbuf[(int64_t) (rb + u) * npad + k] : 0.0f;
+        // the vectors of the first frame (fwd_init_kernel wrote them to pbuf[0]), transposed into the operand layout
+        for (int idx = tid; idx < kClNB * npadL; idx += 256) {
+            const int k = idx / kClNB, u = idx - k * kClNB;
+            pl[((k >> 2) * kClNB + u) * 4 + (k & 3)] = (u < nb && k < npad) ? S.pbuf[(int64_t) (rb + u) * npad + k] : 0.0f;
         }
         __syncthreads();
         const int nsteps = smaxlen - 1;
-        for (int n = 0; n < nsteps; ++n) {
-            const unsigned par = pub & 1u;
-            // ---- this frame's emissions for the elements this thread finishes (in flight under the product)
-            R xe[IT], xw[IT];
+        R xn[IT], wn[IT];                         // emissions (and their frame maxima) of the NEXT frame's elements
+        {
+            constexpr int NF = 0;
 #pragma unroll
             for (int it = 0; it < IT; ++it) {
-                const int idx = tid + 256 * it, u = idx / RW, rr_ = idx - u * RW, i = i0 + rr_;
-                xe[it] = 0; xw[it] = 0;
-                if (u < nb && i < N) {
+                const int idx = tid + 256 * it, u = idx & nbm, rr_ = idx >> nbs, i = i0 + rr_;
+                xn[it] = 0; wn[it] = 0;
+                if (u < nb && rr_ < RW && i < N) {
                     const int len = lens[u], b = rb + u;
-                    if (n < len - 1) {
-                        const int tw = BETA ? len - 2 - n : n + 1;
-                        xe[it] = ((const R *) P.inputs)[(int64_t) tw * P.is0 + (int64_t) b * P.is1 + (int64_t) i * P.is2];
-                        xw[it] = S.emax[(int64_t) tw * B + b];
+                    if (NF < len - 1) {
+                        const int tw = BETA ? len - 2 - (NF) : (NF) + 1;
+                        xn[it] = ((const R *) P.inputs)[(int64_t) tw * P.is0 + (int64_t) b * P.is1 + (int64_t) i * P.is2];
+                        wn[it] = S.emax[(int64_t) tw * B + b];
                     }
                 }
             }
-            if (tid < kClNB) lmax[tid] = fkey(-__builtin_inff());
-            // ---- product: every chain of the batch against the resident slice
-            for (int u = 0; u < nb; ++u) {
-                if (n >= lens[u] - 1) continue;                  // (uniform: this chain has ended)
-                const R *pv = pl + u * npadL + min(kq, nkq - 1) * kClKPT;
-                V2<R> a0 = {0, 0}, a1 = {0, 0};
+        }
+        for (int n = 0; n < nsteps; ++n) {
+            const unsigned par = pub & 1u;
+#ifdef ASG_X_CL_PROBE
+            const unsigned long long c0 = __builtin_readcyclecounter();
+#endif
+            // (this frame's emissions for the elements this thread finishes were requested during the previous frame's
+            // hand-off: no global load is in flight while the matrix pipe runs -- hipcc's waitcnt placement would make the
+            // MFMAs wait for it)
+            R xe[IT], xw[IT];
 #pragma unroll
-                for (int j = 0; j < kClKPT / 4; ++j) {
-                    const V4<R> v = *reinterpret_cast<const V4<R> *>(pv + 4 * j);
-                    a0 = __builtin_elementwise_fma(e2[2 * j], V2<R>{v.x, v.y}, a0);
-                    a1 = __builtin_elementwise_fma(e2[2 * j + 1], V2<R>{v.z, v.w}, a1);
+            for (int it = 0; it < IT; ++it) { xe[it] = xn[it]; xw[it] = wn[it]; }
+            if (tid < kClNB) { pmax[tid] = fkey(-__builtin_inff()); lmax[tid] = fkey(-__builtin_inff()); }
+            // ---- product: 16 rows x 16 chains x this wavefront's K range
+            {
+                V4f acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0}, acc3 = {0, 0, 0, 0};     // (independent chains: the
+                                                                                              // matrix pipe never waits for a result)
+                const V4<R> *bp = reinterpret_cast<const V4<R> *>(pl) + (size_t) (kbase / 4 + (lane >> 4)) * kClNB + (lane & 15);
+                // operand reads two groups ahead of the matrix pipe, unconditional (clamped), so that they are not tied to the
+                // trip-count tests around the MFMAs
+                V4<R> b0 = bp[0], b1 = bp[(size_t) min(1, KS4 - 1) * 4 * kClNB];
+#pragma unroll
+                for (int s4 = 0; s4 < 32; ++s4) {
+                    const V4<R> bv = b0;
+                    b0 = b1;
+                    b1 = bp[(size_t) min(s4 + 2, KS4 - 1) * 4 * kClNB];
+                    if (s4 < KS4) {
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ea[s4].x, bv.x, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ea[s4].y, bv.y, acc1, 0, 0, 0);
+                        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(ea[s4].z, bv.z, acc2, 0, 0, 0);
+                        acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(ea[s4].w, bv.w, acc3, 0, 0, 0);
+                    }
                 }
-                const V2<R> a = a0 + a1;
-                if (mv) red[(kq * kClNB + u) * RW + r] = a.x + a.y;
+                const V4f acc = (acc0 + acc1) + (acc2 + acc3);
+                // element (row 16 mb + 4 (lane >> 4) + q, chain lane & 15) sits in register q
+#pragma unroll
+                for (int q = 0; q < 4; ++q) red[((size_t) kh * RW + 16 * mb + 4 * (lane >> 4) + q) * kClNB + (lane & 15)] = acc[q];
             }
             __syncthreads();
+#ifdef ASG_X_CL_PROBE
+            const unsigned long long c1 = __builtin_readcyclecounter();
+#endif
             // ---- epilogue (fwd_step_mfma's, element for element)
 #pragma unroll
             for (int it = 0; it < IT; ++it) {
-                const int idx = tid + 256 * it, u = idx / RW, rr_ = idx - u * RW, i = i0 + rr_;
-                if (!(u < nb && i < N)) continue;
+                const int idx = tid + 256 * it, u = idx & nbm, rr_ = idx >> nbs, i = i0 + rr_;
+                if (!(u < nb && rr_ < RW && i < N)) continue;
                 const int len = lens[u], b = rb + u;
                 if (!(n < len - 1)) continue;
                 const int t = BETA ? len - 1 - n : n + 1, tw = BETA ? t - 1 : t;
-                R a = 0;
-                for (int q = 0; q < nkq; ++q) a += red[(q * kClNB + u) * RW + rr_];
+                R a = red[(size_t) rr_ * kClNB + u];
+                if (NKH == 2) a += red[((size_t) RW + rr_) * kClNB + u];
                 const R muprev = fmax(mus[u], LZ);
                 const R lg = Num<R>::log2(a);
-                R rr = S.hmax[i] + lg;
+                R rr = hm[it] + lg;
                 if (!(fabs(lg) < Num<R>::lg_limit())) {
                     // exact rare path: log2-sum-exp2 over j of (Tr2[.][.] + q_j) from the log-domain state (other
                     // workgroups' write-through stores of the previous frame: agent-scope loads)
@@ -989,51 +1027,105 @@ __global__ void __launch_bounds__(256) fwd_cluster_kernel(Problem P, StepBuf<flo
                 if (BETA) { stv = rr - muprev; q = emis + stv; }
                 else { stv = emis + rr - muprev; q = stv; }
                 __hip_atomic_store(&S.state[((int64_t) b * T + tw) * N + i], stv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&xb[((size_t) par * kClNB + u) * npadL + i], Num<R>::exp2(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                xe[it] = Num<R>::exp2(q);
                 atomicMax(&lmax[u], fkey((float) q));
                 if (i == 0) {
                     offs[u] += (double) muprev + (double) emw;
                     if (!BETA && S.mulog) S.mulog[(int64_t) tw * B + b] = muprev;
                 }
             }
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const int idx = tid + 256 * it, u = idx & nbm, rr_ = idx >> nbs, i = i0 + rr_;
+                if (!(u < nb && rr_ < RW && i < N)) continue;
+                if (!(n < lens[u] - 1)) continue;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(xe[it]), rxb,
+                                                      (unsigned) ((((size_t) par * (npadL / 4) + (i >> 2)) * kClNB + u) * 16 + (i & 3) * 4), 0u, kClSc1);
+            }
+#ifdef ASG_X_CL_PROBE
+            const unsigned long long c2 = __builtin_readcyclecounter();
+#endif
             __syncthreads();
             if (tid < nb)
-                __hip_atomic_store(&xm[((size_t) par * G + g) * kClNB + tid], lmax[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&xm[((size_t) par * C.G + g) * kClNB + tid], lmax[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wavefront's stores of the frame have been acknowledged
             __syncthreads();
+#ifdef ASG_X_CL_PROBE
+            const unsigned long long c3 = __builtin_readcyclecounter();
+#endif
             if (tid == 0) __hip_atomic_store(&fl[g], pub + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // ---- wait for the G workgroups of the cluster, then take the frame
-            if (tid < G) {
-                int spins = 0;
-                while (__hip_atomic_load(&fl[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < pub + 1u && spins < kSpinMax) {
-                    __builtin_amdgcn_s_sleep(1);
-                    ++spins;
+            {
+                const int NF = n + 1;             // the next frame's emissions: in flight under the hand-off (requested any earlier, hipcc's
+                                                  // waitcnt placement puts their latency on the epilogue's or the product's path)
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const int idx = tid + 256 * it, u = idx & nbm, rr_ = idx >> nbs, i = i0 + rr_;
+                xn[it] = 0; wn[it] = 0;
+                if (u < nb && rr_ < RW && i < N) {
+                    const int len = lens[u], b = rb + u;
+                    if (NF < len - 1) {
+                        const int tw = BETA ? len - 2 - (NF) : (NF) + 1;
+                        xn[it] = ((const R *) P.inputs)[(int64_t) tw * P.is0 + (int64_t) b * P.is1 + (int64_t) i * P.is2];
+                        wn[it] = S.emax[(int64_t) tw * B + b];
+                    }
                 }
+            }
+            }
+            // ---- wait for the G workgroups of the cluster, then take the frame
+            if (tid < C.G) {
+                int spins = 0;
+                while (__hip_atomic_load(&fl[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < pub + 1u && spins < kSpinMax) ++spins;
                 if (spins >= kSpinMax) sfail = 1;
             }
             __syncthreads();
+#ifdef ASG_X_CL_PROBE
+            const unsigned long long c4 = __builtin_readcyclecounter();
+#endif
             if (sfail) break;
-            if (tid < nb && n < lens[tid] - 1) {
-                float m = -__builtin_inff();
-                for (int gg = 0; gg < G; ++gg)
-                    m = fmaxf(m, funkey(__hip_atomic_load(&xm[((size_t) par * G + gg) * kClNB + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
-                mus[tid] = m;
-            }
-            const int n4 = npad / 4;
-            for (int idx = tid; idx < nb * n4; idx += 256) {
-                const int u = idx / n4, k4 = idx - u * n4;
-                if (n < lens[u] - 1) {
-                    // (agent-scope load: the line may sit, two frames old, in this XCD's L2)
-                    const ClU4 w = __builtin_amdgcn_raw_buffer_load_b128(rxb, (unsigned) ((((size_t) par * kClNB + u) * npadL + 4 * k4) * 4), 0u, kClSc1);
-                    *reinterpret_cast<ClU4 *>(pl + u * npadL + 4 * k4) = w;
+            {
+                // (all of a thread's loads go out before the first of them is used: one memory latency, not sixteen)
+                const int total = n4 * nb;
+                constexpr int RL = 4;     // (8 / 16: +4 % at N = 1024, -7 / -15 % at N = 512 -- the matrix rows spill into AGPRs)
+                for (int base = 0; base < total; base += 256 * RL) {
+                    ClU4 v[RL];
+                    int dst[RL];
+#pragma unroll
+                    for (int k = 0; k < RL; ++k) {
+                        const int idx = base + tid + 256 * k, ic = min(idx, total - 1);
+                        const int k4 = ic / nb, u = ic - k4 * nb;
+                        dst[k] = (idx < total && n < lens[u] - 1) ? (k4 * kClNB + u) * 4 : -1;
+                        const unsigned off = (unsigned) ((((size_t) par * (npadL / 4) + k4) * kClNB + u) * 16);
+                        v[k] = __builtin_amdgcn_raw_buffer_load_b128(rxb, off, 0u, kClSc1);      // (agent scope: the line may sit, two frames old, in this XCD's L2)
+                    }
+#pragma unroll
+                    for (int k = 0; k < RL; ++k)
+                        if (dst[k] >= 0) *reinterpret_cast<ClU4 *>(pl + dst[k]) = v[k];
+                }
+                // the frame's normaliser: max q over the cluster's workgroups (keys: max is order-independent)
+                for (int idx = tid; idx < C.G * kClNB; idx += 256) {
+                    const int u = idx & (kClNB - 1);
+                    if (u < nb && n < lens[u] - 1)
+                        atomicMax(&pmax[u], __hip_atomic_load(&xm[(size_t) par * C.G * kClNB + idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                 }
             }
             __syncthreads();
+            if (sfail) break;
+            if (tid < nb && n < lens[tid] - 1) mus[tid] = funkey(pmax[tid]);
+            __syncthreads();
+#ifdef ASG_X_CL_PROBE
+            const unsigned long long c5 = __builtin_readcyclecounter();
+            if (blockIdx.x == 0 && tid == 0) { pr[0] += c1 - c0; pr[1] += c2 - c1; pr[2] += c3 - c2; pr[3] += c4 - c3; pr[4] += c5 - c4; }
+#endif
             ++pub;
         }
         if (sfail) break;
         if (g == 0 && tid < nb && lens[tid] >= 1) S.off[rb + tid] = offs[tid];
     }
+#ifdef ASG_X_CL_PROBE
+    if (blockIdx.x == 0 && tid == 0)
+        printf("[cluster probe] frames %u: product %llu  epilogue %llu  ack+barrier %llu  flags %llu  reload %llu cycles per frame (s_memtime ticks)\n",
+               pub, pr[0] / max(pub, 1u), pr[1] / max(pub, 1u), pr[2] / max(pub, 1u), pr[3] / max(pub, 1u), pr[4] / max(pub, 1u));
+#endif
     if (sfail && g == 0 && tid < kClNB)
         for (int b = cb0 + tid; b < cb1; b += kClNB) S.off[b] = __builtin_nan("");      // (never hang, never return a wrong number quietly)
 }
@@ -1044,7 +1136,7 @@ static bool cluster_alphabet(const Problem &P, size_t elem) {
     const char *ev = getenv("ASG_NO_CLUSTER");
     return !(ev && atoi(ev) != 0);
 }
-constexpr size_t kClusterBytes = 8u << 20;       // exchange vectors + maxima + flags of every cluster (cluster_layout)
+constexpr size_t kClusterBytes = 8u << 20;       // exchange vectors of every cluster
 
 // the medium-alphabet route: fp32, 64 < N <= 256, 32-bit emission offsets (ASG_NO_MID=1: the per-frame launches instead)
 static bool mid_alphabet(const Problem &P, size_t elem) {
@@ -2408,10 +2500,9 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
                 if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
                     cus = 256;
                 ClusterArgs C{};
-                C.nkq = (W.npad + kClKPT - 1) / kClKPT;
-                C.RW = C.nkq <= 4 ? 64 : 32;
+                C.RW = P.N <= 512 ? 64 : 32;
                 C.G = (P.N + C.RW - 1) / C.RW;
-                C.npadL = C.nkq * kClKPT;
+                C.npadL = (W.npad + 31) / 32 * 32;
                 C.ndirs = (do_a && do_b) ? 2 : 1;
                 int ncd = cus / C.G / C.ndirs;
                 if (ncd < 1) ncd = 1;
@@ -2426,12 +2517,12 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
                     C.xmax = (unsigned *) (ca + xb);
                     C.flags = (unsigned *) (ca + xb + xmb);
                     (void) hipMemsetAsync(ca, 0, xb + xmb + flb, stream);
-                    const size_t lds = ((size_t) kClNB * C.npadL + (size_t) C.nkq * kClNB * C.RW) * 4;
-                    static bool attr_set = false;
-                    if (!attr_set) {
-                        (void) hipFuncSetAttribute((const void *) fwd_cluster_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
-                        attr_set = true;
-                    }
+                    // (at least 84 KB of LDS: a compute unit then holds ONE of these workgroups -- two on one unit would share its
+                    // matrix pipes and make their whole clusters wait, while other units stay empty)
+                    size_t lds = ((size_t) kClNB * C.npadL + (size_t) 2 * kClNB * 64) * 4;
+                    if (lds < 84 * 1024) lds = 84 * 1024;
+                    // (per device and cheap: set on every call rather than remembered per process)
+                    (void) hipFuncSetAttribute((const void *) fwd_cluster_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
                     StepBuf<float> A0 = Sd[0], B0 = Sd[1];
                     hipLaunchKernelGGL(fwd_cluster_kernel, dim3(ncl * C.G), dim3(256), lds, stream, P, A0, B0, C, do_a ? 0 : 1);
                     stepped = true;
