@@ -1,5 +1,5 @@
 """Random shapes through the routes between the fused step and the large-alphabet kernels (long targets over small
-alphabets, medium alphabets, both, and the boundaries N = 64/65/256/257, S = 64/65/256/257/512/513) against the fp64
+alphabets, medium alphabets, both, alphabets of 257 .. 1025 labels, and the boundaries N = 64/65/256/257, S = 64/65/256/257/512/513) against the fp64
 oracle: lengths of every kind (infeasible included), all reductions, fp32 and fp64.  tools/fuzz_routes.py is the long form."""
 import numpy as np
 import pytest
@@ -13,13 +13,16 @@ DEV = "cuda:0"
 
 
 def _case(rng):
-    kind = int(rng.integers(0, 4))
+    kind = int(rng.integers(0, 5))
     if kind == 0:
         N, S, T = int(rng.integers(2, 65)), int(rng.integers(65, 1025)), int(rng.integers(1, 500))
     elif kind == 1:
         N, S, T = int(rng.integers(65, 257)), int(rng.integers(1, 65)), int(rng.integers(1, 250))
     elif kind == 2:
         N, S, T = int(rng.integers(65, 257)), int(rng.integers(65, 500)), int(rng.integers(1, 300))
+    elif kind == 4:
+        # 256 < N <= 1024 (matrix resident in a cluster of workgroups) and just beyond (a launch per frame)
+        N, S, T = int(rng.choice([257, 300, 448, 512, 513, 640, 777, 1000, 1024, 1025])), int(rng.integers(1, 90)), int(rng.integers(1, 50))
     else:
         N = int(rng.choice([64, 65, 128, 129, 192, 193, 256, 257]))
         S = int(rng.choice([64, 65, 128, 129, 256, 257, 512, 513]))
