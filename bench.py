@@ -348,6 +348,9 @@ def extras(args):
     # not a BASELINE config: the shape letter-based speech models give the criterion (a few dozen labels, targets of
     # hundreds of positions, ~10 s of frames) -- S > 64 leaves the fused step for the long-target kernels
     attempt("long_targets", lambda: time_small_config("long targets (not a BASELINE config)", 1000, 64, 40, 200, True, 20))
+    # not a BASELINE config either: a word-piece sized alphabet (between cfg 3's 40 labels and cfg 5's 10^4) -- the matrix
+    # stays in the registers of a cluster of workgroups for all frames (fwd_cluster_kernel)
+    attempt("alphabet_512", lambda: time_small_config("512 labels (not a BASELINE config)", 400, 64, 512, 30, True, 10))
     attempt("cfg5", lambda: measure_cfg5(3, 1))
     return ex
 

@@ -932,9 +932,11 @@ def test_long_targets_small_alphabet(T, B, N, L, dtype, rtol):
 # ------------------------------------------------------------------ 256 < N <= 1024: the matrix resident in a cluster of workgroups
 @pytest.mark.gpu
 @pytest.mark.parametrize("T,B,N,L", [(60, 5, 257, 7), (50, 3, 300, 20), (45, 4, 512, 9), (40, 20, 700, 6), (30, 2, 1024, 5),
-                                       (12, 70, 1024, 3), (35, 3, 390, 30), (2, 3, 300, 1), (3, 2, 513, 2)])
+                                       (12, 70, 1024, 3), (35, 3, 390, 30), (2, 3, 300, 1), (3, 2, 513, 2),
+                                       (20, 3, 1025, 4), (16, 20, 1500, 3), (14, 2, 2048, 3), (8, 50, 2000, 2)])
 def test_resident_slice_alphabets(T, B, N, L, monkeypatch):
-    """fp32, 256 < N <= 1024: all frames of the full-lattice recursions in ONE launch (fwd_cluster_kernel: the matrix
+    """fp32, 256 < N <= 2048 (beyond 1024 labels: up to 48 utterances; (8, 50, 2000, 2) takes the launch per frame):
+    all frames of the full-lattice recursions in ONE launch (fwd_cluster_kernel: the matrix
     stays in the registers of a cluster of workgroups that exchange the frame's vectors through write-through stores
     and one progress word each).  Stored states, normaliser log and offsets are the per-frame step kernel's, so the
     same gradient pass follows; ASG_NO_CLUSTER=1 (a launch per frame) must agree to rounding, and the route is deterministic.  Variable lengths, an

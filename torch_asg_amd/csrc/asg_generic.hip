@@ -815,16 +815,18 @@ __global__ void __launch_bounds__(64 * NW) fwd_mid_kernel(Problem P, State W, Fw
     }
 }
 
-// ------------------------------------------------------------------ full lattice, 256 < N <= 1024 (fp32): resident slices
+// ------------------------------------------------------------------ full lattice, 256 < N <= 2048 (fp32): resident slices
 // Between the one-workgroup-per-chain kernel above (the row of a label fits its thread's registers up to N = 256) and
 // the streamed step (N ~ 10^4: 400 MB per frame) the matrix is 0.25 - 4 MB: too large for one compute unit, far too
 // small to be worth a launch per frame (fwd_step_kernel: 14 / 27 us per frame at N = 512 / 1024, a round of dependent
 // memory accesses for 14 - 52 workgroups of work).  Here a CLUSTER of G workgroups keeps the whole matrix in registers
-// for all frames -- workgroup g the RW = 64 (N <= 512) or 32 rows from i0 = g RW, as the A operand of
-// v_mfma_f32_16x16x4_f32 (exact fp32, as in the streamed step): wavefront w the 16-row block w % (RW / 16) and, for
-// RW = 32, the K half w / 2 -- and takes a batch of up to 16 chains of one direction through the frames together:
+// for all frames -- workgroup g the RW = 64 (N <= 512), 32 (N <= 1024) or 16 rows from i0 = g RW, as the A operand of
+// v_mfma_f32_16x16x4_f32 (exact fp32, as in the streamed step): of the workgroup's 16 wavefronts, wavefront w has the
+// 16-row block w % (RW / 16) and the K part w / (RW / 16) (4, 8 or 16 parts: 8 groups of 16 k = 32 registers per lane; four
+// wavefronts per SIMD keep the matrix pipe at its rate -- one alone issues an MFMA every 52 cycles instead of 32) -- and
+// takes a batch of up to 16 chains of one direction through the frames together:
 //   product   s[i][u] = sum_k E[i][k] p_u[k]: the batch's vectors sit in LDS as the B operand ([k / 4][u][k % 4]: one
-//             conflict-free ds_read_b128 feeds four MFMAs), at most 128 MFMAs per wavefront and frame whatever the
+//             conflict-free ds_read_b128 feeds four MFMAs), 32 MFMAs per wavefront and frame whatever the
 //             batch size; the K halves meet in LDS;
 //   epilogue  the streamed step's, element for element (same stored state, normaliser log and offsets: the gradient
 //             pass and fwd_score_kernel do not know which of the two ran): q = x2 + hmax + log2 s - max of the previous
@@ -839,7 +841,8 @@ __global__ void __launch_bounds__(64 * NW) fwd_mid_kernel(Problem P, State W, Fw
 // land on ONE XCD whenever the cluster count is a multiple of 8 and the exchange stays in that XCD's L2.
 // All workgroups must be co-resident (they wait for each other): the launcher sizes the grid to the device's compute
 // units; a wait that runs out (2^26 polls) poisons the scores with NaN instead of hanging the device.
-constexpr int kClNB = 16;
+constexpr int kClNB = 16, kClNT = 1024;        // chains per batch; threads per workgroup (two wavefronts per SIMD: one alone
+                                              // issues an MFMA every 52 cycles, two keep the pipe at its 32)
 constexpr unsigned kClSc1 = 16;   // buffer load aux bit: agent scope
 typedef unsigned ClU4 __attribute__((ext_vector_type(4)));
 struct ClusterArgs {
@@ -850,7 +853,7 @@ struct ClusterArgs {
 };
 static __host__ __device__ inline size_t cluster_xbuf_floats(int ncl, int npadL) { return (size_t) ncl * 2 * kClNB * npadL; }
 
-__global__ void __launch_bounds__(256) fwd_cluster_kernel(Problem P, StepBuf<float> Sa, StepBuf<float> Sb, ClusterArgs C, int dir_base) {
+__global__ void __launch_bounds__(kClNT) fwd_cluster_kernel(Problem P, StepBuf<float> Sa, StepBuf<float> Sb, ClusterArgs C, int dir_base) {
     typedef float R;
     extern __shared__ __attribute__((aligned(16))) float cl_lds[];
     __shared__ unsigned pmax[kClNB], lmax[kClNB];
@@ -868,17 +871,18 @@ __global__ void __launch_bounds__(256) fwd_cluster_kernel(Problem P, StepBuf<flo
     float *pl = cl_lds;                          // [npadL / 4][kClNB][4]: the B operand
     float *red = cl_lds + kClNB * npadL;         // [NKH][RW][kClNB]
     const R L2E = Num<R>::log2e(), LZ = Num<R>::logzero(), NINF = Num<R>::ninf();
-    const int MBW = RW / 16, NKH = 4 / MBW;      // row blocks per workgroup, K parts
+    const int MBW = RW / 16, NKH = (kClNT / 64) / MBW;      // row blocks per workgroup, K parts
     const int mb = wave % MBW, kh = wave / MBW;
     const int kspan = npadL / NKH, kbase = kh * kspan, KS4 = kspan / 16;      // this wavefront's K range, in groups of 16
     const int i0 = g * RW;
     // ---- this lane's elements of the (normalised) matrix: row i0 + 16 mb + (lane & 15), k = kbase + 16 s + 4 (lane >> 4) + c
-    V4<R> ea[32];
+    constexpr int KG = 8192 / kClNT;              // groups of 16 k per wavefront: 128 / (wavefronts per SIMD) matrix registers
+    V4<R> ea[KG];
     {
         const int irow = i0 + 16 * mb + (lane & 15);
         const R *src = S.ehat + (int64_t) min(irow, N - 1) * npad;
 #pragma unroll
-        for (int s4 = 0; s4 < 32; ++s4) {
+        for (int s4 = 0; s4 < KG; ++s4) {
             const int k = kbase + 16 * s4 + 4 * (lane >> 4);
             V4<R> v = {0, 0, 0, 0};
             if (s4 < KS4 && irow < N && k < npad) v = *reinterpret_cast<const V4<R> *>(src + k);
@@ -897,16 +901,16 @@ __global__ void __launch_bounds__(256) fwd_cluster_kernel(Problem P, StepBuf<flo
     unsigned pub = 0;                             // frames this cluster has published (uniform over its workgroups)
     constexpr int kSpinMax = 1 << 26;
     const int cb0 = cd * C.cpc, cb1 = min(B, cb0 + C.cpc);
-    constexpr int IT = 4;                         // epilogue elements per thread: RW * kClNB <= 64 * 16 = 4 * 256
+    constexpr int IT = 64 * kClNB / kClNT;        // epilogue elements per thread: RW * kClNB <= 64 * 16
     const int n4 = npad / 4;
     for (int rb = cb0; rb < cb1; rb += kClNB) {
         const int nb = min(kClNB, cb1 - rb);
         // epilogue elements: (chain u, row rr_) = (idx & nbm, idx >> nbs), the chain count rounded up to a power of two,
         // so that small batches fill the threads of the first pass instead of a quarter of every pass
         const int nbs = nb <= 1 ? 0 : nb <= 2 ? 1 : nb <= 4 ? 2 : nb <= 8 ? 3 : 4, nbm = (1 << nbs) - 1;
-        R hm[4];                                  // hmax of the rows this thread finishes
+        R hm[IT];                                 // hmax of the rows this thread finishes
 #pragma unroll
-        for (int it = 0; it < 4; ++it) hm[it] = S.hmax[min(i0 + ((tid + 256 * it) >> nbs), N - 1)];
+        for (int it = 0; it < IT; ++it) hm[it] = S.hmax[min(i0 + ((tid + kClNT * it) >> nbs), N - 1)];
         __syncthreads();
         if (tid < kClNB) {
             const int b = min(rb + tid, B - 1);
@@ -919,7 +923,7 @@ __global__ void __launch_bounds__(256) fwd_cluster_kernel(Problem P, StepBuf<flo
         __syncthreads();
         if (tid < nb) atomicMax(&smaxlen, lens[tid]);
         // the vectors of the first frame (fwd_init_kernel wrote them to pbuf[0]), transposed into the operand layout
-        for (int idx = tid; idx < kClNB * npadL; idx += 256) {
+        for (int idx = tid; idx < kClNB * npadL; idx += kClNT) {
             const int k = idx / kClNB, u = idx - k * kClNB;
             pl[((k >> 2) * kClNB + u) * 4 + (k & 3)] = (u < nb && k < npad) ? S.pbuf[(int64_t) (rb + u) * npad + k] : 0.0f;
         }
@@ -930,7 +934,7 @@ __global__ void __launch_bounds__(256) fwd_cluster_kernel(Problem P, StepBuf<flo
             constexpr int NF = 0;
 #pragma unroll
             for (int it = 0; it < IT; ++it) {
-                const int idx = tid + 256 * it, u = idx & nbm, rr_ = idx >> nbs, i = i0 + rr_;
+                const int idx = tid + kClNT * it, u = idx & nbm, rr_ = idx >> nbs, i = i0 + rr_;
                 xn[it] = 0; wn[it] = 0;
                 if (u < nb && rr_ < RW && i < N) {
                     const int len = lens[u], b = rb + u;
@@ -963,7 +967,7 @@ __global__ void __launch_bounds__(256) fwd_cluster_kernel(Problem P, StepBuf<flo
                 // trip-count tests around the MFMAs
                 V4<R> b0 = bp[0], b1 = bp[(size_t) min(1, KS4 - 1) * 4 * kClNB];
 #pragma unroll
-                for (int s4 = 0; s4 < 32; ++s4) {
+                for (int s4 = 0; s4 < KG; ++s4) {
                     const V4<R> bv = b0;
                     b0 = b1;
                     b1 = bp[(size_t) min(s4 + 2, KS4 - 1) * 4 * kClNB];
@@ -986,13 +990,13 @@ __global__ void __launch_bounds__(256) fwd_cluster_kernel(Problem P, StepBuf<flo
             // ---- epilogue (fwd_step_mfma's, element for element)
 #pragma unroll
             for (int it = 0; it < IT; ++it) {
-                const int idx = tid + 256 * it, u = idx & nbm, rr_ = idx >> nbs, i = i0 + rr_;
+                const int idx = tid + kClNT * it, u = idx & nbm, rr_ = idx >> nbs, i = i0 + rr_;
                 if (!(u < nb && rr_ < RW && i < N)) continue;
                 const int len = lens[u], b = rb + u;
                 if (!(n < len - 1)) continue;
                 const int t = BETA ? len - 1 - n : n + 1, tw = BETA ? t - 1 : t;
-                R a = red[(size_t) rr_ * kClNB + u];
-                if (NKH == 2) a += red[((size_t) RW + rr_) * kClNB + u];
+                R a = 0;
+                for (int h = 0; h < NKH; ++h) a += red[((size_t) h * RW + rr_) * kClNB + u];
                 const R muprev = fmax(mus[u], LZ);
                 const R lg = Num<R>::log2(a);
                 R rr = hm[it] + lg;
@@ -1036,7 +1040,7 @@ __global__ void __launch_bounds__(256) fwd_cluster_kernel(Problem P, StepBuf<flo
             }
 #pragma unroll
             for (int it = 0; it < IT; ++it) {
-                const int idx = tid + 256 * it, u = idx & nbm, rr_ = idx >> nbs, i = i0 + rr_;
+                const int idx = tid + kClNT * it, u = idx & nbm, rr_ = idx >> nbs, i = i0 + rr_;
                 if (!(u < nb && rr_ < RW && i < N)) continue;
                 if (!(n < lens[u] - 1)) continue;
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(xe[it]), rxb,
@@ -1059,7 +1063,7 @@ __global__ void __launch_bounds__(256) fwd_cluster_kernel(Problem P, StepBuf<flo
                                                   // waitcnt placement puts their latency on the epilogue's or the product's path)
 #pragma unroll
             for (int it = 0; it < IT; ++it) {
-                const int idx = tid + 256 * it, u = idx & nbm, rr_ = idx >> nbs, i = i0 + rr_;
+                const int idx = tid + kClNT * it, u = idx & nbm, rr_ = idx >> nbs, i = i0 + rr_;
                 xn[it] = 0; wn[it] = 0;
                 if (u < nb && rr_ < RW && i < N) {
                     const int len = lens[u], b = rb + u;
@@ -1086,12 +1090,12 @@ __global__ void __launch_bounds__(256) fwd_cluster_kernel(Problem P, StepBuf<flo
                 // (all of a thread's loads go out before the first of them is used: one memory latency, not sixteen)
                 const int total = n4 * nb;
                 constexpr int RL = 4;     // (8 / 16: +4 % at N = 1024, -7 / -15 % at N = 512 -- the matrix rows spill into AGPRs)
-                for (int base = 0; base < total; base += 256 * RL) {
+                for (int base = 0; base < total; base += kClNT * RL) {
                     ClU4 v[RL];
                     int dst[RL];
 #pragma unroll
                     for (int k = 0; k < RL; ++k) {
-                        const int idx = base + tid + 256 * k, ic = min(idx, total - 1);
+                        const int idx = base + tid + kClNT * k, ic = min(idx, total - 1);
                         const int k4 = ic / nb, u = ic - k4 * nb;
                         dst[k] = (idx < total && n < lens[u] - 1) ? (k4 * kClNB + u) * 4 : -1;
                         const unsigned off = (unsigned) ((((size_t) par * (npadL / 4) + k4) * kClNB + u) * 16);
@@ -1102,7 +1106,7 @@ __global__ void __launch_bounds__(256) fwd_cluster_kernel(Problem P, StepBuf<flo
                         if (dst[k] >= 0) *reinterpret_cast<ClU4 *>(pl + dst[k]) = v[k];
                 }
                 // the frame's normaliser: max q over the cluster's workgroups (keys: max is order-independent)
-                for (int idx = tid; idx < C.G * kClNB; idx += 256) {
+                for (int idx = tid; idx < C.G * kClNB; idx += kClNT) {
                     const int u = idx & (kClNB - 1);
                     if (u < nb && n < lens[u] - 1)
                         atomicMax(&pmax[u], __hip_atomic_load(&xm[(size_t) par * C.G * kClNB + idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -1130,9 +1134,9 @@ __global__ void __launch_bounds__(256) fwd_cluster_kernel(Problem P, StepBuf<flo
         for (int b = cb0 + tid; b < cb1; b += kClNB) S.off[b] = __builtin_nan("");      // (never hang, never return a wrong number quietly)
 }
 
-// the resident-slice route: fp32, 256 < N <= 1024 (ASG_NO_CLUSTER=1: the per-frame launches instead)
+// the resident-slice route: fp32, 256 < N <= 2048 (ASG_NO_CLUSTER=1: the per-frame launches instead)
 static bool cluster_alphabet(const Problem &P, size_t elem) {
-    if (elem != 4 || P.N <= 256 || P.N > 1024) return false;
+    if (elem != 4 || P.N <= 256 || P.N > 2048) return false;
     const char *ev = getenv("ASG_NO_CLUSTER");
     return !(ev && atoi(ev) != 0);
 }
@@ -2413,7 +2417,7 @@ size_t step_tile_bytes_generic(int elem, int N) {
 size_t fwd_work_bytes_generic(int elem, int T, int B, int N) {
     const size_t npad = (size_t) (N + 3) / 4 * 4;
     return au((size_t) T * B * elem) + 2 * au(2 * (size_t) B * npad * elem) + 2 * au(3 * (size_t) B * 4) + 2 * au((size_t) B * 8) +
-           au((size_t) T * B * elem) + ((elem == 4 && N > 256 && N <= 1024) ? kClusterBytes : 0) + 4096;
+           au((size_t) T * B * elem) + ((elem == 4 && N > 256 && N <= 2048) ? kClusterBytes : 0) + 4096;
 }
 // offset of the alpha pass's per-frame normaliser log inside the work area (its last member)
 static size_t work_mulog_offset(size_t elem, int T, int B, int npad) {
@@ -2500,9 +2504,9 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
                 if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
                     cus = 256;
                 ClusterArgs C{};
-                C.RW = P.N <= 512 ? 64 : 32;
+                C.RW = P.N <= 512 ? 64 : P.N <= 1024 ? 32 : 16;
                 C.G = (P.N + C.RW - 1) / C.RW;
-                C.npadL = (W.npad + 31) / 32 * 32;
+                C.npadL = (W.npad + 255) / 256 * 256;
                 C.ndirs = (do_a && do_b) ? 2 : 1;
                 int ncd = cus / C.G / C.ndirs;
                 if (ncd < 1) ncd = 1;
@@ -2512,19 +2516,22 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
                 const int ncl = C.ndirs * C.ncd;
                 char *ca = bar_area - kClusterBytes;
                 const size_t xb = au(cluster_xbuf_floats(ncl, C.npadL) * 4), xmb = au((size_t) ncl * 2 * C.G * kClNB * 4), flb = au((size_t) ncl * C.G * 4);
-                if (ncl * C.G <= cus && xb + xmb + flb <= kClusterBytes) {
+                // beyond 1024 labels a cluster is half the device (one per direction) and takes the batch 16 chains at a time:
+                // worth it up to three rounds (B <= 48), after that the launch per frame (32 us for ALL chains) is the faster one
+                const bool few_rounds = P.N <= 1024 || (C.cpc + kClNB - 1) / kClNB <= 3;
+                if (few_rounds && ncl * C.G <= cus && xb + xmb + flb <= kClusterBytes) {
                     C.xbuf = (float *) ca;
                     C.xmax = (unsigned *) (ca + xb);
                     C.flags = (unsigned *) (ca + xb + xmb);
                     (void) hipMemsetAsync(ca, 0, xb + xmb + flb, stream);
                     // (at least 84 KB of LDS: a compute unit then holds ONE of these workgroups -- two on one unit would share its
                     // matrix pipes and make their whole clusters wait, while other units stay empty)
-                    size_t lds = ((size_t) kClNB * C.npadL + (size_t) 2 * kClNB * 64) * 4;
+                    size_t lds = ((size_t) kClNB * C.npadL + (size_t) (kClNT / 64) * 16 * kClNB) * 4;
                     if (lds < 84 * 1024) lds = 84 * 1024;
                     // (per device and cheap: set on every call rather than remembered per process)
-                    (void) hipFuncSetAttribute((const void *) fwd_cluster_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+                    (void) hipFuncSetAttribute((const void *) fwd_cluster_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
                     StepBuf<float> A0 = Sd[0], B0 = Sd[1];
-                    hipLaunchKernelGGL(fwd_cluster_kernel, dim3(ncl * C.G), dim3(256), lds, stream, P, A0, B0, C, do_a ? 0 : 1);
+                    hipLaunchKernelGGL(fwd_cluster_kernel, dim3(ncl * C.G), dim3(kClNT), lds, stream, P, A0, B0, C, do_a ? 0 : 1);
                     stepped = true;
                 }
             }
@@ -2568,7 +2575,7 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
 // has only a few 128 x 128 tiles (N <= 1024), each slice at least 256 rows long
 static int gemm_slices(int N, int K) {
     const int tiles = ((N + 127) / 128) * ((N + 127) / 128);
-    if (tiles >= 64) return 1;
+    if (tiles >= 512) return 1;          // (64 tiles = N of 1024 ran on a quarter of the chip: 1.9 ms where 8 slices take 0.5)
     int n = (512 + tiles - 1) / tiles;
     if (n > K / 256) n = K / 256;
     return n < 1 ? 1 : n;
