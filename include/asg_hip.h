@@ -144,7 +144,14 @@ int asg_viterbi(asg_ctx *ctx, const asg_problem *p, void *work, size_t work_byte
 #define ASG_REDUCTION_MEAN 2
 
 /* loss = reduce_b(full[b] - aligned[b]); `loss` is [B] (none) or [1]; `scores` is a [2][B] work buffer that
- * receives full_scores then aligned_scores. */
+ * receives full_scores then aligned_scores.
+ * Alphabets of 257 .. 1024 labels (.. 2048 while B <= 48), float32, in every forward entry point: the full-lattice
+ * recursions of all frames are ONE launch whose workgroups wait for each other frame by frame (the transition matrix
+ * stays in their registers), sized to the device's compute units.  It therefore wants the device to itself: another
+ * kernel that keeps compute units for seconds (a second process running the same route, say) can keep part of the
+ * grid from starting, and a wait that runs out (~2^22 polls) makes the affected SCORES NaN -- never a wrong number,
+ * never a hang.  ASG_NO_CLUSTER=1 in the environment selects the launch-per-frame kernels instead (2-3x slower,
+ * no co-residency needed). */
 int asg_loss_forward(asg_ctx *ctx, const asg_problem *p, void *state, size_t state_bytes, int reduction,
                      void *loss, void *scores, int flags, void *stream);
 

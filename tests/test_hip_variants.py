@@ -7,6 +7,9 @@ __graft_entry__.build()) through ASG_HIP_LIB, each in its own process:
   delay    utterance 1's aligned workgroup and utterance 2's full-alpha workgroup start ~0.2 s late, past every bounded
            wait of their partners: the time-out -> flag -> exact redo route, the claim protocol on UttSync::adone, and
            the "sync words are zero again on exit" contract.
+  stall    workgroup 1 of every cluster of the resident-slice kernel (256 < N <= 2048) never announces a frame: the
+           bounded waits of its peers run out and the scores come back NaN -- the documented failure mode when the grid
+           cannot be co-resident (include/asg_hip.h): no hang, no wrong number.
 """
 import os
 import subprocess
@@ -82,3 +85,37 @@ print("DELAY-OK")
 def test_late_workgroups_time_out_into_the_exact_redo_without_hanging():
     out = _run(["-c", DELAY_SCRIPT], _lib("delay"), 300)
     assert "DELAY-OK" in out
+
+
+STALL_SCRIPT = r'''
+import sys, time
+import numpy as np, torch
+sys.path.insert(0, "tests")
+import util
+import torch_asg_amd
+from torch_asg_amd import _lib
+assert "stall" in _lib.LIB_PATH
+T, B, N, L = 30, 5, 400, 6
+tr, x, tg, il, tl = util.synth(T, B, N, L, 31, True)
+m = torch_asg_amd.ASGLoss(N, reduction="none").to("cuda:0")
+with torch.no_grad():
+    m.transition.copy_(tr)
+t0 = time.time()
+xd = x.to("cuda:0").requires_grad_(True)
+loss = m(xd, tg.to("cuda:0"), il.to("cuda:0"), tl.to("cuda:0"))
+torch.cuda.synchronize()
+dt = time.time() - t0
+assert dt < 30.0, "the waits are bounded: %.1f s" % dt
+assert torch.isnan(loss).all(), "a cluster that cannot complete must poison every score it owns: %s" % loss
+# small alphabets do not go through that kernel: the same library still answers them
+tr2, x2, tg2, il2, tl2 = util.synth(40, 4, 20, 6, 3, True)
+m2 = torch_asg_amd.ASGLoss(20).to("cuda:0")
+v = m2(x2.to("cuda:0"), tg2.to("cuda:0"), il2.to("cuda:0"), tl2.to("cuda:0"))
+assert torch.isfinite(v)
+print("STALL-OK")
+'''
+
+
+def test_a_cluster_that_cannot_complete_returns_nan_and_does_not_hang():
+    out = _run(["-c", STALL_SCRIPT], _lib("stall"), 120)
+    assert "STALL-OK" in out, out[-2000:]

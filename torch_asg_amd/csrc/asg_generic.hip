@@ -840,7 +840,7 @@ __global__ void __launch_bounds__(64 * NW) fwd_mid_kernel(Problem P, State W, Fw
 // Clusters are placed with the workgroup index as the slow coordinate (block = g * ncl + c), so a cluster's workgroups
 // land on ONE XCD whenever the cluster count is a multiple of 8 and the exchange stays in that XCD's L2.
 // All workgroups must be co-resident (they wait for each other): the launcher sizes the grid to the device's compute
-// units; a wait that runs out (2^26 polls) poisons the scores with NaN instead of hanging the device.
+// units; a wait that runs out (2^22 polls) poisons the scores with NaN instead of hanging the device.
 constexpr int kClNB = 16, kClNT = 1024;        // chains per batch; threads per workgroup (two wavefronts per SIMD: one alone
                                               // issues an MFMA every 52 cycles, two keep the pipe at its 32)
 constexpr unsigned kClSc1 = 16;   // buffer load aux bit: agent scope
@@ -899,7 +899,11 @@ __global__ void __launch_bounds__(kClNT) fwd_cluster_kernel(Problem P, StepBuf<f
     unsigned long long pr[5] = {0, 0, 0, 0, 0};
 #endif
     unsigned pub = 0;                             // frames this cluster has published (uniform over its workgroups)
-    constexpr int kSpinMax = 1 << 26;
+#ifdef ASG_X_CL_SPINMAX
+    constexpr int kSpinMax = ASG_X_CL_SPINMAX;    // (developer variant: tests/test_hip_variants.py)
+#else
+    constexpr int kSpinMax = 1 << 22;             // (~0.5 us per poll: a couple of seconds)
+#endif
     const int cb0 = cd * C.cpc, cb1 = min(B, cb0 + C.cpc);
     constexpr int IT = 64 * kClNB / kClNT;        // epilogue elements per thread: RW * kClNB <= 64 * 16
     const int n4 = npad / 4;
@@ -1057,7 +1061,11 @@ __global__ void __launch_bounds__(kClNT) fwd_cluster_kernel(Problem P, StepBuf<f
 #ifdef ASG_X_CL_PROBE
             const unsigned long long c3 = __builtin_readcyclecounter();
 #endif
+#ifdef ASG_X_CL_TEST_STALL
+            if (tid == 0 && g != 1) __hip_atomic_store(&fl[g], pub + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // (workgroup 1 never says so)
+#else
             if (tid == 0) __hip_atomic_store(&fl[g], pub + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
             {
                 const int NF = n + 1;             // the next frame's emissions: in flight under the hand-off (requested any earlier, hipcc's
                                                   // waitcnt placement puts their latency on the epilogue's or the product's path)
