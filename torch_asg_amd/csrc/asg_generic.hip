@@ -823,7 +823,9 @@ __global__ void __launch_bounds__(64 * NW) fwd_mid_kernel(Problem P, State W, Fw
 // for all frames -- workgroup g the RW = 64 (N <= 512), 32 (N <= 1024) or 16 rows from i0 = g RW, as the A operand of
 // v_mfma_f32_16x16x4_f32 (exact fp32, as in the streamed step): of the workgroup's 16 wavefronts, wavefront w has the
 // 16-row block w % (RW / 16) and the K part w / (RW / 16) (4, 8 or 16 parts: 8 groups of 16 k = 32 registers per lane; four
-// wavefronts per SIMD keep the matrix pipe at its rate -- one alone issues an MFMA every 52 cycles instead of 32) -- and
+// wavefronts per SIMD hide each other's operand reads and bookkeeping: with one per SIMD the product took 6 600 cycles
+// for its 128 MFMAs, with four 4 700 for the same 128 per SIMD -- the pipe's rate, 32 cycles apiece whether one
+// wavefront issues them or four, tools/ubench/mfma_issue.hip, would be 4 100) -- and
 // takes a batch of up to 16 chains of one direction through the frames together:
 //   product   s[i][u] = sum_k E[i][k] p_u[k]: the batch's vectors sit in LDS as the B operand ([k / 4][u][k % 4]: one
 //             conflict-free ds_read_b128 feeds four MFMAs), 32 MFMAs per wavefront and frame whatever the
@@ -841,8 +843,7 @@ __global__ void __launch_bounds__(64 * NW) fwd_mid_kernel(Problem P, State W, Fw
 // land on ONE XCD whenever the cluster count is a multiple of 8 and the exchange stays in that XCD's L2.
 // All workgroups must be co-resident (they wait for each other): the launcher sizes the grid to the device's compute
 // units; a wait that runs out (2^22 polls) poisons the scores with NaN instead of hanging the device.
-constexpr int kClNB = 16, kClNT = 1024;        // chains per batch; threads per workgroup (two wavefronts per SIMD: one alone
-                                              // issues an MFMA every 52 cycles, two keep the pipe at its 32)
+constexpr int kClNB = 16, kClNT = 1024;        // chains per batch; threads per workgroup (four wavefronts per SIMD: see above)
 constexpr unsigned kClSc1 = 16;   // buffer load aux bit: agent scope
 typedef unsigned ClU4 __attribute__((ext_vector_type(4)));
 struct ClusterArgs {
