@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Developer probe (GPU): the shared-matrix step (ASG_STEP2=1) against the two-copy step and the fp64 oracle on small T."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import numpy as np, torch, torch_asg_amd, util
 from oracle import asg_oracle as orc
 dev = "cuda:0"
