@@ -13,13 +13,15 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 bad = 0
 t_start = time.time()
 for c in range(ncases):
-    kind = rng.integers(0, 4)
+    kind = rng.integers(0, 5)
     if kind == 0:      # long targets, small alphabet
         N = int(rng.integers(2, 65)); S = int(rng.integers(65, 1025)); T = int(rng.integers(1, 700))
     elif kind == 1:    # medium alphabet, short targets
         N = int(rng.integers(65, 257)); S = int(rng.integers(1, 65)); T = int(rng.integers(1, 300))
     elif kind == 2:    # both
         N = int(rng.integers(65, 257)); S = int(rng.integers(65, 600)); T = int(rng.integers(1, 400))
+    elif kind == 4:    # 257 .. 2048 labels: the matrix resident in a cluster of workgroups (and just beyond it)
+        N = int(rng.integers(257, 2100)); S = int(rng.integers(1, 120)); T = int(rng.integers(1, 40))
     else:              # boundaries
         N = int(rng.choice([64, 65, 128, 129, 192, 193, 256, 257])); S = int(rng.choice([64, 65, 128, 129, 256, 257, 512, 513])); T = int(rng.integers(2, 200))
     B = int(rng.integers(1, 5))
