@@ -875,8 +875,9 @@ def test_bf16_emissions_fp32_accumulate():
 @pytest.mark.gpu
 def test_generic_one_launch_forward_equals_per_frame_launches(monkeypatch):
     """ASG_PERSIST=1 runs all T-1 frames of the large-alphabet recursion in ONE cooperative launch (a grid barrier per
-    direction between frames, write-through hand-offs); results must be bit-identical to the T-1 launches."""
-    T, B, N, L = 40, 5, 300, 9
+    direction between frames, write-through hand-offs); results must be bit-identical to the T-1 launches.
+    (N beyond 2048: smaller alphabets take the resident-slice kernel whatever ASG_PERSIST says.)"""
+    T, B, N, L = 14, 3, 2100, 5
     tr, x, tg, il, tl = util.synth(T, B, N, L, 11, True)
     outs = []
     for env in ("0", "1"):
