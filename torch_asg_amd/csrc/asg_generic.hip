@@ -643,25 +643,35 @@ __global__ void __launch_bounds__(256) fwd_persist_kernel(Problem P, StepBuf<flo
 //   beta:  y_t = x2_t + b_t,  p = exp2(y - max y),  b_{t-1}[i] = cmax_i + log2 sum_j Fhat[j][i] p[j]  (:32-47)
 // Stored states are relative to a per-frame offset (max = 0): the gradient pass (bwd_post_kernel<.., false> + both
 // contractions) is offset-free per frame.  A row sum outside [2^-100, 2^100] is redone as an exact log-sum-exp.
+// NW = 4 (192 < N <= 256): 256 row elements per thread do not fit the architectural registers, so TWO threads share a
+// label -- thread i the columns 0 .. 127, thread i + 256 the columns 128 .. 255 of label i's row; the upper half hands its
+// partial sum over through LDS (one more barrier per frame) and otherwise only keeps the barriers company.
 template <int NW>
-__global__ void __launch_bounds__(64 * NW) fwd_mid_kernel(Problem P, State W, FwdOut O, int mask) {
+__global__ void __launch_bounds__(NW == 4 ? 512 : 64 * NW) fwd_mid_kernel(Problem P, State W, FwdOut O, int mask) {
     typedef float R;
     constexpr int NP = 64 * NW;
+    constexpr bool SPLIT = NW == 4;
+    constexpr int NC = SPLIT ? NP / 2 : NP;                      // columns of its row a thread holds
+    constexpr int NWT = SPLIT ? 2 * NW : NW;                     // wavefronts of the workgroup
     __shared__ __attribute__((aligned(16))) float pbuf[NP];      // exp-domain vector of the frame being consumed
     __shared__ float qbuf[NP];                                   // its log-domain twin (exact path)
+    __shared__ float part[SPLIT ? NP : 1];                       // partial sums of the upper half
     __shared__ float red[8];
     const int b = blockIdx.x;
     const bool beta = (mask == kFullBeta) || (mask == (kFullAlpha | kFullBeta) && blockIdx.y == 1);
-    const int i = threadIdx.x, lane = i & 63, wave = i >> 6;
+    const bool upper = SPLIT && threadIdx.x >= NP;
+    const int i = SPLIT ? (int) threadIdx.x & (NP - 1) : (int) threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c0 = upper ? NC : 0;                               // first column of this thread's share
     const int N = P.N, T = P.T;
     const int len = P.in_len ? gclampi(P.in_len[b], 0, T) : T;
     const R L2E = Num<R>::log2e(), LZ = Num<R>::logzero(), NINF = Num<R>::ninf();
-    const bool act = i < N;
-    const int ic = act ? i : 0;
+    const bool rowact = i < N;
+    const bool act = rowact && !upper;
+    const int ic = rowact ? i : 0;
     const R *tr = (const R *) P.transition;
     R *score_out = (R *) (beta ? O.full_scores : O.full_scores_alpha);
     if (len < 1) {
-        if (i == 0 && score_out) score_out[b] = NINF;
+        if (threadIdx.x == 0 && score_out) score_out[b] = NINF;
         return;
     }
     // this label's row (alpha: Tr[i][.], scores of arriving at i) / column (beta: Tr[.][i], of leaving i), normalised
@@ -669,11 +679,12 @@ __global__ void __launch_bounds__(64 * NW) fwd_mid_kernel(Problem P, State W, Fw
     R hmax = NINF;
     for (int j = 0; j < N; ++j) hmax = fmax(hmax, tr[tbase + (int64_t) j * tstep] * L2E);
     hmax = fmax(hmax, LZ);
-    V2<R> e2[NP / 2];
+    V2<R> e2[NC / 2];
 #pragma unroll
-    for (int j = 0; j < NP / 2; ++j) {
-        const R ea = (act && 2 * j < N) ? Num<R>::exp2(tr[tbase + (int64_t) min(2 * j, N - 1) * tstep] * L2E - hmax) : R(0);
-        const R eb = (act && 2 * j + 1 < N) ? Num<R>::exp2(tr[tbase + (int64_t) min(2 * j + 1, N - 1) * tstep] * L2E - hmax) : R(0);
+    for (int j = 0; j < NC / 2; ++j) {
+        const int ca = c0 + 2 * j, cb = ca + 1;
+        const R ea = (rowact && ca < N) ? Num<R>::exp2(tr[tbase + (int64_t) min(ca, N - 1) * tstep] * L2E - hmax) : R(0);
+        const R eb = (rowact && cb < N) ? Num<R>::exp2(tr[tbase + (int64_t) min(cb, N - 1) * tstep] * L2E - hmax) : R(0);
         e2[j] = V2<R>{ea, eb};
     }
     // emissions of this label: frame offset in an SGPR, label offset in a VGPR (32-bit: checked by the launcher)
@@ -689,26 +700,27 @@ __global__ void __launch_bounds__(64 * NW) fwd_mid_kernel(Problem P, State W, Fw
         __syncthreads();
         R r = red[0];
 #pragma unroll
-        for (int w = 1; w < NW; ++w) r = fmax(r, red[w]);
+        for (int w = 1; w < NWT; ++w) r = fmax(r, red[w]);
         return r;
     };
     auto matvec = [&]() -> R {                 // sum_j e[j] p[j], the vector broadcast from LDS
         V2<R> a0 = {0, 0}, a1 = {0, 0};
 #pragma unroll
-        for (int q = 0; q < NP / 4; ++q) {
-            const V4<R> pv = *reinterpret_cast<const V4<R> *>(&pbuf[4 * q]);
-            if constexpr (NW <= 3) {
-                a0 = __builtin_elementwise_fma(e2[2 * q], V2<R>{pv.x, pv.y}, a0);          // v_pk_fma_f32
-                a1 = __builtin_elementwise_fma(e2[2 * q + 1], V2<R>{pv.z, pv.w}, a1);
-            } else {
-                // 256 row elements do not fit the 256 architectural registers: part of them lives in accumulation registers,
-                // and moving a PAIR back for a packed FMA costs more than it saves (679 vs 1007 us at N = 256, T = 400)
-                a0 = V2<R>{fmaf(e2[2 * q].x, pv.x, a0.x), fmaf(e2[2 * q].y, pv.y, a0.y)};
-                a1 = V2<R>{fmaf(e2[2 * q + 1].x, pv.z, a1.x), fmaf(e2[2 * q + 1].y, pv.w, a1.y)};
-            }
+        for (int q = 0; q < NC / 4; ++q) {
+            const V4<R> pv = *reinterpret_cast<const V4<R> *>(&pbuf[c0 + 4 * q]);
+            a0 = __builtin_elementwise_fma(e2[2 * q], V2<R>{pv.x, pv.y}, a0);          // v_pk_fma_f32
+            a1 = __builtin_elementwise_fma(e2[2 * q + 1], V2<R>{pv.z, pv.w}, a1);
         }
         const V2<R> a = a0 + a1;
-        return a.x + a.y;
+        R sum = a.x + a.y;
+        if constexpr (SPLIT) {
+            // the two halves of a row meet in LDS (192 < N <= 256; before the split the 256 row elements spilled into
+            // accumulation registers and cost 1007 -> 679 us only by giving up the packed FMAs)
+            if (upper) part[i] = sum;
+            __syncthreads();
+            if (!upper) sum += part[i];
+        }
+        return sum;
     };
     auto exact = [&]() -> R {                  // log2 sum_j 2^(Tr2 + q_j) for this label, from the log-domain vector
         R mx = NINF;
@@ -728,8 +740,7 @@ __global__ void __launch_bounds__(64 * NW) fwd_mid_kernel(Problem P, State W, Fw
         R ah = a - m;
         M = (double) m;
         if (act) st[0] = ah;
-        pbuf[i] = act ? Num<R>::exp2(ah) : R(0);
-        qbuf[i] = act ? ah : NINF;
+        if (!upper) { pbuf[i] = act ? Num<R>::exp2(ah) : R(0); qbuf[i] = act ? ah : NINF; }
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < PF; ++u) x2[u] = emis(1 + u) * L2E;
@@ -749,8 +760,7 @@ __global__ void __launch_bounds__(64 * NW) fwd_mid_kernel(Problem P, State W, Fw
                     ah = a - m;
                     M += (double) m;
                     if (act) st[(int64_t) t * N] = ah;
-                    pbuf[i] = act ? Num<R>::exp2(ah) : R(0);
-                    qbuf[i] = act ? ah : NINF;
+                    if (!upper) { pbuf[i] = act ? Num<R>::exp2(ah) : R(0); qbuf[i] = act ? ah : NINF; }
                     __syncthreads();
                 }
             }
@@ -760,10 +770,10 @@ __global__ void __launch_bounds__(64 * NW) fwd_mid_kernel(Problem P, State W, Fw
             __syncthreads();
             if (lane == 0) red[wave] = sm;
             __syncthreads();
-            if (i == 0) {
+            if (threadIdx.x == 0) {
                 R tot = red[0];
 #pragma unroll
-                for (int w = 1; w < NW; ++w) tot += red[w];
+                for (int w = 1; w < NWT; ++w) tot += red[w];
                 const double sc = M + (double) Num<R>::log2(tot);
                 score_out[b] = (sc < -1e29) ? NINF : (R) (sc * kLn2);
             }
@@ -783,8 +793,7 @@ __global__ void __launch_bounds__(64 * NW) fwd_mid_kernel(Problem P, State W, Fw
                     const R y = act ? xe + bh : NINF;
                     const R my = fmax(wg_max(y), LZ);
                     M += (double) my;
-                    pbuf[i] = act ? Num<R>::exp2(y - my) : R(0);
-                    qbuf[i] = act ? y - my : NINF;
+                    if (!upper) { pbuf[i] = act ? Num<R>::exp2(y - my) : R(0); qbuf[i] = act ? y - my : NINF; }
                     __syncthreads();
                     const R s = matvec();
                     const R lg = Num<R>::log2(s);
@@ -804,10 +813,10 @@ __global__ void __launch_bounds__(64 * NW) fwd_mid_kernel(Problem P, State W, Fw
             __syncthreads();
             if (lane == 0) red[wave] = sm;
             __syncthreads();
-            if (i == 0) {
+            if (threadIdx.x == 0) {
                 R tot = red[0];
 #pragma unroll
-                for (int w = 1; w < NW; ++w) tot += red[w];
+                for (int w = 1; w < NWT; ++w) tot += red[w];
                 const double sc = M + (double) my + (double) Num<R>::log2(tot);
                 score_out[b] = (sc < -1e29) ? NINF : (R) (sc * kLn2);
             }
@@ -2472,7 +2481,7 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
             const int nw = (P.N + 63) / 64;
             if (nw <= 2) hipLaunchKernelGGL((fwd_mid_kernel<2>), grid, dim3(128), 0, stream, P, W, O, full_mask);
             else if (nw == 3) hipLaunchKernelGGL((fwd_mid_kernel<3>), grid, dim3(192), 0, stream, P, W, O, full_mask);
-            else hipLaunchKernelGGL((fwd_mid_kernel<4>), grid, dim3(256), 0, stream, P, W, O, full_mask);
+            else hipLaunchKernelGGL((fwd_mid_kernel<4>), grid, dim3(512), 0, stream, P, W, O, full_mask);
         }
     } else if (full_mask) {
         if (!W.work) return hipErrorInvalidValue;
