@@ -643,14 +643,15 @@ __global__ void __launch_bounds__(256) fwd_persist_kernel(Problem P, StepBuf<flo
 //   beta:  y_t = x2_t + b_t,  p = exp2(y - max y),  b_{t-1}[i] = cmax_i + log2 sum_j Fhat[j][i] p[j]  (:32-47)
 // Stored states are relative to a per-frame offset (max = 0): the gradient pass (bwd_post_kernel<.., false> + both
 // contractions) is offset-free per frame.  A row sum outside [2^-100, 2^100] is redone as an exact log-sum-exp.
-// NW = 4 (192 < N <= 256): 256 row elements per thread do not fit the architectural registers, so TWO threads share a
-// label -- thread i the columns 0 .. 127, thread i + 256 the columns 128 .. 255 of label i's row; the upper half hands its
-// partial sum over through LDS (one more barrier per frame) and otherwise only keeps the barriers company.
+// TWO threads share a label -- thread i the first half of the columns of label i's row, thread i + NP the second half
+// (at most 128 row elements per thread: 256 in one thread spilled into accumulation registers and cost 1360 us at N = 256
+// where the pair takes 787; 724 -> 676 at N = 192, 575 -> 553 at N = 128); the upper half hands its partial sum over
+// through LDS (one more barrier per frame) and otherwise only keeps the barriers company.
 template <int NW>
-__global__ void __launch_bounds__(NW == 4 ? 512 : 64 * NW) fwd_mid_kernel(Problem P, State W, FwdOut O, int mask) {
+__global__ void __launch_bounds__(128 * NW) fwd_mid_kernel(Problem P, State W, FwdOut O, int mask) {
     typedef float R;
     constexpr int NP = 64 * NW;
-    constexpr bool SPLIT = NW == 4;
+    constexpr bool SPLIT = true;                                 // (false: one thread per label, the round-3 original)
     constexpr int NC = SPLIT ? NP / 2 : NP;                      // columns of its row a thread holds
     constexpr int NWT = SPLIT ? 2 * NW : NW;                     // wavefronts of the workgroup
     __shared__ __attribute__((aligned(16))) float pbuf[NP];      // exp-domain vector of the frame being consumed
@@ -660,7 +661,7 @@ __global__ void __launch_bounds__(NW == 4 ? 512 : 64 * NW) fwd_mid_kernel(Proble
     const int b = blockIdx.x;
     const bool beta = (mask == kFullBeta) || (mask == (kFullAlpha | kFullBeta) && blockIdx.y == 1);
     const bool upper = SPLIT && threadIdx.x >= NP;
-    const int i = SPLIT ? (int) threadIdx.x & (NP - 1) : (int) threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = (int) threadIdx.x - (upper ? NP : 0), lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c0 = upper ? NC : 0;                               // first column of this thread's share
     const int N = P.N, T = P.T;
     const int len = P.in_len ? gclampi(P.in_len[b], 0, T) : T;
@@ -2479,8 +2480,8 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
         if constexpr (sizeof(R) == 4) {
             dim3 grid(P.B, __builtin_popcount(full_mask));
             const int nw = (P.N + 63) / 64;
-            if (nw <= 2) hipLaunchKernelGGL((fwd_mid_kernel<2>), grid, dim3(128), 0, stream, P, W, O, full_mask);
-            else if (nw == 3) hipLaunchKernelGGL((fwd_mid_kernel<3>), grid, dim3(192), 0, stream, P, W, O, full_mask);
+            if (nw <= 2) hipLaunchKernelGGL((fwd_mid_kernel<2>), grid, dim3(256), 0, stream, P, W, O, full_mask);
+            else if (nw == 3) hipLaunchKernelGGL((fwd_mid_kernel<3>), grid, dim3(384), 0, stream, P, W, O, full_mask);
             else hipLaunchKernelGGL((fwd_mid_kernel<4>), grid, dim3(512), 0, stream, P, W, O, full_mask);
         }
     } else if (full_mask) {
