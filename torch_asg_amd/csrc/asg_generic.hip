@@ -655,7 +655,8 @@ __global__ void __launch_bounds__(128 * NW) fwd_mid_kernel(Problem P, State W, F
     constexpr int NC = SPLIT ? NP / 2 : NP;                      // columns of its row a thread holds
     constexpr int NWT = SPLIT ? 2 * NW : NW;                     // wavefronts of the workgroup
     __shared__ __attribute__((aligned(16))) float pbuf[NP];      // exp-domain vector of the frame being consumed
-    __shared__ float qbuf[NP];                                   // its log-domain twin (exact path)
+    __shared__ float qbuf[2][NP];                                // its log-domain twin (exact path), double buffered: the exact path
+                                                                 // of a slow thread may still read it when a fast one writes the next
     __shared__ float part[SPLIT ? NP : 1];                       // partial sums of the upper half
     __shared__ float red[8];
     const int b = blockIdx.x;
@@ -723,17 +724,30 @@ __global__ void __launch_bounds__(128 * NW) fwd_mid_kernel(Problem P, State W, F
         }
         return sum;
     };
+    int qp = 0;                                // qbuf[qp] = the vector being consumed
     auto exact = [&]() -> R {                  // log2 sum_j 2^(Tr2 + q_j) for this label, from the log-domain vector
         R mx = NINF;
-        for (int j = 0; j < N; ++j) { const R v = tr[tbase + (int64_t) j * tstep] * L2E + qbuf[j]; mx = (v == v) ? fmax(mx, v) : mx; }
+        for (int j = 0; j < N; ++j) { const R v = tr[tbase + (int64_t) j * tstep] * L2E + qbuf[qp][j]; mx = (v == v) ? fmax(mx, v) : mx; }
         if (mx == NINF) return NINF;
         R sm = 0;
-        for (int j = 0; j < N; ++j) { const R v = tr[tbase + (int64_t) j * tstep] * L2E + qbuf[j]; sm += (v == v) ? Num<R>::exp2(v - mx) : R(0); }
+        for (int j = 0; j < N; ++j) { const R v = tr[tbase + (int64_t) j * tstep] * L2E + qbuf[qp][j]; sm += (v == v) ? Num<R>::exp2(v - mx) : R(0); }
         return mx + Num<R>::log2(sm);
     };
     constexpr int PF = 4;
     double M = 0.0;
     R x2[PF];
+    // The frame's normaliser LAGS by one frame: a frame's vector is taken relative to the maximum of the PREVIOUS stored
+    // vector, which every wavefront left in red[] before the barrier that published that vector -- so no workgroup-wide
+    // maximum (a dependent LDS round trip and a barrier of its own) sits between the product and the next vector.  Stored
+    // states are relative to a per-frame offset either way (the gradient pass is offset-free per frame); their maximum is
+    // now the growth of one frame instead of 0.
+    auto leave_max = [&](R v) { const R m = wave_allmax(v); if (lane == 0) red[wave] = m; };
+    auto lagged_max = [&]() -> R {             // (after the barrier that follows leave_max)
+        R r = red[0];
+#pragma unroll
+        for (int w = 1; w < NWT; ++w) r = fmax(r, red[w]);
+        return fmax(r, LZ);
+    };
     if (!beta) {
         // frame 0
         R a = act ? emis(0) * L2E : NINF;
@@ -741,7 +755,8 @@ __global__ void __launch_bounds__(128 * NW) fwd_mid_kernel(Problem P, State W, F
         R ah = a - m;
         M = (double) m;
         if (act) st[0] = ah;
-        if (!upper) { pbuf[i] = act ? Num<R>::exp2(ah) : R(0); qbuf[i] = act ? ah : NINF; }
+        if (!upper) { pbuf[i] = act ? Num<R>::exp2(ah) : R(0); qbuf[0][i] = act ? ah : NINF; }
+        R mu = 0;                                  // max of the stored frame 0: exactly 0
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < PF; ++u) x2[u] = emis(1 + u) * L2E;
@@ -757,17 +772,21 @@ __global__ void __launch_bounds__(128 * NW) fwd_mid_kernel(Problem P, State W, F
                     R rr = hmax + lg;
                     if (act && !(fabs(lg) < Num<R>::lg_limit())) rr = exact();      // (rare)
                     a = act ? xe + rr : NINF;
-                    m = fmax(wg_max(a), LZ);           // (barrier: every thread has read the old vector)
-                    ah = a - m;
-                    M += (double) m;
+                    ah = a - mu;                       // (every thread has read the old vector: the barrier inside matvec)
+                    M += (double) mu;
                     if (act) st[(int64_t) t * N] = ah;
-                    if (!upper) { pbuf[i] = act ? Num<R>::exp2(ah) : R(0); qbuf[i] = act ? ah : NINF; }
+                    if (!upper) { pbuf[i] = act ? Num<R>::exp2(ah) : R(0); qbuf[qp ^ 1][i] = act ? ah : NINF; }
+                    leave_max(ah);
                     __syncthreads();
+                    qp ^= 1;
+                    mu = lagged_max();
                 }
             }
         }
         if (score_out) {
-            const R sm = wave_allsum(act ? Num<R>::exp2(ah) : R(0));
+            __syncthreads();
+            const R ml = fmax(wg_max(ah), LZ);
+            const R sm = wave_allsum(act ? Num<R>::exp2(ah - ml) : R(0));
             __syncthreads();
             if (lane == 0) red[wave] = sm;
             __syncthreads();
@@ -775,7 +794,7 @@ __global__ void __launch_bounds__(128 * NW) fwd_mid_kernel(Problem P, State W, F
                 R tot = red[0];
 #pragma unroll
                 for (int w = 1; w < NWT; ++w) tot += red[w];
-                const double sc = M + (double) Num<R>::log2(tot);
+                const double sc = M + (double) ml + (double) Num<R>::log2(tot);
                 score_out[b] = (sc < -1e29) ? NINF : (R) (sc * kLn2);
             }
         }
@@ -784,6 +803,9 @@ __global__ void __launch_bounds__(128 * NW) fwd_mid_kernel(Problem P, State W, F
         if (act) st[(int64_t) (len - 1) * N] = R(0);
 #pragma unroll
         for (int u = 0; u < PF; ++u) x2[u] = emis(len - 1 - u) * L2E;
+        // the first vector is normalised by its own maximum (nothing to lag behind yet)
+        R mu = fmax(wg_max(act ? x2[0] + bh : NINF), LZ);
+        __syncthreads();
         for (int t0 = len - 1; t0 >= 1; t0 -= PF) {
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
@@ -792,17 +814,19 @@ __global__ void __launch_bounds__(128 * NW) fwd_mid_kernel(Problem P, State W, F
                     const R xe = x2[u];
                     x2[u] = emis(t - PF) * L2E;
                     const R y = act ? xe + bh : NINF;
-                    const R my = fmax(wg_max(y), LZ);
-                    M += (double) my;
-                    if (!upper) { pbuf[i] = act ? Num<R>::exp2(y - my) : R(0); qbuf[i] = act ? y - my : NINF; }
+                    const R q = y - mu;
+                    M += (double) mu;
+                    if (!upper) { pbuf[i] = act ? Num<R>::exp2(q) : R(0); qbuf[qp ^ 1][i] = act ? q : NINF; }
+                    leave_max(q);
                     __syncthreads();
-                    const R s = matvec();
-                    const R lg = Num<R>::log2(s);
+                    qp ^= 1;
+                    mu = lagged_max();
+                    const R s = matvec();              // (its barrier comes after every thread's reads of the vector: the
+                    const R lg = Num<R>::log2(s);      //  next frame may rewrite it)
                     R rr = hmax + lg;
                     if (act && !(fabs(lg) < Num<R>::lg_limit())) rr = exact();      // (rare)
                     bh = act ? rr : NINF;
                     if (act) st[(int64_t) (t - 1) * N] = bh;
-                    __syncthreads();                   // (the vector is rewritten in the next frame)
                 }
             }
         }
