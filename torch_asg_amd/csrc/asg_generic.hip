@@ -643,6 +643,11 @@ __global__ void __launch_bounds__(256) fwd_persist_kernel(Problem P, StepBuf<flo
 //   beta:  y_t = x2_t + b_t,  p = exp2(y - max y),  b_{t-1}[i] = cmax_i + log2 sum_j Fhat[j][i] p[j]  (:32-47)
 // Stored states are relative to a per-frame offset (max = 0): the gradient pass (bwd_post_kernel<.., false> + both
 // contractions) is offset-free per frame.  A row sum outside [2^-100, 2^100] is redone as an exact log-sum-exp.
+// (work_mulog_offset below, for device code: the work area is [emax T B | vectors | maxima | offsets | normaliser log T B])
+__host__ __device__ inline size_t mid_au(size_t x) { return (x + 255) & ~(size_t) 255; }
+__host__ __device__ inline size_t mid_mulog_offset(size_t elem, int T, int B, int npad) {
+    return mid_au((size_t) T * B * elem) + 2 * mid_au(2 * (size_t) B * npad * elem) + 2 * mid_au(3 * (size_t) B * 4) + 2 * mid_au((size_t) B * 8);
+}
 // TWO threads share a label -- thread i the first half of the columns of label i's row, thread i + NP the second half
 // (at most 128 row elements per thread: 256 in one thread spilled into accumulation registers and cost 1360 us at N = 256
 // where the pair takes 787; 724 -> 676 at N = 192, 575 -> 553 at N = 128); the upper half hands its partial sum over
@@ -736,6 +741,12 @@ __global__ void __launch_bounds__(128 * NW) fwd_mid_kernel(Problem P, State W, F
     constexpr int PF = 4;
     double M = 0.0;
     R x2[PF];
+    // what the gradient pass needs to recover a frame's row sums from the stored states (bwd_post_kernel<.., true>):
+    //   log2 sum_j Ehat[i][j] 2^ah[t-1][j] = ah[t][i] - x2[t][i] - hmax_i + (the normaliser subtracted at frame t)
+    // -- the alpha chain logs that normaliser per frame where the streamed step logs its own, and zeros where the streamed
+    // step keeps the emissions' frame maxima (none are subtracted here)
+    R *ezero = W.work ? (R *) W.work : nullptr;
+    R *mulog = W.work ? (R *) ((char *) W.work + mid_mulog_offset(sizeof(R), T, (int) P.B, W.npad)) : nullptr;
     // The frame's normaliser LAGS by one frame: a frame's vector is taken relative to the maximum of the PREVIOUS stored
     // vector, which every wavefront left in red[] before the barrier that published that vector -- so no workgroup-wide
     // maximum (a dependent LDS round trip and a barrier of its own) sits between the product and the next vector.  Stored
@@ -774,6 +785,7 @@ __global__ void __launch_bounds__(128 * NW) fwd_mid_kernel(Problem P, State W, F
                     a = act ? xe + rr : NINF;
                     ah = a - mu;                       // (every thread has read the old vector: the barrier inside matvec)
                     M += (double) mu;
+                    if (threadIdx.x == 0 && mulog) { mulog[(int64_t) t * P.B + b] = mu; ezero[(int64_t) t * P.B + b] = R(0); }
                     if (act) st[(int64_t) t * N] = ah;
                     if (!upper) { pbuf[i] = act ? Num<R>::exp2(ah) : R(0); qbuf[qp ^ 1][i] = act ? ah : NINF; }
                     leave_max(ah);
@@ -2671,28 +2683,8 @@ hipError_t launch_bwd_generic(const Problem &P, const State &W, const BwdArgs &A
         (void) hipMemsetAsync(anybad, 0, sizeof(int), stream);
         const R *emax = (const R *) W.work;
         const R *mulog = (const R *) ((const char *) W.work + work_mulog_offset(e, P.T, P.B, npad));
-        const bool mid = mid_alphabet(P, e);
-        if (mid) {
-            if constexpr (StepUsesMfma<R>::v) {
-                // medium alphabets: the forward pass (fwd_mid_kernel) stores per-frame-normalised states, so the row sums
-                // come from the contraction (MODE 0), then the outer product, its frame axis split over workgroups
-                hipLaunchKernelGGL((bwd_post_kernel<R, false>), dim3(P.T, P.B), dim3(256), 0, stream, P, W, A, Pm, Gm, npad, emax, mulog, anybad,
-                                   (const int *) nullptr);
-                hipLaunchKernelGGL((bwd_gemm_mfma<0>), dim3((P.N + 127) / 128, (K + 127) / 128), dim3(256), 0, stream,
-                                   (const float *) W.ehat, (const float *) Pm, (float *) Gm, (float *) gtr, P.N, npad, K, anybad,
-                                   (const int *) nullptr, 0, (float *) nullptr);
-                const int nsl = gemm_slices(P.N, K);
-                const int kslice = ((K + nsl - 1) / nsl + ASG_X_GEMM_BK - 1) / ASG_X_GEMM_BK * ASG_X_GEMM_BK;
-                hipLaunchKernelGGL((bwd_gemm_mfma<1>), dim3((P.N + 127) / 128, (P.N + 127) / 128, nsl), dim3(256), 0, stream,
-                                   (const float *) W.ehat, (const float *) Pm, (float *) Gm, (float *) gtr, P.N, npad, K, anybad,
-                                   (const int *) nullptr, kslice, nsl > 1 ? (float *) gpart : (float *) nullptr);
-                if (nsl > 1)
-                    hipLaunchKernelGGL(gemm_combine_kernel, dim3((P.N * P.N + 255) / 256), dim3(256), 0, stream, (const float *) gpart,
-                                       nsl, (const float *) W.ehat, P.N, npad, (float *) gtr);
-            }
-            hipLaunchKernelGGL((bwd_fix_kernel<R>), dim3(P.T, P.B), dim3(256), 0, stream, P, W, A, Gm, gtr, npad, anybad,
-                               (const int *) nullptr);
-        } else {
+        // (medium alphabets, fwd_mid_kernel, log the same per-frame normaliser as the streamed step since round 3: one branch)
+        {
         if constexpr (StepUsesMfma<R>::v) {
             if (!W.work) return hipErrorInvalidValue;
             hipLaunchKernelGGL(rowoff_kernel, dim3(1), dim3(64), 0, stream, P, rowoff);
