@@ -2677,10 +2677,14 @@ hipError_t launch_bwd_generic(const Problem &P, const State &W, const BwdArgs &A
     R *gpart = (R *) sc;
     const bool do_full = parts & 1, do_ali = parts & 2, have_full = (parts & 5) != 0;
     R *gtr = (R *) A.grad_transition;
+    bool fx_cleared = false;
     if (do_full) {
         if (P.N <= 64) return hipErrorInvalidValue;      // the small kernel owns this case
         const int K = P.B * P.T;
-        (void) hipMemsetAsync(anybad, 0, sizeof(int), stream);
+        // one clear for the flag word and, when the aligned part follows with its fixed-point scatter buffer (64 < N <= 2048), for
+        // that buffer too: only the row-offset table lies between them, and it is written later on this stream
+        fx_cleared = do_ali && P.N > 64 && P.N <= 2048;
+        (void) hipMemsetAsync(anybad, 0, fx_cleared ? (size_t) ((char *) atiles - (char *) anybad) + (size_t) P.N * P.N * 8 : sizeof(int), stream);
         const R *emax = (const R *) W.work;
         const R *mulog = (const R *) ((const char *) W.work + work_mulog_offset(e, P.T, P.B, npad));
         // (medium alphabets, fwd_mid_kernel, log the same per-frame normaliser as the streamed step since round 3: one branch)
@@ -2740,7 +2744,7 @@ hipError_t launch_bwd_generic(const Problem &P, const State &W, const BwdArgs &A
             dim3 grid(P.B, A.nchunks);
             unsigned long long *fx = (unsigned long long *) atiles;
             const int64_t n2 = (int64_t) P.N * P.N;
-            (void) hipMemsetAsync(fx, 0, (size_t) n2 * 8, stream);
+            if (!fx_cleared) (void) hipMemsetAsync(fx, 0, (size_t) n2 * 8, stream);
             if (P.S <= 128) hipLaunchKernelGGL((bwd_aligned_long_kernel<R, 2, 256>), grid, dim3(256), 0, stream, P, W, A, (R *) nullptr, 1, fx);
             else if (P.S <= 256) hipLaunchKernelGGL((bwd_aligned_long_kernel<R, 4, 256>), grid, dim3(256), 0, stream, P, W, A, (R *) nullptr, 1, fx);
             else if (P.S <= 512) hipLaunchKernelGGL((bwd_aligned_long_kernel<R, 8, 256>), grid, dim3(256), 0, stream, P, W, A, (R *) nullptr, 1, fx);
@@ -2752,7 +2756,7 @@ hipError_t launch_bwd_generic(const Problem &P, const State &W, const BwdArgs &A
             if (P.N > 64 && P.N <= 2048) {
                 unsigned long long *fx = (unsigned long long *) atiles;
                 const int64_t n2 = (int64_t) P.N * P.N;
-                (void) hipMemsetAsync(fx, 0, (size_t) n2 * 8, stream);
+                if (!fx_cleared) (void) hipMemsetAsync(fx, 0, (size_t) n2 * 8, stream);
                 hipLaunchKernelGGL((aligned_tr_scatter_fx_kernel<R>), dim3(P.B), dim3(256), 0, stream, P, W, A, (const R *) gHD, fx);
                 hipLaunchKernelGGL((fx_to_grad_kernel<R>), dim3((unsigned) ((n2 + 255) / 256)), dim3(256), 0, stream,
                                    (const unsigned long long *) fx, n2, gtr, have_full ? 1 : 0);
