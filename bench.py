@@ -355,6 +355,29 @@ def extras(args):
     return ex
 
 
+def free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def self_launch(n, real_stdout):
+    """`python bench.py --gpus N` without a launcher: re-run this command line under torch.distributed.run (one rank per
+    GPU, rendezvous on 127.0.0.1), pass rank 0's JSON line through, fail loudly if the ranks did not all finish."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["ASG_BENCH_SELF_LAUNCHED"] = "1"
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    if p.returncode != 0 or len(lines) != 1:
+        raise SystemExit("bench.py: the %d-rank run failed (exit code %d, %d JSON lines)" % (n, p.returncode, len(lines)))
+    os.write(real_stdout, (lines[0] + "\n").encode())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -386,15 +409,30 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher -- one rank per GPU under torch.distributed.run on this node
+        return self_launch(args.gpus, real_stdout)
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
-                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ..." % (args.gpus, args.gpus))
+        raise SystemExit("bench.py --gpus %d was started by a launcher with WORLD_SIZE=%d: launch with --nproc-per-node %d "
+                         "(or without a launcher: bench.py then starts its own ranks)" % (args.gpus, world, args.gpus))
     if args.dry_run:
         gs = graph_steps_for(args.steps, args.graph_steps) if args.mode == "graph" else 1
+        joined = 1
+        if world > 1:        # prove that every rank the launcher started reaches a collective (gloo: no GPU is touched)
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            one = torch.ones(1, dtype=torch.int64)
+            dist.all_reduce(one)
+            joined = int(one.item())
+            dist.barrier()
+            dist.destroy_process_group()
         if rank == 0:
             os.write(real_stdout, (json.dumps({"dry_run": True, "world": world, "gpus": args.gpus, "steps": args.steps,
                                                "warmup": args.warmup, "mode": args.mode, "steps_per_graph": gs,
                                                "global_batch": B * world, "uses_dist": world > 1 or args.force_dist,
+                                               "ranks_joined": joined,
+                                               "self_launched": os.environ.get("ASG_BENCH_SELF_LAUNCHED") == "1",
                                                "master": os.environ.get("MASTER_ADDR", "127.0.0.1")}) + "\n").encode())
         return
     torch.cuda.set_device(local_rank)
@@ -488,10 +526,16 @@ def main():
         return float(t.item())
 
     blocks = timed_blocks(step_group, args.steps // gsteps, fence, agree)
+    ranks_joined = 1
     if use_dist:
         tb = torch.tensor(blocks, dtype=torch.float64, device=dev)
         dist.all_reduce(tb, op=dist.ReduceOp.MAX)          # every block: the slowest rank's time
         blocks = [float(v) for v in tb.tolist()]
+        rj = torch.ones(1, dtype=torch.int64, device=dev)
+        dist.all_reduce(rj)                                # ranks that ran every timed block and got here
+        ranks_joined = int(rj.item())
+        if ranks_joined != world:
+            raise SystemExit("bench.py: %d of %d ranks reached the end of the timed region" % (ranks_joined, world))
     dt = median(blocks)
 
     # ---- dominant-kernel duration, measured live with HIP events on the launch stream: a hipGraph holding ONLY that
@@ -556,7 +600,7 @@ def main():
             "metric": "utterances/sec fwd+bwd, T=400 B=64 N=40; achieved HBM GB/s vs roofline",
             "value": value,
             "unit": "utterances/s",
-            "n_gpus": world,
+            "n_gpus": ranks_joined,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
@@ -572,6 +616,9 @@ def main():
                        "global_batch": global_batch, "per_gpu_batch": B, "T": T, "N": N, "L": L,
                        "step_mode": mode if mode != "graph" else "graph (%d consecutive steps per hipGraph replay)" % gsteps,
                        "launch_mode": args.launch,
+                       "graph_has_collective": bool(graph_has_collective),
+                       "launcher": "self (bench.py started its ranks)" if os.environ.get("ASG_BENCH_SELF_LAUNCHED") == "1"
+                                   else ("torch.distributed.run" if world > 1 else "none"),
                        "parallelism": "batch-sharded x%d" % world},
             "timing": {"protocol": "blocks of exactly `steps` steps, each between barrier + synchronize fences; "
                                    "ms_per_step and value come from the MEDIAN block",

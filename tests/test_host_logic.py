@@ -109,10 +109,19 @@ def test_bench_launcher_and_argument_path_dry_run():
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads(out.stdout.strip().splitlines()[-1])
     assert d["dry_run"] and d["world"] == 1 and d["steps_per_graph"] == 10 and d["global_batch"] == 64 and not d["uses_dist"]
-    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dry-run", "--gpus", "2"], capture_output=True,
-                         text=True, timeout=300)
-    assert bad.returncode != 0 and "torch.distributed.run" in (bad.stderr + bad.stdout)
     env = dict(os.environ, OMP_NUM_THREADS="1")
+    # the plain way, no launcher: bench.py starts its own two ranks, both reach the collective, ONE line comes back
+    plain = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dry-run", "--gpus", "2"], capture_output=True,
+                           text=True, timeout=600, env={k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    lines = [l for l in plain.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, plain.stdout
+    d = json.loads(lines[0])
+    assert d["world"] == 2 and d["ranks_joined"] == 2 and d["self_launched"] and d["global_batch"] == 128
+    # a launcher whose world size contradicts --gpus is still refused
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dry-run", "--gpus", "2"], capture_output=True,
+                         text=True, timeout=300, env=dict(env, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0"))
+    assert bad.returncode != 0 and "WORLD_SIZE=3" in (bad.stderr + bad.stdout)
     run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", "29611", os.path.join(root, "bench.py"),
                           "--gpus", "2", "--steps", "20", "--warmup", "4", "--dry-run"], capture_output=True, text=True,
@@ -122,6 +131,7 @@ def test_bench_launcher_and_argument_path_dry_run():
     assert len(lines) == 1, run.stdout
     d = json.loads(lines[0])
     assert d["world"] == 2 and d["global_batch"] == 128 and d["uses_dist"] and d["steps_per_graph"] == 10
+    assert d["ranks_joined"] == 2 and not d["self_launched"]
 
 
 def test_fused_route_policy_and_new_options(asg):
