@@ -59,8 +59,10 @@ Layout make_layout(const asg_problem *p) {
     size_t off = 0;
     L.ah = off; off = align_up(off + B * T * N * e);
     L.bh = off; off = align_up(off + B * T * N * e);
-    L.ab = off; off = align_up(off + B * T * S * e);
-    L.bb = off; off = align_up(off + B * T * S * e);
+    // aligned states: the problem's type on the small path, doubles from the long-target kernels (S > 64: asg_generic.hip, AlignedState)
+    const size_t ea = small_aligned((int64_t) S) ? e : 8;
+    L.ab = off; off = align_up(off + B * T * S * ea);
+    L.bb = off; off = align_up(off + B * T * S * ea);
     L.npad = small_full(p->N) ? (int) ((N + 7) / 8 * 8) : (int) ((N + 3) / 4 * 4);
     L.ehat = off; off = align_up(off + N * L.npad * e);
     L.rmax = off; off = align_up(off + N * e);

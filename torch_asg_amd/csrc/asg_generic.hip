@@ -1236,6 +1236,16 @@ __global__ void __launch_bounds__(256) fwd_score_kernel(Problem P, StepBuf<R> S,
 }
 
 
+// Stored states of the aligned lattice on the long-target routes (S > 64) are DOUBLES, whatever the problem's precision.
+// A state is stored relative to ONE reference per frame and direction (the direction's largest state, or an extrapolation
+// of it); with transition scores of tens of nats and slack between target and input length the state ON the dominant path
+// can sit ~1000 log2 units below that reference while the other direction's state compensates, and 1000 costs a float
+// 6e-5: the posterior exp2(ab + bb - max) was off by up to 1.2e-4 (round 3: tools/fuzz_routes.py).  The recursions carry
+// their states in double anyway; storing them unrounded costs S * T * B * 8 more bytes of traffic and holds 1e-4.
+// (S <= 64: the one-wavefront chains of asg_chains.h store the problem's type; tools/stress_duo.py bounds them at 7e-5.)
+typedef double AlignedState;
+template <typename SR> __device__ __forceinline__ double load_state(const SR *p, int64_t i) { return (double) p[i]; }
+
 // ------------------------------------------------------------------ aligned lattice, long targets (64 < S <= 512)
 // grid = (B, 2), block = 64: ONE wavefront per chain, lane l owns the K CONSECUTIVE target positions K l .. K l + K - 1
 // (K = 2, 4, 8), so all but one neighbour of a frame's update sit in the lane's own registers and the last one comes
@@ -1261,8 +1271,8 @@ __global__ void __launch_bounds__(64) aligned_long_kernel(Problem P, State W, Fw
     // frames through buffer accesses: lane offset in a VGPR, frame offset in an SGPR (launch_fwd_generic checks that both
     // fit 32 bits); stores of positions >= S go out of bounds = nowhere (no EXEC juggling per position)
     __amdgpu_buffer_rsrc_t rin = make_rsrc((R *) inb, 0xffffffffu);
-    __amdgpu_buffer_rsrc_t rout = make_rsrc((R *) (beta ? W.bb : W.ab) + (int64_t) b * T * S, STORE ? (unsigned) ((int64_t) T * S * sizeof(R)) : 0u);
-    const unsigned frame_bytes = (unsigned) P.is0 * (unsigned) sizeof(R), row_bytes = (unsigned) S * (unsigned) sizeof(R);
+    __amdgpu_buffer_rsrc_t rout = make_rsrc((AlignedState *) (beta ? W.bb : W.ab) + (int64_t) b * T * S, STORE ? (unsigned) ((int64_t) T * S * sizeof(AlignedState)) : 0u);
+    const unsigned frame_bytes = (unsigned) P.is0 * (unsigned) sizeof(R), row_bytes = (unsigned) S * (unsigned) sizeof(AlignedState);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const int p = lane * K + k;
@@ -1277,7 +1287,7 @@ __global__ void __launch_bounds__(64) aligned_long_kernel(Problem P, State W, Fw
         Dx[k] = (double) (beta ? dn : dp);
         ebias[k] = act[k] ? 0.0 : -1e30;
         eoff[k] = (unsigned) (cur * (int) P.is2) * (unsigned) sizeof(R);
-        soffv[k] = p < S ? (unsigned) p * (unsigned) sizeof(R) : kOobOffset;
+        soffv[k] = p < S ? (unsigned) p * (unsigned) sizeof(AlignedState) : kOobOffset;
         if (STORE && !beta && p < S) {
             V2<R> u = {h2, dp};
             reinterpret_cast<V2<R> *>(W.asu)[(int64_t) b * S + p] = u;
@@ -1296,7 +1306,7 @@ __global__ void __launch_bounds__(64) aligned_long_kernel(Problem P, State W, Fw
         const R d = (R) (fmin(x, y) - m);
         return m + (double) Num<R>::log2(R(1) + Num<R>::exp2(d));
     };
-    auto st = [&](double x) { return (R) fmax(x, kZ); };
+    auto st = [&](double x) { return (AlignedState) fmax(x, kZ); };
     auto store_row = [&](int t, const double (&v)[K]) {
         if (!STORE) return;
         const unsigned so = (unsigned) __builtin_amdgcn_readfirstlane(t) * row_bytes;
@@ -1487,8 +1497,8 @@ __global__ void __launch_bounds__(1024) aligned_pipe_kernel(Problem P, State W, 
     auto emis = [&](int f) -> R {
         return buf_load<R>(rin, eoff, (unsigned) __builtin_amdgcn_readfirstlane(gclampi(f, 0, len - 1)) * frame_bytes);
     };
-    __amdgpu_buffer_rsrc_t rout = make_rsrc((R *) (beta ? W.bb : W.ab) + (int64_t) b * T * S, STORE ? (unsigned) ((int64_t) T * S * sizeof(R)) : 0u);
-    const unsigned soff = s < S ? (unsigned) s * (unsigned) sizeof(R) : kOobOffset, row_bytes = (unsigned) S * (unsigned) sizeof(R);
+    __amdgpu_buffer_rsrc_t rout = make_rsrc((AlignedState *) (beta ? W.bb : W.ab) + (int64_t) b * T * S, STORE ? (unsigned) ((int64_t) T * S * sizeof(AlignedState)) : 0u);
+    const unsigned soff = s < S ? (unsigned) s * (unsigned) sizeof(AlignedState) : kOobOffset, row_bytes = (unsigned) S * (unsigned) sizeof(AlignedState);
     // reference offset of the stored states: frame-0 emission of the first target label to start with (every thread can
     // compute it), then the block maxima
     double Cref;
@@ -1504,7 +1514,7 @@ __global__ void __launch_bounds__(1024) aligned_pipe_kernel(Problem P, State W, 
     int Cstep = 0;                                   // the step Cref belongs to
     bool Chave = false;
     auto store = [&](int t, int n, double v) {       // frame t, step n
-        if (STORE) buf_store((R) fmax(v - fma(Cslope, (double) (n - Cstep), Cref), kZ), rout, soff,
+        if (STORE) buf_store((AlignedState) fmax(v - fma(Cslope, (double) (n - Cstep), Cref), kZ), rout, soff,
                              (unsigned) __builtin_amdgcn_readfirstlane(t) * row_bytes);
     };
     // step n = 1, 2, ...: block boundary bookkeeping.  End of block k (n & 15 == 15): publish this wavefront's largest
@@ -1672,7 +1682,7 @@ __global__ void __launch_bounds__(1024) aligned_wide_kernel(Problem P, State W, 
     const R Dprev = (act && s >= 1) ? fmax(tr[(int64_t) cur * P.ts0 + (int64_t) prv * P.ts1] * L2E, LZ) : LZ;
     const R Dnext = (s + 1 < ol) ? fmax(tr[(int64_t) nxt * P.ts0 + (int64_t) cur * P.ts1] * L2E, LZ) : LZ;
     const R *in = (const R *) P.inputs + (int64_t) b * P.is1 + (int64_t) cur * P.is2;
-    R *out = (R *) (beta ? W.bb : W.ab) + (int64_t) b * T * S;
+    AlignedState *out = (AlignedState *) (beta ? W.bb : W.ab) + (int64_t) b * T * S;
     if (STORE && !beta && s < S) {
         V2<R> u = {H2, Dprev};
         reinterpret_cast<V2<R> *>(W.asu)[(int64_t) b * S + s] = u;
@@ -1692,7 +1702,7 @@ __global__ void __launch_bounds__(1024) aligned_wide_kernel(Problem P, State W, 
         const R d = (R) (fmin(x, y) - m);
         return m + (double) Num<R>::log2(R(1) + Num<R>::exp2(d));
     };
-    auto st = [&](double x) { return (R) fmax(x, kZ); };
+    auto st = [&](double x) { return (AlignedState) fmax(x, kZ); };
     double C = 0.0;
     double v;
     if (!beta) {
@@ -2113,7 +2123,10 @@ template <typename R> struct GlobalFix { static constexpr double scale = sizeof(
 // (aligned_tr_scatter_kernel: 2.5 ms at T = 1000 B = 64 S = 200).  Restates force_aligned_lattice.cpp:156-264.
 // NL = 256 (64 < N <= 256): label rows of 256 words; the edge posteriors go straight into the [N][N] 64-bit fixed-point
 // accumulator in memory (`gfx`, as aligned_tr_scatter_fx_kernel) instead of an LDS tile.
-template <typename R, int K, int NL>
+// SR: type of the stored aligned states (AlignedState = double when the long-target kernels wrote them, S > 64; the
+// problem's type when the one-wavefront chains of the small path did, S <= 64).  With SR = double and R = float the sums
+// ab + bb and the differences between neighbouring states are formed in double and only then rounded.
+template <typename R, int K, int NL, typename SR>
 __global__ void __launch_bounds__(256) bwd_aligned_long_kernel(Problem P, State W, BwdArgs A, R *tiles, int add_to_inputs,
                                                                unsigned long long *gfx) {
     typedef typename FrameFix<R>::T FX;
@@ -2148,43 +2161,48 @@ __global__ void __launch_bounds__(256) bwd_aligned_long_kernel(Problem P, State 
         accH[k] = 0; accD[k] = 0;
     }
     __syncthreads();
-    const R *abp = (const R *) W.ab + (int64_t) b * T * S;
-    const R *bbp = (const R *) W.bb + (int64_t) b * T * S;
+    const SR *abp = (const SR *) W.ab + (int64_t) b * T * S;
+    const SR *bbp = (const SR *) W.bb + (int64_t) b * T * S;
+    const SR LZs = (SR) LZ;
     const int t0 = chunk * A.chunk, t1 = min(min(T, t0 + A.chunk), len);
     for (int t = t0 + wave; t < t1; t += 4) {
+        SR gs[K];
         R gam[K], m = LZ;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const int p = lane * K + k;
-            gam[k] = p < S ? abp[(int64_t) t * S + p] + bbp[(int64_t) t * S + p] : LZ;
-            m = fmax(m, gam[k]);
+            gs[k] = p < S ? abp[(int64_t) t * S + p] + bbp[(int64_t) t * S + p] : LZs + LZs;
+            m = fmax(m, (R) gs[k]);
         }
-        m = wave_allmax(m);
+        m = wave_allmax(m);                      // (any value near the largest sum serves as the common reference)
         R z = 0;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            gam[k] = (m > R(-1e29)) ? Num<R>::exp2(gam[k] - m) : R(0);
+            gam[k] = (m > R(-1e29)) ? Num<R>::exp2((R) (gs[k] - (SR) m)) : R(0);
             z += gam[k];
         }
         z = wave_allsum(z);
-        R apl = LZ;                              // alpha-bar of the previous frame at the position left of this lane's first
-        R ap[K];
+        SR apl = LZs;                            // alpha-bar of the previous frame at the position left of this lane's first
+        SR ap[K];
         if (t >= 1) {
 #pragma unroll
-            for (int k = 0; k < K; ++k) ap[k] = act[k] ? abp[(int64_t) (t - 1) * S + lane * K + k] : LZ;
-            apl = prev_lane_or_zero<R>(ap[K - 1]);
-            if (lane == 0) apl = R(0);           // (position 0 has no arrive edge: Dp is log-zero there)
+            for (int k = 0; k < K; ++k) ap[k] = act[k] ? abp[(int64_t) (t - 1) * S + lane * K + k] : LZs;
+            apl = prev_lane_or_zero<SR>(ap[K - 1]);
+            if (lane == 0) apl = SR(0);          // (position 0 has no arrive edge: Dp is log-zero there)
         }
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const R post = (z > 0 && act[k]) ? gam[k] / z : R(0);
             atomicAdd(&fxI[wave][tgt[k]], FrameFix<R>::to(post));
             if (t >= 1 && act[k]) {
-                const R al = k == 0 ? apl : ap[k - 1];
-                const R pc0 = ap[k] + H2[k], pc1 = al + Dp[k];
-                const R l = lse2<R>(pc0, pc1);
-                accH[k] += (double) (post * Num<R>::exp2(pc0 - l));
-                accD[k] += (double) (post * Num<R>::exp2(pc1 - l));
+                // stay / arrive shares of the state posterior: softmax over the two incoming edges, from their DIFFERENCE
+                // (formed in the stored type): 1 / (1 + 2^-|d|) and its complement
+                const SR al = k == 0 ? apl : ap[k - 1];
+                const R d = (R) ((al + (SR) Dp[k]) - (ap[k] + (SR) H2[k]));
+                const R tt = Num<R>::exp2(-fabs(d));
+                const R big = R(1) / (R(1) + tt), small = tt * big;
+                accH[k] += (double) (post * (d <= R(0) ? big : small));
+                accD[k] += (double) (post * (d <= R(0) ? small : big));
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -2261,7 +2279,7 @@ __global__ void __launch_bounds__(1024) add_tiles_kernel(const R *tiles, int G, 
 // l, l+64, ...  Duplicate labels inside an utterance are folded onto their FIRST occurrence in a fixed order,
 // so the read-modify-write of grad_inputs needs no atomics and is deterministic.
 // Edge posteriors are written per (b, chunk) to gHD[(b*nchunks+chunk)][2][S].
-template <typename R>
+template <typename R, typename SR>
 __global__ void __launch_bounds__(256) bwd_aligned_kernel(Problem P, State W, BwdArgs A, R *gHD, int add_to_inputs) {
     constexpr int MAXK = 16;                       // S <= 1024
     __shared__ R post_s[4][1024];
@@ -2299,23 +2317,25 @@ __global__ void __launch_bounds__(256) bwd_aligned_kernel(Problem P, State W, Bw
         tgt[k] = v ? asi[s].x : 0;
         accH[k] = 0; accD[k] = 0;
     }
-    const R *abp = (const R *) W.ab + (int64_t) b * T * S;
-    const R *bbp = (const R *) W.bb + (int64_t) b * T * S;
+    const SR *abp = (const SR *) W.ab + (int64_t) b * T * S;
+    const SR *bbp = (const SR *) W.bb + (int64_t) b * T * S;
+    const SR LZs = (SR) LZ;
     const int t0 = chunk * A.chunk, t1 = min(T, t0 + A.chunk);
     for (int t = t0 + wave; t < t1; t += 4) {
         if (t >= len) continue;
+        SR gs[MAXK];
         R gam[MAXK], m = LZ;
 #pragma unroll
         for (int k = 0; k < MAXK; ++k) {
             int s = lane + 64 * k;
-            gam[k] = (k < K && s < S) ? abp[(int64_t) t * S + s] + bbp[(int64_t) t * S + s] : LZ;
-            m = fmax(m, gam[k]);
+            gs[k] = (k < K && s < S) ? abp[(int64_t) t * S + s] + bbp[(int64_t) t * S + s] : LZs + LZs;
+            m = fmax(m, (R) gs[k]);
         }
         m = wave_allmax(m);
         R z = 0;
 #pragma unroll
         for (int k = 0; k < MAXK; ++k) {
-            gam[k] = (k < K && m > R(-1e29)) ? Num<R>::exp2(gam[k] - m) : R(0);
+            gam[k] = (k < K && m > R(-1e29)) ? Num<R>::exp2((R) (gs[k] - (SR) m)) : R(0);
             z += gam[k];
         }
         z = wave_allsum(z);
@@ -2325,12 +2345,14 @@ __global__ void __launch_bounds__(256) bwd_aligned_kernel(Problem P, State W, Bw
             R post = (z > 0 && k < K && s < ol) ? gam[k] / z : R(0);
             if (k < K && s < S) post_s[wave][s] = post;
             if (t >= 1 && k < K && s < ol) {
-                R ap = abp[(int64_t) (t - 1) * S + s];
-                R al = s >= 1 ? abp[(int64_t) (t - 1) * S + s - 1] : R(0);
-                R pc0 = ap + H2[k], pc1 = al + Dp[k];
-                R l = lse2<R>(pc0, pc1);
-                accH[k] += post * Num<R>::exp2(pc0 - l);
-                accD[k] += post * Num<R>::exp2(pc1 - l);
+                // (shares of the two incoming edges from their difference, formed in the stored type: bwd_aligned_long_kernel)
+                const SR ap = abp[(int64_t) (t - 1) * S + s];
+                const SR al = s >= 1 ? abp[(int64_t) (t - 1) * S + s - 1] : SR(0);
+                const R d = (R) ((al + (SR) Dp[k]) - (ap + (SR) H2[k]));
+                const R tt = Num<R>::exp2(-fabs(d));
+                const R big = R(1) / (R(1) + tt), small = tt * big;
+                accH[k] += post * (d <= R(0) ? big : small);
+                accD[k] += post * (d <= R(0) ? small : big);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -2495,7 +2517,7 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
         // thread and a workgroup barrier per frame
         const double fr = (double) (P.T - 1) * (double) P.is0 * sizeof(R), ln = (double) (P.N - 1) * (double) P.is2 * sizeof(R);
         const bool off32 = P.is0 >= 0 && P.is2 >= 0 && fr < 4294967296.0 && ln < 2147483648.0 &&
-                           (double) P.T * P.S * sizeof(R) < 4294967296.0;
+                           (double) P.T * P.S * sizeof(AlignedState) < 4294967296.0;
         const char *ak = getenv("ASG_ALIGNED_KERNEL");        // developer A/B: "long" (K positions per lane), "wide" (barrier per frame)
         const bool use_pipe = off32 && ((P.S > 256 && !(ak && (ak[0] == 'l' || ak[0] == 'w'))) || (ak && ak[0] == 'p'));
         if (use_pipe) {
@@ -2731,10 +2753,10 @@ hipError_t launch_bwd_generic(const Problem &P, const State &W, const BwdArgs &A
         unsigned long long *nofx = nullptr;
         if (P.N <= 64 && P.S > 64 && P.S <= 1024) {
             dim3 grid(P.B, A.nchunks);
-            if (P.S <= 128) hipLaunchKernelGGL((bwd_aligned_long_kernel<R, 2, 64>), grid, dim3(256), 0, stream, P, W, A, atiles, 1, nofx);
-            else if (P.S <= 256) hipLaunchKernelGGL((bwd_aligned_long_kernel<R, 4, 64>), grid, dim3(256), 0, stream, P, W, A, atiles, 1, nofx);
-            else if (P.S <= 512) hipLaunchKernelGGL((bwd_aligned_long_kernel<R, 8, 64>), grid, dim3(256), 0, stream, P, W, A, atiles, 1, nofx);
-            else hipLaunchKernelGGL((bwd_aligned_long_kernel<R, 16, 64>), grid, dim3(256), 0, stream, P, W, A, atiles, 1, nofx);
+            if (P.S <= 128) hipLaunchKernelGGL((bwd_aligned_long_kernel<R, 2, 64, AlignedState>), grid, dim3(256), 0, stream, P, W, A, atiles, 1, nofx);
+            else if (P.S <= 256) hipLaunchKernelGGL((bwd_aligned_long_kernel<R, 4, 64, AlignedState>), grid, dim3(256), 0, stream, P, W, A, atiles, 1, nofx);
+            else if (P.S <= 512) hipLaunchKernelGGL((bwd_aligned_long_kernel<R, 8, 64, AlignedState>), grid, dim3(256), 0, stream, P, W, A, atiles, 1, nofx);
+            else hipLaunchKernelGGL((bwd_aligned_long_kernel<R, 16, 64, AlignedState>), grid, dim3(256), 0, stream, P, W, A, atiles, 1, nofx);
             const int n2 = P.N * P.N;
             hipLaunchKernelGGL((add_tiles_kernel<R>), dim3((n2 + 31) / 32), dim3(1024), 0, stream, (const R *) atiles,
                                P.B * A.nchunks, n2, gtr, have_full ? 1 : 0);
@@ -2745,14 +2767,17 @@ hipError_t launch_bwd_generic(const Problem &P, const State &W, const BwdArgs &A
             unsigned long long *fx = (unsigned long long *) atiles;
             const int64_t n2 = (int64_t) P.N * P.N;
             if (!fx_cleared) (void) hipMemsetAsync(fx, 0, (size_t) n2 * 8, stream);
-            if (P.S <= 128) hipLaunchKernelGGL((bwd_aligned_long_kernel<R, 2, 256>), grid, dim3(256), 0, stream, P, W, A, (R *) nullptr, 1, fx);
-            else if (P.S <= 256) hipLaunchKernelGGL((bwd_aligned_long_kernel<R, 4, 256>), grid, dim3(256), 0, stream, P, W, A, (R *) nullptr, 1, fx);
-            else if (P.S <= 512) hipLaunchKernelGGL((bwd_aligned_long_kernel<R, 8, 256>), grid, dim3(256), 0, stream, P, W, A, (R *) nullptr, 1, fx);
-            else hipLaunchKernelGGL((bwd_aligned_long_kernel<R, 16, 256>), grid, dim3(256), 0, stream, P, W, A, (R *) nullptr, 1, fx);
+            // (S <= 64: the states are the one-wavefront chains' (asg_chains.h), stored in the problem's type)
+            if (P.S <= 64) hipLaunchKernelGGL((bwd_aligned_long_kernel<R, 2, 256, R>), grid, dim3(256), 0, stream, P, W, A, (R *) nullptr, 1, fx);
+            else if (P.S <= 128) hipLaunchKernelGGL((bwd_aligned_long_kernel<R, 2, 256, AlignedState>), grid, dim3(256), 0, stream, P, W, A, (R *) nullptr, 1, fx);
+            else if (P.S <= 256) hipLaunchKernelGGL((bwd_aligned_long_kernel<R, 4, 256, AlignedState>), grid, dim3(256), 0, stream, P, W, A, (R *) nullptr, 1, fx);
+            else if (P.S <= 512) hipLaunchKernelGGL((bwd_aligned_long_kernel<R, 8, 256, AlignedState>), grid, dim3(256), 0, stream, P, W, A, (R *) nullptr, 1, fx);
+            else hipLaunchKernelGGL((bwd_aligned_long_kernel<R, 16, 256, AlignedState>), grid, dim3(256), 0, stream, P, W, A, (R *) nullptr, 1, fx);
             hipLaunchKernelGGL((fx_to_grad_kernel<R>), dim3((unsigned) ((n2 + 255) / 256)), dim3(256), 0, stream,
                                (const unsigned long long *) fx, n2, gtr, have_full ? 1 : 0);
         } else {
-            hipLaunchKernelGGL((bwd_aligned_kernel<R>), dim3(P.B, A.nchunks), dim3(256), 0, stream, P, W, A, gHD, 1);
+            if (P.S <= 64) hipLaunchKernelGGL((bwd_aligned_kernel<R, R>), dim3(P.B, A.nchunks), dim3(256), 0, stream, P, W, A, gHD, 1);
+            else hipLaunchKernelGGL((bwd_aligned_kernel<R, AlignedState>), dim3(P.B, A.nchunks), dim3(256), 0, stream, P, W, A, gHD, 1);
             if (P.N > 64 && P.N <= 2048) {
                 unsigned long long *fx = (unsigned long long *) atiles;
                 const int64_t n2 = (int64_t) P.N * P.N;
