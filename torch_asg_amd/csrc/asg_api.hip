@@ -45,7 +45,7 @@ inline int hip_status(hipError_t e) { return e == hipSuccess ? ASG_OK : ASG_ERR_
 inline size_t align_up(size_t x) { return (x + 255) & ~(size_t) 255; }
 
 struct Layout {
-    size_t ah, bh, ab, bb, ehat, fhat, rmax, cmax, etile, ftile, asu, asi, dbg, ticket, work, total;
+    size_t ah, bh, ab, bb, ehat, fhat, rmax, cmax, etile, ftile, asu, asi, dbg, ticket, xflags, work, total;
     int npad;
 };
 
@@ -77,6 +77,7 @@ Layout make_layout(const asg_problem *p) {
     L.asi = off; off = align_up(off + B * S * 2 * sizeof(int));
     L.dbg = off; off = align_up(off + 512);      // developer timing stamps (ASG_PROBE builds only)
     L.ticket = off; off = align_up(off + 256);   // arrival ticket of the in-kernel loss reduction (zeroed per call)
+    if (small_full(p->N)) { L.xflags = off; off = align_up(off + 2 * B * sizeof(int)); }      // batched forward -> clean-up launch
     if (!small_full(p->N)) { L.work = off; off = align_up(off + fwd_work_bytes_generic((int) e, (int) T, (int) B, (int) N)); }
     L.total = off;
     return L;
@@ -128,6 +129,7 @@ State to_state(const asg_problem *p, const void *state) {
         W.dbg = base + L.dbg;
         W.ticket = (unsigned *) (base + L.ticket);
         if (!small_full(p->N)) W.work = base + L.work;
+        else W.xflags = (int *) (base + L.xflags);
     }
     W.npad = L.npad;
     return W;
@@ -194,7 +196,10 @@ int run_forward(asg_ctx *ctx, const asg_problem *p, void *state, void *full_scor
         return ASG_OK;
     }
     hipError_t e;
-    if ((flags & ASG_FLAG_STREAMS) && ctx && full_mask && ali_mask) {
+    // large batches: the full-lattice chains run on the matrix cores (asg_batched.hip) and leave most of the VALU to the aligned
+    // chains, which are a launch of their own there anyway: the two overlap on two streams also in the default launch mode
+    const bool batched_two = (flags & ASG_FLAG_SINGLE_LAUNCH) && sizeof(R) == 4 && batched_forward_applies(P, W, mask);
+    if (((flags & ASG_FLAG_STREAMS) || batched_two) && ctx && full_mask && ali_mask) {
         // fork: aligned passes on the side stream, full passes on the caller's stream; join back.
         if ((e = hipEventRecord(ctx->fork, stream)) != hipSuccess) return hip_status(e);
         if ((e = hipStreamWaitEvent(ctx->side, ctx->fork, 0)) != hipSuccess) return hip_status(e);

@@ -37,6 +37,8 @@ struct State {
     int *asi;
     void *dbg;
     unsigned *ticket;   // 256 B, zeroed per call: arrival counter of the in-kernel loss reduction
+    int *xflags;        // small path: [2][B] full-lattice alpha | beta chains that the batched forward kernel (asg_batched.hip) hands
+                        // to the per-utterance kernel (a row sum left the safe range)
     void *work;      // generic path: forward work buffers (emission maxima, p vectors, normalisers, offsets)
     int npad;
 };
@@ -107,6 +109,10 @@ hipError_t launch_fwd_small(const Problem &P, const State &W, const FwdOut &O, i
                             hipStream_t stream);
 template <typename R>
 hipError_t launch_bwd_small(const Problem &P, const State &W, const BwdArgs &A, int parts, hipStream_t stream);
+// large batches, fp32: the full-lattice chains sixteen utterances per workgroup on the matrix cores (asg_batched.hip); writes
+// W.xflags, which the per-utterance kernel's clean-up launch reads (launch_fwd_small does both)
+bool batched_forward_applies(const Problem &P, const State &W, int chain_mask);
+hipError_t launch_fwd_batched(const Problem &P, const State &W, const FwdOut &O, int chain_mask, hipStream_t stream);
 hipError_t launch_fused_forward(const Problem &P, const State &W, const FusedArgs &F, hipStream_t stream);
 hipError_t launch_fused_backward(const Problem &P, const State &W, const FusedArgs &F, hipStream_t stream);
 // loss[b] = full[b] - aligned[b], reduced: 0 = none ([B] out), 1 = sum, 2 = mean ([1] out); fixed-order tree
