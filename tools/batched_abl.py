@@ -12,7 +12,12 @@ for B in [int(a) for a in sys.argv[1:]] or [512, 4096]:
     g = torch.Generator().manual_seed(0)
     tr = torch.rand(N, N, generator=g).to(dev); x = torch.randn(T, B, N, generator=g).to(dev)
     il = torch.full((B,), T, dtype=torch.int64, device=dev)
-    def fn(): be.full_forward(x, tr, il)
+    L = 30
+    tg = torch.randint(0, N, (B, L), generator=g).to(dev); tl = torch.full((B,), L, dtype=torch.int64, device=dev)
+    if os.environ.get("ASG_ABL_WHAT", "full") == "aligned":
+        def fn(): be.aligned_forward(x, tg, tr, il, tl)
+    else:
+        def fn(): be.full_forward(x, tr, il)
     s = torch.cuda.Stream()
     with torch.cuda.stream(s):
         for _ in range(3): fn()
@@ -24,4 +29,4 @@ for B in [int(a) for a in sys.argv[1:]] or [512, 4096]:
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(10): gr.replay()
     torch.cuda.synchronize(); out.append("B=%d %.1f us" % (B, (time.perf_counter() - t0) / 10 / 5 * 1e6))
-print("%-40s %s" % (os.path.basename(os.environ.get("ASG_HIP_LIB", "shipped")), "   ".join(out)))
+print("%-12s %-8s %s" % (os.path.basename(os.environ.get("ASG_HIP_LIB", "shipped")), os.environ.get("ASG_ABL_WHAT", "full"), "   ".join(out)))

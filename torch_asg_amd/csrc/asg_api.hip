@@ -12,12 +12,14 @@ using namespace asg;
 
 namespace asg {
 size_t bwd_scratch_bytes_small(int elem, int T, int B, int N, int S, int *chunk, int *nchunks) {
-    // aim for ~512 workgroups (2 per CU; flat between 512 and 768 on MI355X) but at least 16 frames per workgroup
+    // at most ~512 workgroups: the assembly kernel holds two workgroups per compute unit (243 VGPRs), so 512 are ONE round on 256
+    // CUs; anything above it is a second, mostly empty round (round 3 rounded UP: B = 192 got 3 x 192 = 576 workgroups and ran
+    // slower than B = 256 with 2 x 256).  At least 16 frames per workgroup.
     int target = 512;
 #ifdef ASG_DEV_PROBES
     if (const char *ev = getenv("ASG_BWD_WGS")) target = atoi(ev) > 0 ? atoi(ev) : target;   // developer probe
 #endif
-    int nch = (target + B - 1) / B;
+    int nch = target / B;
     if (nch < 1) nch = 1;
     int ch = (T + nch - 1) / nch;
     if (ch < 16) ch = 16;
@@ -198,7 +200,8 @@ int run_forward(asg_ctx *ctx, const asg_problem *p, void *state, void *full_scor
     hipError_t e;
     // large batches: the full-lattice chains run on the matrix cores (asg_batched.hip) and leave most of the VALU to the aligned
     // chains, which are a launch of their own there anyway: the two overlap on two streams also in the default launch mode
-    const bool batched_two = (flags & ASG_FLAG_SINGLE_LAUNCH) && sizeof(R) == 4 && batched_forward_applies(P, W, mask);
+    const bool batched_two = (flags & ASG_FLAG_SINGLE_LAUNCH) && sizeof(R) == 4 && batched_forward_applies(P, W, mask) &&
+                             !(getenv("ASG_BATCHED_SEQ") && atoi(getenv("ASG_BATCHED_SEQ")) != 0);      // (developer A/B: one stream)
     if (((flags & ASG_FLAG_STREAMS) || batched_two) && ctx && full_mask && ali_mask) {
         // fork: aligned passes on the side stream, full passes on the caller's stream; join back.
         if ((e = hipEventRecord(ctx->fork, stream)) != hipSuccess) return hip_status(e);

@@ -46,6 +46,11 @@ __device__ __forceinline__ void wg_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// Make values opaque at this point of the program: what computes them stays above (MachineSink moves a computation whose
+// result is only used behind a later branch down into that block -- out of the matrix instructions' shadow), no consumer above.
+__device__ __forceinline__ void pin(V4<float> &v) { asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3])); }
+__device__ __forceinline__ void pin(float &v) { asm volatile("" : "+v"(v)); }
+
 // sum / max over the four lane groups (lanes n, n + 16, n + 32, n + 48), result in all of them
 __device__ __forceinline__ float grp_sum(float x) {
     float a = x, b = x;
@@ -117,6 +122,9 @@ template <int NP, bool BETA, int MODE>
 __device__ void full_chain_x16(const Problem &P, const State &W, const FwdOut &O, int grp, int *flags, X16Lds &L) {
     typedef float R;
     constexpr int KS = NP / 4, NT = (NP + 15) / 16;
+    // sixteen chains ride on every wavefront of this kernel, and each step is a dependent chain of instructions: the aligned
+    // chains that share the SIMD (one utterance or two per wavefront) yield to it and take the issue slots it leaves
+    __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int N = P.N, T = P.T, B = P.B;

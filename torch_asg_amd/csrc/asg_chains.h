@@ -839,6 +839,217 @@ __device__ void aligned_beta_chain(const Problem &P, const State &W, const FwdOu
     publish_score<R>(O, (R *) O.aligned_scores, b, P.B, score_out<R>(C + y0), lane);
 }
 
+// ------------------------------------------------------------------ aligned lattice, TWO utterances per wavefront (S <= 32)
+// A short target leaves half of a wavefront's lanes idle (cfg 3 / cfg 4: 30 positions), and the double-precision steps of the
+// aligned recursion cost the same for 30 active lanes as for 60.  For S <= 32 lanes 0-31 carry utterance 2 p and lanes 32-63
+// utterance 2 p + 1, same direction: one instruction stream, half the wavefronts.  (Round 2 put the alpha AND beta chain of ONE
+// utterance into a wavefront and lost: two directions make every frame index a per-lane quantity and leave one dependent
+// chain where two wavefronts had two.  Two utterances of one direction share the frame index in the alpha loop; in the beta
+// loop each half counts down from its own last frame, which costs two integer instructions per frame.)
+// Formulas, stored states and scores are aligned_alpha_chain / aligned_beta_chain's, lane for lane; the neighbour exchange
+// needs nothing new: position 0 has no arrive edge and position ol - 1 <= 31 no leave edge (log-zero weights), so what crosses
+// the middle of the wavefront is absorbed.  Per-utterance lengths: the loop runs to the longer one, the shorter half is frozen
+// (its state kept, its stores out of bounds).
+template <typename R> __device__ __forceinline__ void half_reduce_prep_max(R &v);
+template <> __device__ __forceinline__ void half_reduce_prep_max<float>(float &v) {
+    asm volatile("s_nop 1\n"
+                 "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n" "s_nop 1\n"
+                 "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n" "s_nop 1\n"
+                 "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n" "s_nop 1\n"
+                 "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n" "s_nop 1\n"
+                 : "+v"(v));
+}
+template <> __device__ __forceinline__ void half_reduce_prep_max<double>(double &v) {
+    v = fmax(v, dpp_mov<kDppXor1>(v, v));
+    v = fmax(v, dpp_mov<kDppXor2>(v, v));
+    v = fmax(v, dpp_mov<kDppHalfMirror>(v, v));
+    v = fmax(v, dpp_mov<kDppMirror>(v, v));
+}
+template <typename R> __device__ __forceinline__ void half_reduce_prep_sum(R &v);
+template <> __device__ __forceinline__ void half_reduce_prep_sum<float>(float &v) {
+    asm volatile("s_nop 1\n"
+                 "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n" "s_nop 1\n"
+                 "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n" "s_nop 1\n"
+                 "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n" "s_nop 1\n"
+                 "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n" "s_nop 1\n"
+                 : "+v"(v));
+}
+template <> __device__ __forceinline__ void half_reduce_prep_sum<double>(double &v) {
+    v += dpp_mov<kDppXor1>(v, v);
+    v += dpp_mov<kDppXor2>(v, v);
+    v += dpp_mov<kDppHalfMirror>(v, v);
+    v += dpp_mov<kDppMirror>(v, v);
+}
+// maximum / sum over the lanes of this lane's HALF of the wavefront (lanes 0-31 | 32-63), in every lane of the half
+template <typename R> __device__ __forceinline__ R half_allmax(R v, bool upper) {
+    half_reduce_prep_max<R>(v);                  // every 16-lane row holds its own maximum
+    const R lo = fmax(readlane(v, 0), readlane(v, 16)), hi = fmax(readlane(v, 32), readlane(v, 48));
+    return upper ? hi : lo;
+}
+template <typename R> __device__ __forceinline__ R half_allsum(R v, bool upper) {
+    half_reduce_prep_sum<R>(v);
+    const R lo = readlane(v, 0) + readlane(v, 16), hi = readlane(v, 32) + readlane(v, 48);
+    return upper ? hi : lo;
+}
+
+// Up to two scores at once (lanes 0 and 32 with `pub`): the wavefront draws its tickets with one atomic.
+template <typename R>
+__device__ __forceinline__ void publish_score_pair(const FwdOut &O, R *slot, int b, int B, R score, bool pub, int lane) {
+    if (!O.loss) {
+        if (pub) slot[b] = score;
+        return;
+    }
+    const unsigned cnt = (unsigned) __popcll(__ballot(pub));
+    if (cnt == 0) return;
+    if (pub) __hip_atomic_store(slot + b, score, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned ticket = 0;
+    if (lane == 0) ticket = __hip_atomic_fetch_add(O.counter, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ticket = __builtin_amdgcn_readfirstlane(ticket);
+    if (ticket + cnt != (unsigned) O.expected) return;
+    const R *full = (const R *) O.full_scores, *ali = (const R *) O.aligned_scores;
+    R *loss = (R *) O.loss;
+    double s = 0;
+    for (int q = lane; q < B; q += 64) {
+        R f = __hip_atomic_load(full + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        R a = __hip_atomic_load(ali + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        R l = f - a;
+        if (O.reduction == 0) loss[q] = l;
+        s += (double) l;
+    }
+    if (O.reduction != 0) {
+        s = wave_allsum(s);
+        if (lane == 0) loss[0] = (R) (O.reduction == 2 ? s / B : s);
+    }
+    if (lane == 0) __hip_atomic_store(O.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+constexpr unsigned kNoStore = 0xfffffff0u;       // voffset past any buffer (soffset 0): the store is dropped
+
+// pair = index of the utterance pair (2 pair, 2 pair + 1).  Needs S <= 32 and 31-bit byte offsets into the emissions
+// (aligned_pairs_apply in asg_small_impl.inc).
+template <typename R, bool BETA>
+__device__ void aligned_pair_chain(const Problem &P, const State &W, const FwdOut &O, int pair) {
+    const int lane = threadIdx.x & 63, s = lane & 31;
+    const bool upper = lane >= 32;
+    const int T = P.T, S = P.S, B = P.B;
+    const R NINF = Num<R>::ninf();
+    const int b = 2 * pair + (upper ? 1 : 0);
+    const bool uv = b < B;
+    const int bc = uv ? b : B - 1;
+    const AlignedSetup<R> A = aligned_setup<R>(P, bc, s, uv);
+    const int len = uv ? A.len : 0, ol = A.ol;
+    const int lmax = max(__builtin_amdgcn_readlane(len, 0), __builtin_amdgcn_readlane(len, 32));
+    const unsigned row_bytes = (unsigned) S * sizeof(R);
+    const bool no_store = O.no_store != 0;
+    __amdgpu_buffer_rsrc_t rs = make_rsrc(BETA ? W.bb : W.ab, no_store ? 0u : (unsigned) ((int64_t) B * T * S * sizeof(R)));
+    const bool can_store = uv && s < S;
+    const unsigned sbase = can_store ? (unsigned) ((((int64_t) b * T) * S + s) * sizeof(R)) : 0u;
+    // emissions of this lane's label: one 32-bit byte offset per lane (signed arithmetic below: the launcher keeps it under 2^31)
+    __amdgpu_buffer_rsrc_t rin = make_rsrc((void *) P.inputs, 0xffffffffu);
+    const int fstride = (int) (P.is0 * (int64_t) sizeof(R));
+    const int e0 = (int) (((int64_t) bc * P.is1 + (int64_t) A.tgt * P.is2) * (int64_t) sizeof(R));      // frame 0
+    const int elast = e0 + (len >= 1 ? len - 1 : 0) * fstride;                                              // frame len - 1
+    const double L2Ed = 1.4426950408889634, H2 = (double) A.H2, Dx = (double) (BETA ? A.Dnext : A.Dprev);
+
+    if (!BETA && !no_store && uv && s < S) {
+        V2<R> u = {A.H2, A.Dprev};
+        reinterpret_cast<V2<R> *>(W.asu)[(int64_t) b * S + s] = u;
+        int2 ii = {A.tgt, A.prv};
+        reinterpret_cast<int2 *>(W.asi)[(int64_t) b * S + s] = ii;
+    }
+    R *score_slot = (R *) (BETA ? O.aligned_scores : O.aligned_scores_alpha);
+    const bool dead = len < 1 || ol < 1;            // this half has no chain: score -inf
+    double C = 0.0;
+    double v = kLZd;
+    // step n = 0 .. len - 2 of this lane's utterance; alpha: consumes frame n + 1 and writes it; beta: consumes frame
+    // len - 1 - n and writes frame len - 2 - n
+    const int nst = dead ? 0 : len - 1, nstmax = lmax >= 1 ? lmax - 1 : 0;
+    int eoff;                                        // byte offset of the emission the next load takes
+    unsigned soff;                                   // byte offset of the row the next step writes
+    if (!BETA) {
+        if (!dead) v = (s == 0) ? fmax(fma((double) buf_load<R>(rin, (unsigned) e0, 0u), L2Ed, (double) A.ebias), kLZd) : kLZd;
+        buf_store(to_state<R>(v), rs, (dead || !can_store) ? kNoStore : sbase, 0u);
+        eoff = min(e0 + fstride, elast);
+        soff = sbase + row_bytes;
+    } else {
+        if (!dead) v = (s == ol - 1) ? 0.0 : kLZd;
+        buf_store(to_state<R>(v), rs, (dead || !can_store) ? kNoStore : sbase + (unsigned) (len - 1) * row_bytes, 0u);
+        eoff = elast;
+        soff = sbase + (unsigned) (len >= 2 ? len - 2 : 0) * row_bytes;
+    }
+    R cur[kPF], nxt[kPF];
+    auto fetch = [&](R (&dst)[kPF]) {
+#pragma unroll
+        for (int k = 0; k < kPF; ++k) {
+            dst[k] = buf_load<R>(rin, (unsigned) eoff, 0u);
+            eoff = BETA ? max(eoff - fstride, e0) : min(eoff + fstride, elast);
+        }
+    };
+    fetch(cur);
+    for (int done = 0; done < nstmax; done += kPF) {
+        if (done + kPF < nstmax) fetch(nxt);
+        // renormalise once per block: the log domain is offset-free, this only bounds magnitudes
+        const R m = half_allmax<R>((R) v, upper);
+        if (m > R(-1e29)) { v = fmax(v - (double) m, kLZd); C += (double) m; }
+        // common offset of the block's emissions: their mean over this utterance's live frames and positions (see aligned_block_scale)
+        R zs = 0, zl = NINF;
+        int nlive = 0;
+#pragma unroll
+        for (int k = 0; k < kPF; ++k) {
+            const bool live = done + k < nst && A.act;
+            zs += live ? cur[k] : R(0);
+            zl = live ? fmax(zl, cur[k]) : zl;
+            nlive += (done + k < nst) ? 1 : 0;
+        }
+        R z = half_allsum<R>(zs, upper) / (R) (nlive * (ol > 0 ? ol : 1)) * Num<R>::log2e();
+        if (!(z > R(-1e29) && z < R(1e29))) {
+            const R zmax = half_allmax<R>(zl, upper) * Num<R>::log2e();
+            z = (zmax > R(-1e29) && zmax < R(1e29)) ? zmax : R(0);
+        }
+        C += (double) z * (double) nlive;
+        const double ebias = (double) A.ebias - (double) z;
+#pragma unroll
+        for (int k = 0; k < kPF; ++k) {
+            if (done + k < nstmax) {                 // (wave-uniform)
+                const bool live = done + k < nst;
+                const double em = fma((double) cur[k], L2Ed, ebias);
+                double nv;
+                if (!BETA) {
+                    const double stay = v + H2;
+                    const double come = prev_lane_or_zero<double>(v) + Dx;       // position 0: 0 + log-zero
+                    nv = fmax(em + lse2_acc<R>(stay, come), kLZd);
+                } else {
+                    const double y = fmax(em + v, kLZd);
+                    const double stay = y + H2;
+                    const double go = next_lane_or_zero<double>(y) + Dx;         // position ol - 1: log-zero edge
+                    nv = fmax(lse2_acc<R>(stay, go), kLZd);
+                }
+                v = live ? nv : v;
+                buf_store(to_state<R>(v), rs, (live && can_store) ? soff : kNoStore, 0u);
+                soff = BETA ? soff - row_bytes : soff + row_bytes;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kPF; ++k) cur[k] = nxt[k];
+    }
+    if (!score_slot) return;
+    double sc;
+    if (!BETA) {
+        // alpha: the state of position ol - 1 at the last frame
+        const int at = (upper ? 32 : 0) + (ol >= 1 ? ol - 1 : 0);
+        const double last = __shfl(v, at);
+        sc = dead ? -1e300 : C + last;
+    } else {
+        // S_aligned = beta_0[0] + I~_0[0]   (force_aligned_lattice.cpp:316)
+        const double y = fma((double) buf_load<R>(rin, (unsigned) e0, 0u), L2Ed, (double) A.ebias) + v;
+        sc = dead ? -1e300 : C + y;                  // (lanes 0 and 32 hold position 0)
+    }
+    const R out = dead ? NINF : score_out<R>(sc);
+    if (BETA) publish_score_pair<R>(O, score_slot, b, B, out, uv && s == 0, lane);
+    else if (uv && s == 0) score_slot[b] = out;
+}
+
 // ------------------------------------------------------------------ full lattice, two wavefronts per chain (fp32)
 // A lone wavefront issues one instruction every 4 cycles, whatever its kind: the recursion is bound by its
 // instruction COUNT.  The duo path therefore leaves on the recursion wavefront ("main") only what is on the
