@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define ASG_HIP_VERSION 200
+#define ASG_HIP_VERSION 210
 
 #define ASG_DTYPE_F32 0
 #define ASG_DTYPE_F64 1
@@ -74,6 +74,12 @@ typedef struct asg_ctx asg_ctx;
 
 int asg_hip_version(void);
 const char *asg_hip_strerror(int status);
+
+/* Fault report (no reference counterpart): how many launches of the resident-slice forward kernel (fp32, 256 < N <= 2048:
+ * a grid of co-resident workgroups that wait for each other) of THIS process ran out of their bounded waits -- part of the
+ * grid never became resident.  Such a call returns NaN scores; from then on the library takes the per-frame launches (which need
+ * no co-residency).  Read from host-pinned memory, no synchronisation; the count of a call is visible once that call has run. */
+unsigned asg_cluster_timeouts(void);
 
 int asg_ctx_create(asg_ctx **out);
 int asg_ctx_destroy(asg_ctx *ctx);

@@ -166,3 +166,53 @@ def test_handles_survive_autograd_saving_and_foreign_tensors_are_refused():
     with pytest.raises(RuntimeError, match="does not come from"):
         nat.fast_asg_gpu_backward(torch.ones(B, device=DEV), -torch.ones(B, device=DEV), stranger, stranger,
                                   stranger, stranger, tgd, ild, tld, T, B, N, S)
+
+
+@pytest.mark.gpu
+def test_saved_tensor_hooks_that_replace_tensors_are_fine():
+    """torch.autograd.graph.save_on_cpu moves every saved tensor to the host and hands a NEW device tensor back in backward:
+    nothing on this route may be keyed by tensor identity or address -- the state, the transition matrix, the lengths and the
+    emissions travel in the data of the tensors asg.py saves."""
+    import torch_asg_amd.native_shim as nat
+    tr, x, tg, il, tl = _case(seed=11)
+    T, B, N = x.shape
+    S = tg.shape[1]
+    tgd, ild, tld = tg.to(DEV), il.to(DEV), tl.to(DEV)
+
+    class Serial(torch.autograd.Function):            # FCC of asg.py:37-55
+        @staticmethod
+        def forward(ctx, transition, inputs):
+            scores, alpha, beta, pc = nat.fully_connected_forward(inputs, transition, ild, T, B, N)
+            ctx.save_for_backward(alpha, beta, pc)
+            return scores
+
+        @staticmethod
+        def backward(ctx, g):
+            alpha, beta, pc = ctx.saved_tensors
+            gtr, gin = nat.fully_connected_backward(g, alpha, beta, pc, T, B, N)
+            return gtr, gin
+
+    class Aligned(torch.autograd.Function):           # FAC of asg.py:7-34
+        @staticmethod
+        def forward(ctx, transition, inputs):
+            scores, alpha, beta, pc = nat.force_aligned_forward(inputs, tgd, transition, ild, tld, T, B, N, S)
+            ctx.save_for_backward(alpha, beta, pc)
+            return scores
+
+        @staticmethod
+        def backward(ctx, g):
+            alpha, beta, pc = ctx.saved_tensors
+            gtr, gin = nat.force_aligned_backward(g, alpha, beta, pc, tgd, ild, tld, T, B, N, S)
+            return gtr, gin
+
+    xd = x.to(DEV).requires_grad_(True)
+    trd = tr.to(DEV).requires_grad_(True)
+    with torch.autograd.graph.save_on_cpu():
+        loss = (Serial.apply(trd, xd) - Aligned.apply(trd, xd)).sum()
+    loss.backward()
+    torch.cuda.synchronize()
+    o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il.numpy(), tl.numpy(), "sum")
+    for name, a, b in (("loss", loss.detach().cpu().numpy(), o["loss"]), ("grad_inputs", xd.grad.cpu().numpy(), o["grad_inputs"]),
+                       ("grad_transition", trd.grad.cpu().numpy(), o["grad_transition"])):
+        ok, e = util.tol_ok(a, b, 1e-4)
+        assert ok, (name, e)

@@ -18,7 +18,8 @@ SYMBOLS = ["asg_hip_version", "asg_hip_strerror", "asg_ctx_create", "asg_ctx_des
            "asg_aligned_backward", "asg_forward", "asg_forward_only", "asg_backward", "asg_loss_forward",
            "asg_loss_backward", "asg_viterbi_work_bytes", "asg_viterbi", "asg_loss_fused_supported",
            "asg_loss_fused_scratch_bytes", "asg_loss_fused_sync_bytes", "asg_loss_fused_forward",
-           "asg_loss_fused_backward"]
+           "asg_loss_fused_backward", "asg_cluster_timeouts"]
+ABI_VERSION = 210        # include/asg_hip.h: ASG_HIP_VERSION this package was written against
 
 
 class AsgProblem(ctypes.Structure):
@@ -46,6 +47,11 @@ def lib():
     vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
     pp = ctypes.POINTER(AsgProblem)
     L.asg_hip_version.restype = ci
+    if int(L.asg_hip_version()) != ABI_VERSION:
+        raise RuntimeError("torch_asg_amd: %s reports ABI version %d, this package needs %d -- rebuild it with "
+                           "`python torch_asg_amd/csrc/build.py`" % (LIB_PATH, int(L.asg_hip_version()), ABI_VERSION))
+    L.asg_cluster_timeouts.restype = ctypes.c_uint
+    L.asg_cluster_timeouts.argtypes = []
     L.asg_hip_strerror.restype = ctypes.c_char_p
     L.asg_hip_strerror.argtypes = [ci]
     L.asg_ctx_create.argtypes = [ctypes.POINTER(vp)]
@@ -99,6 +105,14 @@ def binding(backend):
     the Python statements in asg.py then do the same work, only slower (host time)."""
     if os.environ.get("ASG_NO_BINDING", "0") not in ("", "0") or not os.path.exists(BINDING_PATH):
         return None
-    from . import _binding
     L = lib()
-    return _binding.Fast([ctypes.cast(getattr(L, n), ctypes.c_void_p).value for n in BINDING_SYMBOLS], backend)
+    try:
+        # a stale or ABI-mismatched _binding.so (torch upgraded, other C++ ABI, missing libtorch_hip) must not take the package
+        # down: the Python statements do the same work
+        from . import _binding
+        return _binding.Fast([ctypes.cast(getattr(L, n), ctypes.c_void_p).value for n in BINDING_SYMBOLS], backend)
+    except (ImportError, OSError, RuntimeError, AttributeError) as e:
+        import warnings
+        warnings.warn("torch_asg_amd: the C++ host fast path (_binding.so) is unusable (%s: %s); using the Python path -- rebuild "
+                      "with `python torch_asg_amd/csrc/build.py --binding`" % (type(e).__name__, e))
+        return None

@@ -53,7 +53,20 @@ class HipBackend:
         self._tickets = {}
         self._pools = {}
         self._pool_keep = []
+        self._retired = []            # contexts evicted from _ctx: destroyed in release(), never while a call may still hold them
+        self._faults = 0              # resident-slice launches that timed out, as last seen (asg_cluster_timeouts)
         self.binding = _lib.binding(self)        # C++ fast path of ASGLossFunction, or None (csrc/binding.cpp)
+
+    def check_faults(self):
+        """Raise if a resident-slice forward launch (fp32, 256 < N <= 2048) of this process has timed out since the last look:
+        that call's scores were NaN.  Host-pinned counter, no synchronisation; the library has already switched to the
+        per-frame launches, so the NEXT call is sound."""
+        n = int(_lib.lib().asg_cluster_timeouts())
+        if n != self._faults:
+            self._faults = n
+            raise RuntimeError("torch_asg_amd: a resident-slice forward launch timed out (part of its grid never became resident: "
+                               "another process on the device, a CU-masked stream?); that call returned NaN scores.  The library "
+                               "takes the per-frame launches from now on; repeat the step.")
 
     def _cu_count(self, idx):
         cus = self._cus.get(idx)
@@ -168,10 +181,11 @@ class HipBackend:
                 if h is None:
                     h = ctypes.c_void_p()
                     if len(self._ctx) >= self.MAX_CONTEXTS:
-                        # streams come and go in long runs: drop the oldest handle (stream / event destruction is
-                        # deferred by the runtime until their pending work has finished)
+                        # streams come and go in long runs: forget the handle that was created first.  It is NOT destroyed here --
+                        # another thread may be inside a call that holds it (ctypes releases the GIL) -- but moved to a retire
+                        # list that release() empties; a context is a stream and two events
                         old = next(iter(self._ctx))
-                        _lib.lib().asg_ctx_destroy(self._ctx.pop(old))
+                        self._retired.append(self._ctx.pop(old))
                         if self.binding is not None:
                             self.binding.reset()
                     with torch.cuda.device(idx):
@@ -198,6 +212,8 @@ class HipBackend:
 
     # -- granular (reference "serial" route) ---------------------------------------------------
     def full_forward(self, inputs, transition, input_lengths, flags=0):
+        if inputs.shape[2] > 256:
+            self.check_faults()          # (resident-slice route: a timed-out launch of an earlier call must not stay silent)
         self._check(inputs, transition, None, input_lengths, None)
         L = _lib.lib()
         with self._guard(inputs.device):
@@ -249,6 +265,8 @@ class HipBackend:
 
     # -- fused (reference GPU fast route) --------------------------------------------------------
     def forward(self, inputs, targets, transition, input_lengths, target_lengths, flags=_lib.FLAG_STREAMS):
+        if inputs.shape[2] > 256:
+            self.check_faults()          # (resident-slice route: a timed-out launch of an earlier call must not stay silent)
         self._check(inputs, transition, targets, input_lengths, target_lengths)
         L = _lib.lib()
         B = inputs.shape[1]
@@ -263,6 +281,8 @@ class HipBackend:
         return scores[0], scores[1], state
 
     def forward_only(self, inputs, targets, transition, input_lengths, target_lengths, flags=_lib.FLAG_STREAMS):
+        if inputs.shape[2] > 256:
+            self.check_faults()          # (resident-slice route: a timed-out launch of an earlier call must not stay silent)
         self._check(inputs, transition, targets, input_lengths, target_lengths)
         L = _lib.lib()
         T, B, N = inputs.shape
@@ -368,9 +388,10 @@ class HipBackend:
     def release(self):
         """Destroy the side-stream contexts and drop the sync pools (call when no launch of this process is in flight)."""
         with self._lock:
-            for h in self._ctx.values():
+            for h in list(self._ctx.values()) + self._retired:
                 _lib.lib().asg_ctx_destroy(h)
             self._ctx.clear()
+            self._retired.clear()
             self._tickets.clear()
             self._pools.clear()
             self._pool_keep.clear()
@@ -402,6 +423,8 @@ class HipBackend:
         self._check(inputs, transition, targets, input_lengths, target_lengths)
         L = _lib.lib()
         T, B, N = inputs.shape
+        if N > 256:
+            self.check_faults()          # (resident-slice route: a timed-out launch of an earlier call must not stay silent)
         red = self._RED[reduction]
         dev = inputs.device
         with self._guard(dev):
@@ -601,6 +624,8 @@ class ASGLossFunction(torch.autograd.Function):
         be = native()
         r = None
         bd = getattr(be, "binding", None)
+        if inputs.dim() == 3 and inputs.shape[2] > 256:
+            be.check_faults()            # (resident-slice route: a timed-out launch of an earlier call must not stay silent)
         if bd is not None:
             # the plain case (everything on the device, contiguous lengths) entirely in C++; None = not that case
             r = bd.try_loss_forward(inputs, transition, outputs, input_lengths, output_lengths,

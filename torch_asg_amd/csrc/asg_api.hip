@@ -270,6 +270,8 @@ const char *asg_hip_strerror(int status) {
     return "unknown error";
 }
 
+unsigned asg_cluster_timeouts(void) { return cluster_timeouts(); }
+
 int asg_ctx_create(asg_ctx **out) {
     if (!out) return ASG_ERR_INVALID;
     asg_ctx *c = new (std::nothrow) asg_ctx();

@@ -896,8 +896,34 @@ struct ClusterArgs {
     float *xbuf;        // [ncl][2][npadL / 4][kClNB][4]   exp-domain vectors of the frame just produced (pad columns stay zero)
     unsigned *xmax;     // [ncl][2][G][kClNB]             key(max q) over each workgroup's rows
     unsigned *flags;    // [ncl][G]                       frames published so far (zero on entry)
+    unsigned *fault;    // host-mapped word (or nullptr): incremented when a bounded wait runs out (cluster_fault_word)
     int G, RW, npadL, ncd, cpc, ndirs;
 };
+
+// A bounded wait of fwd_cluster_kernel that runs out (part of the grid never became resident: another process on the device, a
+// CU-masked stream, a partitioned device) poisons the scores with NaN -- and must not stay silent: the kernel also bumps ONE
+// host-pinned word of this process.  The host reads it without a synchronisation: launch_fwd_generic stops taking the resident
+// route once it is non-zero (the per-frame launches need no co-residency), asg_cluster_timeouts() reports the count, and
+// torch_asg_amd raises on it.  This word is the library's only state between calls; it records faults, it carries no data.
+struct ClusterFault {
+    unsigned *host = nullptr, *dev = nullptr;
+    bool tried = false, warned = false;
+};
+static ClusterFault &cluster_fault(bool create = true) {
+    static ClusterFault F;
+    if (!F.tried && create) {
+        F.tried = true;
+        void *h = nullptr, *d = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess && h) {
+            *(volatile unsigned *) h = 0;
+            if (hipHostGetDevicePointer(&d, h, 0) == hipSuccess && d) { F.host = (unsigned *) h; F.dev = (unsigned *) d; }
+            else (void) hipHostFree(h);
+        }
+        (void) hipGetLastError();
+    }
+    return F;
+}
+
 static __host__ __device__ inline size_t cluster_xbuf_floats(int ncl, int npadL) { return (size_t) ncl * 2 * kClNB * npadL; }
 
 __global__ void __launch_bounds__(kClNT) fwd_cluster_kernel(Problem P, StepBuf<float> Sa, StepBuf<float> Sb, ClusterArgs C, int dir_base) {
@@ -1187,6 +1213,7 @@ __global__ void __launch_bounds__(kClNT) fwd_cluster_kernel(Problem P, StepBuf<f
 #endif
     if (sfail && g == 0 && tid < kClNB)
         for (int b = cb0 + tid; b < cb1; b += kClNB) S.off[b] = __builtin_nan("");      // (never hang, never return a wrong number quietly)
+    if (sfail && tid == 0 && C.fault) __hip_atomic_fetch_add(C.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // the resident-slice route: fp32, 256 < N <= 2048 (ASG_NO_CLUSTER=1: the per-frame launches instead)
@@ -2461,6 +2488,11 @@ inline size_t au(size_t x) { return (x + 255) & ~(size_t) 255; }
 
 }  // namespace
 
+unsigned cluster_timeouts() {
+    ClusterFault &F = cluster_fault(false);         // (a query never allocates: nothing can have timed out before the first launch)
+    return F.host ? *(volatile unsigned *) F.host : 0u;
+}
+
 // ---------------------------------------------------------------------------------------------- host side
 template <typename R>
 hipError_t launch_prep_generic(const Problem &P, const State &W, hipStream_t stream) {
@@ -2583,6 +2615,17 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
                 int dev = 0, cus = 0;
                 if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
                     cus = 256;
+                // (a CU-masked stream sees fewer compute units than the device has: the grid is sized to what the STREAM may use)
+                {
+                    uint32_t mask[16] = {0};
+                    if (hipExtStreamGetCUMask(stream, 16, mask) == hipSuccess) {
+                        int bits = 0;
+                        for (int q = 0; q < 16; ++q) bits += __builtin_popcount(mask[q]);
+                        if (bits > 0 && bits < cus) cus = bits;
+                    } else {
+                        (void) hipGetLastError();
+                    }
+                }
                 ClusterArgs C{};
                 C.RW = P.N <= 512 ? 64 : P.N <= 1024 ? 32 : 16;
                 C.G = (P.N + C.RW - 1) / C.RW;
@@ -2599,17 +2642,38 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
                 // beyond 1024 labels a cluster is half the device (one per direction) and takes the batch 16 chains at a time:
                 // worth it up to three rounds (B <= 48), after that the launch per frame (32 us for ALL chains) is the faster one
                 const bool few_rounds = P.N <= 1024 || (C.cpc + kClNB - 1) / kClNB <= 3;
-                if (few_rounds && ncl * C.G <= cus && xb + xmb + flb <= kClusterBytes) {
+                // (at least 84 KB of LDS: a compute unit then holds ONE of these workgroups -- two on one unit would share its
+                // matrix pipes and make their whole clusters wait, while other units stay empty)
+                size_t lds = ((size_t) kClNB * C.npadL + (size_t) (kClNT / 64) * 16 * kClNB) * 4;
+                if (lds < 84 * 1024) lds = 84 * 1024;
+                // The workgroups of a cluster wait for each other: the route is taken only if (a) no earlier launch of this process
+                // ever timed out (cluster_fault), (b) the kernel can have its LDS (per device and cheap: asked on every call) and the
+                // runtime says a workgroup of it fits a compute unit, (c) the grid fits the compute units this stream may use (above).
+                // Otherwise: the per-frame launches below, which need none of it.
+                ClusterFault &CF = cluster_fault();
+                bool resident_ok = CF.host != nullptr && *(volatile unsigned *) CF.host == 0u;
+                if (CF.host && !resident_ok && !CF.warned) {
+                    CF.warned = true;
+                    fprintf(stderr, "[torch_asg_amd] a resident-slice forward launch timed out earlier in this process (its scores were NaN): "
+                                    "taking the per-frame launches from now on\n");
+                }
+                if (resident_ok && hipFuncSetAttribute((const void *) fwd_cluster_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) {
+                    (void) hipGetLastError();
+                    resident_ok = false;
+                }
+                if (resident_ok) {
+                    int per_cu = 0;
+                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *) fwd_cluster_kernel, kClNT, lds) != hipSuccess || per_cu < 1) {
+                        (void) hipGetLastError();
+                        resident_ok = false;
+                    }
+                }
+                if (resident_ok && few_rounds && ncl * C.G <= cus && xb + xmb + flb <= kClusterBytes) {
                     C.xbuf = (float *) ca;
                     C.xmax = (unsigned *) (ca + xb);
                     C.flags = (unsigned *) (ca + xb + xmb);
+                    C.fault = CF.dev;
                     (void) hipMemsetAsync(ca, 0, xb + xmb + flb, stream);
-                    // (at least 84 KB of LDS: a compute unit then holds ONE of these workgroups -- two on one unit would share its
-                    // matrix pipes and make their whole clusters wait, while other units stay empty)
-                    size_t lds = ((size_t) kClNB * C.npadL + (size_t) (kClNT / 64) * 16 * kClNB) * 4;
-                    if (lds < 84 * 1024) lds = 84 * 1024;
-                    // (per device and cheap: set on every call rather than remembered per process)
-                    (void) hipFuncSetAttribute((const void *) fwd_cluster_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
                     StepBuf<float> A0 = Sd[0], B0 = Sd[1];
                     hipLaunchKernelGGL(fwd_cluster_kernel, dim3(ncl * C.G), dim3(kClNT), lds, stream, P, A0, B0, C, do_a ? 0 : 1);
                     stepped = true;

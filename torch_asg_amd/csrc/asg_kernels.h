@@ -133,6 +133,9 @@ hipError_t launch_bwd_generic(const Problem &P, const State &W, const BwdArgs &A
 template <typename R>
 hipError_t launch_viterbi_small(const Problem &P, void *work, void *scores, void *path, hipStream_t stream);
 
+// launches of the resident-slice forward kernel (256 < N <= 2048) of this process whose bounded waits ran out (asg_generic.hip)
+unsigned cluster_timeouts();
+
 size_t bwd_scratch_bytes_small(int elem, int T, int B, int N, int S, int *chunk, int *nchunks);
 size_t bwd_scratch_bytes_generic(int elem, int T, int B, int N, int S);
 size_t fwd_work_bytes_generic(int elem, int T, int B, int N);
