@@ -21,7 +21,7 @@ Rank 0 prints ONE JSON line.  Besides the driver's contract fields it carries
   roofline     -- dominant kernel (the fused recursion + assembly kernel): algorithmic bytes / its measured duration
   cpu_baseline -- the reference's own compiled CPU path (oracle/_ref) timed on this box's host cores (N=1 only)
   extra        -- (N=1 only) the other BASELINE.json configurations timed in the same process: cfg 2, cfg 4 on one GPU
-                  (B=512), the evaluation route, eager (no hipGraph) cfg 3, and cfg 5 (large alphabet) with its own
+                  (B=512), B=4096, the evaluation route, eager (no hipGraph) cfg 3, and cfg 5 (large alphabet) with its own
                   roofline object measured live
 """
 import argparse
@@ -275,7 +275,7 @@ def measure_cfg5(steps, warmup):
     a_alg = 3 * (T5 - 1) * N5 * N5 * w + 2 * T5 * B5 * N5 * w      # alpha, beta and gradient passes over Tr
     ms_per_step = dt / steps * 1e3
     achieved = a_alg_step / (kern_ms * 1e-3) / 1e9
-    traffic5, traffic5_src = committed_traffic(("r03_pmc_cfg5.json", "r02_pmc_cfg5.json"))
+    traffic5, traffic5_src = committed_traffic(("r04_pmc_cfg5.json", "r03_pmc_cfg5.json", "r02_pmc_cfg5.json"))
     del x, tr, m
     torch.cuda.empty_cache()
     return {
@@ -342,6 +342,8 @@ def extras(args):
 
     attempt("cfg2", lambda: time_small_config("cfg2", 150, 16, 30, 20, False, 100))
     attempt("cfg4_one_gpu", lambda: time_small_config("cfg4 on one GPU", 400, 512, 40, 30, False, 50))
+    # not a BASELINE config: the batch size at which the stand-alone route's throughput levels off (round-3 verdict, item 1)
+    attempt("batch_4096", lambda: time_small_config("T=400 N=40 L=30 at B=4096 on one GPU (not a BASELINE config)", 400, 4096, 40, 30, False, 20))
     attempt("cfg3_eval", lambda: time_small_config("cfg3", T, B, N, L, False, 100, eval_route=True))
     attempt("cfg3_eager", lambda: time_small_config("cfg3", T, B, N, L, False, 100, eager=True))
     attempt("cfg3_streams", lambda: time_small_config("cfg3, launch_mode=streams", T, B, N, L, False, 50, launch="streams"))
@@ -595,7 +597,7 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         value = global_batch * args.steps / dt
         achieved = a_alg / (kern_ms_med * 1e-3) / 1e9
-        traffic, traffic_source = committed_traffic(("r03_pmc_cfg3.json", "r02_pmc_cfg3.json")) if fused_step else (None, None)
+        traffic, traffic_source = committed_traffic(("r04_pmc_cfg3.json", "r03_pmc_cfg3.json", "r02_pmc_cfg3.json")) if fused_step else (None, None)
         out = {
             "metric": "utterances/sec fwd+bwd, T=400 B=64 N=40; achieved HBM GB/s vs roofline",
             "value": value,
