@@ -612,7 +612,8 @@ def _path_score(x, tr, tg, pos):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 @pytest.mark.parametrize("T,B,N,L,variable", [(6, 2, 7, 5, True), (23, 5, 9, 7, True), (150, 16, 30, 20, True),
                                               (400, 64, 40, 30, False), (70, 3, 64, 64, True), (1, 2, 4, 1, False),
-                                              (150, 3, 30, 100, True), (300, 2, 12, 300, False), (1030, 1, 5, 1000, True)])
+                                              (150, 3, 30, 100, True), (300, 2, 12, 300, False), (1030, 1, 5, 1000, True),
+                                              (1600, 2, 9, 1500, True), (4200, 1, 6, 4096, False), (1100, 3, 40, 1025, True)])
 def test_viterbi_vs_oracle(T, B, N, L, variable, dtype):
     A = _asg()
     tr, x, tg, il, tl = util.synth(T, B, N, L, 7, variable, dtype)
@@ -658,8 +659,8 @@ def test_viterbi_edge_cases_and_module_method():
     so, po = orc.viterbi(xt.numpy(), tg2[:, :6].numpy(), np.zeros((4, 4)), None, np.array([6, 6, 6]))
     assert np.array_equal(sc2.cpu().numpy(), so) and np.array_equal(pos2.cpu().numpy(), po)
     with pytest.raises(RuntimeError):
-        A.viterbi_align(torch.randn(1100, 1, 4, device=DEV), torch.zeros(1, 1025, dtype=torch.long, device=DEV),
-                        torch.zeros(4, 4, device=DEV))        # S > 1024: not supported, fails loudly
+        A.viterbi_align(torch.randn(4200, 1, 4, device=DEV), torch.zeros(1, 4097, dtype=torch.long, device=DEV),
+                        torch.zeros(4, 4, device=DEV))        # S > 4096: not supported, fails loudly
 
 
 def _stress():
@@ -1049,3 +1050,35 @@ def test_medium_alphabet_exact_path_and_eval_route():
         m.transition.copy_(tr)
         ev = m(x.to(DEV), tg.to(DEV), il.to(DEV), tl.to(DEV))
     util.assert_close(ev.cpu().numpy(), o["loss"], 1e-4, "medium alphabet eval")
+
+
+# ------------------------------------------------------------------ very long targets (1024 < S <= 4096)
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,B,N,L,dtype,rtol", [(1300, 2, 30, 1100, torch.float32, 1e-4), (1600, 3, 40, 1500, torch.float32, 1e-4),
+                                                 (4200, 1, 28, 4096, torch.float32, 1e-4), (1100, 2, 12, 1025, torch.float64, 1e-9),
+                                                 (1200, 2, 200, 1100, torch.float32, 1e-4), (1150, 2, 600, 1030, torch.float32, 1e-4)])
+def test_very_long_targets(T, B, N, L, dtype, rtol):
+    """1024 < S <= 4096 (the reference has no limit: force_aligned_lattice.cpp:84-154): strip-mined recursion (four positions per
+    thread, the frame through LDS) and a frame-by-frame gradient kernel with a fixed-point label row; small, medium and
+    resident-slice alphabets; variable lengths, one infeasible utterance when B >= 3; run-to-run determinism."""
+    rng = np.random.default_rng(T + L)
+    tr, x, tg, _, _ = util.synth(T, B, N, L, L + N)
+    il = rng.integers(max(L, T - 60), T + 1, B)
+    tl = rng.integers(max(1025, L - 40), L + 1, B)
+    tl[0] = L
+    il[0] = T
+    if B >= 3:
+        il[2], tl[2] = 1030, 1100                   # target longer than the input: +inf loss, NaN-free gradients
+    o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il, tl, "none")
+    r = run_hip(x, tg, tr, il, tl, "none", dtype)
+    for k in ("loss", "grad_inputs", "grad_transition"):
+        util.assert_close(r[k], o[k], rtol, "very long targets T%d B%d N%d L%d %s" % (T, B, N, L, k))
+    assert not np.isnan(r["grad_inputs"]).any() and not np.isnan(r["grad_transition"]).any()
+    r3 = run_hip(x, tg, tr, il, tl, "none", dtype)
+    assert np.array_equal(r["grad_inputs"], r3["grad_inputs"]) and np.array_equal(r["grad_transition"], r3["grad_transition"])
+    A = _asg()
+    m = A.ASGLoss(N, reduction="none").to(DEV).to(dtype).eval()
+    with torch.no_grad():
+        m.transition.copy_(tr.to(dtype))
+        ev = m(x.to(DEV, dtype), tg.to(DEV), torch.as_tensor(il).to(DEV), torch.as_tensor(tl).to(DEV))
+    util.assert_close(ev.cpu().numpy(), o["loss"], rtol, "very long targets, evaluation route")

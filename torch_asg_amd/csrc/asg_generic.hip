@@ -1796,6 +1796,264 @@ __global__ void __launch_bounds__(1024) aligned_wide_kernel(Problem P, State W, 
     }
 }
 
+// ------------------------------------------------------------------ aligned lattice, very long targets (1024 < S <= 4096)
+// The reference takes any target length (force_aligned_lattice.cpp:84-154 has no limit); the kernels above stop at one
+// position per thread of a 1024-thread workgroup.  Beyond that the same recursion is strip-mined: thread s owns positions
+// s, s + 1024, ... (KP of them), the whole frame's states travel through a double-buffered LDS row (one barrier per frame, as
+// aligned_wide_kernel).  A correctness route, not a tuned one: targets of thousands of positions are hours of audio.
+// grid = (B, 2), block = 1024, dynamic LDS = 2 (S + 2) doubles.
+template <typename R, bool STORE, int KP>
+__global__ void __launch_bounds__(1024) aligned_strip_kernel(Problem P, State W, FwdOut O, int mask) {
+    extern __shared__ __attribute__((aligned(16))) double strip_row[];      // [2][S + 2]
+    __shared__ R red[16];
+    const int b = blockIdx.x;
+    const bool beta = (mask == kAlignedBeta) || (mask == (kAlignedAlpha | kAlignedBeta) && blockIdx.y == 1);
+    const int tid = threadIdx.x, S = P.S, T = P.T, N = P.N;
+    const R L2E = Num<R>::log2e(), LZ = Num<R>::logzero();
+    const int len = P.in_len ? gclampi(P.in_len[b], 0, T) : T;
+    const int ol = P.tg_len ? gclampi(P.tg_len[b], 0, S) : S;
+    const int64_t *tg = P.targets + (int64_t) b * P.gs0;
+    const R *tr = (const R *) P.transition;
+    double *row0 = strip_row, *row1 = strip_row + (S + 2);
+    bool act[KP];
+    double H2[KP], Dx[KP];
+    const R *in[KP];
+    AlignedState *out = (AlignedState *) (beta ? W.bb : W.ab) + (int64_t) b * T * S;
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+        const int p = tid + 1024 * k;
+        act[k] = p < ol;
+        const int cur = act[k] ? gclampi(tg[(int64_t) p * P.gs1], 0, N - 1) : 0;
+        const int prv = (act[k] && p >= 1) ? gclampi(tg[(int64_t) (p - 1) * P.gs1], 0, N - 1) : 0;
+        const int nxt = (p + 1 < ol) ? gclampi(tg[(int64_t) (p + 1) * P.gs1], 0, N - 1) : 0;
+        const R h2 = act[k] ? fmax(tr[(int64_t) cur * P.ts0 + (int64_t) cur * P.ts1] * L2E, LZ) : R(0);
+        const R dp = (act[k] && p >= 1) ? fmax(tr[(int64_t) cur * P.ts0 + (int64_t) prv * P.ts1] * L2E, LZ) : LZ;
+        const R dn = (p + 1 < ol) ? fmax(tr[(int64_t) nxt * P.ts0 + (int64_t) cur * P.ts1] * L2E, LZ) : LZ;
+        H2[k] = (double) h2;
+        Dx[k] = (double) (beta ? dn : dp);
+        in[k] = (const R *) P.inputs + (int64_t) b * P.is1 + (int64_t) cur * P.is2;
+        if (STORE && !beta && p < S) {
+            V2<R> u = {h2, dp};
+            reinterpret_cast<V2<R> *>(W.asu)[(int64_t) b * S + p] = u;
+            int2 ii = {cur, prv};
+            reinterpret_cast<int2 *>(W.asi)[(int64_t) b * S + p] = ii;
+        }
+    }
+    R *score_out = (R *) (beta ? O.aligned_scores : O.aligned_scores_alpha);
+    if (len < 1 || ol < 1) {
+        if (tid == 0 && score_out) score_out[b] = Num<R>::ninf();
+        return;
+    }
+    const double kZ = -1e30, L2Ed = 1.4426950408889634;
+    auto lse2d = [&](double x, double y) {
+        const double m = fmax(x, y);
+        const R d = (R) (fmin(x, y) - m);
+        return m + (double) Num<R>::log2(R(1) + Num<R>::exp2(d));
+    };
+    // renormalise now and then: the log domain is offset free (the stored states are doubles: AlignedState)
+    auto renorm = [&](double (&v)[KP], double &C) {
+        R m = LZ;
+#pragma unroll
+        for (int k = 0; k < KP; ++k) m = fmax(m, (R) v[k]);
+        m = wave_allmax(m);
+        if ((tid & 63) == 0) red[tid >> 6] = m;
+        __syncthreads();
+        R mm = red[0];
+        for (int w = 1; w < 16; ++w) mm = fmax(mm, red[w]);
+        if (mm > R(-1e29)) {
+#pragma unroll
+            for (int k = 0; k < KP; ++k) v[k] = fmax(v[k] - (double) mm, kZ);
+            C += (double) mm;
+        }
+        __syncthreads();
+    };
+    double C = 0.0, v[KP];
+    if (!beta) {
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            const int p = tid + 1024 * k;
+            v[k] = (p == 0 && act[k]) ? fmax((double) in[k][0] * L2Ed, kZ) : kZ;
+            if (STORE && p < S) out[p] = (AlignedState) v[k];
+        }
+        for (int t = 1; t < len; ++t) {
+            double *rw = (t & 1) ? row1 : row0;
+#pragma unroll
+            for (int k = 0; k < KP; ++k) { const int p = tid + 1024 * k; if (p < S) rw[p + 1] = v[k]; }
+            if (tid == 0) rw[0] = kZ;
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < KP; ++k) {
+                const int p = tid + 1024 * k;
+                const double em = act[k] ? (double) in[k][(int64_t) t * P.is0] * L2Ed : kZ;
+                const double left = p < S ? rw[p] : kZ;
+                v[k] = fmax(em + lse2d(v[k] + H2[k], left + Dx[k]), kZ);
+            }
+            if ((t & 15) == 0) renorm(v, C);
+            if (STORE) {
+#pragma unroll
+                for (int k = 0; k < KP; ++k) { const int p = tid + 1024 * k; if (p < S) out[(int64_t) t * S + p] = (AlignedState) v[k]; }
+            }
+        }
+        if (score_out) {
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < KP; ++k) { const int p = tid + 1024 * k; if (p < S) row0[p] = v[k]; }
+            __syncthreads();
+            if (tid == 0) {
+                const double sc = C + row0[ol - 1];
+                score_out[b] = (sc < -1e29) ? Num<R>::ninf() : (R) (sc * kLn2);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            const int p = tid + 1024 * k;
+            v[k] = (p == ol - 1) ? 0.0 : kZ;
+            if (STORE && p < S) out[(int64_t) (len - 1) * S + p] = (AlignedState) v[k];
+        }
+        for (int t = len - 1; t >= 1; --t) {
+            double *rw = (t & 1) ? row1 : row0;
+            double y[KP];
+#pragma unroll
+            for (int k = 0; k < KP; ++k) {
+                const int p = tid + 1024 * k;
+                const double em = act[k] ? (double) in[k][(int64_t) t * P.is0] * L2Ed : kZ;
+                y[k] = fmax(em + v[k], kZ);
+                if (p < S) rw[p] = y[k];
+            }
+            if (tid == 0) rw[S] = kZ;
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < KP; ++k) {
+                const int p = tid + 1024 * k;
+                const double right = p < S ? rw[p + 1] : kZ;
+                v[k] = fmax(lse2d(y[k] + H2[k], right + Dx[k]), kZ);
+            }
+            if ((t & 15) == 0) renorm(v, C);
+            if (STORE) {
+#pragma unroll
+                for (int k = 0; k < KP; ++k) { const int p = tid + 1024 * k; if (p < S) out[(int64_t) (t - 1) * S + p] = (AlignedState) v[k]; }
+            }
+        }
+        if (score_out && tid == 0) {
+            const double em = act[0] ? (double) in[0][0] * L2Ed : kZ;
+            const double sc = C + (em + v[0]);
+            score_out[b] = (sc < -1e29) ? Num<R>::ninf() : (R) (sc * kLn2);
+        }
+    }
+}
+
+// Gradient of the same: grid = (B, nchunks), block = 256.  The workgroup walks the frames of its chunk ONE AT A TIME, thread tid owns
+// positions tid, tid + 256, ... (KQ = 16 of them: S <= 4096) with their edge-posterior sums in registers; per frame two
+// block reductions (maximum, sum: the reference's masked softmax over positions), the posteriors scattered to the labels
+// through ONE fixed-point LDS row (integer adds commute: deterministic, repeated labels included; N <= 2048), read back and
+// added to grad_inputs.  Edge posteriors per (b, chunk) go to gHD as from bwd_aligned_kernel (aligned_tr_scatter_fx_kernel follows).
+// Restates force_aligned_lattice.cpp:156-264.
+template <typename R>
+__global__ void __launch_bounds__(256) bwd_aligned_strip_kernel(Problem P, State W, BwdArgs A, R *gHD, int add_to_inputs) {
+    constexpr int KQ = 16;
+    typedef typename FrameFix<R>::T FX;
+    __shared__ FX fxl[2048];
+    __shared__ R red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, chunk = blockIdx.y;
+    const int S = P.S, T = P.T, N = P.N;
+    const R LZ = Num<R>::logzero();
+    const int len = P.in_len ? gclampi(P.in_len[b], 0, T) : T;
+    const int ol = P.tg_len ? gclampi(P.tg_len[b], 0, S) : S;
+    const R g0 = (R) ((double) ((const R *) (A.grad_aligned ? A.grad_aligned : A.grad_full))[(int64_t) b * A.gstride] * A.gscale);
+    const R ga = (A.grad_aligned || !A.neg_aligned) ? g0 : -g0;
+    const int2 *asi = reinterpret_cast<const int2 *>(W.asi) + (int64_t) b * S;
+    const V2<R> *asu = reinterpret_cast<const V2<R> *>(W.asu) + (int64_t) b * S;
+    for (int q = tid; q < 2048; q += 256) fxl[q] = 0;
+    R H2[KQ], Dp[KQ], accH[KQ], accD[KQ];
+    int tgt[KQ];
+    bool act[KQ];
+#pragma unroll
+    for (int k = 0; k < KQ; ++k) {
+        const int p = tid + 256 * k;
+        act[k] = p < ol;
+        const V2<R> u = p < S ? asu[p] : V2<R>{0, LZ};
+        H2[k] = u.x; Dp[k] = u.y;
+        tgt[k] = act[k] ? asi[p].x : 0;
+        accH[k] = 0; accD[k] = 0;
+    }
+    __syncthreads();
+    const AlignedState *abp = (const AlignedState *) W.ab + (int64_t) b * T * S;
+    const AlignedState *bbp = (const AlignedState *) W.bb + (int64_t) b * T * S;
+    auto block_max = [&](R v) -> R {
+        v = wave_allmax(v);
+        if (lane == 0) red[wave] = v;
+        __syncthreads();
+        const R r = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+        __syncthreads();
+        return r;
+    };
+    auto block_sum = [&](R v) -> R {
+        v = wave_allsum(v);
+        if (lane == 0) red[wave] = v;
+        __syncthreads();
+        const R r = (red[0] + red[1]) + (red[2] + red[3]);      // fixed order
+        __syncthreads();
+        return r;
+    };
+    const int t0 = chunk * A.chunk, t1 = min(min(T, t0 + A.chunk), len);
+    for (int t = t0; t < t1; ++t) {
+        double gs[KQ];
+        R m = LZ + LZ;
+#pragma unroll
+        for (int k = 0; k < KQ; ++k) {
+            const int p = tid + 256 * k;
+            gs[k] = p < S ? abp[(int64_t) t * S + p] + bbp[(int64_t) t * S + p] : -2e30;
+            m = fmax(m, (R) gs[k]);
+        }
+        m = block_max(m);
+        R e[KQ], z = 0;
+#pragma unroll
+        for (int k = 0; k < KQ; ++k) {
+            e[k] = (m > R(-1e29) && act[k]) ? Num<R>::exp2((R) (gs[k] - (double) m)) : R(0);
+            z += e[k];
+        }
+        z = block_sum(z);
+#pragma unroll
+        for (int k = 0; k < KQ; ++k) {
+            const int p = tid + 256 * k;
+            const R post = (z > 0 && act[k]) ? e[k] / z : R(0);
+            if (post != R(0)) atomicAdd(&fxl[tgt[k]], FrameFix<R>::to(post));
+            if (t >= 1 && act[k]) {
+                // shares of the two incoming edges from their difference (formed in double): bwd_aligned_long_kernel
+                const double ap = abp[(int64_t) (t - 1) * S + p];
+                const double al = p >= 1 ? abp[(int64_t) (t - 1) * S + p - 1] : 0.0;
+                const R d = (R) ((al + (double) Dp[k]) - (ap + (double) H2[k]));
+                const R tt = Num<R>::exp2(-fabs(d));
+                const R big = R(1) / (R(1) + tt), small = tt * big;
+                accH[k] += post * (d <= R(0) ? big : small);
+                accD[k] += post * (d <= R(0) ? small : big);
+            }
+        }
+        __syncthreads();
+        for (int lab = tid; lab < N; lab += 256) {
+            const FX fv = fxl[lab];
+            if (fv != 0) {
+                fxl[lab] = 0;
+                R *gin = (R *) A.grad_inputs + ((int64_t) t * P.B + b) * N + lab;
+                const R add = ga * FrameFix<R>::from(fv);
+                *gin = add_to_inputs ? *gin + add : add;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < KQ; ++k) {
+        const int p = tid + 256 * k;
+        if (p < S) {
+            R *dst = gHD + ((int64_t) b * A.nchunks + chunk) * 2 * S;
+            dst[p] = accH[k];
+            dst[S + p] = accD[k];
+        }
+    }
+}
+
 // ------------------------------------------------------------------ gradient: full lattice
 // per (b,t) posterior + exp-domain previous frame.  grid = (T, B), block = 256.
 //   grad_inputs[t][b][:] = g_b * softmax(ah+bh)      (zeros for t >= len; the aligned part is added later)
@@ -2541,7 +2799,16 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
                               hipStream_t stream) {
     const int full_mask = chain_mask & (kFullAlpha | kFullBeta);
     const int ali_mask = chain_mask & (kAlignedAlpha | kAlignedBeta);
-    if (ali_mask) {
+    if (ali_mask && P.S > 1024) {
+        // very long targets (up to 4096 positions): four positions per thread, the frame's states through LDS
+        if (P.S > 4096) return hipErrorInvalidValue;
+        dim3 grid(P.B, __builtin_popcount(ali_mask));
+        const size_t dyn = (size_t) 2 * (P.S + 2) * sizeof(double);
+        (void) hipFuncSetAttribute((const void *) aligned_strip_kernel<R, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) dyn);
+        (void) hipFuncSetAttribute((const void *) aligned_strip_kernel<R, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) dyn);
+        if (store) hipLaunchKernelGGL((aligned_strip_kernel<R, true, 4>), grid, dim3(1024), dyn, stream, P, W, O, ali_mask);
+        else hipLaunchKernelGGL((aligned_strip_kernel<R, false, 4>), grid, dim3(1024), dyn, stream, P, W, O, ali_mask);
+    } else if (ali_mask) {
         const int threads = ((P.S + 63) / 64) * 64;
         if (threads > 1024) return hipErrorInvalidValue;
         dim3 grid(P.B, __builtin_popcount(ali_mask));
@@ -2741,6 +3008,7 @@ size_t bwd_scratch_bytes_generic(int elem, int T, int B, int N, int S) {
     generic_chunks(T, B, &ch, &nch);
     size_t tiles = N <= 64 ? au((size_t) B * nch * N * N * elem) : 0;             // bwd_aligned_long_kernel
     if (N > 64 && N <= 2048) tiles = au((size_t) N * N * 8);                      // aligned_tr_scatter_fx_kernel
+    if (S > 1024 && tiles < au((size_t) N * N * 8)) tiles = au((size_t) N * N * 8);      // (very long targets: the same accumulator for any N <= 2048)
     if (elem == 4 && N > 64) tiles += au((size_t) gemm_slices(N, B * T) * N * N * 4);       // split contraction: partial sums
     return 2 * au((size_t) B * T * npad * elem) + au((size_t) B * nch * 2 * S * elem) + 512 + au(((size_t) B + 1) * 4) + tiles;
 }
@@ -2758,8 +3026,11 @@ hipError_t launch_bwd_generic(const Problem &P, const State &W, const BwdArgs &A
     int *anybad = (int *) sc; sc += 512;
     int *rowoff = (int *) sc; sc += au(((size_t) P.B + 1) * 4);
     R *atiles = (R *) sc;
-    if (P.N <= 64) sc += au((size_t) P.B * A.nchunks * P.N * P.N * e);
-    else if (P.N <= 2048) sc += au((size_t) P.N * P.N * 8);
+    {
+        size_t tb = P.N <= 64 ? au((size_t) P.B * A.nchunks * P.N * P.N * e) : (P.N <= 2048 ? au((size_t) P.N * P.N * 8) : 0);
+        if (P.S > 1024 && tb < au((size_t) P.N * P.N * 8)) tb = au((size_t) P.N * P.N * 8);      // (as bwd_scratch_bytes_generic)
+        sc += tb;
+    }
     R *gpart = (R *) sc;
     const bool do_full = parts & 1, do_ali = parts & 2, have_full = (parts & 5) != 0;
     R *gtr = (R *) A.grad_transition;
@@ -2812,10 +3083,20 @@ hipError_t launch_bwd_generic(const Problem &P, const State &W, const BwdArgs &A
         }
     }
     if (do_ali) {
-        if (P.S > 1024) return hipErrorInvalidValue;
+        if (P.S > 4096 || (P.S > 1024 && P.N > 2048)) return hipErrorInvalidValue;
         if (!have_full) (void) hipMemsetAsync(A.grad_inputs, 0, (size_t) P.T * P.B * P.N * e, stream);
         unsigned long long *nofx = nullptr;
-        if (P.N <= 64 && P.S > 64 && P.S <= 1024) {
+        if (P.S > 1024) {
+            // very long targets (N <= 2048): frame-by-frame workgroups, label scatter through a fixed-point LDS row; the edge
+            // posteriors into the 64-bit fixed-point accumulator, as for the medium alphabets
+            unsigned long long *fx = (unsigned long long *) atiles;
+            const int64_t n2 = (int64_t) P.N * P.N;
+            if (!fx_cleared) (void) hipMemsetAsync(fx, 0, (size_t) n2 * 8, stream);
+            hipLaunchKernelGGL((bwd_aligned_strip_kernel<R>), dim3(P.B, A.nchunks), dim3(256), 0, stream, P, W, A, gHD, 1);
+            hipLaunchKernelGGL((aligned_tr_scatter_fx_kernel<R>), dim3(P.B), dim3(256), 0, stream, P, W, A, (const R *) gHD, fx);
+            hipLaunchKernelGGL((fx_to_grad_kernel<R>), dim3((unsigned) ((n2 + 255) / 256)), dim3(256), 0, stream,
+                               (const unsigned long long *) fx, n2, gtr, have_full ? 1 : 0);
+        } else if (P.N <= 64 && P.S > 64 && P.S <= 1024) {
             dim3 grid(P.B, A.nchunks);
             if (P.S <= 128) hipLaunchKernelGGL((bwd_aligned_long_kernel<R, 2, 64, AlignedState>), grid, dim3(256), 0, stream, P, W, A, atiles, 1, nofx);
             else if (P.S <= 256) hipLaunchKernelGGL((bwd_aligned_long_kernel<R, 4, 64, AlignedState>), grid, dim3(256), 0, stream, P, W, A, atiles, 1, nofx);

@@ -1,5 +1,5 @@
 // torch_asg_amd/csrc/asg_viterbi.hip -- best-path (Viterbi) force alignment on gfx950 (S <= 64: one wavefront per
-// utterance; S <= 1024: one workgroup per utterance).
+// utterance; S <= 4096: one workgroup per utterance, up to four positions per thread).
 //
 // The force-aligned lattice of /root/reference/torch_asg/native/force_aligned_lattice.cpp:84-111 in the tropical
 // semiring (max instead of log-sum-exp: doc/tech_report.tex:84-88; a TODO in the reference's README.md:33 -- the
@@ -101,14 +101,14 @@ __global__ void __launch_bounds__(64) viterbi_small_kernel(Problem P, unsigned l
     }
 }
 
-// S up to 1024: one workgroup per utterance, thread s = target position, 64 positions per wavefront.  The left
-// neighbour crosses wavefront boundaries through a double-buffered LDS line (one __syncthreads per frame); every
-// wavefront stores its own 64 back-pointer bits per frame (masks[b][t][wave]).  The backtrace runs in wavefront 0, 64
-// frames at a time: within 64 frames the position moves by at most 64, so the two mask words a frame can need are
-// loaded up front by its lane and the walk itself touches no memory.
-template <typename R>
+// S up to 1024 (KP = 1) / 4096 (KP = 4): one workgroup per utterance, thread tid owns target positions tid + 1024 k, 64 positions
+// per mask word.  The left neighbour crosses thread boundaries through a double-buffered LDS line (one __syncthreads per
+// frame); every 64-position strip stores its own 64 back-pointer bits per frame (masks[b][t][strip]).  The backtrace runs
+// in wavefront 0, 64 frames at a time: within 64 frames the position moves by at most 64, so the two mask words a frame can
+// need are loaded up front by its lane and the walk itself touches no memory.
+template <typename R, int KP>
 __global__ void __launch_bounds__(1024) viterbi_wide_kernel(Problem P, unsigned long long *masks, R *scores, long long *path) {
-    __shared__ R line[2][1024 + 1];
+    __shared__ R line[2][1024 * KP + 1];
     __shared__ R best_sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x;
@@ -125,47 +125,66 @@ __global__ void __launch_bounds__(1024) viterbi_wide_kernel(Problem P, unsigned 
         if (tid == 0) scores[b] = NINF;
         return;
     }
-    const bool act = tid < ol;
-    const int sc = act ? tid : 0, sp = (act && tid >= 1) ? tid - 1 : 0;
     const int64_t *tg = P.targets + (int64_t) b * P.gs0;
-    const int64_t cur64 = tg[(int64_t) sc * P.gs1], prv64 = tg[(int64_t) sp * P.gs1];
-    const int cur = (int) (cur64 < 0 ? 0 : (cur64 > P.N - 1 ? P.N - 1 : cur64));
-    const int prv = (int) (prv64 < 0 ? 0 : (prv64 > P.N - 1 ? P.N - 1 : prv64));
     const R *tr = (const R *) P.transition;
-    const R H = tr[(long long) cur * P.ts0 + (long long) cur * P.ts1];
-    const R Dp = (act && tid >= 1) ? tr[(long long) cur * P.ts0 + (long long) prv * P.ts1] : NINF;
-    const R *in = (const R *) P.inputs + (long long) b * P.is1 + (long long) cur * P.is2;
-
-    R v = (tid == 0) ? in[0] : NINF;
+    bool act[KP], in_s[KP];
+    R H[KP], Dp[KP], v[KP];
+    const R *in[KP];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+        const int p = tid + 1024 * k;
+        act[k] = p < ol;
+        in_s[k] = p < nw * 64;                           // (its strip has a mask word)
+        const int sc = act[k] ? p : 0, sp = (act[k] && p >= 1) ? p - 1 : 0;
+        const int64_t cur64 = tg[(int64_t) sc * P.gs1], prv64 = tg[(int64_t) sp * P.gs1];
+        const int cur = (int) (cur64 < 0 ? 0 : (cur64 > P.N - 1 ? P.N - 1 : cur64));
+        const int prv = (int) (prv64 < 0 ? 0 : (prv64 > P.N - 1 ? P.N - 1 : prv64));
+        H[k] = tr[(long long) cur * P.ts0 + (long long) cur * P.ts1];
+        Dp[k] = (act[k] && p >= 1) ? tr[(long long) cur * P.ts0 + (long long) prv * P.ts1] : NINF;
+        in[k] = (const R *) P.inputs + (long long) b * P.is1 + (long long) cur * P.is2;
+        v[k] = (p == 0) ? in[k][0] : NINF;
+    }
     if (tid == 0) { line[0][0] = NINF; line[1][0] = NINF; }     // the neighbour of position 0
-    constexpr int PF = 8;
-    R ring[PF];
+    constexpr int PF = KP == 1 ? 8 : 2;
+    R ring[PF][KP];
 #pragma unroll
-    for (int k = 0; k < PF; ++k) ring[k] = in[(long long) min(1 + k, len - 1) * P.is0];
+    for (int q = 0; q < PF; ++q)
+#pragma unroll
+        for (int k = 0; k < KP; ++k) ring[q][k] = in[k][(long long) min(1 + q, len - 1) * P.is0];
     for (int t0 = 1; t0 < len; t0 += PF) {
-        R nxt[PF];
+        R nxt[PF][KP];
 #pragma unroll
-        for (int k = 0; k < PF; ++k) nxt[k] = in[(long long) min(t0 + PF + k, len - 1) * P.is0];
+        for (int q = 0; q < PF; ++q)
 #pragma unroll
-        for (int k = 0; k < PF; ++k) {
-            const int t = t0 + k;
+            for (int k = 0; k < KP; ++k) nxt[q][k] = in[k][(long long) min(t0 + PF + q, len - 1) * P.is0];
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+            const int t = t0 + q;
             if (t < len) {                                       // uniform
                 R *ln = line[t & 1];
-                ln[tid + 1] = v;
+#pragma unroll
+                for (int k = 0; k < KP; ++k) ln[tid + 1024 * k + 1] = v[k];
                 __syncthreads();
-                const R stay = v + H;
-                const R come = ln[tid] + Dp;
-                const bool take = come > stay;
-                const unsigned long long m = __ballot(take);
-                const R em = act ? ring[k] : NINF;
-                v = em + (take ? come : stay);
-                if (lane == 0) mb[(long long) t * nw + wave] = m;
+#pragma unroll
+                for (int k = 0; k < KP; ++k) {
+                    const R stay = v[k] + H[k];
+                    const R come = ln[tid + 1024 * k] + Dp[k];
+                    const bool take = come > stay;
+                    const unsigned long long m = __ballot(take);
+                    const R em = act[k] ? ring[q][k] : NINF;
+                    v[k] = em + (take ? come : stay);
+                    if (lane == 0 && in_s[k]) mb[(long long) t * nw + wave + 16 * k] = m;
+                }
             }
         }
 #pragma unroll
-        for (int k = 0; k < PF; ++k) ring[k] = nxt[k];
+        for (int q = 0; q < PF; ++q)
+#pragma unroll
+            for (int k = 0; k < KP; ++k) ring[q][k] = nxt[q][k];
     }
-    if (tid == ol - 1) best_sh = v;
+#pragma unroll
+    for (int k = 0; k < KP; ++k)
+        if (tid + 1024 * k == ol - 1) best_sh = v[k];
     __threadfence_block();
     __syncthreads();                      // also orders the mask stores of all wavefronts before the loads below
     const R best = best_sh;
@@ -206,9 +225,14 @@ hipError_t launch_viterbi_small(const Problem &P, void *work, void *scores, void
     if (P.S <= 64)
         hipLaunchKernelGGL((viterbi_small_kernel<R>), dim3(P.B), dim3(64), 0, stream, P, (unsigned long long *) work,
                            (R *) scores, (long long *) path);
-    else
-        hipLaunchKernelGGL((viterbi_wide_kernel<R>), dim3(P.B), dim3((P.S + 63) / 64 * 64), 0, stream, P,
+    else if (P.S <= 1024)
+        hipLaunchKernelGGL((viterbi_wide_kernel<R, 1>), dim3(P.B), dim3((P.S + 63) / 64 * 64), 0, stream, P,
                            (unsigned long long *) work, (R *) scores, (long long *) path);
+    else if (P.S <= 4096)
+        hipLaunchKernelGGL((viterbi_wide_kernel<R, 4>), dim3(P.B), dim3(1024), 0, stream, P,
+                           (unsigned long long *) work, (R *) scores, (long long *) path);
+    else
+        return hipErrorInvalidValue;
     return hipGetLastError();
 }
 template hipError_t launch_viterbi_small<float>(const Problem &, void *, void *, void *, hipStream_t);
