@@ -648,27 +648,29 @@ __host__ __device__ inline size_t mid_au(size_t x) { return (x + 255) & ~(size_t
 __host__ __device__ inline size_t mid_mulog_offset(size_t elem, int T, int B, int npad) {
     return mid_au((size_t) T * B * elem) + 2 * mid_au(2 * (size_t) B * npad * elem) + 2 * mid_au(3 * (size_t) B * 4) + 2 * mid_au((size_t) B * 8);
 }
-// TWO threads share a label -- thread i the first half of the columns of label i's row, thread i + NP the second half
-// (at most 128 row elements per thread: 256 in one thread spilled into accumulation registers and cost 1360 us at N = 256
-// where the pair takes 787; 724 -> 676 at N = 192, 575 -> 553 at N = 128); the upper half hands its partial sum over
-// through LDS (one more barrier per frame) and otherwise only keeps the barriers company.
-template <int NW>
-__global__ void __launch_bounds__(128 * NW) fwd_mid_kernel(Problem P, State W, FwdOut O, int mask) {
-    typedef float R;
+// (fp32, measured: 256 row elements in one thread spilled into accumulation registers and cost 1360 us at N = 256 where two
+// threads per label take 787; 724 -> 676 at N = 192, 575 -> 553 at N = 128.)
+// SP threads share a label (SP = 2 for float, 4 for double: at most 128 / 64 row elements = 128 VGPRs per thread) -- thread
+// i + q NP holds columns [q NC, (q + 1) NC) of label i's row; parts q >= 1 hand their partial sums over through LDS (one more
+// barrier per frame) and otherwise only keep the barriers company.  fp64 (round 4): the reference is double-capable everywhere
+// (utils.h:33-39); before, fp64 problems with 64 < N <= 256 took T - 1 launches of fwd_step_kernel<double> (~10 us each).
+template <typename R, int NW, int SP>
+__global__ void __launch_bounds__(64 * NW * SP) fwd_mid_kernel(Problem P, State W, FwdOut O, int mask) {
     constexpr int NP = 64 * NW;
-    constexpr bool SPLIT = true;                                 // (false: one thread per label, the round-3 original)
-    constexpr int NC = SPLIT ? NP / 2 : NP;                      // columns of its row a thread holds
-    constexpr int NWT = SPLIT ? 2 * NW : NW;                     // wavefronts of the workgroup
-    __shared__ __attribute__((aligned(16))) float pbuf[NP];      // exp-domain vector of the frame being consumed
-    __shared__ float qbuf[2][NP];                                // its log-domain twin (exact path), double buffered: the exact path
+    constexpr bool SPLIT = true;
+    constexpr int NC = NP / SP;                                  // columns of its row a thread holds
+    constexpr int NWT = SP * NW;                                 // wavefronts of the workgroup
+    __shared__ __attribute__((aligned(16))) R pbuf[NP];          // exp-domain vector of the frame being consumed
+    __shared__ R qbuf[2][NP];                                    // its log-domain twin (exact path), double buffered: the exact path
                                                                  // of a slow thread may still read it when a fast one writes the next
-    __shared__ float part[SPLIT ? NP : 1];                       // partial sums of the upper half
-    __shared__ float red[8];
+    __shared__ R part[SP - 1][NP];                               // partial sums of the other parts
+    __shared__ R red[16];
     const int b = blockIdx.x;
     const bool beta = (mask == kFullBeta) || (mask == (kFullAlpha | kFullBeta) && blockIdx.y == 1);
-    const bool upper = SPLIT && threadIdx.x >= NP;
-    const int i = (int) threadIdx.x - (upper ? NP : 0), lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c0 = upper ? NC : 0;                               // first column of this thread's share
+    const int partq = (int) threadIdx.x / NP;                    // which part of the row
+    const bool upper = partq > 0;
+    const int i = (int) threadIdx.x - partq * NP, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c0 = partq * NC;                                   // first column of this thread's share
     const int N = P.N, T = P.T;
     const int len = P.in_len ? gclampi(P.in_len[b], 0, T) : T;
     const R L2E = Num<R>::log2e(), LZ = Num<R>::logzero(), NINF = Num<R>::ninf();
@@ -696,7 +698,7 @@ __global__ void __launch_bounds__(128 * NW) fwd_mid_kernel(Problem P, State W, F
     }
     // emissions of this label: frame offset in an SGPR, label offset in a VGPR (32-bit: checked by the launcher)
     __amdgpu_buffer_rsrc_t rin = make_rsrc((R *) P.inputs + (int64_t) b * P.is1, 0xffffffffu);
-    const unsigned eoff = (unsigned) (ic * (int) P.is2) * 4u, frame_bytes = (unsigned) P.is0 * 4u;
+    const unsigned eoff = (unsigned) (ic * (int) P.is2) * (unsigned) sizeof(R), frame_bytes = (unsigned) P.is0 * (unsigned) sizeof(R);
     auto emis = [&](int f) -> R {
         return buf_load<R>(rin, eoff, (unsigned) __builtin_amdgcn_readfirstlane(gclampi(f, 0, len - 1)) * frame_bytes);
     };
@@ -721,11 +723,14 @@ __global__ void __launch_bounds__(128 * NW) fwd_mid_kernel(Problem P, State W, F
         const V2<R> a = a0 + a1;
         R sum = a.x + a.y;
         if constexpr (SPLIT) {
-            // the two halves of a row meet in LDS (192 < N <= 256; before the split the 256 row elements spilled into
-            // accumulation registers and cost 1007 -> 679 us only by giving up the packed FMAs)
-            if (upper) part[i] = sum;
+            // the parts of a row meet in LDS (before the split the 256 row elements of N = 256 spilled into accumulation
+            // registers and cost 1007 -> 679 us only by giving up the packed FMAs)
+            if (upper) part[partq - 1][i] = sum;
             __syncthreads();
-            if (!upper) sum += part[i];
+            if (!upper) {
+#pragma unroll
+                for (int q = 0; q < SP - 1; ++q) sum += part[q][i];
+            }
         }
         return sum;
     };
@@ -1226,10 +1231,10 @@ constexpr size_t kClusterBytes = 8u << 20;       // exchange vectors of every cl
 
 // the medium-alphabet route: fp32, 64 < N <= 256, 32-bit emission offsets (ASG_NO_MID=1: the per-frame launches instead)
 static bool mid_alphabet(const Problem &P, size_t elem) {
-    if (elem != 4 || P.N <= 64 || P.N > 256) return false;
+    if (P.N <= 64 || P.N > 256) return false;
     const char *ev = getenv("ASG_NO_MID");
     if (ev && atoi(ev) != 0) return false;
-    const double fr = (double) (P.T - 1) * (double) P.is0 * 4.0, ln = (double) (P.N - 1) * (double) P.is2 * 4.0;
+    const double fr = (double) (P.T - 1) * (double) P.is0 * (double) elem, ln = (double) (P.N - 1) * (double) P.is2 * (double) elem;
     return P.is0 >= 0 && P.is2 >= 0 && fr < 4294967296.0 && ln < 2147483648.0;
 }
 
@@ -2146,21 +2151,26 @@ __global__ void __launch_bounds__(64) rowoff_kernel(Problem P, int *rowoff) {
 //                        Gm[n][m] <- (ok) ? Gm[n][m] / C : 0          (U overwrites G in place)
 //   MODE 1 (outer prod): A(m,k) = Gm[k][m] (m contiguous), B(k,n) = Pm[k][n] (n contiguous), epilogue
 //                        out[m][n] = C * ehat[m][n]
+// MODE 1 with kslice > 0: blockIdx.z takes rows [z kslice, (z + 1) kslice) of the frame axis and writes its partial sums to
+// partial[z] (no E factor: gemm_combine_kernel adds the slices in order and applies it) -- an output of a few 64 x 64 tiles
+// otherwise leaves the device to a handful of workgroups (fp64, N = 128: 4 workgroups, 5.2 ms for a 25 600-row contraction).
 template <typename R, int MODE>
 __global__ void __launch_bounds__(256) bwd_gemm_kernel(const R *ehat, const R *Pm, R *Gm, R *out, int N, int npad, int K,
-                                                       int *anybad) {
+                                                       int *anybad, int kslice = 0, R *partial = nullptr) {
     constexpr int BK = 16;
     __shared__ __attribute__((aligned(16))) R As[BK][64 + 4];
     __shared__ __attribute__((aligned(16))) R Bs[BK][64 + 4];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
-    const int Mdim = N, Ndim = MODE == 0 ? K : N, Kdim = MODE == 0 ? npad : K;
+    const int Mdim = N, Ndim = MODE == 0 ? K : N;
+    const int kbeg = (MODE == 1 && kslice > 0) ? (int) blockIdx.z * kslice : 0;
+    const int Kdim = MODE == 0 ? npad : ((MODE == 1 && kslice > 0) ? min(K, kbeg + kslice) : K);
     R acc[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[a][c] = 0;
-    for (int k0 = 0; k0 < Kdim; k0 += BK) {
+    for (int k0 = kbeg; k0 < Kdim; k0 += BK) {
         for (int e = threadIdx.x; e < 64 * BK; e += 256) {
             if (MODE == 0) {
                 int mm = e / BK, kk = e - mm * BK;
@@ -2207,6 +2217,8 @@ __global__ void __launch_bounds__(256) bwd_gemm_kernel(const R *ehat, const R *P
                 const bool mark = !ok && g != R(0);
                 Gm[(int64_t) gn * npad + gm_] = ok ? g / sden : (mark ? Num<R>::ninf() : R(0));
                 if (mark) *anybad = 1;
+            } else if (kslice > 0) {
+                partial[(int64_t) blockIdx.z * N * N + (int64_t) gm_ * N + gn] = acc[a][c];
             } else {
                 out[(int64_t) gm_ * N + gn] = acc[a][c] * ehat[(int64_t) gm_ * npad + gn];
             }
@@ -2329,11 +2341,12 @@ __global__ void __launch_bounds__(256) bwd_gemm_mfma(const float *ehat, const fl
 }
 
 // out[m][n] = ehat[m][n] * sum over the slices of partial[z][m][n], slices in ascending order.  grid = ceil(N^2 / 256).
-__global__ void __launch_bounds__(256) gemm_combine_kernel(const float *partial, int nslices, const float *ehat, int N, int npad, float *out) {
+template <typename R>
+__global__ void __launch_bounds__(256) gemm_combine_kernel(const R *partial, int nslices, const R *ehat, int N, int npad, R *out) {
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= N * N) return;
     const int m = k / N, n = k - m * N;
-    float a[4] = {0, 0, 0, 0};
+    R a[4] = {0, 0, 0, 0};
     int z = 0;
     for (; z + 4 <= nslices; z += 4) {
 #pragma unroll
@@ -2837,13 +2850,12 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
         }
     }
     if (full_mask && mid_alphabet(P, sizeof(R))) {
-        if constexpr (sizeof(R) == 4) {
-            dim3 grid(P.B, __builtin_popcount(full_mask));
-            const int nw = (P.N + 63) / 64;
-            if (nw <= 2) hipLaunchKernelGGL((fwd_mid_kernel<2>), grid, dim3(256), 0, stream, P, W, O, full_mask);
-            else if (nw == 3) hipLaunchKernelGGL((fwd_mid_kernel<3>), grid, dim3(384), 0, stream, P, W, O, full_mask);
-            else hipLaunchKernelGGL((fwd_mid_kernel<4>), grid, dim3(512), 0, stream, P, W, O, full_mask);
-        }
+        dim3 grid(P.B, __builtin_popcount(full_mask));
+        const int nw = (P.N + 63) / 64;
+        constexpr int SP = sizeof(R) == 4 ? 2 : 4;          // threads per label (fwd_mid_kernel)
+        if (nw <= 2) hipLaunchKernelGGL((fwd_mid_kernel<R, 2, SP>), grid, dim3(128 * SP), 0, stream, P, W, O, full_mask);
+        else if (nw == 3) hipLaunchKernelGGL((fwd_mid_kernel<R, 3, SP>), grid, dim3(192 * SP), 0, stream, P, W, O, full_mask);
+        else hipLaunchKernelGGL((fwd_mid_kernel<R, 4, SP>), grid, dim3(256 * SP), 0, stream, P, W, O, full_mask);
     } else if (full_mask) {
         if (!W.work) return hipErrorInvalidValue;
         char *wk = (char *) W.work;
@@ -3009,7 +3021,7 @@ size_t bwd_scratch_bytes_generic(int elem, int T, int B, int N, int S) {
     size_t tiles = N <= 64 ? au((size_t) B * nch * N * N * elem) : 0;             // bwd_aligned_long_kernel
     if (N > 64 && N <= 2048) tiles = au((size_t) N * N * 8);                      // aligned_tr_scatter_fx_kernel
     if (S > 1024 && tiles < au((size_t) N * N * 8)) tiles = au((size_t) N * N * 8);      // (very long targets: the same accumulator for any N <= 2048)
-    if (elem == 4 && N > 64) tiles += au((size_t) gemm_slices(N, B * T) * N * N * 4);       // split contraction: partial sums
+    if (N > 64) tiles += au((size_t) gemm_slices(N, B * T) * N * N * elem);       // split contraction: partial sums
     return 2 * au((size_t) B * T * npad * elem) + au((size_t) B * nch * 2 * S * elem) + 512 + au(((size_t) B + 1) * 4) + tiles;
 }
 
@@ -3064,7 +3076,7 @@ hipError_t launch_bwd_generic(const Problem &P, const State &W, const BwdArgs &A
                 hipLaunchKernelGGL((bwd_gemm_mfma<1>), dim3((P.N + 127) / 128, (P.N + 127) / 128, nsl), dim3(256), 0, stream,
                                    (const float *) W.ehat, (const float *) Pm, (float *) Gm, (float *) gtr, P.N, npad, K, anybad,
                                    (const int *) (rowoff + P.B), kslice, (float *) gpart);
-                hipLaunchKernelGGL(gemm_combine_kernel, dim3((P.N * P.N + 255) / 256), dim3(256), 0, stream, (const float *) gpart,
+                hipLaunchKernelGGL((gemm_combine_kernel<float>), dim3((P.N * P.N + 255) / 256), dim3(256), 0, stream, (const float *) gpart,
                                    nsl, (const float *) W.ehat, P.N, npad, (float *) gtr);
             } else {
                 hipLaunchKernelGGL((bwd_gemm_mfma<1>), dim3((P.N + 127) / 128, (P.N + 127) / 128), dim3(256), 0, stream,
@@ -3075,8 +3087,17 @@ hipError_t launch_bwd_generic(const Problem &P, const State &W, const BwdArgs &A
         } else {
             hipLaunchKernelGGL((bwd_gemm_kernel<R, 0>), dim3((P.N + 63) / 64, (K + 63) / 64), dim3(256), 0, stream,
                                (const R *) W.ehat, Pm, Gm, gtr, P.N, npad, K, anybad);
-            hipLaunchKernelGGL((bwd_gemm_kernel<R, 1>), dim3((P.N + 63) / 64, (P.N + 63) / 64), dim3(256), 0, stream,
-                               (const R *) W.ehat, Pm, Gm, gtr, P.N, npad, K, anybad);
+            const int nsl = gemm_slices(P.N, K);
+            if (nsl > 1) {
+                const int kslice = ((K + nsl - 1) / nsl + 15) / 16 * 16;
+                hipLaunchKernelGGL((bwd_gemm_kernel<R, 1>), dim3((P.N + 63) / 64, (P.N + 63) / 64, nsl), dim3(256), 0, stream,
+                                   (const R *) W.ehat, Pm, Gm, gtr, P.N, npad, K, anybad, kslice, gpart);
+                hipLaunchKernelGGL((gemm_combine_kernel<R>), dim3((P.N * P.N + 255) / 256), dim3(256), 0, stream, (const R *) gpart,
+                                   nsl, (const R *) W.ehat, P.N, npad, gtr);
+            } else {
+                hipLaunchKernelGGL((bwd_gemm_kernel<R, 1>), dim3((P.N + 63) / 64, (P.N + 63) / 64), dim3(256), 0, stream,
+                                   (const R *) W.ehat, Pm, Gm, gtr, P.N, npad, K, anybad);
+            }
         }
         hipLaunchKernelGGL((bwd_fix_kernel<R>), dim3(P.T, P.B), dim3(256), 0, stream, P, W, A, Gm, gtr, npad, anybad,
                            StepUsesMfma<R>::v ? (const int *) rowoff : (const int *) nullptr);
