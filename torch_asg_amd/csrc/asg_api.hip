@@ -138,10 +138,28 @@ State to_state(const asg_problem *p, const void *state) {
     return W;
 }
 
+// Is `stream` being captured into a hipGraph?  (ASG_FORK_IN_CAPTURE=1 / 0: developer override of what run_forward does with it.)
+inline bool capturing(hipStream_t stream) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &st) != hipSuccess) { (void) hipGetLastError(); return false; }
+    return st == hipStreamCaptureStatusActive;
+}
+
 template <typename R>
 int run_forward(asg_ctx *ctx, const asg_problem *p, void *state, void *full_scores, void *aligned_scores,
                 int mask, bool store, int flags, hipStream_t stream, void *loss = nullptr, int reduction = 0) {
     Problem P = to_problem(p);
+    // Two streams (fork / join through ctx) only help when the two lattices' kernels really run side by side.  Recorded into a
+    // hipGraph, ROCm 7.2 replays the two branches of the SHORT kernels one after the other with ~12 us per cross-queue edge
+    // (profiles/r04_streams_graph_trace.txt: cfg 3, fwd_duo_kernel 48.6 us, then a 13 us gap, then the aligned chains 37 us,
+    // then 11 us before the backward launch): while capturing, the small path records its passes on the caller's stream.
+    bool fork_ok = true;
+    {
+        const char *ev = getenv("ASG_FORK_IN_CAPTURE");
+        const int mode = ev ? atoi(ev) : -1;             // -1: default policy
+        if (mode == 0) fork_ok = !capturing(stream);
+        else if (mode < 0) fork_ok = !(small_full(p->N) && small_aligned(p->S) && capturing(stream));
+    }
     State W = to_state(p, state);
     FwdOut O{};
     O.full_scores = full_scores;
@@ -176,7 +194,7 @@ int run_forward(asg_ctx *ctx, const asg_problem *p, void *state, void *full_scor
         // two streams also for the default launch mode: on this route the two lattices are separate launches anyway (one
         // launch per lattice, or per frame), and overlapping them is worth more than the fork / join costs (T=1000 B=64
         // N=40 S=200: 492 -> 420 us per step inside a hipGraph)
-        bool two = (flags & (ASG_FLAG_STREAMS | ASG_FLAG_SINGLE_LAUNCH)) && ctx && full_mask && ali_mask;
+        bool two = (flags & (ASG_FLAG_STREAMS | ASG_FLAG_SINGLE_LAUNCH)) && ctx && full_mask && ali_mask && fork_ok;
         hipStream_t s2 = two ? ctx->side : stream;
         if (two) {
             if ((e = hipEventRecord(ctx->fork, stream)) != hipSuccess) return hip_status(e);
@@ -203,7 +221,7 @@ int run_forward(asg_ctx *ctx, const asg_problem *p, void *state, void *full_scor
     // chains, which are a launch of their own there anyway: the two overlap on two streams also in the default launch mode
     const bool batched_two = (flags & ASG_FLAG_SINGLE_LAUNCH) && sizeof(R) == 4 && batched_forward_applies(P, W, mask) &&
                              !(getenv("ASG_BATCHED_SEQ") && atoi(getenv("ASG_BATCHED_SEQ")) != 0);      // (developer A/B: one stream)
-    if (((flags & ASG_FLAG_STREAMS) || batched_two) && ctx && full_mask && ali_mask) {
+    if (((flags & ASG_FLAG_STREAMS) || batched_two) && ctx && full_mask && ali_mask && fork_ok) {
         // fork: aligned passes on the side stream, full passes on the caller's stream; join back.
         if ((e = hipEventRecord(ctx->fork, stream)) != hipSuccess) return hip_status(e);
         if ((e = hipStreamWaitEvent(ctx->side, ctx->fork, 0)) != hipSuccess) return hip_status(e);
