@@ -259,10 +259,13 @@ def test_generic_edge_cases(T, B, N, L, il, tl):
 def test_unsupported_shapes_fail_loudly():
     A = _asg()
     m = A.ASGLoss(5).to(DEV)
-    x = torch.randn(1100, 1, 5, device=DEV)
-    tg = torch.zeros(1, 1025, dtype=torch.long, device=DEV)
+    x = torch.randn(4200, 1, 5, device=DEV)
+    tg = torch.zeros(1, 4097, dtype=torch.long, device=DEV)          # targets beyond 4096 positions
     with pytest.raises(RuntimeError, match="unsupported"):
         m(x, tg)
+    m2 = A.ASGLoss(2100).to(DEV)                                         # ... and beyond 1024 only up to 2048 labels
+    with pytest.raises(RuntimeError, match="unsupported"):
+        m2(torch.randn(1100, 1, 2100, device=DEV), torch.zeros(1, 1025, dtype=torch.long, device=DEV))
 
 
 def test_generic_forward_only_and_determinism():
