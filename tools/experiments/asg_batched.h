@@ -1,3 +1,7 @@
+// NOT BUILT, NOT SHIPPED: the round-2 experiment (sixteen utterances per ONE wavefront), kept for the record with its numbers in
+// README.md.  The product code of that idea's successor is torch_asg_amd/csrc/asg_batched.h + asg_batched.hip (round 4, a group of
+// sixteen utterances spread over the wavefronts of a workgroup); the first line below names the path this file had when it was built.
+//
 // torch_asg_amd/csrc/asg_batched.h -- full-lattice alpha / beta recursions for LARGE batches (fp32, N <= 64):
 // SIXTEEN utterances per wavefront, the per-step product  s[i][b] = sum_j E[i][j] u[j][b]  on the matrix cores.
 //
