@@ -179,9 +179,9 @@ def test_alpha_and_beta_scores_agree():
     util.assert_close(ali[B:], o["aligned_scores"], 1e-5, "aligned alpha")
 
 
-@pytest.mark.parametrize("launch_mode", ["single", "serial"])
+@pytest.mark.parametrize("launch_mode", ["single", "serial", "serial-rowsum"])
 @pytest.mark.parametrize("case", ["wide_transitions", "neginf_transitions", "huge_emission_range", "logit_scale"])
-def test_exact_fallback_paths(case, launch_mode):
+def test_exact_fallback_paths(case, launch_mode, monkeypatch):
     """Inputs that push row sums of the exp-domain mat-vec out of fp32 range, so the kernels must take their
     exact log-sum-exp path (forward) / exact softmax path (backward); checked against the fp64 oracle."""
     g = torch.Generator().manual_seed(42)
@@ -205,7 +205,11 @@ def test_exact_fallback_paths(case, launch_mode):
     tl = torch.tensor([6, 4, 5])
     o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il.numpy(), tl.numpy(), "none")
     assert np.isfinite(o["loss"]).all()
-    # 'serial' = the stand-alone kernels (the MFMA assembly flags a workgroup and redoes it with the per-frame code)
+    # 'serial' = the stand-alone kernels (the MFMA assembly flags a workgroup and redoes it with the per-frame code: on a NaN in the
+    # alpha pass's scale log, or -- 'serial-rowsum', the large-batch kernel -- on a recomputed row sum outside the safe range)
+    if launch_mode == "serial-rowsum":
+        monkeypatch.setenv("ASG_BWD_ROWSUM", "1")
+        launch_mode = "serial"
     r = run_hip(x, tg, tr, il, tl, "none", launch_mode=launch_mode)
     for k in ("loss", "grad_inputs", "grad_transition"):
         util.assert_close(r[k], o[k], 1e-4, "%s/%s/%s" % (case, launch_mode, k))
@@ -770,11 +774,15 @@ def test_large_batch_routes_to_standalone_kernels_and_agrees():
             util.assert_close(r[k], o[k], 1e-4, "B=%d %s" % (B, k))
 
 
+@pytest.mark.parametrize("rowsum", ["0", "1"])
 @pytest.mark.parametrize("T,B,N,L", [(70, 5, 40, 30), (33, 3, 63, 50), (16, 2, 5, 3), (129, 2, 17, 33), (47, 4, 64, 64),
-                                     (401, 3, 40, 30), (15, 3, 33, 15), (64, 2, 48, 32)])
-def test_standalone_assembly_blocks(T, B, N, L):
+                                     (401, 3, 40, 30), (15, 3, 33, 15), (64, 2, 48, 32), (200, 130, 40, 30)])
+def test_standalone_assembly_blocks(T, B, N, L, rowsum, monkeypatch):
     """The stand-alone route's gradient assembly works on 16-frame blocks (full lattice on the matrix cores, aligned
-    lattice batched in the same layout): block tails, every label / target-position tile count, variable lengths."""
+    lattice batched in the same layout): block tails, every label / target-position tile count, variable lengths.
+    Both fp32 kernels: row sums from the alpha pass's scale log (ASG_BWD_ROWSUM=0: what small working sets get; B = 130 has the
+    one-wavefront chains write the log, the smaller batches the three-wavefront chains) and recomputed (=1: large ones)."""
+    monkeypatch.setenv("ASG_BWD_ROWSUM", rowsum)
     tr, x, tg, il, tl = util.synth(T, B, N, L, T + N, True)
     o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il.numpy(), tl.numpy(), "none")
     r = run_hip(x, tg, tr, il, tl, "none", launch_mode="serial")

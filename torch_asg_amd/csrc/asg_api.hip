@@ -47,7 +47,7 @@ inline int hip_status(hipError_t e) { return e == hipSuccess ? ASG_OK : ASG_ERR_
 inline size_t align_up(size_t x) { return (x + 255) & ~(size_t) 255; }
 
 struct Layout {
-    size_t ah, bh, ab, bb, ehat, fhat, rmax, cmax, etile, ftile, asu, asi, dbg, ticket, xflags, work, total;
+    size_t ah, bh, ab, bb, klog, ehat, fhat, rmax, cmax, etile, ftile, asu, asi, dbg, ticket, xflags, work, total;
     int npad;
 };
 
@@ -65,6 +65,7 @@ Layout make_layout(const asg_problem *p) {
     const size_t ea = small_aligned((int64_t) S) ? e : 8;
     L.ab = off; off = align_up(off + B * T * S * ea);
     L.bb = off; off = align_up(off + B * T * S * ea);
+    if (small_full(p->N)) { L.klog = off; off = align_up(off + B * T * 2 * e); }      // scale log of the alpha pass (ScaleLog)
     L.npad = small_full(p->N) ? (int) ((N + 7) / 8 * 8) : (int) ((N + 3) / 4 * 4);
     L.ehat = off; off = align_up(off + N * L.npad * e);
     L.rmax = off; off = align_up(off + N * e);
@@ -132,7 +133,7 @@ State to_state(const asg_problem *p, const void *state) {
         W.dbg = base + L.dbg;
         W.ticket = (unsigned *) (base + L.ticket);
         if (!small_full(p->N)) W.work = base + L.work;
-        else W.xflags = (int *) (base + L.xflags);
+        else { W.xflags = (int *) (base + L.xflags); W.klog = base + L.klog; }
     }
     W.npad = L.npad;
     return W;

@@ -319,11 +319,15 @@ __device__ __forceinline__ float bsel(unsigned mk, float x, float other) {
 }
 __device__ __forceinline__ float band(unsigned mk, float x) { return __uint_as_float(__float_as_uint(x) & mk); }
 
+// ---- variant that RECOMPUTES the row sums (round 2's kernel): for batches whose states and emissions do not fit the 256 MB
+// memory-side cache.  It reads nothing but the four state arrays (the scale-log variant below reads the emissions again: 22 %
+// more traffic, which at B = 4096 costs more than its 30 matrix instructions save: 937 against 890 us per step; at B = 512,
+// where everything the forward launch touched is still cache-resident, it is the other way round: 131 against 139 us).
 // The aligned lattice's share of the same frames is batched the same way: lane 16 g + m holds target position 16 r + m of
 // frame tb + 4 g + q, the per-frame softmax is a 16-lane DPP row reduction, the scatter back to labels goes through a
 // per-wavefront fixed-point LDS frame buffer (integer adds commute: deterministic) that is read back in the natural
 // layout, so every grad_inputs row is written once, complete.
-template <int NP> struct MfmaLds {
+template <int NP> struct MfmaRsLds {
     static constexpr int NT = (NP + 15) / 16, KS = (NP + 3) / 4, STR = 16 * NT + 4;
     union {
         struct {
@@ -337,16 +341,16 @@ template <int NP> struct MfmaLds {
 };
 
 template <int NP, int ST>
-__global__ void __launch_bounds__(256, ST <= 2 ? 2 : 1) bwd_mfma_kernel(Problem P, State W, BwdArgs A, int parts) {
+__global__ void __launch_bounds__(256, ST <= 2 ? 2 : 1) bwd_mfma_rs_kernel(Problem P, State W, BwdArgs A, int parts) {
     typedef float R;
     constexpr int NT = (NP + 15) / 16, KS = (NP + 3) / 4, STR = 16 * NT + 4;
     union Lds {
         AssembleLds<float, NP, 4> S;             // the per-frame code (exact redo of a flagged workgroup)
-        MfmaLds<NP> M;
+        MfmaRsLds<NP> M;
     };
     __shared__ Lds L;
     __shared__ int s_bad;
-    MfmaLds<NP> &M = L.M;
+    MfmaRsLds<NP> &M = L.M;
     const int b = blockIdx.x, chunk = blockIdx.y;
     R *tile_out = (R *) A.scratch + ((int64_t) b * A.nchunks + chunk) * P.N * P.N;
     const bool do_ali = (parts & 2) && P.targets;
@@ -632,6 +636,404 @@ __global__ void __launch_bounds__(256, ST <= 2 ? 2 : 1) bwd_mfma_kernel(Problem 
 
     for (int tb = t0 + 16 * wave; tb < t1; tb += 64) process(X0, tb);
     if (do_ali) {
+#pragma unroll
+        for (int r = 0; r < ST; ++r) {
+            const int s = 16 * r + m;
+            if (s < ol) {
+                if (accH[r] != R(0)) atomicAdd(&M.fxT[tgt[r] * N + tgt[r]], to_fix<R>(accH[r]));
+                if (s >= 1 && accD[r] != R(0)) atomicAdd(&M.fxT[tgt[r] * N + prv[r]], to_fix<R>(accD[r]));
+            }
+        }
+    }
+    if (__any(bad) && lane == 0) s_bad = 1;
+    __syncthreads();
+    if (s_bad) {         // rare: the per-frame code owns the exact treatment of unusable row sums
+        assemble_frames<float, NP, 4>(P, W, A, parts, b, chunk, tile_out, L.S);
+        return;
+    }
+    // one partial tile per workgroup: the four wavefronts' accumulators in a fixed order, scaled by Ehat
+    constexpr int CT = (NP * NP + 255) / 256;
+    R eh[CT];
+#pragma unroll
+    for (int n = 0; n < CT; ++n) {           // in flight during the combine below
+        const int k = min((int) threadIdx.x + 256 * n, N * N - 1), i = k / N, j = k - i * N;
+        eh[n] = ehat[(int64_t) i * W.npad + j];
+    }
+    // every wavefront stores its accumulators to its own slot (plain pipelined LDS writes; a read-modify-write per
+    // element pays the LDS latency per element); alphabets too large for four slots take two rounds
+    constexpr int TW = NP <= 48 ? 4 : 2;
+    for (int ph = 0; ph < 4 / TW; ++ph) {
+        if (wave / TW == ph) {
+            float *slot = M.tileF[wave % TW];
+#pragma unroll
+            for (int ri = 0; ri < NT; ++ri)
+#pragma unroll
+                for (int rj = 0; rj < NT; ++rj)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int i = 16 * ri + 4 * g + q, j = 16 * rj + m;
+                        const int at = (i < N && j < N) ? i * NP + j : NP * NP;
+                        slot[at] = (ph == 0 ? 0.f : slot[at]) + acc[ri * NT + rj][q];
+                    }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int n = 0; n < CT; ++n) {
+        const int k = threadIdx.x + 256 * n;
+        if (k < N * N) {
+            const int i = k / N, j = k - i * N;
+            R t = M.tileF[0][i * NP + j];
+#pragma unroll
+            for (int w2 = 1; w2 < TW; ++w2) t += M.tileF[w2][i * NP + j];      // fixed order
+            R v = t * eh[n];
+            const unsigned long long fv = M.fxT[k];
+            if (fv != 0) v += ga * from_fix<R>(fv);
+            tile_out[k] = v;
+        }
+    }
+}
+
+// The aligned lattice's share of the same frames is batched the same way: lane 16 g + m holds target position 16 r + m of
+// frame tb + 4 g + q, the per-frame softmax is a 16-lane DPP row reduction, the scatter back to labels goes through a
+// per-wavefront fixed-point LDS frame buffer (integer adds commute: deterministic) that is read back in the natural
+// layout, so every grad_inputs row is written once, complete.
+//
+// Round 4: the row sums are not recomputed.  u_i = posterior_i / s_i with s_i = 2^(ah[t][i] - arg_i), arg_i the exponent of the
+// emission factor the alpha pass used (its ScaleLog, asg_kernels.h, gives the two frame scalars; the emission is read again):
+//     u_i = g * 2^(bh[t][i] + arg_i - max_t) / Z_t            -- ah[t][i] cancels
+// so the first product (30 of the 66 matrix instructions at N = 40, which on gfx950 run on the same vector ALU as everything
+// else), its LDS transpose and the per-element range test are gone; a frame the alpha pass produced with its exact per-node
+// code has a NaN in the log and sends the workgroup to the per-frame code.  No per-element selects: frames outside the
+// utterance load a valid frame's states instead (clamped rows) and drop out through their per-frame factor.
+#ifndef ASG_BWD_ABL
+#define ASG_BWD_ABL 0           // developer timing probes (wrong results): 1 no row stores, 2 no state / emission loads, 4 no matrix
+#endif                          // instructions, 8 no LDS scatter of the aligned posteriors
+template <int NP> struct MfmaLds {
+    static constexpr int NT = (NP + 15) / 16;
+    union {
+        unsigned fxI[4][16][16 * NT];            // per wavefront: aligned state posteriors of the block, scattered to labels
+        float tileF[NP <= 48 ? 4 : 2][NP * NP + 1];   // after the frame loop: the wavefronts' tiles (+1: dump slot of padding)
+    };
+    unsigned long long fxT[NP * NP];             // aligned edge posteriors (unscaled, fixed point)
+};
+
+template <int NP, int ST, bool ALI>
+__global__ void __launch_bounds__(256, ST <= 2 ? 2 : 1) bwd_mfma_kernel(Problem P, State W, BwdArgs A, int parts) {
+    typedef float R;
+    constexpr int NT = (NP + 15) / 16;
+    union Lds {
+        AssembleLds<float, NP, 4> S;             // the per-frame code (exact redo of a flagged workgroup)
+        MfmaLds<NP> M;
+    };
+    __shared__ Lds L;
+    __shared__ int s_bad;
+    MfmaLds<NP> &M = L.M;
+    const int b = blockIdx.x, chunk = blockIdx.y;
+    R *tile_out = (R *) A.scratch + ((int64_t) b * A.nchunks + chunk) * P.N * P.N;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // which quarter of the chunk's blocks this wavefront takes: rotated with the workgroup's position in the launch, so that the
+    // wavefronts that get one block more than the others (25 blocks over 4 wavefronts at T = 400) do not all sit on SIMD 0
+    const int wq = (wave + ((blockIdx.x + gridDim.x * blockIdx.y) >> 8)) & 3;
+    const int g = lane >> 4, m = lane & 15;
+    const int N = P.N, T = P.T, S = P.S;
+    const R NINF = Num<R>::ninf(), LZ = Num<R>::logzero(), L2E = Num<R>::log2e();
+    const int len = P.in_len ? clampi(P.in_len[b], 0, T) : T;
+    const int ol = ALI ? (P.tg_len ? clampi(P.tg_len[b], 0, S) : S) : 0;
+    const int t0 = chunk * A.chunk, t1 = min(T, t0 + A.chunk), lim = min(t1, len);
+    const R g0 = A.unit_grad ? (R) A.gscale
+                             : (A.grad_full ? (R) ((double) ((const R *) A.grad_full)[(int64_t) b * A.gstride] * A.gscale) : R(0));
+    const R gf = g0;
+    const R ga = ALI ? (A.neg_aligned ? -g0 : (R) ((double) ((const R *) A.grad_aligned)[(int64_t) b * A.gstride] * A.gscale))
+                     : R(0);
+    // states through raw buffer loads: lane offset = (clamped frame row) * row bytes + 4 m, the label / position tile is
+    // the instruction's immediate offset; elements past a row's end are masked below, past the buffer's end read 0
+    __amdgpu_buffer_rsrc_t r_ah = make_rsrc((R *) W.ah + (int64_t) b * T * N, (unsigned) T * (unsigned) N * 4u);
+    __amdgpu_buffer_rsrc_t r_bh = make_rsrc((R *) W.bh + (int64_t) b * T * N, (unsigned) T * (unsigned) N * 4u);
+    __amdgpu_buffer_rsrc_t r_ab = make_rsrc((R *) W.ab + (int64_t) b * T * S, (unsigned) T * (unsigned) S * 4u);
+    __amdgpu_buffer_rsrc_t r_bb = make_rsrc((R *) W.bb + (int64_t) b * T * S, (unsigned) T * (unsigned) S * 4u);
+    __amdgpu_buffer_rsrc_t r_k = make_rsrc((R *) W.klog + (int64_t) b * T * 2, (unsigned) T * 8u);
+    // emissions: frame and label offsets in elements of the caller's strides (launch_bwd_small checks that they fit 32 bits)
+    __amdgpu_buffer_rsrc_t r_in = make_rsrc((R *) P.inputs + (int64_t) b * P.is1, 0xffffffffu);
+    __amdgpu_buffer_rsrc_t rs_g = make_rsrc((R *) A.grad_inputs + (int64_t) b * N,
+                                            (unsigned) ((int64_t) (T - 1) * P.B * N + N) * 4u);
+    const unsigned rbN = (unsigned) N * 4u, rbS = (unsigned) S * 4u, rbG = (unsigned) P.B * (unsigned) N * 4u;
+    const unsigned rbX = (unsigned) P.is0 * 4u, tileX = 16u * (unsigned) P.is2 * 4u;
+    // (labels past N in the last tile read label N - 1: inside the tensor whatever its strides; their values only reach tile rows >= N)
+    const unsigned m4 = (unsigned) m * 4u, mX = (unsigned) m * (unsigned) P.is2 * 4u;
+    const unsigned mXl = (unsigned) min(16 * (NT - 1) + m, N - 1) * (unsigned) P.is2 * 4u;
+    // position s - 1 of the previous frame: one element to the left (position 0 has no left neighbour: masked by Dp = logzero)
+    const unsigned m4l = m4 >= 4u ? m4 - 4u : 0u;
+    struct BlockRegs {
+        R a[NT][4], bh[NT][4], ap0[NT], x[NT][4];
+        V2<R> k[4];                              // scale log of the lane group's four frames: {zb, ex}
+    };
+    struct AlignedRegs {
+        R xa[ST][4], xb[ST][4], xm[ST][4], xp0[ST];
+    };
+    // Frame rows are clamped into the utterance's part of the chunk, [0, lim): a frame outside it reads a valid frame's states
+    // (finite, so nothing below needs a per-element select) and is taken out by its per-frame factor (Zw / Zu / Z2 below).
+    const int rmaxf = max(lim, 1) - 1;
+    auto issue_aligned = [&](AlignedRegs &X, int tb) {
+        if (ASG_BWD_ABL & 2) {
+#pragma unroll
+            for (int r = 0; r < ST; ++r) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { asm volatile("" : "=v"(X.xa[r][q])); asm volatile("" : "=v"(X.xb[r][q])); asm volatile("" : "=v"(X.xm[r][q])); }
+                asm volatile("" : "=v"(X.xp0[r]));
+            }
+            return;
+        }
+        const int tf = tb + 4 * g;
+        unsigned row[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) row[q] = (unsigned) min(tf + q, rmaxf);
+        const unsigned rowp = (unsigned) clampi(tf - 1, 0, rmaxf);
+#pragma unroll
+        for (int r = 0; r < ST; ++r) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                X.xa[r][q] = buf_load<R>(r_ab, row[q] * rbS + m4 + 64u * r, 0u);
+                X.xb[r][q] = buf_load<R>(r_bb, row[q] * rbS + m4 + 64u * r, 0u);
+                const unsigned rp = q == 0 ? rowp : row[q - 1];
+                X.xm[r][q] = buf_load<R>(r_ab, rp * rbS + (r == 0 ? m4l : m4 + 64u * r - 4u), 0u);
+            }
+            X.xp0[r] = buf_load<R>(r_ab, rowp * rbS + m4 + 64u * r, 0u);
+        }
+    };
+    auto issue_loads = [&](BlockRegs &X, int tb) {
+        if (ASG_BWD_ABL & 2) {
+#pragma unroll
+            for (int r = 0; r < NT; ++r) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { asm volatile("" : "=v"(X.a[r][q])); asm volatile("" : "=v"(X.bh[r][q])); asm volatile("" : "=v"(X.x[r][q])); }
+                asm volatile("" : "=v"(X.ap0[r]));
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) X.k[q] = V2<R>{R(1), R(0)};
+            return;
+        }
+        const int tf = tb + 4 * g;
+        unsigned row[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) row[q] = (unsigned) min(tf + q, rmaxf);
+        const unsigned rowp = (unsigned) clampi(tf - 1, 0, rmaxf);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            typedef unsigned u2v __attribute__((ext_vector_type(2)));
+            const u2v kk = __builtin_amdgcn_raw_buffer_load_b64(r_k, row[q] * 8u, 0u, 0);
+            X.k[q] = V2<R>{__uint_as_float(kk.x), __uint_as_float(kk.y)};
+        }
+#pragma unroll
+        for (int r = 0; r < NT; ++r) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                X.a[r][q] = buf_load<R>(r_ah, row[q] * rbN + m4 + 64u * r, 0u);
+                X.bh[r][q] = buf_load<R>(r_bh, row[q] * rbN + m4 + 64u * r, 0u);
+                X.x[r][q] = r == NT - 1 ? buf_load<R>(r_in, row[q] * rbX + mXl, 0u) : buf_load<R>(r_in, row[q] * rbX + mX, tileX * (unsigned) r);
+            }
+            X.ap0[r] = buf_load<R>(r_ah, rowp * rbN + m4 + 64u * r, 0u);
+        }
+    };
+    // the first block's states are requested before anything else: the prologue below then runs inside their latency
+    BlockRegs X0;
+    if (t0 + 16 * wq < lim) issue_loads(X0, t0 + 16 * wq);
+    const R *ehat = (const R *) W.ehat;
+    const R mark = ((const R *) W.klog)[(int64_t) b * T * 2];
+    R Ri[NT];
+#pragma unroll
+    for (int r = 0; r < NT; ++r) Ri[r] = ((const R *) W.rmax)[min(16 * r + m, N - 1)];
+    for (int k = threadIdx.x; k < N * N; k += 256) M.fxT[k] = 0;
+    if (ALI)
+        for (int k = lane; k < 16 * 16 * NT; k += 64) (&M.fxI[wave][0][0])[k] = 0;
+    if (threadIdx.x == 0) s_bad = 0;
+
+    const bool lv_last = 16 * (NT - 1) + m < N;          // (tiles before the last are complete: NP - 8 < N)
+    // aligned lattice: this lane's target positions
+    bool sv[ST];
+    int tgt[ST], prv[ST];
+    R H2[ST], Dp[ST], accH[ST], accD[ST];
+#pragma unroll
+    for (int r = 0; r < ST; ++r) {
+        const int s = 16 * r + m;
+        sv[r] = ALI && s < S;
+        const int sc = sv[r] ? s : 0;
+        V2<R> hd = {0, 0};
+        int2 tp = {0, 0};
+        if (ALI) {
+            hd = reinterpret_cast<const V2<R> *>(W.asu)[(int64_t) b * S + sc];
+            tp = reinterpret_cast<const int2 *>(W.asi)[(int64_t) b * S + sc];
+        }
+        H2[r] = hd.x; Dp[r] = hd.y; tgt[r] = tp.x; prv[r] = tp.y;
+        accH[r] = 0; accD[r] = 0;
+    }
+    V4<R> acc[NT * NT];
+#pragma unroll
+    for (int q = 0; q < NT * NT; ++q) acc[q] = V4<R>{0, 0, 0, 0};
+    // an alpha pass that left no scale log (none does: a stale buffer would say so) -> the per-frame code
+    bool bad = len >= 1 && !(mark == R(kScaleLogMark));
+    __syncthreads();
+
+    const unsigned lvm_last = bmask(lv_last), lvo_last = lv_last ? 0u : kOobOffset;
+    unsigned svm[ST];
+#pragma unroll
+    for (int r = 0; r < ST; ++r) svm[r] = bmask(sv[r]);
+    const R LZ2 = LZ + LZ;
+
+    auto process = [&](BlockRegs &C, int tb) {
+        const int tf = tb + 4 * g;               // first of this lane group's four frames
+        if (tb >= lim) {                          // beyond the utterance: zero rows
+#pragma unroll
+            for (int r = 0; r < NT; ++r)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    buf_store(R(0), rs_g, ((r < NT - 1 || lv_last) && tf + q < t1) ? (unsigned) (tf + q) * rbG + m4 + 64u * r : kOobOffset, 0u);
+            return;
+        }
+        unsigned fvm[4], t1m[4];                  // frame inside the utterance / has a predecessor
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { fvm[q] = bmask(tf + q < lim); t1m[q] = fvm[q] & bmask(tf + q >= 1); }
+        AlignedRegs Q;
+        if (ALI) issue_aligned(Q, tb);          // consumed after the full-lattice part of the block
+        // ---- full lattice
+        R w[NT][4], p[NT][4], ua[NT][4];
+        R mg[4], Z[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const R kz = C.k[q].x, kx = C.k[q].y;
+            bad |= !(kz == kz);                  // NaN: a frame of the exact per-node code
+            R mx = NINF;
+#pragma unroll
+            for (int r = 0; r < NT; ++r) {
+                // (labels past N: whatever the neighbouring row holds; they only reach tile rows / columns >= N)
+                p[r][q] = Num<R>::exp2(q == 0 ? C.ap0[r] : C.a[r][q - 1]);
+                R ww = C.a[r][q] + C.bh[r][q];
+                if (r == NT - 1) ww = bsel(lvm_last, ww, NINF);
+                w[r][q] = ww;
+                mx = fmaxf(mx, ww);
+                // exponent of the alpha pass's emission factor, rounded as the alpha pass rounded it
+                ua[r][q] = C.bh[r][q] + (__builtin_fmaf(C.x[r][q], L2E, Ri[r] - kz) - kx);
+            }
+            mg[q] = fmaxf(mx, LZ);
+        }
+        // the states are consumed: the next block's travel in the same registers while the rest of this one is processed
+        // (a second register set instead cost 27 VGPRs and 9 % at B = 4096)
+        __builtin_amdgcn_sched_barrier(0);
+        if (tb + 64 < lim) issue_loads(C, tb + 64);
+        __builtin_amdgcn_sched_barrier(0);
+        row16_allmax4(mg);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            R z = 0;
+#pragma unroll
+            for (int r = 0; r < NT; ++r) {
+                w[r][q] = Num<R>::exp2(w[r][q] - mg[q]);
+                z += w[r][q];
+            }
+            Z[q] = z;
+        }
+        row16_allsum4(Z);
+        R Zw[4], Zu[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const R zi = band(bmask(Z[q] > 0), gf * Num<R>::rcp(Z[q]));
+            Zw[q] = band(fvm[q], zi);            // frames outside the utterance: zero row, no edge
+            Zu[q] = band(t1m[q], zi);            // frame 0: no edge
+        }
+        R u[NT][4];
+#pragma unroll
+        for (int r = 0; r < NT; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                u[r][q] = Num<R>::exp2(ua[r][q] - mg[q]) * Zu[q];           // posterior / row sum
+                w[r][q] *= Zw[q];                                            // posterior (times the upstream gradient)
+            }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int ri = 0; ri < NT; ++ri)
+#pragma unroll
+                for (int rj = 0; rj < NT; ++rj)
+                    if (ASG_BWD_ABL & 4) acc[ri * NT + rj][q] += u[ri][q] * p[rj][q];
+                    else acc[ri * NT + rj] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[ri][q], p[rj][q], acc[ri * NT + rj], 0, 0, 0);
+        // ---- aligned lattice: state posteriors -> label frame buffer, edge posteriors -> accH / accD
+        __builtin_amdgcn_sched_barrier(0);
+        if (ALI) {
+            R gm[ST][4], mg2[4], Z2[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                R mx = LZ2;
+#pragma unroll
+                for (int r = 0; r < ST; ++r) {
+                    gm[r][q] = bsel(svm[r], Q.xa[r][q] + Q.xb[r][q], LZ2);
+                    mx = fmaxf(mx, gm[r][q]);
+                }
+                mg2[q] = mx;
+            }
+            row16_allmax4(mg2);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                R z = 0;
+#pragma unroll
+                for (int r = 0; r < ST; ++r) {
+                    gm[r][q] = Num<R>::exp2(gm[r][q] - mg2[q]);
+                    z += gm[r][q];
+                }
+                Z2[q] = z;
+            }
+            row16_allsum4(Z2);
+            R Z2e[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {    // an infeasible alignment (all states at log zero) has no posterior
+                const R zi = band(bmask(mg2[q] > R(-1e29)) & bmask(Z2[q] > 0), Num<R>::rcp(Z2[q]));
+                Z2[q] = band(fvm[q], zi);
+                Z2e[q] = band(t1m[q], zi);
+            }
+#pragma unroll
+            for (int r = 0; r < ST; ++r)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (!(ASG_BWD_ABL & 8)) atomicAdd(&M.fxI[wave][4 * g + q][tgt[r]], FrameFix<R>::to(gm[r][q] * Z2[q]));
+                    // stay / arrive shares of the state posterior: softmax over the two incoming edges,
+                    // 1 / (1 + 2^-|d|) and its complement (one exp2 and one rcp instead of a log-sum-exp and two exp2).
+                    // Position 0 has no left neighbour: its arrive share dies with Dp = log zero (the state read for it is
+                    // position 0's own, finite).
+                    const R post2 = gm[r][q] * Z2e[q];
+                    const R pc0 = (q == 0 ? Q.xp0[r] : Q.xa[r][q - 1]) + H2[r];
+                    const R pc1 = Q.xm[r][q] + Dp[r];
+                    const R d = pc1 - pc0;
+                    const R tt = Num<R>::exp2(-fabsf(d));
+                    const R big = Num<R>::rcp(R(1) + tt), small = tt * big;
+                    accH[r] += post2 * (d <= R(0) ? big : small);
+                    accD[r] += post2 * (d <= R(0) ? small : big);
+                }
+        }
+        // ---- rows: full posterior + the aligned posteriors scattered to this label
+        __builtin_amdgcn_sched_barrier(0);
+        unsigned so[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) so[q] = tf + q < t1 ? (unsigned) (tf + q) * rbG + m4 : kOobOffset;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < NT; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                R v = w[r][q];
+                if (ALI) {
+                    unsigned *fp = &M.fxI[wave][4 * g + q][16 * r + m];
+                    v += ga * FrameFix<R>::from(*fp);
+                    *fp = 0;
+                }
+                if (ASG_BWD_ABL & 1) { if (v == R(12345.678f)) buf_store(v, rs_g, so[q], 0u); }
+                else buf_store(v, rs_g, r == NT - 1 ? max(so[q] + 64u * r, lvo_last) : so[q] + 64u * r, 0u);
+            }
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    for (int tb = t0 + 16 * wq; tb < t1; tb += 64) process(X0, tb);
+    if (ALI) {
 #pragma unroll
         for (int r = 0; r < ST; ++r) {
             const int s = 16 * r + m;

@@ -200,6 +200,11 @@ __device__ void full_chain_x16(const Problem &P, const State &W, const FwdOut &O
     __amdgpu_buffer_rsrc_t rst = make_rsrc(BETA ? (R *) W.bh : (R *) W.ah, O.no_store ? 0u : (unsigned) ((int64_t) B * T * N) * 4u);
     const unsigned fstride = (ones && padlane) ? 0u : (unsigned) P.is0 * 4u, row_bytes = (unsigned) N * 4u;
     const int lenm1 = len >= 1 ? len - 1 : 0;
+    // alpha: the scale log of the stored states (ScaleLog, asg_kernels.h), one entry per frame and utterance, by lane group 0 of
+    // wavefront 0
+    __amdgpu_buffer_rsrc_t rsk = make_rsrc((R *) W.klog, (!BETA && !O.no_store) ? (unsigned) ((int64_t) B * T * 2) * 4u : 0u);
+    const bool klane = !BETA && w == 0 && g == 0 && uv;
+    const unsigned koff = (unsigned) ((int64_t) b * T * 2) * 4u;
 
     // frame `t` of this lane's utterance (clamped to the utterance: what lies beyond its end is never read)
     auto load_frame = [&](V4<R> &x, int t) {
@@ -392,6 +397,7 @@ __device__ void full_chain_x16(const Problem &P, const State &W, const FwdOut &O
 #pragma unroll
             for (int r = 0; r < 4; ++r) { row[r] = tl[r] - m0; mine[r] = Num<R>::exp2(row[r]); }
             store_row(row, 0, len >= 1);
+            buf_store2(V2<R>{R(kScaleLogMark), R(0)}, rsk, (klane && len >= 1) ? koff : kOobOffset, 0u);
         } else {
             // beta: the utterances whose last frame is f0 join here with beta = 0, i.e. d = 2^-X; the others run on their clamped
             // last frame until their own join overwrites them
@@ -449,13 +455,14 @@ __device__ void full_chain_x16(const Problem &P, const State &W, const FwdOut &O
         }
         const int ex = Rng<R>::expo(nrm);
         const R exf = (VEC && padlane && ones) ? R(0) : (R) ex;
+        if (!BETA) buf_store2(V2<R>{zb, (R) ex}, rsk, (klane && nn < len) ? koff + (unsigned) nn * 8u : kOobOffset, 0u);
         __builtin_amdgcn_sched_barrier(0);
         mfma_range(d0, d1, 2 * G, 3 * G);
         __builtin_amdgcn_sched_barrier(0);
         // ---- (3) this frame's emission factors: arguments
         V4<R> e;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) e[r] = fmaf(xr[r], L2Er[r], Xz[r] - exf);
+        for (int r = 0; r < 4; ++r) e[r] = fmaf(xr[r], L2Er[r], Xz[r]) - exf;      // (rounded as the scale log says)
         if (BETA) csum += ex;
         else if (want_score) csum += nn < len ? ex : 0;
         __builtin_amdgcn_sched_barrier(0);

@@ -250,12 +250,13 @@ template <typename R, int NP, int MV, bool STORE, bool GUARD>
 __device__ __forceinline__ bool full_alpha_block(const R (&cur)[kPF], int nsteps, unsigned soff0, unsigned row_bytes,
                                                  const V2<R> (&e2)[NP / 2], R RiX, unsigned long long actmask, int N,
                                                  R *lds, int lane, __amdgpu_buffer_rsrc_t rs, unsigned voff,
-                                                 R &p, R &ah, double &C
+                                                 R &p, R &ah, double &C, __amdgpu_buffer_rsrc_t rsk, unsigned koff
 #ifdef ASG_PROBE
                                                  , long long (&prb)[4]
 #endif
                                                  ) {
     const R L2E = Num<R>::log2e();
+    R kx = 0;      // lane k: the power-of-two exponent folded into frame k's emission factor (scale log of the gradient pass)
 #ifdef ASG_PROBE
     const long long pc0 = clock64();
 #endif
@@ -293,6 +294,7 @@ __device__ __forceinline__ bool full_alpha_block(const R (&cur)[kPF], int nsteps
                     const int ex = scale_exponent<R, NP>(s_prev, p, N);
                     arg_n -= (R) ex;
                     csum += ex;
+                    if (STORE) kx = lane == k + 1 ? (R) ex : kx;
                 }
                 ee_n = Num<R>::exp2(arg_n);
             }
@@ -318,6 +320,8 @@ __device__ __forceinline__ bool full_alpha_block(const R (&cur)[kPF], int nsteps
         ah = Num<R>::log2(s_prev) + arg_prev;
         if (STORE) buf_store(ah, rs, voff, soff0 + (unsigned) ((GUARD ? nsteps : kPF) - 1) * row_bytes);
     }
+    // scale log: frame k of the block was stored as log2(row sum) + I2 + Ri - zb - kx  (ScaleLog, asg_kernels.h)
+    if (STORE) buf_store2(V2<R>{zb, kx}, rsk, lane < (GUARD ? nsteps : kPF) ? (unsigned) lane * (unsigned) (2 * sizeof(R)) : kOobOffset, koff);
     C += (double) zb * (double) (GUARD ? nsteps : kPF) + (double) csum;
     return (__ballot(wlo < Rng<R>::lo || whi > Rng<R>::hi) & actmask) != 0;
 }
@@ -393,6 +397,12 @@ __device__ void full_alpha_chain(const Problem &P, const State &W, const FwdOut 
     const unsigned row_bytes = (unsigned) N * sizeof(R);
     __amdgpu_buffer_rsrc_t rs = make_rsrc((R *) W.ah + (int64_t) b * T * N, (STORE && !O.no_store) ? (unsigned) T * row_bytes : 0u);
     const unsigned voff = act ? (unsigned) lane * sizeof(R) : kOobOffset;
+    // scale log of this utterance ([T][2]; slot 0 = validity mark): see ScaleLog in asg_kernels.h
+    constexpr unsigned kb = 2u * (unsigned) sizeof(R);
+    __amdgpu_buffer_rsrc_t rsk = make_rsrc((R *) W.klog + (int64_t) b * T * 2, (STORE && !O.no_store) ? (unsigned) T * kb : 0u);
+    auto void_log = [&](int t_first, int n) {      // frames redone by the exact code: no row-sum relation to log
+        buf_store2(V2<R>{Num<R>::nan(), R(0)}, rsk, lane < n ? (unsigned) lane * kb : kOobOffset, (unsigned) t_first * kb);
+    };
 
     double C = 0.0;
     R ah = NINF;
@@ -404,6 +414,7 @@ __device__ void full_alpha_chain(const Problem &P, const State &W, const FwdOut 
             ah = x - m;
             C = (double) m;
             if (STORE) buf_store(ah, rs, voff, 0u);
+            if (STORE) buf_store2(V2<R>{R(kScaleLogMark), R(0)}, rsk, lane == 0 ? 0u : kOobOffset, 0u);
         }
         // frames 1 .. len-1 in blocks of kPF, emissions prefetched one block ahead
         const int nst = len - 1;
@@ -431,7 +442,7 @@ __device__ void full_alpha_chain(const Problem &P, const State &W, const FwdOut 
                 const double C0 = C;
                 const bool redo = full_alpha_block<R, NP, MV, STORE, false>(cur, kPF, (unsigned) (1 + done) * row_bytes,
                                                                             row_bytes, e2, RiX, actmask, N, lds, lane, rs,
-                                                                            voff, p, ah, C ASG_PRB);
+                                                                            voff, p, ah, C, rsk, (unsigned) (1 + done) * kb ASG_PRB);
                 // consume the prefetched frames BEFORE the (rare) branch: the load-completion wait is then an
                 // exact vmcnt(#stores) here, instead of a conservative drain of the store queue after the merge
                 // The 16 prefetch loads were issued before this block's 16 stores: "at most 16 VMEM ops outstanding"
@@ -446,6 +457,7 @@ __device__ void full_alpha_chain(const Problem &P, const State &W, const FwdOut 
                     ah = r.v;
                     C = r.C;
                     p = Num<R>::exp2(ah);
+                    if (STORE) void_log(1 + done, kPF);
                 }
             }
         }
@@ -459,11 +471,12 @@ __device__ void full_alpha_chain(const Problem &P, const State &W, const FwdOut 
             const R ah0 = ah;
             const double C0 = C;
             if (full_alpha_block<R, NP, MV, STORE, true>(cur, nst - done, (unsigned) (1 + done) * row_bytes, row_bytes, e2,
-                                                         RiX, actmask, N, lds, lane, rs, voff, p, ah, C ASG_PRB)) {
+                                                         RiX, actmask, N, lds, lane, rs, voff, p, ah, C, rsk, (unsigned) (1 + done) * kb ASG_PRB)) {
                 ChainState<R> r = slow_full_steps<R, false>(in, P.is0, trow, P.ts1, N, lane, 1 + done, nst - done, ah0,
                                                             C0, (R *) W.ah + (int64_t) b * T * N + lc, N, STORE && !O.no_store);
                 ah = r.v;
                 C = r.C;
+                if (STORE) void_log(1 + done, nst - done);
             }
         }
     }
@@ -1085,6 +1098,7 @@ struct DuoLds {
     int prod_done;     // producer -> consumer: zsum is final
     double zsum;       // producer -> consumer: sum of the block scales
     float x[64];       // producer -> consumer: row / column maxima
+    float zb[4];       // producer -> consumer (alpha): block scales of the last four 16-frame blocks (scale log)
     // the buffer main broadcasts step n's vector through, and the helpers' common "stop" test
     static constexpr int kR = kRing;       // ring depth in frames (a multiple of 32)
     __device__ __forceinline__ float *pslot(int) { return p; }
@@ -1101,6 +1115,10 @@ __device__ __forceinline__ void lds_store_rel(int *p, int v) { __hip_atomic_stor
 __device__ __forceinline__ void lds_store_rlx(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ float lds_ldf(float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void lds_stf(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// the producer's block scale for the consumer's scale log (the fused step's rings have no such consumer)
+template <class LdsT> __device__ __forceinline__ void post_block_scale(LdsT &, int, float) {}
+__device__ __forceinline__ void post_block_scale(DuoLds &L, int K, float zb) { lds_stf(&L.zb[K & 3], zb); }
 
 // mat-vec consumer with `EXTRA` younger LDS operations in flight behind the broadcast reads
 // The main wavefront of the duo path is not issue-bound (about 40 instructions per 240-cycle step), so it waits for
@@ -1350,6 +1368,7 @@ __device__ __forceinline__ void duo_producer(const Problem &P, int b, LdsT &L, c
             lds_stf(&L.e[half + j][lane], Num<R>::exp2(arg));
         }
         zsum += (double) zb * (double) nv;
+        if (!BETA && lane == 0) post_block_scale(L, K, zb);
         // one wavefront's LDS operations execute in order: the counter lands after the values, no wait needed
         asm volatile("" ::: "memory");
         lds_store_rlx(&L.e_prod, min((K + 1) * kPF, len));
@@ -1393,6 +1412,10 @@ __device__ __forceinline__ void duo_consumer(const Problem &P, const State &W, c
     const unsigned row_bytes = (unsigned) N * sizeof(R);
     __amdgpu_buffer_rsrc_t rs = make_rsrc((R *) (BETA ? W.bh : W.ah) + (int64_t) b * T * N, (STORE && !O.no_store) ? (unsigned) T * row_bytes : 0u);
     const unsigned voff = act ? (unsigned) lane * sizeof(R) : kOobOffset;
+    // alpha: scale log of the stored states (ScaleLog, asg_kernels.h).  This chain stores log2 s_{n-1} + arg_n and applies the
+    // rescale exponent to the VECTOR of step n (n % 4 == 3, exponent of lane N of s_{n-2}), so entry t carries the exponent of
+    // step t - 1: the gradient pass's row sums are those of 2^ah[t-1], i.e. 2^ex times the recursion's.
+    __amdgpu_buffer_rsrc_t rsk = make_rsrc((R *) W.klog + (int64_t) b * T * 2, (!BETA && STORE && !O.no_store) ? (unsigned) T * 8u : 0u);
     auto frame = [&](int n) { return BETA ? len - 1 - n : n; };
     bool bad = false;
     // X (and block 0 of the rings) are there once the producer has published its first block
@@ -1416,6 +1439,7 @@ __device__ __forceinline__ void duo_consumer(const Problem &P, const State &W, c
         }
     };
     if (STORE && !bad) buf_store((BETA ? XX : lds_ldf(&L.a[0][lane])) + Num<R>::log2(sv), rs, voff, (unsigned) frame(0) * row_bytes);
+    if (STORE && !BETA && !bad) buf_store2(V2<R>{R(kScaleLogMark), R(0)}, rsk, lane == 0 ? 0u : kOobOffset, 0u);
     int n = 1;
     constexpr int GS = 8;                     // frames per poll: amortises the LDS round trips
     while (n < len && !bad) {
@@ -1423,6 +1447,15 @@ __device__ __forceinline__ void duo_consumer(const Problem &P, const State &W, c
         // same addresses), which keeps the code free of predicates
         const int g = min(GS, len - n);
         if (!wait_slot(n + g - 2)) { bad = true; break; }
+        if (!BETA) {      // arg (and the block scale) of the group's last frame: the producer is normally a block ahead of this
+            int spins = 0;
+            while (lds_load_rlx(&L.e_prod) < n + g) {
+                if (++spins > kSpinCap || lds_load_rlx(&L.kill)) { bad = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (bad) break;
+            asm volatile("" ::: "memory");
+        }
         R sg[GS], ag[GS];
 #pragma unroll
         for (int q = 0; q < GS; ++q) {
@@ -1447,6 +1480,14 @@ __device__ __forceinline__ void duo_consumer(const Problem &P, const State &W, c
 #pragma unroll
             for (int q = 0; q < GS; ++q)
                 buf_store(ag[q] + Num<R>::log2(sg[q]), rs, voff, (unsigned) frame(n + min(q, g - 1)) * row_bytes);
+        }
+        if (STORE && !BETA) {
+            // groups start at n = 1 (mod 8): frames n + 3 and n + 7 follow a rescaled step
+            static_assert(GS == 8 && kRenorm == 4, "scale log of the three-wavefront chain");
+            const int ex3 = __builtin_amdgcn_readlane(Rng<R>::expo(sg[1]), N), ex7 = __builtin_amdgcn_readlane(Rng<R>::expo(sg[5]), N);
+            const R zbv = lds_ldf(&L.zb[((n + lane) >> 4) & 3]);
+            const R kxv = lane == 3 ? (R) ex3 : (lane == 7 ? (R) ex7 : R(0));
+            buf_store2(V2<R>{zbv, kxv}, rsk, lane < g ? (unsigned) (n + lane) * 8u : kOobOffset, 0u);
         }
         sv = sg[GS - 1];
         n += g;

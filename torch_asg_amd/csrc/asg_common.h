@@ -24,6 +24,7 @@ template <typename R> struct Num;
 
 template <> struct Num<float> {
     static __device__ __forceinline__ float ninf() { return -__builtin_inff(); }
+    static __device__ __forceinline__ float nan() { return __builtin_nanf(""); }
     static __device__ __forceinline__ float exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32
     static __device__ __forceinline__ float log2(float x) { return __builtin_amdgcn_logf(x); }    // v_log_f32
     static __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }      // v_rcp_f32
@@ -35,6 +36,7 @@ template <> struct Num<float> {
 
 template <> struct Num<double> {
     static __device__ __forceinline__ double ninf() { return -__builtin_inf(); }
+    static __device__ __forceinline__ double nan() { return __builtin_nan(""); }
     static __device__ __forceinline__ double exp2(double x) { return ::exp2(x); }
     static __device__ __forceinline__ double log2(double x) { return ::log2(x); }
     static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
@@ -224,6 +226,17 @@ __device__ __forceinline__ void buf_store(double v, __amdgpu_buffer_rsrc_t rs, u
     typedef unsigned u2 __attribute__((ext_vector_type(2)));
     u2 w = {(unsigned) __double2loint(v), (unsigned) __double2hiint(v)};
     __builtin_amdgcn_raw_buffer_store_b64(w, rs, voff, soff, 0);
+}
+
+// two consecutive elements in one store (a scale-log entry)
+__device__ __forceinline__ void buf_store2(V2<float> v, __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    __builtin_amdgcn_raw_buffer_store_b64(u2{__float_as_uint(v.x), __float_as_uint(v.y)}, rs, voff, soff, 0);
+}
+__device__ __forceinline__ void buf_store2(V2<double> v, __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    __builtin_amdgcn_raw_buffer_store_b128(u4{(unsigned) __double2loint(v.x), (unsigned) __double2hiint(v.x),
+                                              (unsigned) __double2loint(v.y), (unsigned) __double2hiint(v.y)}, rs, voff, soff, 0);
 }
 
 // raw buffer loads: per-lane byte offset in a VGPR, per-frame byte offset in an SGPR (one s_mul / s_add per load

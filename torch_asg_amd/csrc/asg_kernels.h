@@ -29,8 +29,17 @@ struct Problem {
 //   fhat/cmax      column-normalised twin (generic path only)
 //   asu [B][S][2]  per target position: {Tr2[O_s][O_s], Tr2[O_s][O_{s-1}]}  (log-zero where undefined)
 //   asi [B][S][2]  int32 {O_s, O_{s-1}}
+// ScaleLog (small path, klog [B][T][2]): what the full-lattice alpha pass folded into frame t's emission factor besides the
+// emission and the row maximum -- entry t = {zb, ex}: the block scale and the power-of-two exponent, such that
+//     sum_j ehat[i][j] * 2^ah[t-1][j]  =  2^( ah[t][i] - (fma(I[t][i], log2 e, rmax[i] - zb) - ex) )       (t >= 1)
+// holds for the stored states with the chain's own rounding of the bracket.  The gradient pass recovers the row sums of the
+// forward recursion from it (bwd_mfma_kernel) instead of recomputing them.  zb = NaN: the frame was produced by the exact
+// per-node code and has no such relation.  Entry 0 = {kScaleLogMark, 0}, written by every alpha pass that stores states.
+constexpr float kScaleLogMark = 1.0f;
+
 struct State {
     void *ah, *bh, *ab, *bb;
+    void *klog;
     void *ehat, *fhat, *rmax, *cmax;
     void *etile, *ftile;   // generic path, fp32: ehat / fhat again in the MFMA step kernel's operand order (asg_generic.hip)
     void *asu;
