@@ -881,6 +881,7 @@ __global__ void __launch_bounds__(256, ST <= 2 ? 2 : 1) bwd_mfma_kernel(Problem 
 #pragma unroll
     for (int r = 0; r < ST; ++r) svm[r] = bmask(sv[r]);
     const R LZ2 = LZ + LZ;
+    const R gafx = ga * (1.0f / 1073741824.0f);          // aligned gradient weight times the fixed-point quantum of the label scatter
 
     auto process = [&](BlockRegs &C, int tb) {
         const int tf = tb + 4 * g;               // first of this lane group's four frames
@@ -988,14 +989,14 @@ __global__ void __launch_bounds__(256, ST <= 2 ? 2 : 1) bwd_mfma_kernel(Problem 
 #pragma unroll
             for (int q = 0; q < 4; ++q) {    // an infeasible alignment (all states at log zero) has no posterior
                 const R zi = band(bmask(mg2[q] > R(-1e29)) & bmask(Z2[q] > 0), Num<R>::rcp(Z2[q]));
-                Z2[q] = band(fvm[q], zi);
+                Z2[q] = band(fvm[q], zi) * R(1073741824.0);      // (times the fixed-point scale of the label scatter: FrameFix<float>)
                 Z2e[q] = band(t1m[q], zi);
             }
 #pragma unroll
             for (int r = 0; r < ST; ++r)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    if (!(ASG_BWD_ABL & 8)) atomicAdd(&M.fxI[wave][4 * g + q][tgt[r]], FrameFix<R>::to(gm[r][q] * Z2[q]));
+                    if (!(ASG_BWD_ABL & 8)) atomicAdd(&M.fxI[wave][4 * g + q][tgt[r]], (unsigned) __builtin_rintf(gm[r][q] * Z2[q]));
                     // stay / arrive shares of the state posterior: softmax over the two incoming edges,
                     // 1 / (1 + 2^-|d|) and its complement (one exp2 and one rcp instead of a log-sum-exp and two exp2).
                     // Position 0 has no left neighbour: its arrive share dies with Dp = log zero (the state read for it is
@@ -1023,7 +1024,7 @@ __global__ void __launch_bounds__(256, ST <= 2 ? 2 : 1) bwd_mfma_kernel(Problem 
                 R v = w[r][q];
                 if (ALI) {
                     unsigned *fp = &M.fxI[wave][4 * g + q][16 * r + m];
-                    v += ga * FrameFix<R>::from(*fp);
+                    v = __builtin_fmaf((float) *fp, gafx, v);
                     *fp = 0;
                 }
                 if (ASG_BWD_ABL & 1) { if (v == R(12345.678f)) buf_store(v, rs_g, so[q], 0u); }

@@ -337,6 +337,15 @@ __device__ __forceinline__ float buf_load_sc1(__amdgpu_buffer_rsrc_t rs, unsigne
 __device__ __forceinline__ void buf_store_sc1(float v, __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, voff, soff, kSc1);
 }
+// The launches' bulk outputs (gradient rows, aligned posteriors) are written THROUGH the L2 (sc0 sc1) as they are produced instead of
+// being left dirty for the write-back at the end of the kernel: -0.5 us on the forward launch, -0.2 us on the backward launch at
+// cfg 3 (63.9 -> 63.2 us per step; A/B with tools/fused_ab.sh; nt: no gain, backward +0.6 us).  -DASG_X_OUT_AUX=0: plain stores.
+#ifndef ASG_X_OUT_AUX
+#define ASG_X_OUT_AUX 17
+#endif
+__device__ __forceinline__ void buf_store_out(float v, __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, voff, soff, ASG_X_OUT_AUX);
+}
 // global progress word of another workgroup: bounded relaxed agent-scope poll (one lane's value, uniform); the
 // utterance's kill word (same cache line) is polled with it
 __device__ __forceinline__ bool wait_global_ge(unsigned *p, unsigned need, unsigned &seen, const FullCtl &c) {
@@ -642,7 +651,7 @@ __device__ __forceinline__ void fused_consumer(const Problem &P, const State &W,
                 const R uq = div_nr(ex[q0 + q], Z[q]);
                 const R post = sg[q0 + q] * uq;
                 const int m = n + min(q0 + q, g - 1);
-                if (q0 + q < g) buf_store(post * gscale, rs_g, voffg, (unsigned) frame(m) * grow_bytes);
+                if (q0 + q < g) buf_store_out(post * gscale, rs_g, voffg, (unsigned) frame(m) * grow_bytes);
                 // xi: alpha side skips its first assembled index (the beta side's last one covers that transition)
                 const bool take = q0 + q < g && (BETA || n + q0 + q > h);
                 u[q0 + q] = (take && act) ? uq : R(0);
@@ -983,8 +992,8 @@ __device__ __forceinline__ void fused_afin(const Problem &P, const State &W, con
             u4 a = {__float_as_uint(p2v[0]), __float_as_uint(p2v[1]), __float_as_uint(p2v[2]), __float_as_uint(p2v[3])};
             u4 c = {__float_as_uint(p2v[4]), __float_as_uint(p2v[5]), __float_as_uint(p2v[6]), __float_as_uint(p2v[7])};
             // (plain stores: nothing in THIS launch reads them)
-            __builtin_amdgcn_raw_buffer_store_b128(a, rp, vQ, qoff, 0);
-            if (g > 4) __builtin_amdgcn_raw_buffer_store_b128(c, rp, vQ, qoff + (unsigned) S * 16u, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(a, rp, vQ, qoff, ASG_X_OUT_AUX);
+            if (g > 4) __builtin_amdgcn_raw_buffer_store_b128(c, rp, vQ, qoff + (unsigned) S * 16u, ASG_X_OUT_AUX);
         }
 #pragma unroll
         for (int q = 0; q < kGS; ++q) {
@@ -1464,8 +1473,14 @@ __global__ void __launch_bounds__(256) fused_bwd_kernel(Problem P, State W, Fuse
         // (mapping an utterance's blocks onto the XCD whose L2 the forward launch filled with its rows and posteriors was
         // tried: no measurable difference, 63.9 vs 63.5 us per step)
         const int b = (int) blockIdx.x / kCH, c = (int) blockIdx.x - b * kCH;
+        // everything the row pass needs to know about its utterance in ONE round of loads, ahead of the flag test (behind it they
+        // are a second and a third dependent memory round trip of a launch that is made of little else)
         const R g = ((const R *) F.grad_loss)[F.reduction == 0 ? b : 0];
-        const bool flagged = F.flags[b] != 0;
+        const int fl = F.flags[b];
+        const int len_ld = P.in_len ? clampi(P.in_len[b], 0, T) : T;
+        const int ol_ld = P.tg_len ? clampi(P.tg_len[b], 0, P.S) : P.S;
+        const int64_t tg_ld = P.targets[(int64_t) b * P.gs0 + (int64_t) ((threadIdx.x & 63) < P.S ? (threadIdx.x & 63) : 0) * P.gs1];
+        const bool flagged = fl != 0;
         if (flagged) {
             if (c != 0) return;
             FwdOut O{};
@@ -1511,17 +1526,11 @@ __global__ void __launch_bounds__(256) fused_bwd_kernel(Problem P, State W, Fuse
         }
         // ---- the rows of utterance b
         const int Sx = P.S;
-        const int len = __builtin_amdgcn_readfirstlane(P.in_len ? clampi(P.in_len[b], 0, T) : T);
+        const int len = __builtin_amdgcn_readfirstlane(len_ld);
         const int mid = crossing(len);
-        // label of target position `lane` (clamped like aligned_setup); positions >= target length carry posterior 0
-        int tgt = 0;
-        {
-            const int ol = P.tg_len ? clampi(P.tg_len[b], 0, Sx) : Sx;
-            const int sc = lane < ol ? lane : 0;
-            tgt = clampi(P.targets[(int64_t) b * P.gs0 + (int64_t) sc * P.gs1], 0, N - 1);
-            // lanes past the target add 0: give each its OWN word (all of them on one address would serialise the LDS add)
-            if (lane >= ol) tgt = lane;
-        }
+        // label of target position `lane` (clamped like aligned_setup); positions >= target length carry posterior 0:
+        // give each its OWN word (all of them on one address would serialise the LDS add)
+        const int tgt = lane < ol_ld ? clampi(tg_ld, 0, N - 1) : lane;
         const unsigned rbS = (unsigned) Sx * sizeof(R);
         __amdgpu_buffer_rsrc_t rg = make_rsrc((R *) F.rows + (int64_t) b * N,
                                               (unsigned) ((int64_t) (T - 1) * B * N + N) * (unsigned) sizeof(R));
@@ -1577,7 +1586,7 @@ __global__ void __launch_bounds__(256) fused_bwd_kernel(Problem P, State W, Fuse
                         if (r < cnt[u]) {
                             const R v = g * (row[u][r] - gscale * FrameFix<R>::from(fv[r]));
                             if (P.in_bf16) { if (lane < N) gh[(int64_t) fr[u][r] * B * N + lane] = float_to_bf16_bits(v); }
-                            else buf_store(v, rg, voff, (unsigned) fr[u][r] * grow_bytes);
+                            else buf_store_out(v, rg, voff, (unsigned) fr[u][r] * grow_bytes);
                         }
                 }
             }
@@ -1587,9 +1596,12 @@ __global__ void __launch_bounds__(256) fused_bwd_kernel(Problem P, State W, Fuse
     // ---- reducers: wait for the exact redos of the flagged utterances (normally none: no wait at all)
     const int r = (int) blockIdx.x - Bp * kCH;
     {
-        const unsigned nflag = F.ticket2[1];
+        // (both words in one access: the count of flagged utterances was written by the forward launch, the arrivals of this one
+        // normally stay 0)
+        const unsigned long long tk = __hip_atomic_load((const unsigned long long *) F.ticket2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned nflag = (unsigned) (tk >> 32);
         int spins = 0;
-        while (__hip_atomic_load(F.ticket2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nflag) {
+        while ((spins == 0 ? (unsigned) tk : __hip_atomic_load(F.ticket2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < nflag) {
             if (++spins > (1 << 24)) break;               // cannot happen: arrivals never wait on anything
             __builtin_amdgcn_s_sleep(8);
         }
