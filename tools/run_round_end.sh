@@ -7,3 +7,6 @@ timeout 900 bash tools/make_profiles.sh $TAG > $O/make_profiles.log 2>&1; tail -
 timeout 600 python tools/batch_sweep.py > $O/batch_sweep.txt 2> $O/batch_sweep.err; tail -14 $O/batch_sweep.txt
 timeout 200 python tools/host_pieces2.py > $O/host_pieces.txt 2>&1; tail -6 $O/host_pieces.txt
 timeout 200 python tools/mode_times.py > $O/mode_times.txt 2>&1; tail -5 $O/mode_times.txt
+timeout 600 python tools/batch_sweep_fine.py > $O/batch_sweep_fine.txt 2>&1; tail -19 $O/batch_sweep_fine.txt
+timeout 300 python tools/shape_times.py 3000,8,40,2000 5000,8,40,4096 3000,16,128,1500 > $O/strip_times.txt 2>&1; tail -3 $O/strip_times.txt
+bash tools/pmc_standalone.sh > $O/pmc_standalone.txt 2>&1; cp gpurun_out/pmc_standalone/*.txt $O/ 2>/dev/null

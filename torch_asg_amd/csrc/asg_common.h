@@ -219,8 +219,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(void *p, unsigned by
     return __builtin_amdgcn_make_buffer_rsrc(p, 0, bytes, 0x00020000);
 }
 constexpr unsigned kOobOffset = 0x80000000u;   // voffset of lanes that must not store
+#ifndef ASG_X_STORE_AUX
+#define ASG_X_STORE_AUX 0      // developer A/B: cache policy bits of the plain fp32 state / row stores (17 = written through the L2)
+#endif
 __device__ __forceinline__ void buf_store(float v, __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, voff, soff, ASG_X_STORE_AUX);
 }
 __device__ __forceinline__ void buf_store(double v, __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
     typedef unsigned u2 __attribute__((ext_vector_type(2)));

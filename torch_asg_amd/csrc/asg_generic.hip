@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include "asg_common.h"
+#include "asg_outer.h"
 #include "asg_kernels.h"
 
 namespace asg {
@@ -990,6 +991,11 @@ __global__ void __launch_bounds__(kClNT) fwd_cluster_kernel(Problem P, StepBuf<f
         // epilogue elements: (chain u, row rr_) = (idx & nbm, idx >> nbs), the chain count rounded up to a power of two,
         // so that small batches fill the threads of the first pass instead of a quarter of every pass
         const int nbs = nb <= 1 ? 0 : nb <= 2 ? 1 : nb <= 4 ? 2 : nb <= 8 ? 3 : 4, nbm = (1 << nbs) - 1;
+#ifdef ASG_X_CL_NO_FEW
+        const bool few = false;                   // (developer A/B)
+#else
+        const bool few = nb <= 4;                 // the product on 4 x 4 blocks (below)
+#endif
         R hm[IT];                                 // hmax of the rows this thread finishes
 #pragma unroll
         for (int it = 0; it < IT; ++it) hm[it] = S.hmax[min(i0 + ((tid + kClNT * it) >> nbs), N - 1)];
@@ -1041,7 +1047,38 @@ __global__ void __launch_bounds__(kClNT) fwd_cluster_kernel(Problem P, StepBuf<f
             for (int it = 0; it < IT; ++it) { xe[it] = xn[it]; xw[it] = wn[it]; }
             if (tid < kClNB) { pmax[tid] = fkey(-__builtin_inff()); lmax[tid] = fkey(-__builtin_inff()); }
             // ---- product: 16 rows x 16 chains x this wavefront's K range
-            {
+            if (few) {
+                // At most four chains (N = 512 at B = 64: 32 clusters, four chains each): the 16 x 16 x 4 instruction would spend
+                // 32 cycles on sixteen chain columns of which four exist.  v_mfma_f32_4x4x1_16B_f32 is sixteen INDEPENDENT 4 x 4
+                // outer products in 8 cycles; block (lane >> 2) = (row quad (lane >> 2) & 3, k slot lane >> 4) takes
+                // A = E[row 4 quad + (lane & 3)][k] -- which is where this lane's matrix registers already are -- and B = chain
+                // (lane & 3)'s element k: the same 256 multiply-adds per instruction, all of them wanted.
+                V4f acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0}, acc3 = {0, 0, 0, 0};
+                const V4<R> *bp = reinterpret_cast<const V4<R> *>(pl) + (size_t) (kbase / 4 + (lane >> 4)) * kClNB + (lane & 3);
+                V4<R> b0 = bp[0], b1 = bp[(size_t) min(1, KS4 - 1) * 4 * kClNB];
+#pragma unroll
+                for (int s4 = 0; s4 < KG; ++s4) {
+                    const V4<R> bv = b0;
+                    b0 = b1;
+                    b1 = bp[(size_t) min(s4 + 2, KS4 - 1) * 4 * kClNB];
+                    if (s4 < KS4) {
+                        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(ea[s4].x, bv.x, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(ea[s4].y, bv.y, acc1, 0, 0, 0);
+                        acc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(ea[s4].z, bv.z, acc2, 0, 0, 0);
+                        acc3 = __builtin_amdgcn_mfma_f32_4x4x1f32(ea[s4].w, bv.w, acc3, 0, 0, 0);
+                    }
+                }
+                const V4f acc = (acc0 + acc1) + (acc2 + acc3);
+                // element (row 16 mb + 4 ((lane >> 2) & 3) + q, chain lane & 3) of k slot lane >> 4 sits in register q: the four k
+                // slots are the four 16-lane rows of the wavefront -- a reduce-scatter over them (two lane swaps, three adds) leaves
+                // the complete sum of register q in row q, one element per lane
+                float a0 = acc[0], a1 = acc[1], a2 = acc[2], a3 = acc[3];
+                swap_halves(a0, a2);
+                swap_halves(a1, a3);
+                float xs = a0 + a2, ys = a1 + a3;
+                swap_rows(xs, ys);
+                red[((size_t) kh * RW + 16 * mb + 4 * ((lane >> 2) & 3) + (lane >> 4)) * 4 + (lane & 3)] = xs + ys;
+            } else {
                 V4f acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0}, acc3 = {0, 0, 0, 0};     // (independent chains: the
                                                                                               // matrix pipe never waits for a result)
                 const V4<R> *bp = reinterpret_cast<const V4<R> *>(pl) + (size_t) (kbase / 4 + (lane >> 4)) * kClNB + (lane & 15);
@@ -1078,7 +1115,8 @@ __global__ void __launch_bounds__(kClNT) fwd_cluster_kernel(Problem P, StepBuf<f
                 if (!(n < len - 1)) continue;
                 const int t = BETA ? len - 1 - n : n + 1, tw = BETA ? t - 1 : t;
                 R a = 0;
-                for (int h = 0; h < NKH; ++h) a += red[((size_t) h * RW + rr_) * kClNB + u];
+                if (few) { for (int h = 0; h < NKH; ++h) a += red[((size_t) h * RW + rr_) * 4 + u]; }
+                else { for (int h = 0; h < NKH; ++h) a += red[((size_t) h * RW + rr_) * kClNB + u]; }
                 const R muprev = fmax(mus[u], LZ);
                 const R lg = Num<R>::log2(a);
                 R rr = hm[it] + lg;
