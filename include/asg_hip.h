@@ -89,7 +89,10 @@ int asg_ctx_destroy(asg_ctx *ctx);
 int asg_stream_capture_id(void *stream, unsigned long long *id);
 
 /* Bytes of saved lattice state (forward -> backward) and of backward scratch for a problem shape.
- * Only T,B,N,S,dtype of `p` are read. */
+ * Only T,B,N,S,dtype of `p` are read.
+ * The backward entry points take the SAME problem as their forward call: `inputs` and `transition` are read again (the
+ * gradient pass recomputes the edge posteriors from the saved states and the emissions; nothing like the reference's
+ * path_contrib is stored), so both tensors must still hold the values the forward call saw. */
 size_t asg_state_bytes(const asg_problem *p);
 size_t asg_scratch_bytes(const asg_problem *p);
 
