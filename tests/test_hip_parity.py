@@ -793,6 +793,24 @@ def test_standalone_assembly_blocks(T, B, N, L, rowsum, monkeypatch):
         assert np.array_equal(r[k], r2[k]), "not deterministic: " + k
 
 
+@pytest.mark.parametrize("rowsum", ["0", "1"])
+@pytest.mark.parametrize("T,B,N,L,mode", [(31, 4, 27, 16, "serial"), (31, 4, 27, 16, "streams"), (50, 100, 40, 12, "single"), (33, 3, 64, 20, "serial")])
+def test_standalone_route_emission_offsets(T, B, N, L, mode, rowsum, monkeypatch):
+    """Emissions with a common offset of +60 / -40 nats and a spread of 30 (what tools/stress_duo.py draws) through the
+    stand-alone kernels, both assembly kernels: frame 0's state is not scaled like the later frames', and an emission factor
+    formed for it from the scale log would overflow (found by the stress run, round 4: inf * 0 in the frame without an edge)."""
+    monkeypatch.setenv("ASG_BWD_ROWSUM", rowsum)
+    for offset, scale in ((60.0, 30.0), (-40.0, 30.0), (60.0, 1.0)):
+        tr, x, tg, il, tl = util.synth(T, B, N, L, T + B, True)
+        x = x * scale + offset
+        tr = (tr - 0.5) * 8.0
+        o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il.numpy(), tl.numpy(), "none")
+        r = run_hip(x, tg, tr, il, tl, "none", launch_mode=mode)
+        for k in ("loss", "grad_inputs", "grad_transition"):
+            assert np.isfinite(r[k][np.isfinite(o[k])]).all(), "%s not finite (offset %g scale %g)" % (k, offset, scale)
+            util.assert_close(r[k], o[k], 1e-4, "offset %g scale %g %s/%s" % (offset, scale, mode, k))
+
+
 def test_very_large_batch_equals_its_chunks():
     """B = 2100 through the stand-alone route (one workgroup per utterance in the assembly, 2100 x 4 recursion chains)
     against the same utterances in chunks of 64 through the fused step: per-utterance losses and input gradients must

@@ -903,7 +903,10 @@ __global__ void __launch_bounds__(256, ST <= 2 ? 2 : 1) bwd_mfma_kernel(Problem 
         R mg[4], Z[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const R kz = C.k[q].x, kx = C.k[q].y;
+            // a frame without an incoming edge (frame 0 -- whose log entry is the validity mark -- or a clamped repeat of the last
+            // frame) gets an emission exponent of -inf: its u is then exactly 0, whatever its emissions are (u = 2^(..) * 0 with
+            // an overflowing power would be NaN: frame 0's state is not scaled like the others')
+            const R kz = bsel(t1m[q], C.k[q].x, __builtin_inff()), kx = C.k[q].y;
             bad |= !(kz == kz);                  // NaN: a frame of the exact per-node code
             R mx = NINF;
 #pragma unroll
