@@ -1,6 +1,7 @@
 // Developer micro-benchmark (gfx950): how often can ONE wavefront issue an fp32 MFMA, and how many wavefronts per SIMD
 // does it take to keep the matrix pipe at its rate?  (fwd_cluster_kernel measured 52 cycles per v_mfma_f32_16x16x4_f32
 // with one wavefront per SIMD; the pipe's rate is 32.)
+// (round 4: also v_mfma_f32_4x4x1_16B_f32 -- sixteen independent 4 x 4 outer products)
 // build: hipcc -O3 --offload-arch=gfx950 mfma_issue.hip -o mfma_issue ; run: ./mfma_issue
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -22,6 +23,7 @@ __global__ void __launch_bounds__(1024) k(float *out, long long *clk, int iters)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             if (SHAPE == 0) c4[j % NACC] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], c4[j % NACC], 0, 0, 0);
+            else if (SHAPE == 2) c4[j % NACC] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[j], b[j], c4[j % NACC], 0, 0, 0);
             else c16[j % (NACC > 2 ? 2 : NACC)] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], c16[j % (NACC > 2 ? 2 : NACC)], 0, 0, 0);
         }
     }
@@ -47,7 +49,7 @@ void run(const char *what, int threads) {
     float ms = 0; hipEventElapsedTime(&ms, e0, e1);
     long long h = 0; hipMemcpy(&h, clk, 8, hipMemcpyDeviceToHost);
     const double per = (double) h / (iters * 8.0);
-    const double flops = 256.0 * (threads / 64) * iters * 8.0 * 2048.0 * (SHAPE == 0 ? 1.0 : 2.0);
+    const double flops = 256.0 * (threads / 64) * iters * 8.0 * 2048.0 * (SHAPE == 0 ? 1.0 : SHAPE == 2 ? 0.25 : 2.0);
     printf("%-30s %2d wavefront(s) per SIMD: %6.1f ticks per MFMA per wavefront, %5.1f per SIMD; kernel %.3f ms = %.0f TFLOP/s (events)\n", what, threads / 256, per,
            per / (threads / 256), ms, flops / (ms * 1e-3) / 1e12);
     hipFree(out); hipFree(clk);
@@ -58,6 +60,9 @@ int main() {
         run<0, 1>("16x16x4 f32, 1 accumulator", threads);
         run<0, 4>("16x16x4 f32, 4 accumulators", threads);
         run<0, 8>("16x16x4 f32, 8 accumulators", threads);
+        run<2, 1>("4x4x1 (16 blocks) f32, 1 accumulator", threads);
+        run<2, 4>("4x4x1 (16 blocks) f32, 4 accumulators", threads);
+        run<2, 8>("4x4x1 (16 blocks) f32, 8 accumulators", threads);
         run<1, 1>("32x32x2 f32, 1 accumulator", threads);
         run<1, 2>("32x32x2 f32, 2 accumulators", threads);
     }
