@@ -341,7 +341,7 @@ template <int NP> struct MfmaRsLds {
 };
 
 template <int NP, int ST>
-__global__ void __launch_bounds__(256, ST <= 2 ? 2 : 1) bwd_mfma_rs_kernel(Problem P, State W, BwdArgs A, int parts) {
+__global__ void __launch_bounds__(256, (ST <= 2 && NP <= 48) ? 2 : 1) bwd_mfma_rs_kernel(Problem P, State W, BwdArgs A, int parts) {
     typedef float R;
     constexpr int NT = (NP + 15) / 16, KS = (NP + 3) / 4, STR = 16 * NT + 4;
     union Lds {
@@ -719,7 +719,7 @@ template <int NP> struct MfmaLds {
 };
 
 template <int NP, int ST, bool ALI>
-__global__ void __launch_bounds__(256, ST <= 2 ? 2 : 1) bwd_mfma_kernel(Problem P, State W, BwdArgs A, int parts) {
+__global__ void __launch_bounds__(256, (ST <= 2 && NP <= 48) ? 2 : 1) bwd_mfma_kernel(Problem P, State W, BwdArgs A, int parts) {
     typedef float R;
     constexpr int NT = (NP + 15) / 16;
     union Lds {

@@ -237,12 +237,12 @@ __device__ void full_chain_x16(const Problem &P, const State &W, const FwdOut &O
     // own tile (natural layout) -> B-operand order -> the other wavefronts; one barrier; everybody's tile back
 #ifdef ASG_X16_PROBE
     long long prb[6] = {0, 0, 0, 0, 0, 0}, pq0 = 0, pq1 = 0;      // cycles: transposes + write, barrier, read, products + shadow, tail, steps
-#define ASG_PRB(stmt) stmt
+#define ASG_XPRB(stmt) stmt
 #else
-#define ASG_PRB(stmt)
+#define ASG_XPRB(stmt)
 #endif
     auto exchange = [&](const V4<R> &mine, int par) {
-        ASG_PRB(const long long pa = clock64(); prb[4] += pa - pq1;)
+        ASG_XPRB(const long long pa = clock64(); prb[4] += pa - pq1;)
         R tb[4] = {mine[0], mine[1], mine[2], mine[3]};
         frames_to_operands(tb);
         if (ASG_X16_ABL & 2) {
@@ -252,30 +252,21 @@ __device__ void full_chain_x16(const Problem &P, const State &W, const FwdOut &O
         }
         if (NT > 1) {
             *reinterpret_cast<V4<R> *>(&L.xch[par][w][lane][0]) = V4<R>{tb[0], tb[1], tb[2], tb[3]};
-            ASG_PRB(asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long pb = clock64(); prb[0] += pb - pa;)
+            ASG_XPRB(asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long pb = clock64(); prb[0] += pb - pa;)
             if (ASG_X16_ABL & 16) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             else wg_barrier();
-            ASG_PRB(const long long pc = clock64(); prb[1] += pc - pb;)
+            ASG_XPRB(const long long pc = clock64(); prb[1] += pc - pb;)
 #pragma unroll
             for (int ww = 0; ww < NT; ++ww) {
                 const V4<R> o = *reinterpret_cast<const V4<R> *>(&L.xch[par][ww][lane][0]);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) vb[4 * ww + q] = o[q];
             }
-            ASG_PRB(asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); prb[2] += clock64() - pc;)
+            ASG_XPRB(asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); prb[2] += clock64() - pc;)
         } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q) vb[q] = tb[q];
         }
-    };
-    auto product = [&](V4<R> &d) {
-        V4<R> d0 = {0, 0, 0, 0}, d1 = {0, 0, 0, 0};
-#pragma unroll
-        for (int q = 0; q < KS; ++q) {
-            if (q & 1) d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[q], vb[q], d1, 0, 0, 0);
-            else d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[q], vb[q], d0, 0, 0, 0);
-        }
-        d = d0 + d1;
     };
     // L1 norm of the exchanged vector, summed on the VALU (padding slots hold 0 -- or, in `ones` mode, lie outside the sum:
     // the first padding k-step is ceil(N / 4) >= the number of k-steps that carry labels)
@@ -429,7 +420,7 @@ __device__ void full_chain_x16(const Problem &P, const State &W, const FwdOut &O
         constexpr int G = (KS + 4) / 5;               // matrix instructions per group
         const int ft = frame_of(nn);
         V4<R> d0 = {0, 0, 0, 0}, d1 = {0, 0, 0, 0};
-        ASG_PRB(pq0 = clock64(); prb[5] += 1;)
+        ASG_XPRB(pq0 = clock64(); prb[5] += 1;)
         mfma_range(d0, d1, 0, G);
         __builtin_amdgcn_sched_barrier(0);
         // ---- (1) the previous frame's state: log2
@@ -475,7 +466,7 @@ __device__ void full_chain_x16(const Problem &P, const State &W, const FwdOut &O
         __builtin_amdgcn_sched_barrier(0);
         mfma_range(d0, d1, 4 * G, KS);
         __builtin_amdgcn_sched_barrier(0);
-        ASG_PRB(pq1 = clock64(); prb[3] += pq1 - pq0;)
+        ASG_XPRB(pq1 = clock64(); prb[3] += pq1 - pq0;)
         // ---- dependent on the product
         const V4<R> d = d0 + d1;
         watch(d);
