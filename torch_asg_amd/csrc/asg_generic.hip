@@ -1371,10 +1371,13 @@ __global__ void __launch_bounds__(64) aligned_long_kernel(Problem P, State W, Fw
         return;
     }
     const double kZ = -1e30, L2Ed = 1.4426950408889634;
+    // log2(2^x + 2^y) = max + log2(1 + 2^-|x - y|): the difference in double, the correction term in the problem's precision (the
+    // modulus and the sign are source modifiers of the conversion and of v_exp).  No clamp at log zero inside a step: log zero is
+    // -1e30, a state can fall below it by one -1e30 per frame until the next renormalisation (every 4 frames) clamps it --
+    // nowhere near the range of a double -- and the stores clamp what they write.
     auto lse2d = [&](double x, double y) {
-        const double m = fmax(x, y);
-        const R d = (R) (fmin(x, y) - m);
-        return m + (double) Num<R>::log2(R(1) + Num<R>::exp2(d));
+        const R d = (R) fabs(x - y);
+        return fmax(x, y) + (double) Num<R>::log2(R(1) + Num<R>::exp2(-d));
     };
     auto st = [&](double x) { return (AlignedState) fmax(x, kZ); };
     auto store_row = [&](int t, const double (&v)[K]) {
@@ -1433,7 +1436,7 @@ __global__ void __launch_bounds__(64) aligned_long_kernel(Problem P, State W, Fw
                     for (int k = K - 1; k >= 0; --k) {
                         const double em = fma((double) cur[u][k], L2Ed, ebias[k]);
                         const double from = k == 0 ? left : v[k - 1];
-                        v[k] = fmax(em + lse2d(v[k] + H2[k], from + Dx[k]), kZ);
+                        v[k] = em + lse2d(v[k] + H2[k], from + Dx[k]);
                     }
                     if ((t & 3) == 0) renorm();       // (every 4 frames: the stored floats stay within a few frames' growth of the offset)
                     store_row(t, v);
@@ -1473,12 +1476,12 @@ __global__ void __launch_bounds__(64) aligned_long_kernel(Problem P, State W, Fw
                 if (t >= 1) {
                     double y[K];
 #pragma unroll
-                    for (int k = 0; k < K; ++k) y[k] = fmax(fma((double) cur[u][k], L2Ed, ebias[k]) + v[k], kZ);
+                    for (int k = 0; k < K; ++k) y[k] = fma((double) cur[u][k], L2Ed, ebias[k]) + v[k];
                     const double right = next_lane_or_zero<double>(y[0]);      // (lane 63 reads 0; its last position has a log-zero leave edge)
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
                         const double to = k == K - 1 ? right : y[k + 1];
-                        v[k] = fmax(lse2d(y[k] + H2[k], to + Dx[k]), kZ);
+                        v[k] = lse2d(y[k] + H2[k], to + Dx[k]);
                     }
                     if ((t & 3) == 0) renorm();       // (every 4 frames: the stored floats stay within a few frames' growth of the offset)
                     store_row(t - 1, v);
