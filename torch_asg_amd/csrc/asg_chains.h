@@ -709,10 +709,13 @@ __device__ __forceinline__ R aligned_block_scale(const R (&cur)[kPF], int nsteps
 // the whole error budget of the aligned gradient.  Only the bounded correction log2(1 + 2^d), d <= 0, is evaluated in
 // the problem's precision (v_exp_f32 / v_log_f32); the sums are double adds.  Stores round to R once.
 constexpr double kLZd = -1e30;
+// (min - max = -|a - b| exactly: the modulus and the sign ride on the conversion and on v_exp as source modifiers.  Inside a
+// block of frames the states are NOT clamped at log zero, only the emission term is (a -inf emission must not put -inf into a
+// state: two of them side by side are inf - inf): a state falls below log zero by at most one -1e30 per frame until the block's
+// renormalisation clamps it -- nowhere near the range of a double -- and every store clamps what it writes.)
 template <typename R> __device__ __forceinline__ double lse2_acc(double a, double b) {
-    const double m = fmax(a, b);
-    const R d = (R) (fmin(a, b) - m);
-    return m + (double) Num<R>::log2(R(1) + Num<R>::exp2(d));
+    const R d = (R) fabs(a - b);
+    return fmax(a, b) + (double) Num<R>::log2(R(1) + Num<R>::exp2(-d));
 }
 template <typename R> __device__ __forceinline__ R to_state(double v) { return (R) fmax(v, kLZd); }
 
@@ -724,10 +727,10 @@ __device__ __forceinline__ void aligned_alpha_block(const R (&cur)[kPF], int nst
 #pragma unroll
     for (int k = 0; k < kPF; ++k) {
         if (!GUARD || k < nsteps) {
-            const double em = fma((double) cur[k], L2Ed, ebias);
+            const double em = fmax(fma((double) cur[k], L2Ed, ebias), kLZd);
             const double stay = ab + H2;
             const double come = prev_lane_or_zero<double>(ab) + Dprev;      // lane 0: 0 + logzero
-            ab = fmax(em + lse2_acc<R>(stay, come), kLZd);
+            ab = em + lse2_acc<R>(stay, come);
             if (STORE) buf_store(to_state<R>(ab), rs, voff, soff0 + (unsigned) k * row_bytes);
         }
     }
@@ -793,10 +796,10 @@ __device__ __forceinline__ void aligned_beta_block(const R (&cur)[kPF], int nste
 #pragma unroll
     for (int k = 0; k < kPF; ++k) {
         if (!GUARD || k < nsteps) {
-            const double y = fmax(fma((double) cur[k], L2Ed, ebias) + bb, kLZd);
+            const double y = fmax(fma((double) cur[k], L2Ed, ebias), kLZd) + bb;
             const double stay = y + H2;
             const double go = next_lane_or_zero<double>(y) + Dnext;
-            bb = fmax(lse2_acc<R>(stay, go), kLZd);
+            bb = lse2_acc<R>(stay, go);
             if (STORE) buf_store(to_state<R>(bb), rs, voff, soff0 - (unsigned) k * row_bytes);
         }
     }
@@ -1026,17 +1029,17 @@ __device__ void aligned_pair_chain(const Problem &P, const State &W, const FwdOu
         for (int k = 0; k < kPF; ++k) {
             if (done + k < nstmax) {                 // (wave-uniform)
                 const bool live = done + k < nst;
-                const double em = fma((double) cur[k], L2Ed, ebias);
+                const double em = fmax(fma((double) cur[k], L2Ed, ebias), kLZd);
                 double nv;
                 if (!BETA) {
                     const double stay = v + H2;
                     const double come = prev_lane_or_zero<double>(v) + Dx;       // position 0: 0 + log-zero
-                    nv = fmax(em + lse2_acc<R>(stay, come), kLZd);
+                    nv = em + lse2_acc<R>(stay, come);
                 } else {
-                    const double y = fmax(em + v, kLZd);
+                    const double y = em + v;
                     const double stay = y + H2;
                     const double go = next_lane_or_zero<double>(y) + Dx;         // position ol - 1: log-zero edge
-                    nv = fmax(lse2_acc<R>(stay, go), kLZd);
+                    nv = lse2_acc<R>(stay, go);
                 }
                 v = live ? nv : v;
                 buf_store(to_state<R>(v), rs, (live && can_store) ? soff : kNoStore, 0u);

@@ -1372,9 +1372,10 @@ __global__ void __launch_bounds__(64) aligned_long_kernel(Problem P, State W, Fw
     }
     const double kZ = -1e30, L2Ed = 1.4426950408889634;
     // log2(2^x + 2^y) = max + log2(1 + 2^-|x - y|): the difference in double, the correction term in the problem's precision (the
-    // modulus and the sign are source modifiers of the conversion and of v_exp).  No clamp at log zero inside a step: log zero is
-    // -1e30, a state can fall below it by one -1e30 per frame until the next renormalisation (every 4 frames) clamps it --
-    // nowhere near the range of a double -- and the stores clamp what they write.
+    // modulus and the sign are source modifiers of the conversion and of v_exp).  Inside a step only the emission term is clamped at
+    // log zero (-1e30; a -inf emission must not put -inf into a state: two of them side by side are inf - inf); a state can fall
+    // below it by one -1e30 per frame until the next renormalisation (every 4 frames) clamps it -- nowhere near the range of a
+    // double -- and the stores clamp what they write.
     auto lse2d = [&](double x, double y) {
         const R d = (R) fabs(x - y);
         return fmax(x, y) + (double) Num<R>::log2(R(1) + Num<R>::exp2(-d));
@@ -1434,7 +1435,7 @@ __global__ void __launch_bounds__(64) aligned_long_kernel(Problem P, State W, Fw
                     const double left = prev_lane_or_zero<double>(v[K - 1]);
 #pragma unroll
                     for (int k = K - 1; k >= 0; --k) {
-                        const double em = fma((double) cur[u][k], L2Ed, ebias[k]);
+                        const double em = fmax(fma((double) cur[u][k], L2Ed, ebias[k]), kZ);      // (a -inf emission stays finite)
                         const double from = k == 0 ? left : v[k - 1];
                         v[k] = em + lse2d(v[k] + H2[k], from + Dx[k]);
                     }
@@ -1476,7 +1477,7 @@ __global__ void __launch_bounds__(64) aligned_long_kernel(Problem P, State W, Fw
                 if (t >= 1) {
                     double y[K];
 #pragma unroll
-                    for (int k = 0; k < K; ++k) y[k] = fma((double) cur[u][k], L2Ed, ebias[k]) + v[k];
+                    for (int k = 0; k < K; ++k) y[k] = fmax(fma((double) cur[u][k], L2Ed, ebias[k]), kZ) + v[k];
                     const double right = next_lane_or_zero<double>(y[0]);      // (lane 63 reads 0; its last position has a log-zero leave edge)
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
