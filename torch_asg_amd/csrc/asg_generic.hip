@@ -322,6 +322,138 @@ __device__ __forceinline__ void fwd_step_body(const Problem &P, const StepBuf<R>
     }
 }
 
+// ---- the same frame in double precision on the matrix cores (64 < N <= 2048: round 4) -----------------------------
+// fwd_step_body is built for N = 10^4 (64 x 32 output tiles: every tile of E fetched once per frame); at N = 512, B = 64 that is 32
+// workgroups of dependent LDS-staged VALU products: 48 us per frame, 19 ms per step where the fp32 routes take 1.9.
+// Here a workgroup owns a 16 x 16 output tile (16 rows, 16 utterances: N / 16 x B / 16 x directions workgroups -- 256 at N = 512,
+// B = 64), its four wavefronts a quarter of K each, on v_mfma_f64_16x16x4_f64.  The order of a dot product's terms is free, so the
+// k slot of a lane group is not "k mod 4" but a CONTIGUOUS slice of K: lane (m, kq) of wavefront w walks k = (4 w + kq) KL + j,
+// j = 0 .. KL - 1, and loads its row of E and its utterance's vector sixteen bytes at a time, straight from memory (the matrix is
+// L2 / memory-side-cache resident at these sizes).  Epilogue: fwd_step_body's, one element per thread.
+typedef double V2dd __attribute__((ext_vector_type(2)));
+// NBT = utterance tiles per workgroup (16 NBT utterances share every element of E that is loaded: 2 from N > 512, where the
+// matrix no longer sits in the L2 and B / 16 readers per row cost more than the workgroups they add)
+template <bool BETA, int NBT>
+__device__ __forceinline__ void fwd_step_f64(const Problem &P, const StepBuf<double> &S, int n) {
+    typedef double R;
+    __shared__ double red[4][NBT][16][17];
+    __shared__ unsigned qk[16 * NBT];
+    const int N = P.N, T = P.T, B = P.B, npad = S.npad;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+    const int i0 = blockIdx.x * 16, b0 = blockIdx.y * 16 * NBT;
+    const R *pcur = S.pbuf + (int64_t) (n & 1) * B * npad;
+    R *pnext = S.pbuf + (int64_t) ((n + 1) & 1) * B * npad;
+    const int KL = ((npad + 15) / 16 + 1) & ~1;            // doubles per lane group (even: 16-byte loads)
+    const int k0 = (4 * wave + kq) * KL;
+    const R *erow = S.ehat + (int64_t) min(i0 + m, N - 1) * npad;
+    const R *prow[NBT];
+#pragma unroll
+    for (int c = 0; c < NBT; ++c) prow[c] = pcur + (int64_t) min(b0 + 16 * c + m, B - 1) * npad;
+    if (tid < 16 * NBT) qk[tid] = fkey(-__builtin_inff());
+    V4d acc0[NBT], acc1[NBT];
+#pragma unroll
+    for (int c = 0; c < NBT; ++c) { acc0[c] = V4d{0, 0, 0, 0}; acc1[c] = V4d{0, 0, 0, 0}; }
+    constexpr int CH = 8;                                  // doubles per chunk and operand
+    struct Chunk { V2dd a[CH / 2], b[NBT][CH / 2]; };
+    auto fetch = [&](int j0, Chunk &X) {
+#pragma unroll
+        for (int c = 0; c < CH / 2; ++c) {
+            const int k = k0 + j0 + 2 * c;
+            const bool in = j0 + 2 * c < KL && k < npad;
+            X.a[c] = in ? *reinterpret_cast<const V2dd *>(erow + k) : V2dd{0, 0};
+#pragma unroll
+            for (int t = 0; t < NBT; ++t) X.b[t][c] = in ? *reinterpret_cast<const V2dd *>(prow[t] + k) : V2dd{0, 0};
+        }
+    };
+    Chunk cur, nxt;
+    fetch(0, cur);
+    for (int j0 = 0; j0 < KL; j0 += CH) {
+        fetch(j0 + CH, nxt);
+#pragma unroll
+        for (int c = 0; c < CH / 2; ++c)
+#pragma unroll
+            for (int t = 0; t < NBT; ++t) {
+                acc0[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.a[c].x, cur.b[t][c].x, acc0[t], 0, 0, 0);
+                acc1[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.a[c].y, cur.b[t][c].y, acc1[t], 0, 0, 0);
+            }
+        cur = nxt;
+    }
+    // accumulator register q of lane l = element (row (l >> 4) + 4 q, utterance l & 15)
+#pragma unroll
+    for (int t = 0; t < NBT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) red[wave][t][kq + 4 * q][m] = acc0[t][q] + acc1[t][q];
+    __syncthreads();
+    // ---- epilogue: thread = (row r = tid >> 4, utterance u = tid & 15) of every utterance tile
+    const R L2E = Num<R>::log2e(), LZ = Num<R>::logzero();
+    const int r = tid >> 4, i = i0 + r;
+#pragma unroll
+    for (int ut = 0; ut < NBT; ++ut) {
+        const int u = tid & 15, b = b0 + 16 * ut + u;
+        const bool bvalid = b < B;
+        const int bc = bvalid ? b : 0;
+        const int len = P.in_len ? gclampi(P.in_len[bc], 0, T) : T;
+        const int t = BETA ? len - 1 - n : n + 1;          // frame whose q is consumed (beta) / produced (alpha)
+        const bool active = bvalid && (BETA ? (t >= 1) : (t < len));
+        if (active && i < N) {
+            const R muprev = fmax((R) funkey(S.mu[(n % 3) * B + bc]), LZ);
+            const int tw = BETA ? t - 1 : t;               // frame written
+            const R emw = S.emax[(int64_t) tw * B + bc];
+            const R a = (red[0][ut][r][u] + red[1][ut][r][u]) + (red[2][ut][r][u] + red[3][ut][r][u]);
+            R lg = Num<R>::log2(a);
+            R rr = S.hmax[i] + lg;
+            if (!(fabs(lg) < Num<R>::lg_limit())) {
+                // exact rare path: log2-sum-exp2 over j of (Tr2[.][.] + q_j) from the log-domain state
+                const R *tr = (const R *) P.transition;
+                const int tq = BETA ? t : t - 1;
+                const R *stq = S.state + ((int64_t) b * T + tq) * N;
+                const R *inq = (const R *) P.inputs + (int64_t) tq * P.is0 + (int64_t) b * P.is1;
+                const R emq = S.emax[(int64_t) tq * B + b];
+                R mx = Num<R>::ninf();
+                for (int j = 0; j < N; ++j) {
+                    R qj = BETA ? inq[(int64_t) j * P.is2] * L2E - emq + stq[j] : stq[j];
+                    R trv = BETA ? tr[(int64_t) j * P.ts0 + (int64_t) i * P.ts1] : tr[(int64_t) i * P.ts0 + (int64_t) j * P.ts1];
+                    R v = trv * L2E + qj;
+                    mx = (v == v) ? fmax(mx, v) : mx;
+                }
+                R sm = 0;
+                for (int j = 0; j < N; ++j) {
+                    R qj = BETA ? inq[(int64_t) j * P.is2] * L2E - emq + stq[j] : stq[j];
+                    R trv = BETA ? tr[(int64_t) j * P.ts0 + (int64_t) i * P.ts1] : tr[(int64_t) i * P.ts0 + (int64_t) j * P.ts1];
+                    R v = trv * L2E + qj;
+                    sm += (v == v && mx != Num<R>::ninf()) ? Num<R>::exp2(v - mx) : R(0);
+                }
+                rr = (mx == Num<R>::ninf()) ? mx : mx + Num<R>::log2(sm);
+            }
+            const R emis = ((const R *) P.inputs)[(int64_t) tw * P.is0 + (int64_t) b * P.is1 + (int64_t) i * P.is2] * L2E - emw;
+            R stv, q;
+            if (BETA) { stv = rr - muprev; q = emis + stv; }
+            else { stv = emis + rr - muprev; q = stv; }
+            S.state[((int64_t) b * T + tw) * N + i] = stv;
+            pnext[(int64_t) b * npad + i] = Num<R>::exp2(q);
+            // the utterance's maximum of q over this tile's rows (max is order-independent: deterministic)
+            atomicMax(&qk[16 * ut + u], fkey((float) q));
+            if (i == 0) {
+                S.off[b] += (double) muprev + (double) emw;
+                S.mu[((n + 2) % 3) * B + b] = fkey(-__builtin_inff());
+                if (!BETA && S.mulog) S.mulog[(int64_t) tw * B + b] = muprev;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < 16 * NBT) {        // one global atomic per tile and utterance
+        const int bb = b0 + tid;
+        const unsigned key = qk[tid];
+        if (bb < B && key != fkey(-__builtin_inff())) atomicMax(&S.mu[((n + 1) % 3) * B + bb], key);
+    }
+}
+template <int NBT>
+__global__ void __launch_bounds__(256) fwd_step_f64_kernel(Problem P, StepBuf<double> Sa, StepBuf<double> Sb, int n, int dir_base) {
+    if ((int) blockIdx.z + dir_base == 0) fwd_step_f64<false, NBT>(P, Sa, n);
+    else fwd_step_f64<true, NBT>(P, Sb, n);
+}
+
 // ---- the same frame on the matrix cores (fp32 only) ------------------------------------------------------------
 // The large-alphabet step IS a dense product, [N x N] (normalised transitions) x [N x B] (the batch's vectors), 8 FMAs
 // per byte of E streamed: at B = 32 the HBM and the fp32 arithmetic ceilings of MI355X coincide (~100 us per frame and
@@ -3021,6 +3153,19 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
                 if (ce == hipSuccess) stepped = true;
                 else (void) hipGetLastError();          // too large for one wave of workgroups: fall back
                 if (getenv("ASG_DBG_PERSIST")) fprintf(stderr, "[asg] cooperative forward launch: %s (grid %u x %u x %u)\n", hipGetErrorString(ce), sgrid.x, sgrid.y, sgrid.z);
+            }
+        }
+        if constexpr (sizeof(R) == 8) {
+            // double precision below the streaming regime: 16 x 16 tiles on the fp64 matrix instruction (ASG_NO_F64_MFMA=1: the VALU body)
+            const char *ev = getenv("ASG_NO_F64_MFMA");
+            if (!stepped && P.N <= 2048 && !(ev && atoi(ev) != 0)) {
+                const int nbt = (P.N > 512 && P.B > 16) ? 2 : 1;
+                const dim3 dgrid((P.N + 15) / 16, (P.B + 16 * nbt - 1) / (16 * nbt), (do_a && do_b) ? 2 : 1);
+                for (int n = 0; n + 1 < P.T; ++n) {
+                    if (nbt == 2) hipLaunchKernelGGL(fwd_step_f64_kernel<2>, dgrid, dim3(256), 0, stream, P, Sd[0], Sd[1], n, do_a ? 0 : 1);
+                    else hipLaunchKernelGGL(fwd_step_f64_kernel<1>, dgrid, dim3(256), 0, stream, P, Sd[0], Sd[1], n, do_a ? 0 : 1);
+                }
+                stepped = true;
             }
         }
         if (!stepped)
