@@ -234,9 +234,9 @@ def test_generic_path_vs_oracle(T, B, N, L, dtype, rtol):
 
 @pytest.mark.parametrize("T,B,N,L", [(30, 3, 257, 6), (25, 20, 300, 5), (20, 40, 600, 4), (14, 5, 1030, 4), (10, 18, 2048, 3), (1, 2, 300, 1)])
 def test_f64_alphabets_below_the_streaming_regime(T, B, N, L, monkeypatch):
-    """fp64, 256 < N <= 2048: the per-frame step on v_mfma_f64_16x16x4_f64 (fwd_step_f64_kernel: 16 x 16 output tiles, one or
+    """fp64, 256 < N <= 2048: the per-frame step on v_mfma_f64_16x16x4_f64 (fwd_step_tile_kernel: 16 x 16 output tiles, one or
     two utterance tiles per workgroup, K in contiguous slices per lane group) against the oracle at 1e-9, against the VALU step
-    (ASG_NO_F64_MFMA=1) to rounding, run-to-run determinism; variable lengths, an infeasible utterance, the evaluation route."""
+    (ASG_NO_TILE_STEP=1) to rounding, run-to-run determinism; variable lengths, an infeasible utterance, the evaluation route."""
     rng = np.random.default_rng(T + N)
     tr, x, tg, _, _ = util.synth(T, B, N, L, N)
     il = rng.integers(max(1, T // 2), T + 1, B)
@@ -246,14 +246,14 @@ def test_f64_alphabets_below_the_streaming_regime(T, B, N, L, monkeypatch):
     o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il, tl, "none")
     outs = []
     for env in ("0", "1"):
-        monkeypatch.setenv("ASG_NO_F64_MFMA", env)
+        monkeypatch.setenv("ASG_NO_TILE_STEP", env)
         r = run_hip(x, tg, tr, il, tl, "none", torch.float64)
         for k in ("loss", "grad_inputs", "grad_transition"):
             util.assert_close(r[k], o[k], 1e-9, "fp64 T%d B%d N%d L%d valu=%s/%s" % (T, B, N, L, env, k))
         outs.append(r)
     for k in ("loss", "grad_inputs", "grad_transition"):
         util.assert_close(outs[0][k], outs[1][k], 1e-11, "matrix-core vs VALU step: %s" % k)
-    monkeypatch.setenv("ASG_NO_F64_MFMA", "0")
+    monkeypatch.setenv("ASG_NO_TILE_STEP", "0")
     again = run_hip(x, tg, tr, il, tl, "none", torch.float64)
     assert np.array_equal(again["grad_inputs"], outs[0]["grad_inputs"]) and np.array_equal(again["loss"], outs[0]["loss"], equal_nan=True)
     A = _asg()
@@ -266,7 +266,7 @@ def test_f64_alphabets_below_the_streaming_regime(T, B, N, L, monkeypatch):
 
 def test_f64_matrix_step_exact_path():
     """Transitions spanning thousands of nats push row sums out of the fp64 exp-domain window (2^+-900) inside
-    fwd_step_f64_kernel: the exact per-node log-sum-exp over the stored log-domain state takes over."""
+    fwd_step_tile_kernel: the exact per-node log-sum-exp over the stored log-domain state takes over."""
     T, B, N, L = 14, 2, 300, 4
     tr, x, tg, il, tl = util.synth(T, B, N, L, 9, True)
     tr = tr * 4000.0 - 2000.0

@@ -322,21 +322,39 @@ __device__ __forceinline__ void fwd_step_body(const Problem &P, const StepBuf<R>
     }
 }
 
-// ---- the same frame in double precision on the matrix cores (64 < N <= 2048: round 4) -----------------------------
-// fwd_step_body is built for N = 10^4 (64 x 32 output tiles: every tile of E fetched once per frame); at N = 512, B = 64 that is 32
-// workgroups of dependent LDS-staged VALU products: 48 us per frame, 19 ms per step where the fp32 routes take 1.9.
-// Here a workgroup owns a 16 x 16 output tile (16 rows, 16 utterances: N / 16 x B / 16 x directions workgroups -- 256 at N = 512,
-// B = 64), its four wavefronts a quarter of K each, on v_mfma_f64_16x16x4_f64.  The order of a dot product's terms is free, so the
+// ---- the same frame in 16 x 16 tiles on the matrix cores (round 4: fp64 with 256 < N <= 2048; fp32: developer switch only, it
+// loses to fwd_step_mfma -- kTileStepMaxN32) ---------------------------------------------------------------------------
+// fwd_step_body / fwd_step_mfma are built for N = 10^4 (64- / 80-row output tiles: every tile of E fetched once per frame); at
+// N = 512, B = 64 the fp64 body is 32 workgroups of dependent LDS-staged VALU products: 48 us per frame, 19 ms per step where the
+// fp32 routes take 1.9.  Here a workgroup owns a 16 x 16 output tile (16 rows, 16 utterances: N / 16 x B / 16 x directions
+// workgroups -- 256 at N = 512, B = 64), its four wavefronts a quarter of K each, on v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32.  The order of a dot product's terms is free, so the
 // k slot of a lane group is not "k mod 4" but a CONTIGUOUS slice of K: lane (m, kq) of wavefront w walks k = (4 w + kq) KL + j,
 // j = 0 .. KL - 1, and loads its row of E and its utterance's vector sixteen bytes at a time, straight from memory (the matrix is
 // L2 / memory-side-cache resident at these sizes).  Epilogue: fwd_step_body's, one element per thread.
-typedef double V2dd __attribute__((ext_vector_type(2)));
+template <typename R> struct TileOps;
+template <> struct TileOps<double> {
+    typedef double Ld __attribute__((ext_vector_type(2)));      // one 16-byte load
+    typedef V4d Acc;
+    static constexpr int EPL = 2;
+    static __device__ __forceinline__ Acc mma(double a, double b, Acc c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int row(int lane, int q) { return (lane >> 4) + 4 * q; }      // accumulator register q of a lane
+};
+template <> struct TileOps<float> {
+    typedef float Ld __attribute__((ext_vector_type(4)));
+    typedef V4<float> Acc;
+    static constexpr int EPL = 4;
+    static __device__ __forceinline__ Acc mma(float a, float b, Acc c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int row(int lane, int q) { return 4 * (lane >> 4) + q; }
+};
 // NBT = utterance tiles per workgroup (16 NBT utterances share every element of E that is loaded: 2 from N > 512, where the
 // matrix no longer sits in the L2 and B / 16 readers per row cost more than the workgroups they add)
-template <bool BETA, int NBT>
-__device__ __forceinline__ void fwd_step_f64(const Problem &P, const StepBuf<double> &S, int n) {
-    typedef double R;
-    __shared__ double red[4][NBT][16][17];
+template <typename R, bool BETA, int NBT>
+__device__ __forceinline__ void fwd_step_tile(const Problem &P, const StepBuf<R> &S, int n) {
+    typedef TileOps<R> Ops;
+    typedef typename Ops::Ld Ld;
+    typedef typename Ops::Acc Acc;
+    constexpr int EPL = Ops::EPL;
+    __shared__ R red[4][NBT][16][17];
     __shared__ unsigned qk[16 * NBT];
     const int N = P.N, T = P.T, B = P.B, npad = S.npad;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -344,26 +362,27 @@ __device__ __forceinline__ void fwd_step_f64(const Problem &P, const StepBuf<dou
     const int i0 = blockIdx.x * 16, b0 = blockIdx.y * 16 * NBT;
     const R *pcur = S.pbuf + (int64_t) (n & 1) * B * npad;
     R *pnext = S.pbuf + (int64_t) ((n + 1) & 1) * B * npad;
-    const int KL = ((npad + 15) / 16 + 1) & ~1;            // doubles per lane group (even: 16-byte loads)
+    const int KL = ((npad + 15) / 16 + EPL - 1) / EPL * EPL;   // elements per lane group (whole 16-byte loads)
     const int k0 = (4 * wave + kq) * KL;
     const R *erow = S.ehat + (int64_t) min(i0 + m, N - 1) * npad;
     const R *prow[NBT];
 #pragma unroll
     for (int c = 0; c < NBT; ++c) prow[c] = pcur + (int64_t) min(b0 + 16 * c + m, B - 1) * npad;
     if (tid < 16 * NBT) qk[tid] = fkey(-__builtin_inff());
-    V4d acc0[NBT], acc1[NBT];
+    Acc acc0[NBT], acc1[NBT];
 #pragma unroll
-    for (int c = 0; c < NBT; ++c) { acc0[c] = V4d{0, 0, 0, 0}; acc1[c] = V4d{0, 0, 0, 0}; }
-    constexpr int CH = 8;                                  // doubles per chunk and operand
-    struct Chunk { V2dd a[CH / 2], b[NBT][CH / 2]; };
+    for (int c = 0; c < NBT; ++c) { acc0[c] = Acc{0, 0, 0, 0}; acc1[c] = Acc{0, 0, 0, 0}; }
+    constexpr int CH = 8, NL = CH / EPL;                   // elements / 16-byte loads per chunk and operand
+    struct Chunk { Ld a[NL], b[NBT][NL]; };
+    const Ld zero = {};
     auto fetch = [&](int j0, Chunk &X) {
 #pragma unroll
-        for (int c = 0; c < CH / 2; ++c) {
-            const int k = k0 + j0 + 2 * c;
-            const bool in = j0 + 2 * c < KL && k < npad;
-            X.a[c] = in ? *reinterpret_cast<const V2dd *>(erow + k) : V2dd{0, 0};
+        for (int c = 0; c < NL; ++c) {
+            const int k = k0 + j0 + EPL * c;
+            const bool in = j0 + EPL * c < KL && k < npad;          // (npad is a multiple of 4: a load is inside or outside as a whole)
+            X.a[c] = in ? *reinterpret_cast<const Ld *>(erow + k) : zero;
 #pragma unroll
-            for (int t = 0; t < NBT; ++t) X.b[t][c] = in ? *reinterpret_cast<const V2dd *>(prow[t] + k) : V2dd{0, 0};
+            for (int t = 0; t < NBT; ++t) X.b[t][c] = in ? *reinterpret_cast<const Ld *>(prow[t] + k) : zero;
         }
     };
     Chunk cur, nxt;
@@ -371,19 +390,21 @@ __device__ __forceinline__ void fwd_step_f64(const Problem &P, const StepBuf<dou
     for (int j0 = 0; j0 < KL; j0 += CH) {
         fetch(j0 + CH, nxt);
 #pragma unroll
-        for (int c = 0; c < CH / 2; ++c)
+        for (int c = 0; c < NL; ++c)
 #pragma unroll
-            for (int t = 0; t < NBT; ++t) {
-                acc0[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.a[c].x, cur.b[t][c].x, acc0[t], 0, 0, 0);
-                acc1[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.a[c].y, cur.b[t][c].y, acc1[t], 0, 0, 0);
-            }
+            for (int e = 0; e < EPL; e += 2)
+#pragma unroll
+                for (int t = 0; t < NBT; ++t) {
+                    acc0[t] = Ops::mma(cur.a[c][e], cur.b[t][c][e], acc0[t]);
+                    acc1[t] = Ops::mma(cur.a[c][e + 1], cur.b[t][c][e + 1], acc1[t]);
+                }
         cur = nxt;
     }
-    // accumulator register q of lane l = element (row (l >> 4) + 4 q, utterance l & 15)
+    // accumulator register q of lane l = element (row Ops::row(l, q), utterance l & 15)
 #pragma unroll
     for (int t = 0; t < NBT; ++t)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) red[wave][t][kq + 4 * q][m] = acc0[t][q] + acc1[t][q];
+        for (int q = 0; q < 4; ++q) red[wave][t][Ops::row(lane, q)][m] = acc0[t][q] + acc1[t][q];
     __syncthreads();
     // ---- epilogue: thread = (row r = tid >> 4, utterance u = tid & 15) of every utterance tile
     const R L2E = Num<R>::log2e(), LZ = Num<R>::logzero();
@@ -448,10 +469,10 @@ __device__ __forceinline__ void fwd_step_f64(const Problem &P, const StepBuf<dou
         if (bb < B && key != fkey(-__builtin_inff())) atomicMax(&S.mu[((n + 1) % 3) * B + bb], key);
     }
 }
-template <int NBT>
-__global__ void __launch_bounds__(256) fwd_step_f64_kernel(Problem P, StepBuf<double> Sa, StepBuf<double> Sb, int n, int dir_base) {
-    if ((int) blockIdx.z + dir_base == 0) fwd_step_f64<false, NBT>(P, Sa, n);
-    else fwd_step_f64<true, NBT>(P, Sb, n);
+template <typename R, int NBT>
+__global__ void __launch_bounds__(256) fwd_step_tile_kernel(Problem P, StepBuf<R> Sa, StepBuf<R> Sb, int n, int dir_base) {
+    if ((int) blockIdx.z + dir_base == 0) fwd_step_tile<R, false, NBT>(P, Sa, n);
+    else fwd_step_tile<R, true, NBT>(P, Sb, n);
 }
 
 // ---- the same frame on the matrix cores (fp32 only) ------------------------------------------------------------
@@ -1398,6 +1419,13 @@ static bool cluster_alphabet(const Problem &P, size_t elem) {
     return !(ev && atoi(ev) != 0);
 }
 constexpr size_t kClusterBytes = 8u << 20;       // exchange vectors of every cluster
+#ifndef ASG_X_TILE_MAX_N32
+#define ASG_X_TILE_MAX_N32 0
+#endif
+// fp32: the 16 x 16 tile step up to this alphabet.  0 = never: measured at T = 400, B = 64 (developer builds with 3072) it LOSES to
+// fwd_step_mfma's pre-tiled operands and 80-row tiles -- N = 1500 17.7 against 12.6 ms per step, N = 2048 24.3 against 15.3, N = 3000
+// 54 against 24 -- so in fp32 the tile step stays a developer switch and fp64 is what it is for.
+constexpr int kTileStepMaxN32 = ASG_X_TILE_MAX_N32;
 
 // the medium-alphabet route: fp32, 64 < N <= 256, 32-bit emission offsets (ASG_NO_MID=1: the per-frame launches instead)
 static bool mid_alphabet(const Problem &P, size_t elem) {
@@ -3155,15 +3183,17 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
                 if (getenv("ASG_DBG_PERSIST")) fprintf(stderr, "[asg] cooperative forward launch: %s (grid %u x %u x %u)\n", hipGetErrorString(ce), sgrid.x, sgrid.y, sgrid.z);
             }
         }
-        if constexpr (sizeof(R) == 8) {
-            // double precision below the streaming regime: 16 x 16 tiles on the fp64 matrix instruction (ASG_NO_F64_MFMA=1: the VALU body)
-            const char *ev = getenv("ASG_NO_F64_MFMA");
-            if (!stepped && P.N <= 2048 && !(ev && atoi(ev) != 0)) {
+        {
+            // below the streaming regime (and, fp32, where the resident-slice kernel did not take the problem): 16 x 16 tiles on the
+            // matrix instruction of the problem's precision (ASG_NO_TILE_STEP=1: the kernels built for N = 10^4)
+            const char *ev = getenv("ASG_NO_TILE_STEP");
+            const int tile_max_n = sizeof(R) == 8 ? 2048 : kTileStepMaxN32;
+            if (!stepped && P.N <= tile_max_n && !(ev && atoi(ev) != 0)) {
                 const int nbt = (P.N > 512 && P.B > 16) ? 2 : 1;
                 const dim3 dgrid((P.N + 15) / 16, (P.B + 16 * nbt - 1) / (16 * nbt), (do_a && do_b) ? 2 : 1);
                 for (int n = 0; n + 1 < P.T; ++n) {
-                    if (nbt == 2) hipLaunchKernelGGL(fwd_step_f64_kernel<2>, dgrid, dim3(256), 0, stream, P, Sd[0], Sd[1], n, do_a ? 0 : 1);
-                    else hipLaunchKernelGGL(fwd_step_f64_kernel<1>, dgrid, dim3(256), 0, stream, P, Sd[0], Sd[1], n, do_a ? 0 : 1);
+                    if (nbt == 2) hipLaunchKernelGGL((fwd_step_tile_kernel<R, 2>), dgrid, dim3(256), 0, stream, P, Sd[0], Sd[1], n, do_a ? 0 : 1);
+                    else hipLaunchKernelGGL((fwd_step_tile_kernel<R, 1>), dgrid, dim3(256), 0, stream, P, Sd[0], Sd[1], n, do_a ? 0 : 1);
                 }
                 stepped = true;
             }
