@@ -277,6 +277,23 @@ def test_f64_matrix_step_exact_path():
     assert not np.isnan(r["grad_inputs"]).any()
 
 
+@pytest.mark.parametrize("T,B,N,L", [(7, 3, 2100, 3), (6, 40, 1100, 2), (6, 2, 3300, 2), (5, 34, 6100, 2)])
+def test_streaming_step_medium_alphabets(T, B, N, L):
+    """fp32 alphabets that take a launch per frame (beyond the resident-slice kernel: N > 2048, or N > 1024 with more than 48
+    utterances): fwd_step_mfma's 80-row tiles with one / several row tiles and utterance tiles, against the oracle, variable
+    lengths, run-to-run determinism."""
+    rng = np.random.default_rng(N)
+    tr, x, tg, _, _ = util.synth(T, B, N, L, N)
+    il = rng.integers(max(1, T // 2), T + 1, B)
+    tl = np.minimum(rng.integers(1, L + 1, B), il)
+    o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il, tl, "none")
+    r = run_hip(x, tg, tr, il, tl, "none")
+    for k in ("loss", "grad_inputs", "grad_transition"):
+        util.assert_close(r[k], o[k], 1e-4, "T%d B%d N%d L%d %s" % (T, B, N, L, k))
+    r2 = run_hip(x, tg, tr, il, tl, "none")
+    assert np.array_equal(r["loss"], r2["loss"]) and np.array_equal(r["grad_inputs"], r2["grad_inputs"])
+
+
 def test_golden_cfg5_reduced_large_alphabet():
     # BASELINE.json configs[4] at the size the reference can still run: T=64 B=4 N=1024 L=16, variable lengths
     g = util.load("cfg5_reduced")
