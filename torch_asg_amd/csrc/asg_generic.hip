@@ -3281,7 +3281,10 @@ hipError_t launch_bwd_generic(const Problem &P, const State &W, const BwdArgs &A
             hipLaunchKernelGGL((bwd_post_kernel<R, true>), dim3(P.T, P.B), dim3(256), 0, stream, P, W, A, Pm, Gm, npad, emax, mulog, anybad,
                                (const int *) rowoff);
         } else {
-            hipLaunchKernelGGL((bwd_post_kernel<R, false>), dim3(P.T, P.B), dim3(256), 0, stream, P, W, A, Pm, Gm, npad, emax, mulog, anybad,
+            // fp64: the row sums from the stored state as well (every double-precision forward logs its normaliser too; round 4) --
+            // rows in place (no compaction: the VALU contraction below takes K = B T)
+            if (!W.work) return hipErrorInvalidValue;
+            hipLaunchKernelGGL((bwd_post_kernel<R, true>), dim3(P.T, P.B), dim3(256), 0, stream, P, W, A, Pm, Gm, npad, emax, mulog, anybad,
                                (const int *) nullptr);
         }
         if constexpr (StepUsesMfma<R>::v) {
@@ -3302,8 +3305,7 @@ hipError_t launch_bwd_generic(const Problem &P, const State &W, const BwdArgs &A
             }
             (void) tiles1;
         } else {
-            hipLaunchKernelGGL((bwd_gemm_kernel<R, 0>), dim3((P.N + 63) / 64, (K + 63) / 64), dim3(256), 0, stream,
-                               (const R *) W.ehat, Pm, Gm, gtr, P.N, npad, K, anybad);
+            // (no row-sum contraction either: bwd_gemm_kernel<R, 0> was 0.5 / 1.9 / 7 ms at N = 512 / 1024 / 2048, T = 400, B = 64)
             const int nsl = gemm_slices(P.N, K);
             if (nsl > 1) {
                 const int kslice = ((K + nsl - 1) / nsl + 15) / 16 * 16;
