@@ -211,13 +211,25 @@ def time_small_config(name, T_, B_, N_, L_, variable, steps, eval_route=False, e
         group()
     blocks = timed_blocks(group, steps // gsteps, torch.cuda.synchronize, target_s=0.12)
     ms = median(blocks) / steps * 1e3
-    return {"workload": "%s: T=%d B=%d N=%d L=%d fp32%s, %s" % (
+    out = {}
+    if launch == "streams":
+        # what the library does with launch_mode='streams' (csrc/asg_api.hip::run_forward): eager calls fork the aligned lattice
+        # onto a side HIP stream (event fork / join: the reference's arrangement, streamlined_fast_gpu.cpp:121-129,220-225);
+        # while the caller's stream is being captured the small path records both lattices on that one stream instead
+        # (cross-queue edges of a replayed graph cost more than these short kernels' overlap saves)
+        forced = os.environ.get("ASG_FORK_IN_CAPTURE")
+        forks = eager or forced == "1"
+        out["overlap"] = ("fork: full-lattice chains on the caller's stream, aligned chains on a side HIP stream, event fork/join"
+                          if forks else "inline (capturing): both lattices recorded on the caller's stream, no fork -- this is the "
+                                        "`serial` arrangement in one call; the fork/join overlap is timed in `cfg3_streams_eager`")
+    out.update({"workload": "%s: T=%d B=%d N=%d L=%d fp32%s, %s" % (
                 name, T_, B_, N_, L_, ", variable lengths" if variable else "",
                 "evaluation route (beta recursions, no gradient)" if eval_route else "forward+backward"),
             "step_mode": "eager" if eager else "graph (%d steps per replay)" % gsteps,
             "ms_per_step": ms, "utt_s": B_ / (ms * 1e-3), "steps": steps, "timed_blocks": len(blocks),
             "algorithmic_bytes": algorithmic_bytes(T_, B_, N_, L_),
-            "step_achieved_gbs": algorithmic_bytes(T_, B_, N_, L_) / (ms * 1e-3) / 1e9}
+            "step_achieved_gbs": algorithmic_bytes(T_, B_, N_, L_) / (ms * 1e-3) / 1e9})
+    return out
 
 
 CFG5 = dict(T=2000, B=32, N=10000, L=60)      # BASELINE.json configs[4]: large alphabet, variable lengths
@@ -347,6 +359,8 @@ def extras(args):
     attempt("cfg3_eval", lambda: time_small_config("cfg3", T, B, N, L, False, 100, eval_route=True))
     attempt("cfg3_eager", lambda: time_small_config("cfg3", T, B, N, L, False, 100, eager=True))
     attempt("cfg3_streams", lambda: time_small_config("cfg3, launch_mode=streams", T, B, N, L, False, 50, launch="streams"))
+    # the same mode where its fork / join really overlaps the two lattices: eager launches (BASELINE.json configs[2])
+    attempt("cfg3_streams_eager", lambda: time_small_config("cfg3, launch_mode=streams", T, B, N, L, False, 50, eager=True, launch="streams"))
     # not a BASELINE config: the shape letter-based speech models give the criterion (a few dozen labels, targets of
     # hundreds of positions, ~10 s of frames) -- S > 64 leaves the fused step for the long-target kernels
     attempt("long_targets", lambda: time_small_config("long targets (not a BASELINE config)", 1000, 64, 40, 200, True, 20))
@@ -618,6 +632,14 @@ def main():
                        "global_batch": global_batch, "per_gpu_batch": B, "T": T, "N": N, "L": L,
                        "step_mode": mode if mode != "graph" else "graph (%d consecutive steps per hipGraph replay)" % gsteps,
                        "launch_mode": args.launch,
+                       "overlap": {"single": "one launch: the four recursions of every utterance (full alpha / beta on two workgroups, both aligned "
+                                             "chains on a third) run concurrently on three compute units, gradient assembly inside the "
+                                             "same launch -- the full and force-aligned passes overlap without streams; the reference's "
+                                             "stream arrangement is launch_mode='streams' (extra.cfg3_streams / cfg3_streams_eager)",
+                                   "streams": "full-lattice passes on the caller's stream, aligned passes on a side HIP stream (fork/join); "
+                                              "inside a hipGraph the small path records both on one stream",
+                                   "serial": "separate launches on one stream"}[args.launch],
+                       "collective": ("rccl all_reduce(transition.grad), %d rank(s)" % world) if use_dist else "none (one process)",
                        "graph_has_collective": bool(graph_has_collective),
                        "launcher": "self (bench.py started its ranks)" if os.environ.get("ASG_BENCH_SELF_LAUNCHED") == "1"
                                    else ("torch.distributed.run" if world > 1 else "none"),

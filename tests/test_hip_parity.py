@@ -294,6 +294,47 @@ def test_streaming_step_medium_alphabets(T, B, N, L):
     assert np.array_equal(r["loss"], r2["loss"]) and np.array_equal(r["grad_inputs"], r2["grad_inputs"])
 
 
+@pytest.mark.parametrize("T,B,N,L", [(7, 3, 2100, 3), (6, 40, 2500, 2), (5, 34, 3300, 2)])
+def test_f64_streaming_step_large_alphabets(T, B, N, L):
+    """fp64 beyond 2048 labels: fwd_step_kernel<double> per frame + bwd_post_kernel<double, true> (row sums from the stored
+    states, no row-sum contraction) against the oracle at 1e-9; variable lengths, an infeasible utterance, the evaluation
+    route, run-to-run determinism.  Reference: double everywhere (/root/reference/torch_asg/native/utils.h:33-39)."""
+    rng = np.random.default_rng(T + N)
+    tr, x, tg, _, _ = util.synth(T, B, N, L, N)
+    il = rng.integers(max(1, T // 2), T + 1, B)
+    tl = np.minimum(rng.integers(1, L + 1, B), il)
+    il[1], tl[1] = 1, L                          # infeasible (L >= 2)
+    o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il, tl, "none")
+    assert np.isinf(o["loss"][1])
+    r = run_hip(x, tg, tr, il, tl, "none", torch.float64)
+    for k in ("loss", "grad_inputs", "grad_transition"):
+        util.assert_close(r[k], o[k], 1e-9, "fp64 T%d B%d N%d L%d %s" % (T, B, N, L, k))
+    assert not np.isnan(r["grad_inputs"]).any() and not np.isnan(r["grad_transition"]).any()
+    again = run_hip(x, tg, tr, il, tl, "none", torch.float64)
+    assert np.array_equal(again["grad_inputs"], r["grad_inputs"]) and np.array_equal(again["loss"], r["loss"])
+    A = _asg()
+    m = A.ASGLoss(N, reduction="none").to(DEV).double().eval()
+    with torch.no_grad():
+        m.transition.copy_(tr.double())
+        ev = m(x.double().to(DEV), tg.to(DEV), torch.from_numpy(il).to(DEV), torch.from_numpy(tl).to(DEV)).cpu().numpy()
+    util.assert_close(ev, o["loss"], 1e-9, "fp64 evaluation route")
+
+
+def test_streaming_step_at_depth():
+    """The per-frame streaming kernels (fwd_step_mfma + bwd_post_kernel + the compacted matrix-core contraction) over 60
+    frames -- the kernels of BASELINE.json configs[4] at a depth where the lagged normaliser, the per-frame offsets and the
+    compaction of the valid rows have all cycled many times -- against the fp64 oracle at 1e-4 (about a minute of oracle)."""
+    T, B, N, L = 60, 34, 2600, 12
+    tr, x, tg, il, tl = util.synth(T, B, N, L, N, True)
+    o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il.numpy(), tl.numpy(), "none")
+    r = run_hip(x, tg, tr, il, tl, "none")
+    for k in ("loss", "grad_inputs", "grad_transition"):
+        util.assert_close(r[k], o[k], 1e-4, "T%d B%d N%d L%d %s" % (T, B, N, L, k))
+    r2 = run_hip(x, tg, tr, il, tl, "none")
+    for k in ("loss", "grad_inputs", "grad_transition"):
+        assert np.array_equal(r[k], r2[k]), "streaming kernels run to run: " + k
+
+
 def test_golden_cfg5_reduced_large_alphabet():
     # BASELINE.json configs[4] at the size the reference can still run: T=64 B=4 N=1024 L=16, variable lengths
     g = util.load("cfg5_reduced")

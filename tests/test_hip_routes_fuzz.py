@@ -1,5 +1,5 @@
 """Random shapes through the routes between the fused step and the large-alphabet kernels (long targets over small
-alphabets, medium alphabets, both, alphabets of 257 .. 1025 labels, and the boundaries N = 64/65/256/257, S = 64/65/256/257/512/513) against the fp64
+alphabets, medium alphabets, both, alphabets of 257 .. 1025 labels (one in five of those draws: 2049 .. 3100), and the boundaries N = 64/65/256/257, S = 64/65/256/257/512/513) against the fp64
 oracle: lengths of every kind (infeasible included), all reductions, fp32 and fp64, 30 % of the cases with transition
 scores scaled to 5 / 40 nats; ONE gate, 1e-4 (1e-9 in fp64).  tools/fuzz_routes.py is the long form."""
 import numpy as np
@@ -24,6 +24,9 @@ def _case(rng):
     elif kind == 4:
         # 256 < N <= 1024 (matrix resident in a cluster of workgroups) and just beyond (a launch per frame)
         N, S, T = int(rng.choice([257, 300, 448, 512, 513, 640, 777, 1000, 1024, 1025])), int(rng.integers(1, 90)), int(rng.integers(1, 50))
+        if rng.random() < 0.2:
+            # one draw in five: beyond 2048 labels (fp32: fwd_step_mfma; fp64: fwd_step_kernel<double> + bwd_post_kernel<double, true>)
+            N, T = int(rng.choice([2049, 2100, 2600, 3100])), int(rng.integers(1, 14))
     else:
         N = int(rng.choice([64, 65, 128, 129, 192, 193, 256, 257]))
         S = int(rng.choice([64, 65, 128, 129, 256, 257, 512, 513]))

@@ -59,11 +59,15 @@ def sharded_asg_loss(loss_module, inputs, targets, input_lengths=None, target_le
     return total
 
 
-def allreduce_transition_grad(loss_module, group=None, async_op=False):
-    """The single collective of the step: all-reduce(SUM) of transition.grad across ranks."""
+def allreduce_transition_grad(loss_module, group=None, async_op=False, force=False):
+    """The single collective of the step: all-reduce(SUM) of transition.grad across ranks.
+    A one-rank group has nothing to add and is skipped; `force=True` issues the collective anyway (tests that want the
+    RCCL call itself to run on a one-GPU box)."""
     g = loss_module.transition.grad
     if g is None:
         raise RuntimeError("transition.grad is None: call backward() first")
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    if dist.get_world_size(group) == 1 and not force:
         return None
     return dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
