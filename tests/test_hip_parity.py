@@ -335,6 +335,23 @@ def test_streaming_step_at_depth():
         assert np.array_equal(r[k], r2[k]), "streaming kernels run to run: " + k
 
 
+def test_large_alphabet_contraction_on_the_bf16_pipe():
+    """Alphabets whose transition gradient is ONE slice of the frame axis (N >= ~2900) take the split-bfloat16 contraction
+    (gemm3_pack_kernel + bwd_gemm_bf3_kernel: every operand the exact sum of three bfloat16, six partial products in fp32): against
+    the fp64 oracle at 1e-4 over 40 frames with variable lengths (valid rows compacted: K is known on the device only), a label
+    count that is no multiple of any tile, run-to-run determinism."""
+    T, B, N, L = 40, 20, 3111, 9
+    tr, x, tg, il, tl = util.synth(T, B, N, L, N, True)
+    o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il.numpy(), tl.numpy(), "none")
+    r = run_hip(x, tg, tr, il, tl, "none")
+    for k in ("loss", "grad_inputs", "grad_transition"):
+        util.assert_close(r[k], o[k], 1e-4, "T%d B%d N%d L%d %s" % (T, B, N, L, k))
+    ok, err = util.tol_ok(r["grad_transition"], o["grad_transition"], 1e-4)
+    assert err < 2e-6, "split-bfloat16 contraction: scaled error %.2e (fp32-equivalent expected)" % err
+    r2 = run_hip(x, tg, tr, il, tl, "none")
+    assert np.array_equal(r["grad_transition"], r2["grad_transition"])
+
+
 def test_golden_cfg5_reduced_large_alphabet():
     # BASELINE.json configs[4] at the size the reference can still run: T=64 B=4 N=1024 L=16, variable lengths
     g = util.load("cfg5_reduced")

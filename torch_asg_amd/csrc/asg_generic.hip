@@ -151,8 +151,45 @@ struct StepBuf {
     const R *etile;   // fp32: the same matrix in the MFMA step's operand order (tile_kernel)
     const R *hmax;    // [N]
     R *mulog;         // alpha only, [T][B]: the normaliser each frame's state was stored against (read by the gradient pass)
+    unsigned short *pb3;   // fp32 streaming step only: p again as three bfloat16 planes [2][3][B][npb] (p = hi + mid + lo exactly), or null
     int npad;
+    int npb;          // row pitch of a plane (npad rounded up to whole 32-k chunks, pad columns zero)
 };
+
+typedef float V4f __attribute__((ext_vector_type(4)));
+// A float as the exact sum of three bfloat16 (8 significant bits each, round to nearest: the remainders are exact in fp32).
+typedef __bf16 BF8 __attribute__((ext_vector_type(8)));
+typedef float F8v __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split3(float v, unsigned short &h, unsigned short &m, unsigned short &l) {
+    const __bf16 bh = (__bf16) v;
+    const float r1 = v - (float) bh;
+    const __bf16 bm = (__bf16) r1;
+    const float r2 = r1 - (float) bm;
+    const __bf16 bl = (__bf16) r2;
+    h = __builtin_bit_cast(unsigned short, bh); m = __builtin_bit_cast(unsigned short, bm); l = __builtin_bit_cast(unsigned short, bl);
+}
+// two floats -> three packed bfloat16 pairs: v_cvt_pk_bf16_f32, the pair widened again (shift / mask), one packed subtraction
+typedef __bf16 BF2 __attribute__((ext_vector_type(2)));
+typedef float F2v __attribute__((ext_vector_type(2)));
+typedef unsigned U4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split3x2(float x, float y, unsigned &h, unsigned &m, unsigned &l) {
+    const F2v v = {x, y};
+    const BF2 bh = __builtin_convertvector(v, BF2);
+    const F2v r1 = v - __builtin_convertvector(bh, F2v);
+    const BF2 bm = __builtin_convertvector(r1, BF2);
+    const F2v r2 = r1 - __builtin_convertvector(bm, F2v);
+    const BF2 bl = __builtin_convertvector(r2, BF2);
+    h = __builtin_bit_cast(unsigned, bh); m = __builtin_bit_cast(unsigned, bm); l = __builtin_bit_cast(unsigned, bl);
+}
+__device__ __forceinline__ void split3x8(const V4f &e0, const V4f &e1, BF8 &h, BF8 &m, BF8 &l) {
+    unsigned uh[4], um[4], ul[4];
+    split3x2(e0.x, e0.y, uh[0], um[0], ul[0]);
+    split3x2(e0.z, e0.w, uh[1], um[1], ul[1]);
+    split3x2(e1.x, e1.y, uh[2], um[2], ul[2]);
+    split3x2(e1.z, e1.w, uh[3], um[3], ul[3]);
+    const U4v vh = {uh[0], uh[1], uh[2], uh[3]}, vm = {um[0], um[1], um[2], um[3]}, vl = {ul[0], ul[1], ul[2], ul[3]};
+    h = __builtin_bit_cast(BF8, vh); m = __builtin_bit_cast(BF8, vm); l = __builtin_bit_cast(BF8, vl);
+}
 
 // init: alpha at frame 0 / beta at frame len-1.  grid = B, block = 256.
 template <typename R, bool BETA>
@@ -177,6 +214,15 @@ __global__ void __launch_bounds__(256) fwd_init_kernel(Problem P, StepBuf<R> S) 
             R q = in[(int64_t) i * P.is2] * L2E - em;          // max over i is exactly 0
             st[i] = BETA ? R(0) : q;
             pb[i] = Num<R>::exp2(q);
+            if constexpr (sizeof(R) == 4) {
+                if (S.pb3) {
+                    unsigned short h, m, l;
+                    split3((float) pb[i], h, m, l);
+                    unsigned short *pl = S.pb3 + (int64_t) b * S.npb + i;       // (parity 0; pad columns were zeroed by the launcher)
+                    const int64_t ps = (int64_t) P.B * S.npb;
+                    pl[0] = h; pl[ps] = m; pl[2 * ps] = l;
+                }
+            }
         } else {
             pb[i] = 0;
         }
@@ -491,13 +537,25 @@ __global__ void __launch_bounds__(256) fwd_step_tile_kernel(Problem P, StepBuf<R
 // Measured at cfg 5 (us per frame, both directions; tools/cfg5_fwd_time.py): 16 rows 356 (1250 workgroups, 3.2 GB of
 // vectors per frame) - 48 rows 213 (418 workgroups = 1.6 per compute unit: half the chip waits for the other half) -
 // 80 rows 151 (250 workgroups, one per compute unit) - 96 rows 161.  The VALU body above: 509 (314 workgroups).
-typedef float V4f __attribute__((ext_vector_type(4)));
 #ifndef ASG_X_STEP_PF
 #define ASG_X_STEP_PF 1
 #endif
 #ifndef ASG_X_STEP_MB
 #define ASG_X_STEP_MB 5
 #endif
+#ifndef ASG_X_STEP_SERP
+#define ASG_X_STEP_SERP 0
+#endif
+#ifndef ASG_X_STEP_NT
+#define ASG_X_STEP_NT 1
+#endif
+#ifndef ASG_X_STEP_BF3
+#define ASG_X_STEP_BF3 0
+#endif
+#ifndef ASG_X_STEP_PF3
+#define ASG_X_STEP_PF3 2
+#endif
+constexpr bool kStepBf3 = ASG_X_STEP_BF3 != 0;
 constexpr int kStepMB = ASG_X_STEP_MB;      // 16-row blocks per workgroup: every workgroup reads the batch's whole vector
                                             // set once (L2 traffic = row tiles x 1.3 MB), so tiles must not be too small
 // The MFMA step's E operand, laid out so that every wavefront load is ONE contiguous kilobyte and a workgroup streams
@@ -541,7 +599,112 @@ __device__ __forceinline__ void fwd_step_mfma(const Problem &P, const StepBuf<fl
     const int i0 = blockIdx.x * (16 * MB), b0 = blockIdx.y * 32;
     const R *pcur = S.pbuf + (int64_t) (n & 1) * B * npad;
     R *pnext = S.pbuf + (int64_t) ((n + 1) & 1) * B * npad;
-    {
+    if constexpr (kStepBf3) {
+        // ---- the product on the bfloat16 matrix pipe, fp32-equivalent ---------------------------------------------------
+        // v_mfma_f32_16x16x4_f32 runs at the vector rate (32 cycles for 1024 multiply-adds) and, fed from a stream of global
+        // loads, issues every ~49 cycles: 6250 of them per wavefront and frame are 128 us -- the loop, not the memory system
+        // (which streams the same 800 MB in 113-118 us: tools/ubench/mall_stream.hip), bounded the frame.  Every float is
+        // EXACTLY the sum of three bfloat16 (8 + 8 + 8 significant bits); the six partial products whose weight is >= 2^-16
+        //   hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi      (dropped: mid*lo + lo*mid + lo*lo <= 2^-25 relative, zero mean)
+        // accumulate in fp32 inside v_mfma_f32_16x16x32_bf16: 6 x 16 cycles for 16 rows x 16 utterances x 32 k against 8 x 32,
+        // on a pipe the vector ALU does not share -- the 180 conversion instructions per chunk run in its shadow.  The
+        // matrix stays fp32 in memory (one stream, split in registers); the vectors arrive already split (three planes,
+        // written by the previous frame's epilogue).  The chunk's two float4 of a lane ARE the instruction's A layout:
+        // row l & 15, k = 8 (l >> 4) .. + 7.
+        const int r = lane & 15, kq = lane >> 4;
+        const size_t nchunks = ((size_t) npad + 31) / 32;
+        const V4f *et = reinterpret_cast<const V4f *>(S.etile) + (size_t) blockIdx.x * nchunks * (MB * 2 * 64) + lane;
+        const int npb = S.npb;
+        const int64_t plane = (int64_t) B * npb;
+        const unsigned short *pb = S.pb3 + (int64_t) (n & 1) * 3 * plane + 8 * kq;
+        const unsigned short *va = pb + (int64_t) min(b0 + r, B - 1) * npb;
+        const unsigned short *vb = pb + (int64_t) min(b0 + 16 + r, B - 1) * npb;
+        // every chunk is whole here: the tile and the planes are zero-padded to 32 k
+        const int nch = (int) nchunks, cpw = (nch + 3) / 4;
+        const int c0 = min(wave * cpw, nch), c1 = min(c0 + cpw, nch);
+        const V4f zero4 = {0, 0, 0, 0};
+        V4f acc[MB][2];
+#pragma unroll
+        for (int m = 0; m < MB; ++m) { acc[m][0] = zero4; acc[m][1] = zero4; }
+        struct Stage { V4f e[MB][2]; BF8 a[3], b[3]; };
+        const bool rev = ASG_X_STEP_SERP && (n & 1);
+        auto load = [&](Stage &st, int cf) {
+            const int c = rev ? c0 + c1 - 1 - cf : cf;
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    st.e[m][h] = ASG_X_STEP_NT ? __builtin_nontemporal_load(&et[((size_t) c * MB * 2 + m * 2 + h) * 64])
+                                               : et[((size_t) c * MB * 2 + m * 2 + h) * 64];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                st.a[q] = *reinterpret_cast<const BF8 *>(va + q * plane + 32 * c);
+                st.b[q] = *reinterpret_cast<const BF8 *>(vb + q * plane + 32 * c);
+            }
+        };
+        auto multiply = [&](const Stage &st) {
+#pragma unroll
+            for (int m = 0; m < MB; ++m) {
+                BF8 eh, em, el;
+#if defined(ASG_X_BF3_ABL) && ASG_X_BF3_ABL == 1      // (developer timing: a third of the conversion; results off by a constant factor per frame)
+                { U4v x; unsigned t0, t1;
+                  split3x2(st.e[m][0].x, st.e[m][0].y, x.x, t0, t1); x.y = __builtin_bit_cast(unsigned, st.e[m][0].z); x.z = __builtin_bit_cast(unsigned, st.e[m][1].x);
+                  x.w = __builtin_bit_cast(unsigned, st.e[m][1].z) & 0x7fff7fffu;
+                  x.y &= 0x3fff3fffu; x.z &= 0x3fff3fffu; x.w &= 0x3fff3fffu;
+                  eh = __builtin_bit_cast(BF8, x); em = eh; el = eh; }
+#else
+                split3x8(st.e[m][0], st.e[m][1], eh, em, el);
+#endif
+#if defined(ASG_X_BF3_ABL) && ASG_X_BF3_ABL == 2      // (developer timing: full conversion, a sixth of the products)
+                { const U4v x = (__builtin_bit_cast(U4v, eh) | (__builtin_bit_cast(U4v, em) & 1u)) | (__builtin_bit_cast(U4v, el) & 1u);
+                  const BF8 ex = __builtin_bit_cast(BF8, x);
+                  acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ex, st.a[0], acc[m][0], 0, 0, 0);
+                  acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ex, st.b[0], acc[m][1], 0, 0, 0);
+                  continue; }
+#endif
+                // (smallest terms first)
+                acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(el, st.a[0], acc[m][0], 0, 0, 0);
+                acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(el, st.b[0], acc[m][1], 0, 0, 0);
+                acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(eh, st.a[2], acc[m][0], 0, 0, 0);
+                acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(eh, st.b[2], acc[m][1], 0, 0, 0);
+                acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(em, st.a[1], acc[m][0], 0, 0, 0);
+                acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(em, st.b[1], acc[m][1], 0, 0, 0);
+                acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(em, st.a[0], acc[m][0], 0, 0, 0);
+                acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(em, st.b[0], acc[m][1], 0, 0, 0);
+                acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(eh, st.a[1], acc[m][0], 0, 0, 0);
+                acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(eh, st.b[1], acc[m][1], 0, 0, 0);
+                acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(eh, st.a[0], acc[m][0], 0, 0, 0);
+                acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(eh, st.b[0], acc[m][1], 0, 0, 0);
+            }
+        };
+        if (c0 < c1) {
+            // (the loop's loads are a memory-latency's worth ahead of their use only if STG - 1 chunks are in flight: the product of a
+            // chunk takes ~0.6 us, a load under this stream ~1.2-2 us)
+            constexpr int STG = ASG_X_STEP_PF3 + 1;
+            Stage st[STG];
+#pragma unroll
+            for (int u = 0; u < STG - 1; ++u) {
+                // (pinned too: if the prologue's stages interleave, the loop header's s_waitcnt has to assume the worst order on
+                // EVERY trip and drains all but the newest stage)
+                __builtin_amdgcn_sched_barrier(0);
+                load(st[u], min(c0 + u, c1 - 1));
+            }
+            for (int c = c0; c < c1; c += STG) {
+#pragma unroll
+                for (int u = 0; u < STG; ++u) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    load(st[(u + STG - 1) % STG], min(c + u + STG - 1, c1 - 1));
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (c + u < c1) multiply(st[u]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { red[wave][8 * m + q][lane] = acc[m][0][q]; red[wave][8 * m + 4 + q][lane] = acc[m][1][q]; }
+    } else {
         // lane l: row / utterance (l & 15), k sub-range 8 (l >> 4) .. +7 of every 32-k chunk: two float4 per operand, so a
         // row's whole 128-byte line goes to one wavefront at once
         const int r = lane & 15, kq = lane >> 4;
@@ -559,7 +722,11 @@ __device__ __forceinline__ void fwd_step_mfma(const Problem &P, const StepBuf<fl
 #pragma unroll
         for (int m = 0; m < MB; ++m) { acc[m][0] = zero4; acc[m][1] = zero4; }
         struct Stage { V4f e[MB][2], a[2], b[2]; };
-        auto load = [&](Stage &st, int c) {
+        // (ASG_X_STEP_SERP: odd frames walk a wavefront's chunks back to front -- what the memory-side cache still holds of
+        // frame n is what frame n + 1 asks for first)
+        const bool rev = ASG_X_STEP_SERP && (n & 1);
+        auto load = [&](Stage &st, int cf) {
+            const int c = rev ? c0 + c1 - 1 - cf : cf;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 st.a[h] = *reinterpret_cast<const V4f *>(va + 32 * c + 4 * h);
@@ -568,7 +735,8 @@ __device__ __forceinline__ void fwd_step_mfma(const Problem &P, const StepBuf<fl
                 for (int m = 0; m < MB; ++m) {
                     // (non-temporal: every element of the matrix is used once per frame, and the lines it would displace in
                     // L2 are the batch's vectors that all workgroups of the XCD read: 144.4 -> 137.9 us per frame at cfg 5)
-                    st.e[m][h] = __builtin_nontemporal_load(&et[((size_t) c * MB * 2 + m * 2 + h) * 64]);
+                    st.e[m][h] = ASG_X_STEP_NT ? __builtin_nontemporal_load(&et[((size_t) c * MB * 2 + m * 2 + h) * 64])
+                                               : et[((size_t) c * MB * 2 + m * 2 + h) * 64];
                 }
             }
         };
@@ -637,6 +805,7 @@ __device__ __forceinline__ void fwd_step_mfma(const Problem &P, const StepBuf<fl
     const int tw = active ? (BETA ? t - 1 : t) : 0;    // frame written
     const R emw = S.emax[(int64_t) tw * B + bc];
     float qkey = -__builtin_inff();
+    unsigned pk3[3] = {0, 0, 0};
 #pragma unroll
     for (int rr2 = 0; rr2 < 2 * MB; ++rr2) {
         const int row = 16 * (rr2 >> 1) + 2 * (threadIdx.x & 7) + (rr2 & 1), i = i0 + row;
@@ -672,12 +841,34 @@ __device__ __forceinline__ void fwd_step_mfma(const Problem &P, const StepBuf<fl
         R stv, q;
         if (BETA) { stv = rr - muprev; q = emis + stv; }
         else { stv = emis + rr - muprev; q = stv; }
+        const R pv = Num<R>::exp2(q);
         if (PERSIST) {
             __hip_atomic_store(&S.state[((int64_t) b * T + tw) * N + i], stv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&pnext[(int64_t) b * npad + i], Num<R>::exp2(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&pnext[(int64_t) b * npad + i], pv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
             S.state[((int64_t) b * T + tw) * N + i] = stv;
-            pnext[(int64_t) b * npad + i] = Num<R>::exp2(q);
+            pnext[(int64_t) b * npad + i] = pv;
+        }
+        if constexpr (kStepBf3) {
+            // the next frame's B operand: p = hi + mid + lo, rows i (even) and i + 1 of a plane in one 32-bit store
+            unsigned short h3, m3, l3;
+            split3(pv, h3, m3, l3);
+            if ((rr2 & 1) == 0) { pk3[0] = h3; pk3[1] = m3; pk3[2] = l3; }
+            if ((rr2 & 1) == 1 || i + 1 >= N) {
+                const int ie = i & ~1;
+                unsigned *dst = reinterpret_cast<unsigned *>(S.pb3 + (int64_t) ((n + 1) & 1) * 3 * B * S.npb + (int64_t) b * S.npb + ie);
+                const int64_t ps = (int64_t) B * S.npb / 2;
+                const unsigned w0 = (rr2 & 1) ? (pk3[0] | ((unsigned) h3 << 16)) : pk3[0];
+                const unsigned w1 = (rr2 & 1) ? (pk3[1] | ((unsigned) m3 << 16)) : pk3[1];
+                const unsigned w2 = (rr2 & 1) ? (pk3[2] | ((unsigned) l3 << 16)) : pk3[2];
+                if (PERSIST) {
+                    __hip_atomic_store(dst, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(dst + ps, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(dst + 2 * ps, w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    dst[0] = w0; dst[ps] = w1; dst[2 * ps] = w2;
+                }
+            }
         }
         qkey = fmaxf(qkey, (float) q);
         if (i == 0) {
@@ -2542,6 +2733,147 @@ __global__ void __launch_bounds__(256) bwd_gemm_mfma(const float *ehat, const fl
         }
 }
 
+// ---- the same contraction on the bfloat16 matrix pipe, fp32-equivalent (round 5; large alphabets: one slice of the frame axis) ----
+// G = U^T P over K ~ 48 000 valid frame rows at cfg 5 is 9.6 TFLOP: at the fp32 matrix rate (v_mfma_f32_16x16x4_f32 = the vector
+// rate, 157 TFLOP/s) 61 ms at best, 85 ms as measured.  Every float is EXACTLY the sum of three bfloat16 (8 + 8 + 8 significant
+// bits, round to nearest at each step, remainders exact), and the six partial products of weight >= 2^-16
+//     hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi           (dropped: mid*lo + lo*mid + lo*lo <= 2^-24 relative, zero mean)
+// accumulated in fp32 by v_mfma_f32_32x32x16_bf16 cost 6 x 32 cycles per 32 x 32 x 16 block where the fp32 instruction takes
+// 16 x 32: 2.7x less matrix-pipe time at the accuracy of an fp32 product chain.  gemm3_pack_kernel splits the two operands ONCE
+// (each element is used by ~80 output tiles) into planes laid out [K/8][npadT][8]: a lane's eight consecutive k of one label are
+// 16 contiguous bytes -- the instruction's operand as it is, in memory, in LDS and in registers.
+constexpr int kG3TM = 256, kG3TN = 128;          // output tile of a workgroup (8 wavefronts, 64 x 64 each)
+__host__ __device__ inline int g3_npadT(int N) { return (N + kG3TM - 1) / kG3TM * kG3TM; }
+__host__ __device__ inline size_t g3_plane_elems(int K, int N) { return (size_t) ((K + 31) / 32 * 32) * g3_npadT(N); }
+
+// grid = (npadT / 256, ceil(Kmax / 8)), block = 256: thread = label m, rows 8 kg .. + 7 of X [K][npad] (-inf markers and rows >= K: 0)
+__global__ void __launch_bounds__(256) gemm3_pack_kernel(const float *X, int npad, int npadT, const int *kdev, int K, unsigned short *planes,
+                                                         size_t plane_elems) {
+    if (kdev) K = __builtin_amdgcn_readfirstlane(*kdev);
+    const int kg = blockIdx.y;
+    if (8 * kg >= (K + 31) / 32 * 32) return;
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int k = 8 * kg + q;
+        float x = (k < K && m < npad) ? X[(int64_t) k * npad + m] : 0.f;
+        v[q] = (x == -__builtin_inff()) ? 0.f : x;
+    }
+    unsigned h[4], mi[4], lo[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) split3x2(v[2 * q], v[2 * q + 1], h[q], mi[q], lo[q]);
+    U4v *dst = reinterpret_cast<U4v *>(planes) + ((size_t) kg * npadT + m);
+    const size_t pu = plane_elems / 8;          // 16-byte units per plane
+    dst[0] = U4v{h[0], h[1], h[2], h[3]};
+    dst[pu] = U4v{mi[0], mi[1], mi[2], mi[3]};
+    dst[2 * pu] = U4v{lo[0], lo[1], lo[2], lo[3]};
+}
+
+typedef float V16f __attribute__((ext_vector_type(16)));
+// grid = 8 x 32 x ceil(blocks / 8) workgroups (1-D), block = 512, dynamic LDS = 2 stages x 72 KB.
+// Workgroup id -> tile: id & 7 is the XCD the dispatcher puts it on; an XCD walks blocks of 4 x 8 tiles (1024 labels x 1024 labels of
+// output: its 32 resident workgroups share 4 row panels and 8 column panels through that XCD's L2).
+__global__ void __launch_bounds__(512) bwd_gemm_bf3_kernel(const unsigned short *Apl, const unsigned short *Bpl, size_t plane_elems,
+                                                           const float *ehat, float *out, int N, int npad, int npadT, const int *kdev, int K,
+                                                           int Mt, int Nt) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char g3_lds[];
+    U4v *lds = reinterpret_cast<U4v *>(g3_lds);
+    constexpr int TM = kG3TM, TN = kG3TN, AU = 3 * 4 * TM, BU = 3 * 4 * TN, SU = AU + BU;      // 16-byte units per stage: 3072 + 1536
+    constexpr int NR = SU / 512;                                                                // units per thread and stage: 9
+    if (kdev) K = __builtin_amdgcn_readfirstlane(*kdev);
+    const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
+    const int mblocks = (Mt + 3) / 4, nblocks = (Nt + 7) / 8;
+    const int g = (j >> 5) * 8 + xcd, r = j & 31;
+    if (g >= mblocks * nblocks) return;
+    const int tm = (g % mblocks) * 4 + (r & 3), tn = (g / mblocks) * 8 + (r >> 2);
+    if (tm >= Mt || tn >= Nt) return;
+    const int m0 = tm * TM, n0 = tn * TN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = (wave & 3) * 64, wn = (wave >> 2) * 64;
+    const size_t pu = plane_elems / 8;
+    const U4v *Au = reinterpret_cast<const U4v *>(Apl), *Bu = reinterpret_cast<const U4v *>(Bpl);
+    // staging: unit e = tid + 512 r of a stage -> (operand, plane, k group, label)
+    const U4v *src[NR];
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+        const int e = (int) threadIdx.x + 512 * q;
+        if (e < AU) { const int pl = e / (4 * TM), rem = e % (4 * TM); src[q] = Au + (size_t) pl * pu + (size_t) (rem / TM) * npadT + m0 + rem % TM; }
+        else { const int f = e - AU, pl = f / (4 * TN), rem = f % (4 * TN); src[q] = Bu + (size_t) pl * pu + (size_t) (rem / TN) * npadT + n0 + rem % TN; }
+    }
+    const size_t kstride = (size_t) 4 * npadT;          // 16-byte units per 32 k
+    const int nkb = (K + 31) / 32;
+    V16f acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[a][c][q] = 0.f;
+    U4v st[NR];
+    if (nkb > 0) {
+#pragma unroll
+        for (int q = 0; q < NR; ++q) st[q] = src[q][0];
+#pragma unroll
+        for (int q = 0; q < NR; ++q) lds[(int) threadIdx.x + 512 * q] = st[q];
+        if (nkb > 1) {
+#pragma unroll
+            for (int q = 0; q < NR; ++q) st[q] = src[q][kstride];
+        }
+    }
+    __syncthreads();
+    for (int kb = 0; kb < nkb; ++kb) {
+        const U4v *cur = lds + (kb & 1) * SU;
+        U4v *nxt = lds + ((kb + 1) & 1) * SU;
+        if (kb + 1 < nkb) {
+#pragma unroll
+            for (int q = 0; q < NR; ++q) nxt[(int) threadIdx.x + 512 * q] = st[q];
+            if (kb + 2 < nkb) {
+#pragma unroll
+                for (int q = 0; q < NR; ++q) st[q] = src[q][(size_t) (kb + 2) * kstride];
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int kg = 2 * s + (lane >> 5), ln = lane & 31;
+            BF8 af[2][3], bf[2][3];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) af[a][pl] = __builtin_bit_cast(BF8, cur[pl * 4 * TM + kg * TM + wm + 32 * a + ln]);
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) bf[c][pl] = __builtin_bit_cast(BF8, cur[AU + pl * 4 * TN + kg * TN + wn + 32 * c + ln]);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][2], bf[c][0], acc[a][c], 0, 0, 0);
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[c][2], acc[a][c], 0, 0, 0);
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][1], bf[c][1], acc[a][c], 0, 0, 0);
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][1], bf[c][0], acc[a][c], 0, 0, 0);
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[c][1], acc[a][c], 0, 0, 0);
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[c][0], acc[a][c], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+    // element (m = 32 a + 8 (q >> 2) + 4 (l >> 5) + (q & 3), n = 32 c + (l & 31)) of the wavefront's 64 x 64 sits in acc[a][c][q]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int gn = n0 + wn + 32 * c + (lane & 31);
+            if (gn >= N) continue;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int gm_ = m0 + wm + 32 * a + 8 * (q >> 2) + 4 * (lane >> 5) + (q & 3);
+                if (gm_ < N) out[(int64_t) gm_ * N + gn] = acc[a][c][q] * ehat[(int64_t) gm_ * npad + gn];
+            }
+        }
+}
+
 // out[m][n] = ehat[m][n] * sum over the slices of partial[z][m][n], slices in ascending order.  grid = ceil(N^2 / 256).
 template <typename R>
 __global__ void __launch_bounds__(256) gemm_combine_kernel(const R *partial, int nslices, const R *ehat, int N, int npad, R *out) {
@@ -2998,11 +3330,18 @@ size_t step_tile_bytes_generic(int elem, int N) {
     return (elem == 4 && StepUsesMfma<float>::v) ? step_tile_floats(N) * sizeof(float) : 0;
 }
 
+// the vectors of the fp32 streaming step as three bfloat16 planes (fwd_step_mfma): [2 frames][3][B][npb] per direction, behind
+// the normaliser log
+static size_t step_plane_bytes(int elem, int B, int N) {
+    if (!(elem == 4 && StepUsesMfma<float>::v && kStepBf3)) return 0;
+    const size_t npb = ((size_t) N + 31) / 32 * 32;
+    return au(2 * 3 * (size_t) B * npb * sizeof(unsigned short));
+}
 // forward work buffers live behind the saved state (see fwd_work_bytes_generic): emax, pbuf x2 dirs, mu, off
 size_t fwd_work_bytes_generic(int elem, int T, int B, int N) {
     const size_t npad = (size_t) (N + 3) / 4 * 4;
     return au((size_t) T * B * elem) + 2 * au(2 * (size_t) B * npad * elem) + 2 * au(3 * (size_t) B * 4) + 2 * au((size_t) B * 8) +
-           au((size_t) T * B * elem) + ((elem == 4 && N > 256 && N <= 2048) ? kClusterBytes : 0) + 4096;
+           au((size_t) T * B * elem) + 2 * step_plane_bytes(elem, B, N) + ((elem == 4 && N > 256 && N <= 2048) ? kClusterBytes : 0) + 4096;
 }
 // offset of the alpha pass's per-frame normaliser log inside the work area (its last member)
 static size_t work_mulog_offset(size_t elem, int T, int B, int npad) {
@@ -3083,6 +3422,11 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
             S.etile = (const R *) (beta ? W.ftile : W.etile);
             S.hmax = (const R *) (beta ? W.cmax : W.rmax);
             S.mulog = beta ? nullptr : (R *) ((char *) W.work + work_mulog_offset(e, P.T, P.B, W.npad));
+            if (const size_t pbytes = step_plane_bytes((int) e, P.B, P.N)) {
+                S.npb = (P.N + 31) / 32 * 32;
+                S.pb3 = (unsigned short *) ((char *) W.work + work_mulog_offset(e, P.T, P.B, W.npad) + au((size_t) P.T * P.B * e) + dir * pbytes);
+                if (dir == 0) (void) hipMemsetAsync(S.pb3, 0, 2 * pbytes, stream);       // (pad columns stay zero)
+            }
             Sd[dir] = S;
         }
         const bool do_a = full_mask & kFullAlpha, do_b = full_mask & kFullBeta;
@@ -3221,6 +3565,14 @@ static int gemm_slices(int N, int K) {
     return n < 1 ? 1 : n;
 }
 
+// the contraction's operands as three bfloat16 planes each (large alphabets, fp32, one slice of the frame axis): bytes per operand
+#ifndef ASG_X_GEMM_BF3
+#define ASG_X_GEMM_BF3 1
+#endif
+static size_t gemm3_plane_bytes(int elem, int T, int B, int N) {
+    if (!(ASG_X_GEMM_BF3 && elem == 4 && StepUsesMfma<float>::v && N > 64 && gemm_slices(N, B * T) == 1)) return 0;
+    return au(3 * g3_plane_elems(B * T, N) * sizeof(unsigned short));
+}
 static void generic_chunks(int T, int B, int *chunk, int *nchunks) {
     int nch = (512 + B - 1) / B;
     if (nch < 1) nch = 1;
@@ -3239,6 +3591,7 @@ size_t bwd_scratch_bytes_generic(int elem, int T, int B, int N, int S) {
     if (N > 64 && N <= 2048) tiles = au((size_t) N * N * 8);                      // aligned_tr_scatter_fx_kernel
     if (S > 1024 && tiles < au((size_t) N * N * 8)) tiles = au((size_t) N * N * 8);      // (very long targets: the same accumulator for any N <= 2048)
     if (N > 64) tiles += au((size_t) gemm_slices(N, B * T) * N * N * elem);       // split contraction: partial sums
+    tiles += 2 * gemm3_plane_bytes(elem, T, B, N);                                  // bfloat16 planes of both operands (bwd_gemm_bf3_kernel)
     return 2 * au((size_t) B * T * npad * elem) + au((size_t) B * nch * 2 * S * elem) + 512 + au(((size_t) B + 1) * 4) + tiles;
 }
 
@@ -3261,6 +3614,8 @@ hipError_t launch_bwd_generic(const Problem &P, const State &W, const BwdArgs &A
         sc += tb;
     }
     R *gpart = (R *) sc;
+    if (P.N > 64) sc += au((size_t) gemm_slices(P.N, P.B * P.T) * P.N * P.N * e);
+    unsigned short *planes3 = (unsigned short *) sc;      // (only when gemm3_plane_bytes says so)
     const bool do_full = parts & 1, do_ali = parts & 2, have_full = (parts & 5) != 0;
     R *gtr = (R *) A.grad_transition;
     bool fx_cleared = false;
@@ -3298,6 +3653,21 @@ hipError_t launch_bwd_generic(const Problem &P, const State &W, const BwdArgs &A
                                    (const int *) (rowoff + P.B), kslice, (float *) gpart);
                 hipLaunchKernelGGL((gemm_combine_kernel<float>), dim3((P.N * P.N + 255) / 256), dim3(256), 0, stream, (const float *) gpart,
                                    nsl, (const float *) W.ehat, P.N, npad, (float *) gtr);
+            } else if (const size_t pbytes = gemm3_plane_bytes((int) e, P.T, P.B, P.N)) {
+                // large alphabets: both operands split into bfloat16 planes once, the product on v_mfma_f32_32x32x16_bf16
+                const int npadT = g3_npadT(P.N);
+                const size_t pe = g3_plane_elems(K, P.N);
+                unsigned short *apl = planes3, *bpl = (unsigned short *) ((char *) planes3 + pbytes);
+                const dim3 pgrid(npadT / 256, (K + 7) / 8);
+                hipLaunchKernelGGL(gemm3_pack_kernel, pgrid, dim3(256), 0, stream, (const float *) Gm, npad, npadT, (const int *) (rowoff + P.B), K, apl, pe);
+                hipLaunchKernelGGL(gemm3_pack_kernel, pgrid, dim3(256), 0, stream, (const float *) Pm, npad, npadT, (const int *) (rowoff + P.B), K, bpl, pe);
+                const int Mt = npadT / kG3TM, Nt = (P.N + kG3TN - 1) / kG3TN;
+                const int blocks = ((Mt + 3) / 4) * ((Nt + 7) / 8);
+                const size_t lds = (size_t) 2 * (3 * 4 * (kG3TM + kG3TN)) * 16;
+                (void) hipFuncSetAttribute((const void *) bwd_gemm_bf3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+                hipLaunchKernelGGL(bwd_gemm_bf3_kernel, dim3(8 * 32 * ((blocks + 7) / 8)), dim3(512), lds, stream, (const unsigned short *) apl,
+                                   (const unsigned short *) bpl, pe, (const float *) W.ehat, (float *) gtr, P.N, npad, npadT,
+                                   (const int *) (rowoff + P.B), K, Mt, Nt);
             } else {
                 hipLaunchKernelGGL((bwd_gemm_mfma<1>), dim3((P.N + 127) / 128, (P.N + 127) / 128), dim3(256), 0, stream,
                                    (const float *) W.ehat, (const float *) Pm, (float *) Gm, (float *) gtr, P.N, npad, K, anybad,
