@@ -2780,7 +2780,7 @@ __global__ void __launch_bounds__(512) bwd_gemm_bf3_kernel(const unsigned short 
     extern __shared__ __attribute__((aligned(16))) unsigned char g3_lds[];
     U4v *lds = reinterpret_cast<U4v *>(g3_lds);
     constexpr int TM = kG3TM, TN = kG3TN, AU = 3 * 4 * TM, BU = 3 * 4 * TN, SU = AU + BU;      // 16-byte units per stage: 3072 + 1536
-    constexpr int NR = SU / 512;                                                                // units per thread and stage: 9
+    constexpr int NR = SU / 512;                                                                // 64-lane transfers per wavefront slot and stage: 9
     if (kdev) K = __builtin_amdgcn_readfirstlane(*kdev);
     const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
     const int mblocks = (Mt + 3) / 4, nblocks = (Nt + 7) / 8;
@@ -2793,13 +2793,22 @@ __global__ void __launch_bounds__(512) bwd_gemm_bf3_kernel(const unsigned short 
     const int wm = (wave & 3) * 64, wn = (wave >> 2) * 64;
     const size_t pu = plane_elems / 8;
     const U4v *Au = reinterpret_cast<const U4v *>(Apl), *Bu = reinterpret_cast<const U4v *>(Bpl);
-    // staging: unit e = tid + 512 r of a stage -> (operand, plane, k group, label)
-    const U4v *src[NR];
+    // Staging is LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 bytes land lane-linear at a wave-uniform LDS address -- the planes'
+    // [k group][label][8] order IS the stage's order, so no register or ds_write is involved), issued by wavefronts 0-3 only: each SIMD
+    // holds wavefronts w and w + 4; while w spends ~1000 cycles issuing its 18 transfers, w + 4 has the matrix pipe to itself, then both
+    // interleave.  Unit e = 512 q + 64 v + lane of a stage (q = 0 .. 8, v = 0 .. 7) -> (operand, plane, k group, label).
+#ifndef ASG_X_G3_LOADERS
+#define ASG_X_G3_LOADERS 4
+#endif
+    constexpr int NLW = ASG_X_G3_LOADERS, ND = NR * 8 / NLW;      // wavefronts that issue transfers (4: w only; 8: all), transfers per wavefront
+    const U4v *src[ND];
+    const int wl = __builtin_amdgcn_readfirstlane(wave) & (NLW - 1);
+    auto slot = [&](int d) { return NLW == 8 ? 512 * d + 64 * wl : 512 * (d >> 1) + 64 * (wl + 4 * (d & 1)); };
 #pragma unroll
-    for (int q = 0; q < NR; ++q) {
-        const int e = (int) threadIdx.x + 512 * q;
-        if (e < AU) { const int pl = e / (4 * TM), rem = e % (4 * TM); src[q] = Au + (size_t) pl * pu + (size_t) (rem / TM) * npadT + m0 + rem % TM; }
-        else { const int f = e - AU, pl = f / (4 * TN), rem = f % (4 * TN); src[q] = Bu + (size_t) pl * pu + (size_t) (rem / TN) * npadT + n0 + rem % TN; }
+    for (int d = 0; d < ND; ++d) {
+        const int e = slot(d) + lane;
+        if (e < AU) { const int pl = e / (4 * TM), rem = e % (4 * TM); src[d] = Au + (size_t) pl * pu + (size_t) (rem / TM) * npadT + m0 + rem % TM; }
+        else { const int f = e - AU, pl = f / (4 * TN), rem = f % (4 * TN); src[d] = Bu + (size_t) pl * pu + (size_t) (rem / TN) * npadT + n0 + rem % TN; }
     }
     const size_t kstride = (size_t) 4 * npadT;          // 16-byte units per 32 k
     const int nkb = (K + 31) / 32;
@@ -2810,55 +2819,73 @@ __global__ void __launch_bounds__(512) bwd_gemm_bf3_kernel(const unsigned short 
         for (int c = 0; c < 2; ++c)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[a][c][q] = 0.f;
-    U4v st[NR];
-    if (nkb > 0) {
+    const bool loader = __builtin_amdgcn_readfirstlane(wave) < NLW;
+    auto dma = [&](int kb) {
+        U4v *dst = lds + (kb & 1) * SU;
+        // (inline asm: hipcc counts a __builtin_amdgcn_global_load_lds against EVERY later LDS read -- s_waitcnt vmcnt(0) in front of the
+        // fragment reads of the stage being multiplied, which is not the stage being filled; the drain is the explicit one ahead of the barrier)
+        const unsigned base = (unsigned) (uintptr_t) (__attribute__((address_space(3))) void *) dst;
 #pragma unroll
-        for (int q = 0; q < NR; ++q) st[q] = src[q][0];
-#pragma unroll
-        for (int q = 0; q < NR; ++q) lds[(int) threadIdx.x + 512 * q] = st[q];
-        if (nkb > 1) {
-#pragma unroll
-            for (int q = 0; q < NR; ++q) st[q] = src[q][kstride];
+        for (int d = 0; d < ND; ++d) {
+            const U4v *g = src[d] + (size_t) kb * kstride;
+            const unsigned l = __builtin_amdgcn_readfirstlane(base + 16u * slot(d));
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(g), "s"(l) : "memory");
         }
-    }
+    };
+    struct Frags { BF8 a[2][3], b[2][3]; };
+    auto fetch = [&](Frags &F, const U4v *cur, int s) {
+        const int kg = 2 * s + (lane >> 5), ln = lane & 31;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) F.a[a][pl] = __builtin_bit_cast(BF8, cur[pl * 4 * TM + kg * TM + wm + 32 * a + ln]);
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) F.b[c][pl] = __builtin_bit_cast(BF8, cur[AU + pl * 4 * TN + kg * TN + wn + 32 * c + ln]);
+    };
+    auto multiply = [&](const Frags &F) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                // (smallest terms first)
+                acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[a][2], F.b[c][0], acc[a][c], 0, 0, 0);
+                acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[a][0], F.b[c][2], acc[a][c], 0, 0, 0);
+                acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[a][1], F.b[c][1], acc[a][c], 0, 0, 0);
+                acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[a][1], F.b[c][0], acc[a][c], 0, 0, 0);
+                acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[a][0], F.b[c][1], acc[a][c], 0, 0, 0);
+                acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[a][0], F.b[c][0], acc[a][c], 0, 0, 0);
+            }
+    };
+    if (nkb > 0 && loader) dma(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int kb = 0; kb < nkb; ++kb) {
         const U4v *cur = lds + (kb & 1) * SU;
-        U4v *nxt = lds + ((kb + 1) & 1) * SU;
-        if (kb + 1 < nkb) {
-#pragma unroll
-            for (int q = 0; q < NR; ++q) nxt[(int) threadIdx.x + 512 * q] = st[q];
-            if (kb + 2 < nkb) {
-#pragma unroll
-                for (int q = 0; q < NR; ++q) st[q] = src[q][(size_t) (kb + 2) * kstride];
-            }
-        }
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int kg = 2 * s + (lane >> 5), ln = lane & 31;
-            BF8 af[2][3], bf[2][3];
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) af[a][pl] = __builtin_bit_cast(BF8, cur[pl * 4 * TM + kg * TM + wm + 32 * a + ln]);
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) bf[c][pl] = __builtin_bit_cast(BF8, cur[AU + pl * 4 * TN + kg * TN + wn + 32 * c + ln]);
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][2], bf[c][0], acc[a][c], 0, 0, 0);
-                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[c][2], acc[a][c], 0, 0, 0);
-                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][1], bf[c][1], acc[a][c], 0, 0, 0);
-                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][1], bf[c][0], acc[a][c], 0, 0, 0);
-                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[c][1], acc[a][c], 0, 0, 0);
-                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[c][0], acc[a][c], 0, 0, 0);
-                }
-        }
+        Frags F0, F1;
+        fetch(F0, cur, 0);
+        fetch(F1, cur, 1);
+        // (pinned: an asm statement orders memory operations only -- left alone, hipcc sinks the second fetch below the first product
+        // and lifts the drain + barrier above half of the MFMAs, which then wait for the transfers)
+        __builtin_amdgcn_sched_barrier(0);
+#if !(defined(ASG_X_G3_ABL) && ASG_X_G3_ABL == 1)
+        if (loader && kb + 1 < nkb) dma(kb + 1);        // into the stage every wavefront finished reading before the last barrier
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+#if !(defined(ASG_X_G3_ABL) && ASG_X_G3_ABL == 2)
+        multiply(F0);
+        multiply(F1);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wavefront's transfers have landed
         __syncthreads();
     }
+#if defined(ASG_X_G3_ABL) && ASG_X_G3_ABL == 2
+    { Frags F0; fetch(F0, lds, 0); multiply(F0); }
+#endif
     // element (m = 32 a + 8 (q >> 2) + 4 (l >> 5) + (q & 3), n = 32 c + (l & 31)) of the wavefront's 64 x 64 sits in acc[a][c][q]
 #pragma unroll
     for (int a = 0; a < 2; ++a)
