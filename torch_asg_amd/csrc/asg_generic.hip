@@ -151,24 +151,13 @@ struct StepBuf {
     const R *etile;   // fp32: the same matrix in the MFMA step's operand order (tile_kernel)
     const R *hmax;    // [N]
     R *mulog;         // alpha only, [T][B]: the normaliser each frame's state was stored against (read by the gradient pass)
-    unsigned short *pb3;   // fp32 streaming step only: p again as three bfloat16 planes [2][3][B][npb] (p = hi + mid + lo exactly), or null
     int npad;
-    int npb;          // row pitch of a plane (npad rounded up to whole 32-k chunks, pad columns zero)
 };
 
-typedef float V4f __attribute__((ext_vector_type(4)));
-// A float as the exact sum of three bfloat16 (8 significant bits each, round to nearest: the remainders are exact in fp32).
+// A float as the exact sum of three bfloat16 (8 significant bits each, round to nearest at every step: the remainders are exact
+// in fp32): two floats -> three packed bfloat16 pairs with v_cvt_pk_bf16_f32, the pair widened again (shift / mask), one packed
+// subtraction per level.  Used by the large-alphabet gradient contraction (gemm3_pack_kernel).
 typedef __bf16 BF8 __attribute__((ext_vector_type(8)));
-typedef float F8v __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ void split3(float v, unsigned short &h, unsigned short &m, unsigned short &l) {
-    const __bf16 bh = (__bf16) v;
-    const float r1 = v - (float) bh;
-    const __bf16 bm = (__bf16) r1;
-    const float r2 = r1 - (float) bm;
-    const __bf16 bl = (__bf16) r2;
-    h = __builtin_bit_cast(unsigned short, bh); m = __builtin_bit_cast(unsigned short, bm); l = __builtin_bit_cast(unsigned short, bl);
-}
-// two floats -> three packed bfloat16 pairs: v_cvt_pk_bf16_f32, the pair widened again (shift / mask), one packed subtraction
 typedef __bf16 BF2 __attribute__((ext_vector_type(2)));
 typedef float F2v __attribute__((ext_vector_type(2)));
 typedef unsigned U4v __attribute__((ext_vector_type(4)));
@@ -180,15 +169,6 @@ __device__ __forceinline__ void split3x2(float x, float y, unsigned &h, unsigned
     const F2v r2 = r1 - __builtin_convertvector(bm, F2v);
     const BF2 bl = __builtin_convertvector(r2, BF2);
     h = __builtin_bit_cast(unsigned, bh); m = __builtin_bit_cast(unsigned, bm); l = __builtin_bit_cast(unsigned, bl);
-}
-__device__ __forceinline__ void split3x8(const V4f &e0, const V4f &e1, BF8 &h, BF8 &m, BF8 &l) {
-    unsigned uh[4], um[4], ul[4];
-    split3x2(e0.x, e0.y, uh[0], um[0], ul[0]);
-    split3x2(e0.z, e0.w, uh[1], um[1], ul[1]);
-    split3x2(e1.x, e1.y, uh[2], um[2], ul[2]);
-    split3x2(e1.z, e1.w, uh[3], um[3], ul[3]);
-    const U4v vh = {uh[0], uh[1], uh[2], uh[3]}, vm = {um[0], um[1], um[2], um[3]}, vl = {ul[0], ul[1], ul[2], ul[3]};
-    h = __builtin_bit_cast(BF8, vh); m = __builtin_bit_cast(BF8, vm); l = __builtin_bit_cast(BF8, vl);
 }
 
 // init: alpha at frame 0 / beta at frame len-1.  grid = B, block = 256.
@@ -214,15 +194,6 @@ __global__ void __launch_bounds__(256) fwd_init_kernel(Problem P, StepBuf<R> S) 
             R q = in[(int64_t) i * P.is2] * L2E - em;          // max over i is exactly 0
             st[i] = BETA ? R(0) : q;
             pb[i] = Num<R>::exp2(q);
-            if constexpr (sizeof(R) == 4) {
-                if (S.pb3) {
-                    unsigned short h, m, l;
-                    split3((float) pb[i], h, m, l);
-                    unsigned short *pl = S.pb3 + (int64_t) b * S.npb + i;       // (parity 0; pad columns were zeroed by the launcher)
-                    const int64_t ps = (int64_t) P.B * S.npb;
-                    pl[0] = h; pl[ps] = m; pl[2 * ps] = l;
-                }
-            }
         } else {
             pb[i] = 0;
         }
@@ -537,25 +508,13 @@ __global__ void __launch_bounds__(256) fwd_step_tile_kernel(Problem P, StepBuf<R
 // Measured at cfg 5 (us per frame, both directions; tools/cfg5_fwd_time.py): 16 rows 356 (1250 workgroups, 3.2 GB of
 // vectors per frame) - 48 rows 213 (418 workgroups = 1.6 per compute unit: half the chip waits for the other half) -
 // 80 rows 151 (250 workgroups, one per compute unit) - 96 rows 161.  The VALU body above: 509 (314 workgroups).
+typedef float V4f __attribute__((ext_vector_type(4)));
 #ifndef ASG_X_STEP_PF
 #define ASG_X_STEP_PF 1
 #endif
 #ifndef ASG_X_STEP_MB
 #define ASG_X_STEP_MB 5
 #endif
-#ifndef ASG_X_STEP_SERP
-#define ASG_X_STEP_SERP 0
-#endif
-#ifndef ASG_X_STEP_NT
-#define ASG_X_STEP_NT 1
-#endif
-#ifndef ASG_X_STEP_BF3
-#define ASG_X_STEP_BF3 0
-#endif
-#ifndef ASG_X_STEP_PF3
-#define ASG_X_STEP_PF3 2
-#endif
-constexpr bool kStepBf3 = ASG_X_STEP_BF3 != 0;
 constexpr int kStepMB = ASG_X_STEP_MB;      // 16-row blocks per workgroup: every workgroup reads the batch's whole vector
                                             // set once (L2 traffic = row tiles x 1.3 MB), so tiles must not be too small
 // The MFMA step's E operand, laid out so that every wavefront load is ONE contiguous kilobyte and a workgroup streams
@@ -599,112 +558,7 @@ __device__ __forceinline__ void fwd_step_mfma(const Problem &P, const StepBuf<fl
     const int i0 = blockIdx.x * (16 * MB), b0 = blockIdx.y * 32;
     const R *pcur = S.pbuf + (int64_t) (n & 1) * B * npad;
     R *pnext = S.pbuf + (int64_t) ((n + 1) & 1) * B * npad;
-    if constexpr (kStepBf3) {
-        // ---- the product on the bfloat16 matrix pipe, fp32-equivalent ---------------------------------------------------
-        // v_mfma_f32_16x16x4_f32 runs at the vector rate (32 cycles for 1024 multiply-adds) and, fed from a stream of global
-        // loads, issues every ~49 cycles: 6250 of them per wavefront and frame are 128 us -- the loop, not the memory system
-        // (which streams the same 800 MB in 113-118 us: tools/ubench/mall_stream.hip), bounded the frame.  Every float is
-        // EXACTLY the sum of three bfloat16 (8 + 8 + 8 significant bits); the six partial products whose weight is >= 2^-16
-        //   hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi      (dropped: mid*lo + lo*mid + lo*lo <= 2^-25 relative, zero mean)
-        // accumulate in fp32 inside v_mfma_f32_16x16x32_bf16: 6 x 16 cycles for 16 rows x 16 utterances x 32 k against 8 x 32,
-        // on a pipe the vector ALU does not share -- the 180 conversion instructions per chunk run in its shadow.  The
-        // matrix stays fp32 in memory (one stream, split in registers); the vectors arrive already split (three planes,
-        // written by the previous frame's epilogue).  The chunk's two float4 of a lane ARE the instruction's A layout:
-        // row l & 15, k = 8 (l >> 4) .. + 7.
-        const int r = lane & 15, kq = lane >> 4;
-        const size_t nchunks = ((size_t) npad + 31) / 32;
-        const V4f *et = reinterpret_cast<const V4f *>(S.etile) + (size_t) blockIdx.x * nchunks * (MB * 2 * 64) + lane;
-        const int npb = S.npb;
-        const int64_t plane = (int64_t) B * npb;
-        const unsigned short *pb = S.pb3 + (int64_t) (n & 1) * 3 * plane + 8 * kq;
-        const unsigned short *va = pb + (int64_t) min(b0 + r, B - 1) * npb;
-        const unsigned short *vb = pb + (int64_t) min(b0 + 16 + r, B - 1) * npb;
-        // every chunk is whole here: the tile and the planes are zero-padded to 32 k
-        const int nch = (int) nchunks, cpw = (nch + 3) / 4;
-        const int c0 = min(wave * cpw, nch), c1 = min(c0 + cpw, nch);
-        const V4f zero4 = {0, 0, 0, 0};
-        V4f acc[MB][2];
-#pragma unroll
-        for (int m = 0; m < MB; ++m) { acc[m][0] = zero4; acc[m][1] = zero4; }
-        struct Stage { V4f e[MB][2]; BF8 a[3], b[3]; };
-        const bool rev = ASG_X_STEP_SERP && (n & 1);
-        auto load = [&](Stage &st, int cf) {
-            const int c = rev ? c0 + c1 - 1 - cf : cf;
-#pragma unroll
-            for (int m = 0; m < MB; ++m)
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
-                    st.e[m][h] = ASG_X_STEP_NT ? __builtin_nontemporal_load(&et[((size_t) c * MB * 2 + m * 2 + h) * 64])
-                                               : et[((size_t) c * MB * 2 + m * 2 + h) * 64];
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                st.a[q] = *reinterpret_cast<const BF8 *>(va + q * plane + 32 * c);
-                st.b[q] = *reinterpret_cast<const BF8 *>(vb + q * plane + 32 * c);
-            }
-        };
-        auto multiply = [&](const Stage &st) {
-#pragma unroll
-            for (int m = 0; m < MB; ++m) {
-                BF8 eh, em, el;
-#if defined(ASG_X_BF3_ABL) && ASG_X_BF3_ABL == 1      // (developer timing: a third of the conversion; results off by a constant factor per frame)
-                { U4v x; unsigned t0, t1;
-                  split3x2(st.e[m][0].x, st.e[m][0].y, x.x, t0, t1); x.y = __builtin_bit_cast(unsigned, st.e[m][0].z); x.z = __builtin_bit_cast(unsigned, st.e[m][1].x);
-                  x.w = __builtin_bit_cast(unsigned, st.e[m][1].z) & 0x7fff7fffu;
-                  x.y &= 0x3fff3fffu; x.z &= 0x3fff3fffu; x.w &= 0x3fff3fffu;
-                  eh = __builtin_bit_cast(BF8, x); em = eh; el = eh; }
-#else
-                split3x8(st.e[m][0], st.e[m][1], eh, em, el);
-#endif
-#if defined(ASG_X_BF3_ABL) && ASG_X_BF3_ABL == 2      // (developer timing: full conversion, a sixth of the products)
-                { const U4v x = (__builtin_bit_cast(U4v, eh) | (__builtin_bit_cast(U4v, em) & 1u)) | (__builtin_bit_cast(U4v, el) & 1u);
-                  const BF8 ex = __builtin_bit_cast(BF8, x);
-                  acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ex, st.a[0], acc[m][0], 0, 0, 0);
-                  acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ex, st.b[0], acc[m][1], 0, 0, 0);
-                  continue; }
-#endif
-                // (smallest terms first)
-                acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(el, st.a[0], acc[m][0], 0, 0, 0);
-                acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(el, st.b[0], acc[m][1], 0, 0, 0);
-                acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(eh, st.a[2], acc[m][0], 0, 0, 0);
-                acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(eh, st.b[2], acc[m][1], 0, 0, 0);
-                acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(em, st.a[1], acc[m][0], 0, 0, 0);
-                acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(em, st.b[1], acc[m][1], 0, 0, 0);
-                acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(em, st.a[0], acc[m][0], 0, 0, 0);
-                acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(em, st.b[0], acc[m][1], 0, 0, 0);
-                acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(eh, st.a[1], acc[m][0], 0, 0, 0);
-                acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(eh, st.b[1], acc[m][1], 0, 0, 0);
-                acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(eh, st.a[0], acc[m][0], 0, 0, 0);
-                acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(eh, st.b[0], acc[m][1], 0, 0, 0);
-            }
-        };
-        if (c0 < c1) {
-            // (the loop's loads are a memory-latency's worth ahead of their use only if STG - 1 chunks are in flight: the product of a
-            // chunk takes ~0.6 us, a load under this stream ~1.2-2 us)
-            constexpr int STG = ASG_X_STEP_PF3 + 1;
-            Stage st[STG];
-#pragma unroll
-            for (int u = 0; u < STG - 1; ++u) {
-                // (pinned too: if the prologue's stages interleave, the loop header's s_waitcnt has to assume the worst order on
-                // EVERY trip and drains all but the newest stage)
-                __builtin_amdgcn_sched_barrier(0);
-                load(st[u], min(c0 + u, c1 - 1));
-            }
-            for (int c = c0; c < c1; c += STG) {
-#pragma unroll
-                for (int u = 0; u < STG; ++u) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    load(st[(u + STG - 1) % STG], min(c + u + STG - 1, c1 - 1));
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (c + u < c1) multiply(st[u]);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int m = 0; m < MB; ++m)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { red[wave][8 * m + q][lane] = acc[m][0][q]; red[wave][8 * m + 4 + q][lane] = acc[m][1][q]; }
-    } else {
+    {
         // lane l: row / utterance (l & 15), k sub-range 8 (l >> 4) .. +7 of every 32-k chunk: two float4 per operand, so a
         // row's whole 128-byte line goes to one wavefront at once
         const int r = lane & 15, kq = lane >> 4;
@@ -722,11 +576,7 @@ __device__ __forceinline__ void fwd_step_mfma(const Problem &P, const StepBuf<fl
 #pragma unroll
         for (int m = 0; m < MB; ++m) { acc[m][0] = zero4; acc[m][1] = zero4; }
         struct Stage { V4f e[MB][2], a[2], b[2]; };
-        // (ASG_X_STEP_SERP: odd frames walk a wavefront's chunks back to front -- what the memory-side cache still holds of
-        // frame n is what frame n + 1 asks for first)
-        const bool rev = ASG_X_STEP_SERP && (n & 1);
-        auto load = [&](Stage &st, int cf) {
-            const int c = rev ? c0 + c1 - 1 - cf : cf;
+        auto load = [&](Stage &st, int c) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 st.a[h] = *reinterpret_cast<const V4f *>(va + 32 * c + 4 * h);
@@ -735,8 +585,7 @@ __device__ __forceinline__ void fwd_step_mfma(const Problem &P, const StepBuf<fl
                 for (int m = 0; m < MB; ++m) {
                     // (non-temporal: every element of the matrix is used once per frame, and the lines it would displace in
                     // L2 are the batch's vectors that all workgroups of the XCD read: 144.4 -> 137.9 us per frame at cfg 5)
-                    st.e[m][h] = ASG_X_STEP_NT ? __builtin_nontemporal_load(&et[((size_t) c * MB * 2 + m * 2 + h) * 64])
-                                               : et[((size_t) c * MB * 2 + m * 2 + h) * 64];
+                    st.e[m][h] = __builtin_nontemporal_load(&et[((size_t) c * MB * 2 + m * 2 + h) * 64]);
                 }
             }
         };
@@ -805,7 +654,6 @@ __device__ __forceinline__ void fwd_step_mfma(const Problem &P, const StepBuf<fl
     const int tw = active ? (BETA ? t - 1 : t) : 0;    // frame written
     const R emw = S.emax[(int64_t) tw * B + bc];
     float qkey = -__builtin_inff();
-    unsigned pk3[3] = {0, 0, 0};
 #pragma unroll
     for (int rr2 = 0; rr2 < 2 * MB; ++rr2) {
         const int row = 16 * (rr2 >> 1) + 2 * (threadIdx.x & 7) + (rr2 & 1), i = i0 + row;
@@ -841,34 +689,12 @@ __device__ __forceinline__ void fwd_step_mfma(const Problem &P, const StepBuf<fl
         R stv, q;
         if (BETA) { stv = rr - muprev; q = emis + stv; }
         else { stv = emis + rr - muprev; q = stv; }
-        const R pv = Num<R>::exp2(q);
         if (PERSIST) {
             __hip_atomic_store(&S.state[((int64_t) b * T + tw) * N + i], stv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&pnext[(int64_t) b * npad + i], pv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&pnext[(int64_t) b * npad + i], Num<R>::exp2(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
             S.state[((int64_t) b * T + tw) * N + i] = stv;
-            pnext[(int64_t) b * npad + i] = pv;
-        }
-        if constexpr (kStepBf3) {
-            // the next frame's B operand: p = hi + mid + lo, rows i (even) and i + 1 of a plane in one 32-bit store
-            unsigned short h3, m3, l3;
-            split3(pv, h3, m3, l3);
-            if ((rr2 & 1) == 0) { pk3[0] = h3; pk3[1] = m3; pk3[2] = l3; }
-            if ((rr2 & 1) == 1 || i + 1 >= N) {
-                const int ie = i & ~1;
-                unsigned *dst = reinterpret_cast<unsigned *>(S.pb3 + (int64_t) ((n + 1) & 1) * 3 * B * S.npb + (int64_t) b * S.npb + ie);
-                const int64_t ps = (int64_t) B * S.npb / 2;
-                const unsigned w0 = (rr2 & 1) ? (pk3[0] | ((unsigned) h3 << 16)) : pk3[0];
-                const unsigned w1 = (rr2 & 1) ? (pk3[1] | ((unsigned) m3 << 16)) : pk3[1];
-                const unsigned w2 = (rr2 & 1) ? (pk3[2] | ((unsigned) l3 << 16)) : pk3[2];
-                if (PERSIST) {
-                    __hip_atomic_store(dst, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(dst + ps, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(dst + 2 * ps, w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                } else {
-                    dst[0] = w0; dst[ps] = w1; dst[2 * ps] = w2;
-                }
-            }
+            pnext[(int64_t) b * npad + i] = Num<R>::exp2(q);
         }
         qkey = fmaxf(qkey, (float) q);
         if (i == 0) {
@@ -3357,18 +3183,11 @@ size_t step_tile_bytes_generic(int elem, int N) {
     return (elem == 4 && StepUsesMfma<float>::v) ? step_tile_floats(N) * sizeof(float) : 0;
 }
 
-// the vectors of the fp32 streaming step as three bfloat16 planes (fwd_step_mfma): [2 frames][3][B][npb] per direction, behind
-// the normaliser log
-static size_t step_plane_bytes(int elem, int B, int N) {
-    if (!(elem == 4 && StepUsesMfma<float>::v && kStepBf3)) return 0;
-    const size_t npb = ((size_t) N + 31) / 32 * 32;
-    return au(2 * 3 * (size_t) B * npb * sizeof(unsigned short));
-}
 // forward work buffers live behind the saved state (see fwd_work_bytes_generic): emax, pbuf x2 dirs, mu, off
 size_t fwd_work_bytes_generic(int elem, int T, int B, int N) {
     const size_t npad = (size_t) (N + 3) / 4 * 4;
     return au((size_t) T * B * elem) + 2 * au(2 * (size_t) B * npad * elem) + 2 * au(3 * (size_t) B * 4) + 2 * au((size_t) B * 8) +
-           au((size_t) T * B * elem) + 2 * step_plane_bytes(elem, B, N) + ((elem == 4 && N > 256 && N <= 2048) ? kClusterBytes : 0) + 4096;
+           au((size_t) T * B * elem) + ((elem == 4 && N > 256 && N <= 2048) ? kClusterBytes : 0) + 4096;
 }
 // offset of the alpha pass's per-frame normaliser log inside the work area (its last member)
 static size_t work_mulog_offset(size_t elem, int T, int B, int npad) {
@@ -3449,11 +3268,6 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
             S.etile = (const R *) (beta ? W.ftile : W.etile);
             S.hmax = (const R *) (beta ? W.cmax : W.rmax);
             S.mulog = beta ? nullptr : (R *) ((char *) W.work + work_mulog_offset(e, P.T, P.B, W.npad));
-            if (const size_t pbytes = step_plane_bytes((int) e, P.B, P.N)) {
-                S.npb = (P.N + 31) / 32 * 32;
-                S.pb3 = (unsigned short *) ((char *) W.work + work_mulog_offset(e, P.T, P.B, W.npad) + au((size_t) P.T * P.B * e) + dir * pbytes);
-                if (dir == 0) (void) hipMemsetAsync(S.pb3, 0, 2 * pbytes, stream);       // (pad columns stay zero)
-            }
             Sd[dir] = S;
         }
         const bool do_a = full_mask & kFullAlpha, do_b = full_mask & kFullBeta;
