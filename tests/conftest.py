@@ -20,3 +20,18 @@ def _restore_default_dtype():
     old = torch.get_default_dtype()
     yield
     torch.set_default_dtype(old)
+
+
+@pytest.fixture(autouse=True)
+def _poison_free_device_memory(request):
+    """GPU tests: what the caching allocator hands out next is NaN / Inf, not the zeros of a fresh process or the leftovers of the
+    previous test -- a kernel that reads scratch it never wrote fails here instead of passing by luck."""
+    if request.node.get_closest_marker("gpu") is None:
+        yield
+        return
+    import torch
+    if torch.cuda.is_available():
+        junk = torch.full((256 * 1024 * 1024,), float("nan"), device="cuda:0")      # 1 GiB
+        junk[::2] = float("inf")
+        del junk
+    yield

@@ -4,6 +4,5 @@ cd $GRAFT_REPO_ROOT; V=$GRAFT_REPO_ROOT/torch_asg_amd/csrc/variants
 timeout 25 python tools/cfg5_fwd_time.py > /dev/null 2>&1
 for rep in 1 2; do
 echo "shipped:"; timeout 25 python tools/cfg5_fwd_time.py 2>&1 | tail -1
-[ -n "$PERSIST" ] && { echo "shipped, one cooperative launch:"; ASG_PERSIST=1 timeout 25 python tools/cfg5_fwd_time.py 2>&1 | tail -1; }
 for L in $LIBS; do echo "$L:"; ASG_HIP_LIB=$V/lib$L.so timeout 25 python tools/cfg5_fwd_time.py 2>&1 | tail -1; done
 done

@@ -13,9 +13,9 @@ typedef float V4 __attribute__((ext_vector_type(4)));
 
 // per wavefront: nv4 float4 "rows" of 64 lanes (1 KB per wavefront load)
 template <bool NT>
-__global__ void __launch_bounds__(256) stream_kernel(const V4 *src, size_t rows_per_wave, int reverse, float *out) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const V4 *p = src + ((size_t) (blockIdx.x * 4 + wave) * rows_per_wave) * 64 + lane;
+__global__ void __launch_bounds__(1024) stream_kernel(const V4 *src, size_t rows_per_wave, int reverse, float *out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const V4 *p = src + ((size_t) (blockIdx.x * nw + wave) * rows_per_wave) * 64 + lane;
     V4 acc = {0, 0, 0, 0};
     constexpr int U = 8;
     const size_t n = rows_per_wave / U * U;
@@ -32,15 +32,16 @@ __global__ void __launch_bounds__(256) stream_kernel(const V4 *src, size_t rows_
     if (acc.x + acc.y + acc.z + acc.w == 12345.678f) out[0] = acc.x;
 }
 
+static int g_waves = 4;
 template <bool NT>
 static double run(const V4 *buf, size_t bytes, int serp, float *out, int frames) {
     const int wgs = 250;
-    const size_t rows_per_wave = bytes / 1024 / (wgs * 4);
+    const size_t rows_per_wave = bytes / 1024 / (wgs * g_waves);
     hipEvent_t e0, e1;
     (void) hipEventCreate(&e0); (void) hipEventCreate(&e1);
-    for (int f = 0; f < 6; ++f) hipLaunchKernelGGL((stream_kernel<NT>), dim3(wgs), dim3(256), 0, 0, buf, rows_per_wave, serp ? (f & 1) : 0, out);
+    for (int f = 0; f < 6; ++f) hipLaunchKernelGGL((stream_kernel<NT>), dim3(wgs), dim3(64 * g_waves), 0, 0, buf, rows_per_wave, serp ? (f & 1) : 0, out);
     (void) hipEventRecord(e0, 0);
-    for (int f = 0; f < frames; ++f) hipLaunchKernelGGL((stream_kernel<NT>), dim3(wgs), dim3(256), 0, 0, buf, rows_per_wave, serp ? (f & 1) : 0, out);
+    for (int f = 0; f < frames; ++f) hipLaunchKernelGGL((stream_kernel<NT>), dim3(wgs), dim3(64 * g_waves), 0, 0, buf, rows_per_wave, serp ? (f & 1) : 0, out);
     (void) hipEventRecord(e1, 0);
     (void) hipEventSynchronize(e1);
     float ms = 0;
@@ -64,6 +65,14 @@ int main() {
                 const double us = nt ? run<true>(buf, bytes, serp, out, 40) : run<false>(buf, bytes, serp, out, 40);
                 printf("%8zu %6s %6s %10.1f %8.2f\n", mb, serp ? "serp" : "cyclic", nt ? "nt" : "dflt", us, bytes / us / 1e6);
             }
+    }
+    // the same 800 MB with more wavefronts per compute unit: is the per-CU rate a per-wavefront limit?
+    printf("waves per CU, 800 MB, cyclic, nt:\n");
+    for (int w : {1, 2, 4, 8, 16}) {
+        g_waves = w;
+        const size_t bytes = ((size_t) 800 << 20) / (1024 * 4000) * (1024 * 4000);
+        const double us = run<true>(buf, bytes, 0, out, 40);
+        printf("%8d waves %10.1f us %8.2f TB/s\n", w, us, bytes / us / 1e6);
     }
     return 0;
 }

@@ -151,6 +151,9 @@ struct StepBuf {
     const R *etile;   // fp32: the same matrix in the MFMA step's operand order (tile_kernel)
     const R *hmax;    // [N]
     R *mulog;         // alpha only, [T][B]: the normaliser each frame's state was stored against (read by the gradient pass)
+    R *ptile;         // fp32 streaming step only: p again, in the MFMA step's operand order (step_ptile_index), [2][...]; or null
+    R *partial;       // fp32 streaming step, K split over several workgroups: [row tile][batch tile][slice][2 MB][256] partial row sums
+    unsigned *tickets;   // ... and one arrival counter per (row tile, batch tile), zero at the start of a forward call
     int npad;
 };
 
@@ -169,6 +172,17 @@ __device__ __forceinline__ void split3x2(float x, float y, unsigned &h, unsigned
     const F2v r2 = r1 - __builtin_convertvector(bm, F2v);
     const BF2 bl = __builtin_convertvector(r2, BF2);
     h = __builtin_bit_cast(unsigned, bh); m = __builtin_bit_cast(unsigned, bm); l = __builtin_bit_cast(unsigned, bl);
+}
+
+// The vectors of the fp32 streaming step in operand order: [batch tile of 32][chunk of 32 k][utterance half u][h][lane][4], lane =
+// 16 (k sub-range kq) + (utterance & 15), k = 32 chunk + 8 kq + 4 h + component -- the 16 bytes lane l of a wavefront wants are at
+// position l of a contiguous kilobyte, so a wavefront load is eight whole 128-byte lines (row-major vectors: sixteen half lines,
+// twice the L2 requests per byte, and it is the L2-resident side traffic that holds the matrix stream back: tools/ubench/stream_side.hip).
+__host__ __device__ inline size_t step_ptile_floats(int B, int npad) { return (size_t) ((B + 31) / 32) * ((npad + 31) / 32) * 2 * 2 * 64 * 4; }
+__host__ __device__ inline size_t step_ptile_index(int b, int i, int npad) {
+    const size_t nch = ((size_t) npad + 31) / 32;
+    const int c = i >> 5, kq = (i >> 3) & 3, h = (i >> 2) & 1, u = (b >> 4) & 1;
+    return ((((size_t) (b >> 5) * nch + c) * 2 + u) * 2 + h) * 256 + (size_t) (kq * 16 + (b & 15)) * 4 + (i & 3);
 }
 
 // init: alpha at frame 0 / beta at frame len-1.  grid = B, block = 256.
@@ -194,6 +208,7 @@ __global__ void __launch_bounds__(256) fwd_init_kernel(Problem P, StepBuf<R> S) 
             R q = in[(int64_t) i * P.is2] * L2E - em;          // max over i is exactly 0
             st[i] = BETA ? R(0) : q;
             pb[i] = Num<R>::exp2(q);
+            if (S.ptile) S.ptile[step_ptile_index(b, i, S.npad)] = pb[i];      // (frame 0's buffer; pad positions were zeroed by the launcher)
         } else {
             pb[i] = 0;
         }
@@ -542,35 +557,186 @@ __global__ void __launch_bounds__(256) tile_kernel(const float *src, int N, int 
     }
 }
 
-// PERSIST: the frame is one iteration of fwd_persist_kernel -- what another workgroup reads in the next frame (the
-// vectors, the log-domain state the rare exact path falls back on) is stored write-through (agent scope), so the grid
-// barrier between frames needs no L2 write-back.
-#ifndef ASG_X_PERSIST_SKEW
-#define ASG_X_PERSIST_SKEW 7000      // 100 MHz ticks the second direction starts late (about half a frame at cfg 5)
-#endif
-template <bool BETA, bool PERSIST>
-__device__ __forceinline__ void fwd_step_mfma(const Problem &P, const StepBuf<float> &S, int n) {
+// What the frame's epilogue needs from memory, requested BEFORE the product: thread -> utterance 32 bt + (tid >> 3), rows
+// i0 + 16 (rr2 >> 1) + 2 (tid & 7) + (rr2 & 1).  (Loaded inside the epilogue, the 2 MB emission values of a thread -- each a miss all the
+// way to memory, behind a rarely taken branch hipcc will not load across -- cost the epilogue 7 of its 9 us at cfg 5.)
+struct StepPre {
+    int b, len, t, tw;
+    bool active;
+    float muprev, emw;
+    float x[2 * kStepMB], hm[2 * kStepMB];          // raw emission at frame tw, hmax, of the thread's rows (0 where there is no row)
+};
+template <bool BETA>
+__device__ __forceinline__ StepPre step_prefetch(const Problem &P, const StepBuf<float> &S, int n, int bt) {
+    constexpr int MB = kStepMB;
+    const int N = P.N, T = P.T, B = P.B;
+    const int i0 = blockIdx.x * (16 * MB);
+    StepPre E;
+    E.b = bt * 32 + (int) (threadIdx.x >> 3);
+    const bool bvalid = E.b < B;
+    const int bc = bvalid ? E.b : 0;
+    E.len = P.in_len ? gclampi(P.in_len[bc], 0, T) : T;
+    E.t = BETA ? E.len - 1 - n : n + 1;          // frame whose q is consumed (beta) / produced (alpha)
+    E.active = bvalid && (BETA ? (E.t >= 1) : (E.t < E.len));
+    E.muprev = fmax(funkey(S.mu[(n % 3) * B + bc]), Num<float>::logzero());
+    E.tw = E.active ? (BETA ? E.t - 1 : E.t) : 0;    // frame written
+    E.emw = S.emax[(int64_t) E.tw * B + bc];
+    const float *in = (const float *) P.inputs + (int64_t) E.tw * P.is0 + (int64_t) bc * P.is1;
+#pragma unroll
+    for (int rr2 = 0; rr2 < 2 * MB; ++rr2) {
+        const int i = i0 + 16 * (rr2 >> 1) + 2 * (int) (threadIdx.x & 7) + (rr2 & 1);
+        const bool on = E.active && i < N;
+        const int ic = on ? i : 0;
+        const float xv = in[(int64_t) ic * P.is2], hv = S.hmax[ic];
+        E.x[rr2] = on ? xv : 0.f;
+        E.hm[rr2] = on ? hv : 0.f;
+    }
+    return E;
+}
+
+// The frame's epilogue: red[w] holds wavefront w's partial tile -- element (row 16 m + 4 (l >> 4) + q, utterance (l & 15) [+ 16]) in
+// red[w][8 m + q (+ 4)][l].  With K split over ks workgroups (slice = this workgroup's), every workgroup leaves its 2 MB sums per
+// thread in S.partial (write-through) and takes a ticket; the LAST one to arrive adds the slices in ascending order (its own from
+// registers, in its place: a fixed order whoever is last, so the result does not depend on the arrival order) and runs the epilogue.
+// Nobody waits for anybody.  Returns without doing anything in the workgroups that were not last.
+template <bool BETA>
+__device__ __forceinline__ void step_epilogue(const Problem &P, const StepBuf<float> &S, int n, const float (*red)[kStepMB * 8][64],
+                                              const StepPre &E, int bt, int slice, int ks) {
     typedef float R;
     constexpr int MB = kStepMB;
-    __shared__ float red[4][MB * 8][64];
     const int N = P.N, T = P.T, B = P.B, npad = S.npad;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i0 = blockIdx.x * (16 * MB), b0 = blockIdx.y * 32;
-    const R *pcur = S.pbuf + (int64_t) (n & 1) * B * npad;
+    const int i0 = blockIdx.x * (16 * MB);
     R *pnext = S.pbuf + (int64_t) ((n + 1) & 1) * B * npad;
+    const int ut = threadIdx.x >> 3, b = E.b;
+    R sums[2 * MB];
+#pragma unroll
+    for (int rr2 = 0; rr2 < 2 * MB; ++rr2) {
+        const int row = 16 * (rr2 >> 1) + 2 * (threadIdx.x & 7) + (rr2 & 1);
+        const int sl = 16 * ((row & 15) >> 2) + (ut & 15), sq = 8 * (row >> 4) + (row & 3) + 4 * (ut >> 4);
+        sums[rr2] = (red[0][sq][sl] + red[1][sq][sl]) + (red[2][sq][sl] + red[3][sq][sl]);
+    }
+    if (ks > 1) {
+        __shared__ int last_arrival;
+        const size_t tile = (size_t) blockIdx.x * gridDim.y / ks + bt;          // (gridDim.y = batch tiles x ks)
+        R *mine = S.partial + ((tile * ks + slice) * (2 * MB)) * 256 + threadIdx.x;
+#pragma unroll
+        for (int rr2 = 0; rr2 < 2 * MB; ++rr2) __hip_atomic_store(mine + rr2 * 256, sums[rr2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (no release fence: an agent-scope release writes back every dirty line of this XCD's L2 -- the frame's state and vector
+        // stores of 32 workgroups.  The partial sums are write-through stores, drained here.)
+#if defined(ASG_X_KS_SYNC) && ASG_X_KS_SYNC == 1
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned t = __hip_atomic_fetch_add(&S.tickets[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last_arrival = (t % (unsigned) ks) == (unsigned) (ks - 1);
+        }
+        __syncthreads();
+        if (!last_arrival) return;
+        // (acquire: invalidates what this XCD's L2 holds of other XCDs' memory -- a slice written in an earlier frame may still be there)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        R total[2 * MB];
+#pragma unroll
+        for (int rr2 = 0; rr2 < 2 * MB; ++rr2) total[rr2] = 0;
+        for (int k = 0; k < ks; ++k) {
+            const R *theirs = S.partial + ((tile * ks + k) * (2 * MB)) * 256 + threadIdx.x;
+#pragma unroll
+            for (int rr2 = 0; rr2 < 2 * MB; ++rr2) {
+                const R v = (k == slice) ? sums[rr2] : __hip_atomic_load(theirs + rr2 * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                total[rr2] = k == 0 ? v : total[rr2] + v;
+            }
+        }
+#pragma unroll
+        for (int rr2 = 0; rr2 < 2 * MB; ++rr2) sums[rr2] = total[rr2];
+    }
+    const R L2E = Num<R>::log2e();
+    const bool active = E.active;
+    const int t = E.t, tw = E.tw;
+    const R muprev = E.muprev, emw = E.emw;
+    float qkey = -__builtin_inff();
+#pragma unroll
+    for (int rr2 = 0; rr2 < 2 * MB; ++rr2) {
+        const int row = 16 * (rr2 >> 1) + 2 * (threadIdx.x & 7) + (rr2 & 1), i = i0 + row;
+        if (!active || i >= N) continue;
+        const R a = sums[rr2];
+        R lg = Num<R>::log2(a);
+        R rr = E.hm[rr2] + lg;
+        if (!(fabs(lg) < Num<R>::lg_limit())) {
+            // exact rare path: log2-sum-exp2 over j of (Tr2[.][.] + q_j) from the log-domain state
+            const R *tr = (const R *) P.transition;
+            const int tq = BETA ? t : t - 1;
+            const R *stq = S.state + ((int64_t) b * T + tq) * N;
+            const R *inq = (const R *) P.inputs + (int64_t) tq * P.is0 + (int64_t) b * P.is1;
+            const R emq = S.emax[(int64_t) tq * B + b];
+            R mx = Num<R>::ninf();
+            for (int j = 0; j < N; ++j) {
+                R qj = BETA ? inq[(int64_t) j * P.is2] * L2E - emq + stq[j] : stq[j];
+                R trv = BETA ? tr[(int64_t) j * P.ts0 + (int64_t) i * P.ts1] : tr[(int64_t) i * P.ts0 + (int64_t) j * P.ts1];
+                R v = trv * L2E + qj;
+                mx = (v == v) ? fmax(mx, v) : mx;
+            }
+            R sm = 0;
+            for (int j = 0; j < N; ++j) {
+                R qj = BETA ? inq[(int64_t) j * P.is2] * L2E - emq + stq[j] : stq[j];
+                R trv = BETA ? tr[(int64_t) j * P.ts0 + (int64_t) i * P.ts1] : tr[(int64_t) i * P.ts0 + (int64_t) j * P.ts1];
+                R v = trv * L2E + qj;
+                sm += (v == v && mx != Num<R>::ninf()) ? Num<R>::exp2(v - mx) : R(0);
+            }
+            rr = (mx == Num<R>::ninf()) ? mx : mx + Num<R>::log2(sm);
+        }
+        const R emis = E.x[rr2] * L2E - emw;
+        R stv, q;
+        if (BETA) { stv = rr - muprev; q = emis + stv; }
+        else { stv = emis + rr - muprev; q = stv; }
+        const R pv = Num<R>::exp2(q);
+        S.state[((int64_t) b * T + tw) * N + i] = stv;
+        pnext[(int64_t) b * npad + i] = pv;
+        S.ptile[(size_t) ((n + 1) & 1) * step_ptile_floats(B, npad) + step_ptile_index(b, i, npad)] = pv;
+        qkey = fmaxf(qkey, (float) q);
+        if (i == 0) {
+            S.off[b] += (double) muprev + (double) emw;
+            S.mu[((n + 2) % 3) * B + b] = fkey(-__builtin_inff());
+            if (!BETA && S.mulog) S.mulog[(int64_t) tw * B + b] = muprev;
+        }
+    }
+    // one atomic per utterance and workgroup at most (max is order-independent: deterministic), and only if it can
+    // change the word: the eight lanes of an utterance reduce with three DPP steps
+    qkey = fmaxf(qkey, dpp_mov<kDppXor1>(qkey, qkey));
+    qkey = fmaxf(qkey, dpp_mov<kDppXor2>(qkey, qkey));
+    qkey = fmaxf(qkey, dpp_mov<kDppHalfMirror>(qkey, qkey));
+    if (active && (threadIdx.x & 7) == 0) {
+        unsigned *word = &S.mu[((n + 1) % 3) * B + b];
+        const unsigned key = fkey(qkey);
+        if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < key) atomicMax(word, key);
+    }
+}
+
+#ifdef ASG_X_STEP_PROBE
+__device__ long long g_step_probe[4096];
+#endif
+template <bool BETA>
+__device__ __forceinline__ void fwd_step_mfma(const Problem &P, const StepBuf<float> &S, int n, float (*red)[kStepMB * 8][64], int ks) {
+    typedef float R;
+    constexpr int MB = kStepMB;
+    const int B = P.B, npad = S.npad;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bt = blockIdx.y / ks, slice = blockIdx.y % ks;          // batch tile of 32 utterances, slice of K
+    const StepPre pre = step_prefetch<BETA>(P, S, n, bt);
     {
         // lane l: row / utterance (l & 15), k sub-range 8 (l >> 4) .. +7 of every 32-k chunk: two float4 per operand, so a
         // row's whole 128-byte line goes to one wavefront at once
-        const int r = lane & 15, kq = lane >> 4;
         const size_t nchunks = ((size_t) npad + 31) / 32;
         const V4f *et = reinterpret_cast<const V4f *>(S.etile) + (size_t) blockIdx.x * nchunks * (MB * 2 * 64) + lane;
-        const R *va = pcur + (int64_t) min(b0 + r, B - 1) * npad + 8 * kq;
-        const R *vb = pcur + (int64_t) min(b0 + 16 + r, B - 1) * npad + 8 * kq;
-        // K in chunks of 32: the FULL chunks go through a two-stage software pipeline of unconditional loads (a bounds
-        // test per load makes hipcc wait for every load before the first MFMA); the tail (npad is a multiple of 4, not
-        // of 32) is one guarded chunk done by the last wavefront
-        const int full = npad / 32, cpw = (full + 3) / 4;
-        const int c0 = min(wave * cpw, full), c1 = min(c0 + cpw, full);
+        // the vectors in operand order (step_ptile_index): kilobyte (chunk, utterance half, h) of this batch tile, position `lane`
+        const V4f *pt = reinterpret_cast<const V4f *>(S.ptile + (size_t) (n & 1) * step_ptile_floats(B, npad)) + (size_t) bt * nchunks * 256 + lane;
+        // K in chunks of 32 (the matrix tile and the vectors are zero-padded to whole chunks: every load is unconditional -- a
+        // bounds test per load makes hipcc wait for every load before the first MFMA): this workgroup's slice, a quarter of it per
+        // wavefront, through a two-stage software pipeline
+        const int per = ((int) nchunks + ks - 1) / ks, s0 = min(slice * per, (int) nchunks), s1 = min(s0 + per, (int) nchunks);
+        const int cpw = (s1 - s0 + 3) / 4;
+        const int c0 = min(s0 + wave * cpw, s1), c1 = min(c0 + cpw, s1);
         const V4f zero4 = {0, 0, 0, 0};
         V4f acc[MB][2];
 #pragma unroll
@@ -579,8 +745,8 @@ __device__ __forceinline__ void fwd_step_mfma(const Problem &P, const StepBuf<fl
         auto load = [&](Stage &st, int c) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                st.a[h] = *reinterpret_cast<const V4f *>(va + 32 * c + 4 * h);
-                st.b[h] = *reinterpret_cast<const V4f *>(vb + 32 * c + 4 * h);
+                st.a[h] = pt[((size_t) c * 4 + h) * 64];
+                st.b[h] = pt[((size_t) c * 4 + 2 + h) * 64];
 #pragma unroll
                 for (int m = 0; m < MB; ++m) {
                     // (non-temporal: every element of the matrix is used once per frame, and the lines it would displace in
@@ -605,12 +771,15 @@ __device__ __forceinline__ void fwd_step_mfma(const Problem &P, const StepBuf<fl
                 }
         };
         if (c0 < c1) {
-            // STG stages: STG - 1 chunks of loads in flight while one is multiplied.  (A compute unit holds only one or
-            // two of these workgroups = one or two wavefronts per SIMD: the depth has to come from the pipeline.)
+            // STG stages: STG - 1 chunks of loads in flight while one is multiplied.  (A compute unit holds one of these
+            // workgroups = one wavefront per SIMD: the depth has to come from the pipeline.)
             constexpr int STG = ASG_X_STEP_PF + 1;
             Stage st[STG];
 #pragma unroll
-            for (int u = 0; u < STG - 1; ++u) load(st[u], min(c0 + u, c1 - 1));
+            for (int u = 0; u < STG - 1; ++u) {
+                __builtin_amdgcn_sched_barrier(0);
+                load(st[u], min(c0 + u, c1 - 1));
+            }
             for (int c = c0; c < c1; c += STG) {
 #pragma unroll
                 for (int u = 0; u < STG; ++u) {
@@ -623,18 +792,6 @@ __device__ __forceinline__ void fwd_step_mfma(const Problem &P, const StepBuf<fl
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (wave == 3 && 32 * full < npad) {
-            Stage st;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const bool in = 32 * full + 8 * kq + 4 * h < npad;
-                st.a[h] = in ? *reinterpret_cast<const V4f *>(va + 32 * full + 4 * h) : zero4;
-                st.b[h] = in ? *reinterpret_cast<const V4f *>(vb + 32 * full + 4 * h) : zero4;
-#pragma unroll
-                for (int m = 0; m < MB; ++m) st.e[m][h] = et[((size_t) full * MB * 2 + m * 2 + h) * 64];      // (zero-padded)
-            }
-            multiply(st);
-        }
         // element (row 16 m + 4 (l >> 4) + q, utterance (l & 15) [+ 16]) of the tile sits in register q of lane l
 #pragma unroll
         for (int m = 0; m < MB; ++m)
@@ -642,84 +799,10 @@ __device__ __forceinline__ void fwd_step_mfma(const Problem &P, const StepBuf<fl
             for (int q = 0; q < 4; ++q) { red[wave][8 * m + q][lane] = acc[m][0][q]; red[wave][8 * m + 4 + q][lane] = acc[m][1][q]; }
     }
     __syncthreads();
-    // ---- epilogue: thread -> utterance b0 + (tid >> 3), rows i0 + 2 (tid & 7) + {0, 1} (+ 16 per row block); as the VALU body's
-    const R L2E = Num<R>::log2e(), LZ = Num<R>::logzero();
-    const int ut = threadIdx.x >> 3, b = b0 + ut;
-    const bool bvalid = b < B;
-    const int bc = bvalid ? b : 0;
-    const int len = P.in_len ? gclampi(P.in_len[bc], 0, T) : T;
-    const int t = BETA ? len - 1 - n : n + 1;          // frame whose q is consumed (beta) / produced (alpha)
-    const bool active = bvalid && (BETA ? (t >= 1) : (t < len));
-    const R muprev = fmax((R) funkey(S.mu[(n % 3) * B + bc]), LZ);
-    const int tw = active ? (BETA ? t - 1 : t) : 0;    // frame written
-    const R emw = S.emax[(int64_t) tw * B + bc];
-    float qkey = -__builtin_inff();
-#pragma unroll
-    for (int rr2 = 0; rr2 < 2 * MB; ++rr2) {
-        const int row = 16 * (rr2 >> 1) + 2 * (threadIdx.x & 7) + (rr2 & 1), i = i0 + row;
-        if (!active || i >= N) continue;
-        const int sl = 16 * ((row & 15) >> 2) + (ut & 15), sq = 8 * (row >> 4) + (row & 3) + 4 * (ut >> 4);
-        const R a = (red[0][sq][sl] + red[1][sq][sl]) + (red[2][sq][sl] + red[3][sq][sl]);
-        R lg = Num<R>::log2(a);
-        R rr = S.hmax[i] + lg;
-        if (!(fabs(lg) < Num<R>::lg_limit())) {
-            // exact rare path: log2-sum-exp2 over j of (Tr2[.][.] + q_j) from the log-domain state
-            const R *tr = (const R *) P.transition;
-            const int tq = BETA ? t : t - 1;
-            const R *stq = S.state + ((int64_t) b * T + tq) * N;
-            const R *inq = (const R *) P.inputs + (int64_t) tq * P.is0 + (int64_t) b * P.is1;
-            const R emq = S.emax[(int64_t) tq * B + b];
-            R mx = Num<R>::ninf();
-            for (int j = 0; j < N; ++j) {
-                R qj = BETA ? inq[(int64_t) j * P.is2] * L2E - emq + stq[j] : stq[j];
-                R trv = BETA ? tr[(int64_t) j * P.ts0 + (int64_t) i * P.ts1] : tr[(int64_t) i * P.ts0 + (int64_t) j * P.ts1];
-                R v = trv * L2E + qj;
-                mx = (v == v) ? fmax(mx, v) : mx;
-            }
-            R sm = 0;
-            for (int j = 0; j < N; ++j) {
-                R qj = BETA ? inq[(int64_t) j * P.is2] * L2E - emq + stq[j] : stq[j];
-                R trv = BETA ? tr[(int64_t) j * P.ts0 + (int64_t) i * P.ts1] : tr[(int64_t) i * P.ts0 + (int64_t) j * P.ts1];
-                R v = trv * L2E + qj;
-                sm += (v == v && mx != Num<R>::ninf()) ? Num<R>::exp2(v - mx) : R(0);
-            }
-            rr = (mx == Num<R>::ninf()) ? mx : mx + Num<R>::log2(sm);
-        }
-        const R emis = ((const R *) P.inputs)[(int64_t) tw * P.is0 + (int64_t) b * P.is1 + (int64_t) i * P.is2] * L2E - emw;
-        R stv, q;
-        if (BETA) { stv = rr - muprev; q = emis + stv; }
-        else { stv = emis + rr - muprev; q = stv; }
-        if (PERSIST) {
-            __hip_atomic_store(&S.state[((int64_t) b * T + tw) * N + i], stv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&pnext[(int64_t) b * npad + i], Num<R>::exp2(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            S.state[((int64_t) b * T + tw) * N + i] = stv;
-            pnext[(int64_t) b * npad + i] = Num<R>::exp2(q);
-        }
-        qkey = fmaxf(qkey, (float) q);
-        if (i == 0) {
-            if (PERSIST) {
-                // (nothing stays dirty in this XCD's L2: the other workgroups' atomics on `mu` execute behind it)
-                __hip_atomic_store(&S.off[b], S.off[b] + ((double) muprev + (double) emw), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&S.mu[((n + 2) % 3) * B + b], fkey(-__builtin_inff()), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (!BETA && S.mulog) __hip_atomic_store(&S.mulog[(int64_t) tw * B + b], muprev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                S.off[b] += (double) muprev + (double) emw;
-                S.mu[((n + 2) % 3) * B + b] = fkey(-__builtin_inff());
-                if (!BETA && S.mulog) S.mulog[(int64_t) tw * B + b] = muprev;
-            }
-        }
-    }
-    // one atomic per utterance and workgroup at most (max is order-independent: deterministic), and only if it can
-    // change the word: the eight lanes of an utterance reduce with three DPP steps
-    qkey = fmaxf(qkey, dpp_mov<kDppXor1>(qkey, qkey));
-    qkey = fmaxf(qkey, dpp_mov<kDppXor2>(qkey, qkey));
-    qkey = fmaxf(qkey, dpp_mov<kDppHalfMirror>(qkey, qkey));
-    if (active && (threadIdx.x & 7) == 0) {
-        unsigned *word = &S.mu[((n + 1) % 3) * B + b];
-        const unsigned key = fkey(qkey);
-        if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < key) atomicMax(word, key);
-    }
+#ifdef ASG_X_STEP_PROBE
+    if (n == 20 && threadIdx.x == 0) { const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x; if (wg < 1024) g_step_probe[wg * 4 + 1] = wall_clock64(); }
+#endif
+    step_epilogue<BETA>(P, S, n, red, pre, bt, slice, ks);
 }
 
 template <typename R> struct StepUsesMfma { static constexpr bool v = false; };
@@ -728,77 +811,37 @@ template <> struct StepUsesMfma<float> { static constexpr bool v = true; };
 #endif
 
 // blockIdx.z selects the direction, so the alpha and beta frames of one step share a launch (they are
-// independent chains): twice the workgroups in flight, half the launches.
+// independent chains): twice the workgroups in flight, half the launches.  fp32: blockIdx.y = batch tile x slice of K (ks slices).
 template <typename R>
-__global__ void __launch_bounds__(256) fwd_step_kernel(Problem P, StepBuf<R> Sa, StepBuf<R> Sb, int n, int dir_base) {
+__global__ void __launch_bounds__(256) fwd_step_kernel(Problem P, StepBuf<R> Sa, StepBuf<R> Sb, int n, int dir_base, int ks) {
     if constexpr (StepUsesMfma<R>::v) {
-        if ((int) blockIdx.z + dir_base == 0) fwd_step_mfma<false, false>(P, Sa, n);
-        else fwd_step_mfma<true, false>(P, Sb, n);
+        __shared__ float red[4][kStepMB * 8][64];
+#ifdef ASG_X_STEP_PROBE
+        const long long t_begin = wall_clock64();
+#endif
+        if ((int) blockIdx.z + dir_base == 0) fwd_step_mfma<false>(P, Sa, n, red, ks);
+        else fwd_step_mfma<true>(P, Sb, n, red, ks);
+#ifdef ASG_X_STEP_PROBE
+        {
+            // frame 20: every workgroup stamps begin / product done / end (100 MHz ticks); frame 30: one thread prints the summary
+            const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+            if (n == 20 && threadIdx.x == 0 && wg < 1024) { g_step_probe[wg * 4 + 0] = t_begin; g_step_probe[wg * 4 + 2] = wall_clock64(); }
+            if (n == 30 && wg == 0 && threadIdx.x == 0) {
+                const int nwg = gridDim.x * gridDim.y * gridDim.z;
+                long long b0 = 0x7fffffffffffffffll, b1 = 0, p0 = b0, p1 = 0, e0 = b0, e1 = 0; int ne = 0; long long esum = 0;
+                for (int w = 0; w < nwg && w < 1024; ++w) {
+                    const long long b = g_step_probe[w * 4], pd = g_step_probe[w * 4 + 1], e = g_step_probe[w * 4 + 2];
+                    b0 = b < b0 ? b : b0; b1 = b > b1 ? b : b1; p0 = pd < p0 ? pd : p0; p1 = pd > p1 ? pd : p1; e0 = e < e0 ? e : e0; e1 = e > e1 ? e : e1;
+                    if (e - pd > 100) { ++ne; esum += e - pd; }
+                }
+                printf("[step probe] %d workgroups: begin %.1f .. %.1f us, product done %.1f .. %.1f us, end %.1f .. %.1f us; %d workgroups ran an epilogue, %.1f us each on average\n",
+                       nwg, 0.0, (b1 - b0) / 100.0, (p0 - b0) / 100.0, (p1 - b0) / 100.0, (e0 - b0) / 100.0, (e1 - b0) / 100.0, ne, ne ? esum / 100.0 / ne : 0.0);
+            }
+        }
+#endif
     } else {
         if ((int) blockIdx.z + dir_base == 0) fwd_step_body<R, false>(P, Sa, n);
         else fwd_step_body<R, true>(P, Sb, n);
-    }
-}
-
-// All T-1 frames in ONE cooperative launch (fp32): every workgroup keeps its tile of rows and walks the frames, with a
-// grid barrier PER DIRECTION between frames (the alpha and the beta recursion are independent chains: while the
-// workgroups of one direction finish a frame -- reduction, logarithms, stores, barrier -- those of the other keep the
-// transition-matrix stream running, where T-1 separate launches drained and refilled the whole memory pipeline 1999
-// times).  bar[16 dir]: arrival counter of the direction, zero on entry.  Cross-workgroup data of a frame is stored
-// write-through (fwd_step_mfma<.., true>), so the barrier is: stores drained (the workgroup barrier), one arrival
-// atomic, a spin on the counter, an L1 / L2 invalidate for the vectors the next frame reads.
-__global__ void __launch_bounds__(256) fwd_persist_kernel(Problem P, StepBuf<float> Sa, StepBuf<float> Sb, int dir_base, int nsteps,
-                                                          unsigned *bar) {
-    const int dir = (int) blockIdx.z + dir_base;
-    const unsigned nwg = gridDim.x * gridDim.y;
-    // Barrier of one direction, two levels: same-address atomics from different XCDs execute one after the other at the
-    // memory side (~50 ns each: 125 arrivals on one word cost more than the launch they replace), so a workgroup arrives
-    // at the word of its XCD (a cache line of its own) and the last one there arrives at the direction's word.
-    //   bar[(dir * 32 + k) * 16], k = 0: arrivals of whole XCDs; k = 1 + xcc: arrivals of the workgroups on that XCD;
-    //   k = 9 + xcc: how many workgroups of this direction the XCD got (counted once, before the first frame); k = 17: that count's barrier
-    unsigned xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    xcc &= 7u;
-    unsigned *top = bar + (dir * 32) * 16, *mine = bar + (dir * 32 + 1 + xcc) * 16, *members = bar + (dir * 32 + 9 + xcc) * 16;
-    unsigned *flat = bar + (dir * 32 + 17) * 16;
-    constexpr int kSpinMax = 1 << 24;          // (a barrier that cannot complete gives up instead of hanging the device)
-    __shared__ unsigned sh_members, sh_groups;
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(members, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(flat, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (int spins = 0; __hip_atomic_load(flat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nwg && spins < kSpinMax; ++spins)
-            __builtin_amdgcn_s_sleep(8);
-        unsigned groups = 0;
-        for (int k = 0; k < 8; ++k)
-            groups += __hip_atomic_load(bar + (dir * 32 + 9 + k) * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ? 1u : 0u;
-        sh_members = __hip_atomic_load(members, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        sh_groups = groups;
-        // the two directions half a frame apart: one streams the matrix while the other is between frames
-        if (dir != dir_base) {
-            const unsigned long long t0 = wall_clock64();
-            while (wall_clock64() - t0 < (unsigned long long) ASG_X_PERSIST_SKEW) __builtin_amdgcn_s_sleep(64);
-        }
-    }
-    __syncthreads();
-    const unsigned msize = sh_members, ngroups = sh_groups;
-    for (int n = 0; n < nsteps; ++n) {
-        if (dir == 0) fwd_step_mfma<false, true>(P, Sa, n);
-        else fwd_step_mfma<true, true>(P, Sb, n);
-        if (n + 1 == nsteps) break;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wavefront's stores of the frame have been acknowledged
-        __syncthreads();
-#ifdef ASG_X_NOBARRIER
-        continue;       // (developer timing: how fast do the frames stream with nothing between them?  results are wrong)
-#endif
-        if (threadIdx.x == 0) {
-            const unsigned before = __hip_atomic_fetch_add(mine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (before + 1 == msize * (unsigned) (n + 1)) __hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned target = ngroups * (unsigned) (n + 1);
-            for (int spins = 0; __hip_atomic_load(top, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && spins < kSpinMax; ++spins)
-                __builtin_amdgcn_s_sleep(2);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        __syncthreads();
     }
 }
 
@@ -3183,11 +3226,29 @@ size_t step_tile_bytes_generic(int elem, int N) {
     return (elem == 4 && StepUsesMfma<float>::v) ? step_tile_floats(N) * sizeof(float) : 0;
 }
 
+// the vectors of the fp32 streaming step a second time, in operand order (step_ptile_index): two frames per direction, behind the
+// normaliser log
+static size_t step_ptile_bytes(int elem, int B, int N) {
+    if (!(elem == 4 && StepUsesMfma<float>::v)) return 0;
+    return au(2 * step_ptile_floats(B, (N + 3) / 4 * 4) * sizeof(float));
+}
+// K slices of the fp32 streaming step (fwd_step_mfma): as many as fill the device, at least ~8 chunks of 32 k each, at most kStepMaxSlices
+constexpr int kStepMaxSlices = 8;
+static int step_slices(int workgroups, int nchunks, int cus) {
+    int ks = cus / (workgroups > 0 ? workgroups : 1);
+    if (ks > nchunks / 8) ks = nchunks / 8;
+    if (ks > kStepMaxSlices) ks = kStepMaxSlices;
+    return ks < 1 ? 1 : ks;
+}
+static size_t step_tiles(int B, int N) { return (size_t) ((N + 16 * kStepMB - 1) / (16 * kStepMB)) * ((B + 31) / 32); }
+static size_t step_ticket_bytes(int B, int N) { return au(step_tiles(B, N) * sizeof(unsigned)); }
+static size_t step_partial_bytes(int B, int N) { return au(step_tiles(B, N) * kStepMaxSlices * (2 * kStepMB) * 256 * sizeof(float)); }
 // forward work buffers live behind the saved state (see fwd_work_bytes_generic): emax, pbuf x2 dirs, mu, off
 size_t fwd_work_bytes_generic(int elem, int T, int B, int N) {
     const size_t npad = (size_t) (N + 3) / 4 * 4;
     return au((size_t) T * B * elem) + 2 * au(2 * (size_t) B * npad * elem) + 2 * au(3 * (size_t) B * 4) + 2 * au((size_t) B * 8) +
-           au((size_t) T * B * elem) + ((elem == 4 && N > 256 && N <= 2048) ? kClusterBytes : 0) + 4096;
+           au((size_t) T * B * elem) + 2 * step_ptile_bytes(elem, B, N) +
+           (step_ptile_bytes(elem, B, N) ? 2 * (step_ticket_bytes(B, N) + step_partial_bytes(B, N)) : 0) + ((elem == 4 && N > 256 && N <= 2048) ? kClusterBytes : 0) + 4096;
 }
 // offset of the alpha pass's per-frame normaliser log inside the work area (its last member)
 static size_t work_mulog_offset(size_t elem, int T, int B, int npad) {
@@ -3268,6 +3329,15 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
             S.etile = (const R *) (beta ? W.ftile : W.etile);
             S.hmax = (const R *) (beta ? W.cmax : W.rmax);
             S.mulog = beta ? nullptr : (R *) ((char *) W.work + work_mulog_offset(e, P.T, P.B, W.npad));
+            if (const size_t pbytes = step_ptile_bytes((int) e, P.B, P.N)) {
+                char *area = (char *) W.work + work_mulog_offset(e, P.T, P.B, W.npad) + au((size_t) P.T * P.B * e);
+                S.ptile = (R *) (area + dir * pbytes);
+                if (dir == 0) (void) hipMemsetAsync(S.ptile, 0, 2 * pbytes, stream);       // (pad positions stay zero)
+                const size_t tb = step_ticket_bytes(P.B, P.N), sb = step_partial_bytes(P.B, P.N);
+                S.tickets = (unsigned *) (area + 2 * pbytes + dir * tb);
+                if (dir == 0) (void) hipMemsetAsync(S.tickets, 0, 2 * tb, stream);
+                S.partial = (R *) (area + 2 * pbytes + 2 * tb + dir * sb);
+            }
             Sd[dir] = S;
         }
         const bool do_a = full_mask & kFullAlpha, do_b = full_mask & kFullBeta;
@@ -3346,28 +3416,6 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
                 }
             }
         }
-        if constexpr (StepUsesMfma<R>::v) {
-            // ASG_PERSIST=1: one cooperative launch when every workgroup fits on the device at once (the runtime refuses
-            // otherwise) and the stream is not being captured.  Measured at cfg 5 (tools/run_cfg5_var.sh): 145.0-145.5 us per
-            // frame against 144.1 us with T-1 launches, whatever the barrier and the offset between the directions -- the
-            // frame is bound by the steady stream (5.5 TB/s = 88 % of what a copy kernel reaches), not by what happens between
-            // frames -- so the launches, which need no co-residency, stay the default.
-            const char *pe = getenv("ASG_PERSIST");
-            const bool persist = !stepped && pe && atoi(pe) != 0;
-            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-            if (persist) (void) hipStreamIsCapturing(stream, &cs);
-            if (persist && cs == hipStreamCaptureStatusNone && P.T >= 3) {
-                unsigned *bar = (unsigned *) bar_area;
-                Problem Pk = P;
-                StepBuf<float> A0 = Sd[0], B0 = Sd[1];
-                int dir_base = do_a ? 0 : 1, nsteps = P.T - 1;
-                void *args[] = {&Pk, &A0, &B0, &dir_base, &nsteps, &bar};
-                const hipError_t ce = hipLaunchCooperativeKernel((const void *) fwd_persist_kernel, sgrid, dim3(256), args, 0, stream);
-                if (ce == hipSuccess) stepped = true;
-                else (void) hipGetLastError();          // too large for one wave of workgroups: fall back
-                if (getenv("ASG_DBG_PERSIST")) fprintf(stderr, "[asg] cooperative forward launch: %s (grid %u x %u x %u)\n", hipGetErrorString(ce), sgrid.x, sgrid.y, sgrid.z);
-            }
-        }
         {
             // below the streaming regime (and, fp32, where the resident-slice kernel did not take the problem): 16 x 16 tiles on the
             // matrix instruction of the problem's precision (ASG_NO_TILE_STEP=1: the kernels built for N = 10^4)
@@ -3383,9 +3431,23 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
                 stepped = true;
             }
         }
-        if (!stepped)
+        if (!stepped) {
+            // fp32: K split over ks workgroups per (row tile, batch tile) so that the grid fills the device: 160-row tiles halve the
+            // vector traffic per byte of the matrix (at cfg 5: 63 row tiles x 2 directions x 2 slices = 252 workgroups)
+            int ks = 1;
+            if constexpr (StepUsesMfma<R>::v) {
+                int dev = 0, cus = 0;
+                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+                    cus = 256;
+                ks = step_slices((int) (sgrid.x * sgrid.y * sgrid.z), (W.npad + 31) / 32, cus);
+#ifdef ASG_DEV_PROBES
+                if (const char *ev = getenv("ASG_STEP_KS")) ks = atoi(ev) >= 1 && atoi(ev) <= kStepMaxSlices ? atoi(ev) : ks;
+#endif
+                sgrid.y *= ks;
+            }
             for (int n = 0; n + 1 < P.T; ++n)
-                hipLaunchKernelGGL((fwd_step_kernel<R>), sgrid, dim3(256), 0, stream, P, Sd[0], Sd[1], n, do_a ? 0 : 1);
+                hipLaunchKernelGGL((fwd_step_kernel<R>), sgrid, dim3(256), 0, stream, P, Sd[0], Sd[1], n, do_a ? 0 : 1, ks);
+        }
         if (do_b)
             hipLaunchKernelGGL((fwd_score_kernel<R, true>), dim3(P.B), dim3(256), 0, stream, P, Sd[1], (R *) O.full_scores);
         if (do_a && O.full_scores_alpha)
@@ -3499,7 +3561,7 @@ hipError_t launch_bwd_generic(const Problem &P, const State &W, const BwdArgs &A
                 const int npadT = g3_npadT(P.N);
                 const size_t pe = g3_plane_elems(K, P.N);
                 unsigned short *apl = planes3, *bpl = (unsigned short *) ((char *) planes3 + pbytes);
-                const dim3 pgrid(npadT / 256, (K + 7) / 8);
+                const dim3 pgrid(npadT / 256, (K + 31) / 32 * 4);          // whole 32-row blocks: the product reads four 8-row groups per block
                 hipLaunchKernelGGL(gemm3_pack_kernel, pgrid, dim3(256), 0, stream, (const float *) Gm, npad, npadT, (const int *) (rowoff + P.B), K, apl, pe);
                 hipLaunchKernelGGL(gemm3_pack_kernel, pgrid, dim3(256), 0, stream, (const float *) Pm, npad, npadT, (const int *) (rowoff + P.B), K, bpl, pe);
                 const int Mt = npadT / kG3TM, Nt = (P.N + kG3TN - 1) / kG3TN;
