@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define ASG_HIP_VERSION 210
+#define ASG_HIP_VERSION 220
 
 #define ASG_DTYPE_F32 0
 #define ASG_DTYPE_F64 1
@@ -80,6 +80,11 @@ const char *asg_hip_strerror(int status);
  * grid never became resident.  Such a call returns NaN scores; from then on the library takes the per-frame launches (which need
  * no co-residency).  Read from host-pinned memory, no synchronisation; the count of a call is visible once that call has run. */
 unsigned asg_cluster_timeouts(void);
+
+/* Developer / test switches (ASG_FORK_IN_CAPTURE, ASG_PAIR_MIN_B, ASG_BWD_ROWSUM, ASG_NO_CLUSTER, ASG_NO_MID, ASG_NO_TILE_STEP,
+ * ASG_ALIGNED_KERNEL) are read from the environment ONCE, at the first call that needs one -- no getenv on the per-call path.
+ * A process that changes them afterwards (the test-suite does) calls this to have them read again.  No reference counterpart. */
+void asg_reload_env(void);
 
 int asg_ctx_create(asg_ctx **out);
 int asg_ctx_destroy(asg_ctx *ctx);

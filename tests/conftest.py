@@ -35,3 +35,16 @@ def _poison_free_device_memory(request):
         junk[::2] = float("inf")
         del junk
     yield
+
+
+@pytest.fixture(autouse=True)
+def _reload_library_switches(request):
+    """The library caches its ASG_* developer switches; tests that change them (util.setenv) must not leak the change: read the
+    environment again once the test -- and monkeypatch's restoration, which runs before this finaliser -- is over."""
+    yield
+    if request.node.get_closest_marker("gpu") is not None:
+        try:
+            from torch_asg_amd import _lib
+            _lib.lib().asg_reload_env()
+        except Exception:
+            pass

@@ -1,11 +1,9 @@
-"""Large-batch routes of the small-alphabet path, forced on at small sizes (-m gpu):
-  * ASG_BATCHED_MIN_B=1: the full-lattice recursions sixteen utterances per workgroup on the matrix cores (csrc/asg_batched.hip;
-    opt-in: DESIGN.md section 5e), with its clean-up launch for flagged utterances;
-  * ASG_PAIR_MIN_B=1: the aligned recursions two utterances per wavefront (aligned_pair_chain, default from B = 2048) and the
-    aligned-only kernel.
-Both against the fp64 oracle AND against the per-utterance chains on the same inputs: variable lengths (one-frame utterances
-included), every alphabet tile, label counts that are not multiples of 4 (scalar accesses), -inf emissions, transition scores
-of tens of nats (flagged utterances -> exact redo), batch-major strided emissions, evaluation route, reductions, launch modes."""
+"""Large-batch routes of the small-alphabet path, forced on at small sizes (-m gpu): ASG_PAIR_MIN_B=1 -- the aligned recursions two
+utterances per wavefront (aligned_pair_chain, default from B = 2048) and the aligned-only kernel.
+Against the fp64 oracle AND against the one-utterance chains on the same inputs: variable lengths (one-frame utterances included), every
+alphabet tile, label counts that are not multiples of 4 (scalar accesses), -inf emissions, transition scores of tens of nats (flagged
+utterances -> exact redo), batch-major strided emissions, evaluation route, reductions, launch modes.
+(Round 4's opt-in matrix-core forward for sixteen utterances per workgroup lost its measurement and lives in tools/experiments/.)"""
 import numpy as np
 import pytest
 import torch
@@ -40,7 +38,7 @@ SHAPES = [(50, 16, 40, 10), (130, 37, 40, 30), (1, 5, 40, 1), (2, 20, 40, 2), (9
 
 
 @pytest.mark.parametrize("variant", ["plain", "scaled", "neginf", "strided"])
-def test_batched_forward_and_pair_chains_against_oracle_and_per_utterance_chains(variant, monkeypatch):
+def test_pair_chains_against_oracle_and_per_utterance_chains(variant, monkeypatch):
     rng = np.random.default_rng(len(variant))
     for (T, B, N, L) in SHAPES:
         tr, x, tg, _, _ = util.synth(T, B, N, L, int(rng.integers(0, 1 << 30)))
@@ -62,12 +60,10 @@ def test_batched_forward_and_pair_chains_against_oracle_and_per_utterance_chains
         o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il.numpy(), tl.numpy(), "none")
         fin = np.isfinite(o["loss"])
         o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il.numpy(), tl.numpy(), "none", grad_out=fin.astype(np.float64))
-        monkeypatch.setenv("ASG_BATCHED_MIN_B", "1")
-        monkeypatch.setenv("ASG_PAIR_MIN_B", "1")
+        util.setenv(monkeypatch, "ASG_PAIR_MIN_B", "1")
         ra = _run(x, tg, tr, il, tl, "none")
         ev = _run(x, tg, tr, il, tl, "none", eval_route=True)
-        monkeypatch.setenv("ASG_BATCHED_MIN_B", str(1 << 30))
-        monkeypatch.setenv("ASG_PAIR_MIN_B", str(1 << 30))
+        util.setenv(monkeypatch, "ASG_PAIR_MIN_B", str(1 << 30))
         rb = _run(x, tg, tr, il, tl, "none")
         what = "T%d B%d N%d L%d %s" % (T, B, N, L, variant)
         for k in ("loss", "grad_inputs", "grad_transition"):
@@ -79,9 +75,8 @@ def test_batched_forward_and_pair_chains_against_oracle_and_per_utterance_chains
 
 @pytest.mark.parametrize("mode", ["single", "streams", "serial"])
 @pytest.mark.parametrize("red", ["mean", "sum"])
-def test_batched_routes_reduced_losses_launch_modes_determinism(mode, red, monkeypatch):
-    monkeypatch.setenv("ASG_BATCHED_MIN_B", "1")
-    monkeypatch.setenv("ASG_PAIR_MIN_B", "1")
+def test_pair_routes_reduced_losses_launch_modes_determinism(mode, red, monkeypatch):
+    util.setenv(monkeypatch, "ASG_PAIR_MIN_B", "1")
     T, B, N, L = 80, 70, 40, 12
     tr, x, tg, il, tl = util.synth(T, B, N, L, 3, True)
     o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il.numpy(), tl.numpy(), red)
@@ -97,9 +92,9 @@ def test_pair_chains_are_the_default_at_2048_utterances_and_match_the_single_cha
     both within 1e-4 of the oracle on a sample of utterances."""
     T, B, N, L = 24, 2048, 40, 9
     tr, x, tg, il, tl = util.synth(T, B, N, L, 9, True)
-    monkeypatch.delenv("ASG_PAIR_MIN_B", raising=False)
+    util.setenv(monkeypatch, "ASG_PAIR_MIN_B", None)
     ra = _run(x, tg, tr, il, tl, "none")
-    monkeypatch.setenv("ASG_PAIR_MIN_B", str(1 << 30))
+    util.setenv(monkeypatch, "ASG_PAIR_MIN_B", str(1 << 30))
     rb = _run(x, tg, tr, il, tl, "none")
     for k in ("loss", "grad_inputs", "grad_transition"):
         util.assert_close(ra[k], rb[k], 2e-5, "pairs vs singles: " + k)

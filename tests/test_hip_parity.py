@@ -208,7 +208,7 @@ def test_exact_fallback_paths(case, launch_mode, monkeypatch):
     # 'serial' = the stand-alone kernels (the MFMA assembly flags a workgroup and redoes it with the per-frame code: on a NaN in the
     # alpha pass's scale log, or -- 'serial-rowsum', the large-batch kernel -- on a recomputed row sum outside the safe range)
     if launch_mode == "serial-rowsum":
-        monkeypatch.setenv("ASG_BWD_ROWSUM", "1")
+        util.setenv(monkeypatch, "ASG_BWD_ROWSUM", "1")
         launch_mode = "serial"
     r = run_hip(x, tg, tr, il, tl, "none", launch_mode=launch_mode)
     for k in ("loss", "grad_inputs", "grad_transition"):
@@ -246,14 +246,14 @@ def test_f64_alphabets_below_the_streaming_regime(T, B, N, L, monkeypatch):
     o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il, tl, "none")
     outs = []
     for env in ("0", "1"):
-        monkeypatch.setenv("ASG_NO_TILE_STEP", env)
+        util.setenv(monkeypatch, "ASG_NO_TILE_STEP", env)
         r = run_hip(x, tg, tr, il, tl, "none", torch.float64)
         for k in ("loss", "grad_inputs", "grad_transition"):
             util.assert_close(r[k], o[k], 1e-9, "fp64 T%d B%d N%d L%d valu=%s/%s" % (T, B, N, L, env, k))
         outs.append(r)
     for k in ("loss", "grad_inputs", "grad_transition"):
         util.assert_close(outs[0][k], outs[1][k], 1e-11, "matrix-core vs VALU step: %s" % k)
-    monkeypatch.setenv("ASG_NO_TILE_STEP", "0")
+    util.setenv(monkeypatch, "ASG_NO_TILE_STEP", "0")
     again = run_hip(x, tg, tr, il, tl, "none", torch.float64)
     assert np.array_equal(again["grad_inputs"], outs[0]["grad_inputs"]) and np.array_equal(again["loss"], outs[0]["loss"], equal_nan=True)
     A = _asg()
@@ -902,7 +902,7 @@ def test_standalone_assembly_blocks(T, B, N, L, rowsum, monkeypatch):
     lattice batched in the same layout): block tails, every label / target-position tile count, variable lengths.
     Both fp32 kernels: row sums from the alpha pass's scale log (ASG_BWD_ROWSUM=0: what small working sets get; B = 130 has the
     one-wavefront chains write the log, the smaller batches the three-wavefront chains) and recomputed (=1: large ones)."""
-    monkeypatch.setenv("ASG_BWD_ROWSUM", rowsum)
+    util.setenv(monkeypatch, "ASG_BWD_ROWSUM", rowsum)
     tr, x, tg, il, tl = util.synth(T, B, N, L, T + N, True)
     o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il.numpy(), tl.numpy(), "none")
     r = run_hip(x, tg, tr, il, tl, "none", launch_mode="serial")
@@ -919,7 +919,7 @@ def test_standalone_route_emission_offsets(T, B, N, L, mode, rowsum, monkeypatch
     """Emissions with a common offset of +60 / -40 nats and a spread of 30 (what tools/stress_duo.py draws) through the
     stand-alone kernels, both assembly kernels: frame 0's state is not scaled like the later frames', and an emission factor
     formed for it from the scale log would overflow (found by the stress run, round 4: inf * 0 in the frame without an edge)."""
-    monkeypatch.setenv("ASG_BWD_ROWSUM", rowsum)
+    util.setenv(monkeypatch, "ASG_BWD_ROWSUM", rowsum)
     for offset, scale in ((60.0, 30.0), (-40.0, 30.0), (60.0, 1.0)):
         tr, x, tg, il, tl = util.synth(T, B, N, L, T + B, True)
         x = x * scale + offset
@@ -1096,7 +1096,7 @@ def test_resident_slice_alphabets(T, B, N, L, monkeypatch):
     o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il, tl, "none")
     outs = []
     for env in ("0", "1"):
-        monkeypatch.setenv("ASG_NO_CLUSTER", env)
+        util.setenv(monkeypatch, "ASG_NO_CLUSTER", env)
         r = run_hip(x, tg, tr, il, tl, "none")
         for k in ("loss", "grad_inputs", "grad_transition"):
             util.assert_close(r[k], o[k], 1e-4, "resident slices T%d B%d N%d L%d no_cluster=%s/%s" % (T, B, N, L, env, k))
@@ -1104,7 +1104,7 @@ def test_resident_slice_alphabets(T, B, N, L, monkeypatch):
         outs.append(r)
     for k in ("loss", "grad_inputs", "grad_transition"):       # (different summation orders: VALU quarters vs MFMA k-steps)
         util.assert_close(outs[0][k], outs[1][k], 3e-5, "cluster vs per-frame launches: %s" % k)
-    monkeypatch.setenv("ASG_NO_CLUSTER", "0")
+    util.setenv(monkeypatch, "ASG_NO_CLUSTER", "0")
     again = run_hip(x, tg, tr, il, tl, "none")
     assert np.array_equal(again["grad_inputs"], outs[0]["grad_inputs"]) and np.array_equal(again["loss"], outs[0]["loss"], equal_nan=True)
 

@@ -166,6 +166,18 @@ def test_handles_survive_autograd_saving_and_foreign_tensors_are_refused():
     with pytest.raises(RuntimeError, match="does not come from"):
         nat.fast_asg_gpu_backward(torch.ones(B, device=DEV), -torch.ones(B, device=DEV), stranger, stranger,
                                   stranger, stranger, tgd, ild, tld, T, B, N, S)
+    # a uint8 tensor of exactly the right size passes the (synchronisation-free) size test; STRICT also reads the header word
+    full, ali, gf, ga, pf, pa = nat.fast_asg_gpu_forward(x.to(DEV), tgd, tr.to(DEV), ild, tld, T, B, N, S)
+    lookalike = torch.zeros_like(pf)
+    nat.STRICT = True
+    try:
+        with pytest.raises(RuntimeError, match="does not come from"):
+            nat.fast_asg_gpu_backward(torch.ones(B, device=DEV), -torch.ones(B, device=DEV), gf, ga, lookalike, pa, tgd, ild, tld, T, B, N, S)
+        gtr, gin = nat.fast_asg_gpu_backward(torch.ones(B, device=DEV) / B, -torch.ones(B, device=DEV) / B, gf, ga, pf, pa, tgd, ild, tld, T, B, N, S)
+        ok, e = util.tol_ok(gin.cpu().numpy(), o["grad_inputs"], 1e-4)
+        assert ok, e
+    finally:
+        nat.STRICT = False
 
 
 @pytest.mark.gpu

@@ -59,3 +59,15 @@ def tol_ok(x, ref, rtol=1e-4):
 def assert_close(x, ref, rtol=1e-4, what=""):
     ok, e = tol_ok(x, ref, rtol)
     assert ok, "%s: scaled max err %.3e > %.1e" % (what, e, rtol)
+
+
+def setenv(monkeypatch, name, value):
+    """Set (value=None: unset) one of the library's ASG_* developer switches for this test and have the library read them again
+    (they are cached after the first call: include/asg_hip.h, asg_reload_env).  The autouse fixture in conftest.py reloads once more
+    after the test, when monkeypatch has restored the environment."""
+    if value is None:
+        monkeypatch.delenv(name, raising=False)
+    else:
+        monkeypatch.setenv(name, str(value))
+    from torch_asg_amd import _lib
+    _lib.lib().asg_reload_env()

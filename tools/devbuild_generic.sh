@@ -5,5 +5,5 @@ R=$(cd "$(dirname "$0")/.." && pwd); C=$R/torch_asg_amd/csrc; name=$1; shift
 mkdir -p $C/variants
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wno-unused-function -Wno-unused-value -ffp-contract=off "$@" -c $C/asg_generic.hip -o $C/variants/generic_$name.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $C/variants/lib$name.so $C/variants/generic_$name.o \
-    $C/asg_small_f32.o $C/asg_small_f64.o $C/asg_bwd_f32.o $C/asg_bwd_f64.o $C/asg_fused.o $C/asg_batched.o $C/asg_viterbi.o $C/asg_api.o
+    $C/asg_small_f32.o $C/asg_small_f64.o $C/asg_bwd_f32.o $C/asg_bwd_f64.o $C/asg_fused.o $C/asg_viterbi.o $C/asg_api.o
 echo $C/variants/lib$name.so

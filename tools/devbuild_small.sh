@@ -7,5 +7,5 @@ mkdir -p $C/variants
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wno-unused-function -ffp-contract=off -DASG_DEV_ONLY_NP=40 "$@" \
     -c $C/asg_small_f32.hip -o $C/variants/small_$name.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $C/variants/lib$name.so $C/variants/small_$name.o \
-    $C/asg_small_f64.o $C/asg_bwd_f32.o $C/asg_bwd_f64.o $C/asg_fused.o $C/asg_generic.o $C/asg_batched.o $C/asg_viterbi.o $C/asg_api.o
+    $C/asg_small_f64.o $C/asg_bwd_f32.o $C/asg_bwd_f64.o $C/asg_fused.o $C/asg_generic.o $C/asg_viterbi.o $C/asg_api.o
 echo $C/variants/lib$name.so

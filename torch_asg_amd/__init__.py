@@ -12,6 +12,16 @@ def reserve(device, nbytes=0):
     return native().reserve(device, nbytes)
 
 
+def check_faults():
+    """Raise RuntimeError if a resident-slice forward launch (fp32, 256 < N <= 2048) of this process timed out since the last look --
+    the step that contained it returned NaN scores and gradients and must be discarded (the library has already switched to kernels
+    that need no co-residency, so repeating the step is sound).  ASGLoss checks at the start of every forward AND backward call with
+    N > 256; a training loop that wants to know before `optimizer.step()` calls this after its own synchronisation point
+    (`loss.item()`): it reads one host-pinned word, no device synchronisation of its own."""
+    from .asg import native
+    return native().check_faults()
+
+
 def release():
     """Destroy the side-stream contexts and drop the sync pools (call when no launch of this process is in flight)."""
     from .asg import native
@@ -19,4 +29,4 @@ def release():
 
 
 __all__ = ["ASGLoss", "ASGLossFunction", "FAC", "FCC", "ASGGPUFast", "ASGGPUFastForwardOnly", "viterbi_align",
-           "shard_batch", "sharded_asg_loss", "allreduce_transition_grad", "reserve", "release"]
+           "shard_batch", "sharded_asg_loss", "allreduce_transition_grad", "reserve", "release", "check_faults"]

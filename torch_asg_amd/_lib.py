@@ -18,8 +18,8 @@ SYMBOLS = ["asg_hip_version", "asg_hip_strerror", "asg_ctx_create", "asg_ctx_des
            "asg_aligned_backward", "asg_forward", "asg_forward_only", "asg_backward", "asg_loss_forward",
            "asg_loss_backward", "asg_viterbi_work_bytes", "asg_viterbi", "asg_loss_fused_supported",
            "asg_loss_fused_scratch_bytes", "asg_loss_fused_sync_bytes", "asg_loss_fused_forward",
-           "asg_loss_fused_backward", "asg_cluster_timeouts"]
-ABI_VERSION = 210        # include/asg_hip.h: ASG_HIP_VERSION this package was written against
+           "asg_loss_fused_backward", "asg_cluster_timeouts", "asg_reload_env"]
+ABI_VERSION = 220        # include/asg_hip.h: ASG_HIP_VERSION this package was written against
 
 
 class AsgProblem(ctypes.Structure):
@@ -52,6 +52,8 @@ def lib():
                            "`python torch_asg_amd/csrc/build.py`" % (LIB_PATH, int(L.asg_hip_version()), ABI_VERSION))
     L.asg_cluster_timeouts.restype = ctypes.c_uint
     L.asg_cluster_timeouts.argtypes = []
+    L.asg_reload_env.restype = None
+    L.asg_reload_env.argtypes = []
     L.asg_hip_strerror.restype = ctypes.c_char_p
     L.asg_hip_strerror.argtypes = [ci]
     L.asg_ctx_create.argtypes = [ctypes.POINTER(vp)]

@@ -168,6 +168,7 @@ class HipBackend:
         return p, keep
 
     MAX_CONTEXTS = 64
+    MAX_RETIRED = 64          # evicted contexts kept alive; the oldest beyond this is destroyed (it left the cache >= 64 evictions ago)
 
     def _context(self, device):
         """Side stream + fork/join events of the 'streams' launch mode, ONE SET PER CALLING STREAM: calls issued on
@@ -186,6 +187,10 @@ class HipBackend:
                         # list that release() empties; a context is a stream and two events
                         old = next(iter(self._ctx))
                         self._retired.append(self._ctx.pop(old))
+                        # ... and the list is bounded: a handle that was evicted MAX_RETIRED evictions ago (each eviction means
+                        # MAX_CONTEXTS newer calling streams exist) is not inside a call any more
+                        while len(self._retired) > self.MAX_RETIRED:
+                            _lib.lib().asg_ctx_destroy(self._retired.pop(0))
                         if self.binding is not None:
                             self.binding.reset()
                     with torch.cuda.device(idx):
@@ -206,19 +211,23 @@ class HipBackend:
         idx = device.index if device.index is not None else torch.cuda.current_device()
         return ctypes.c_void_p(_current_stream_handle(idx))
 
+    def _state_bytes(self, p):
+        """Size of the state buffer of problem p, a whole number of 256-byte units (a tail behind it stays 256-byte aligned)."""
+        return (max(int(self._bytes(p)[0]), 256) + 255) // 256 * 256
+
     @staticmethod
     def _buf(nbytes, device):
         return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
     # -- granular (reference "serial" route) ---------------------------------------------------
-    def full_forward(self, inputs, transition, input_lengths, flags=0):
+    def full_forward(self, inputs, transition, input_lengths, flags=0, tail_bytes=0):
         if inputs.shape[2] > 256:
             self.check_faults()          # (resident-slice route: a timed-out launch of an earlier call must not stay silent)
         self._check(inputs, transition, None, input_lengths, None)
         L = _lib.lib()
         with self._guard(inputs.device):
             p, keep = self._problem(inputs, transition, None, input_lengths, None)
-            state = self._buf(self._bytes(p)[0], inputs.device)
+            state = self._buf(self._state_bytes(p) + tail_bytes, inputs.device)      # (tail: room the caller wants behind the state)
             scores = torch.empty(inputs.shape[1], dtype=inputs.dtype, device=inputs.device)
             _lib.check(L.asg_full_forward(ctypes.byref(p), state.data_ptr(), state.numel(), scores.data_ptr(),
                                           flags, self._stream(inputs.device)), "asg_full_forward")
@@ -227,6 +236,8 @@ class HipBackend:
     def full_backward(self, state, grad_out, inputs, transition, input_lengths):
         L = _lib.lib()
         T, B, N = inputs.shape
+        if N > 256:
+            self.check_faults()          # (the forward of THIS step may have been the launch that timed out: its gradients are NaN)
         with self._guard(inputs.device):
             p, keep = self._problem(inputs, transition, None, input_lengths, None)
             g = grad_out.to(inputs.dtype).contiguous()
@@ -238,12 +249,12 @@ class HipBackend:
                                            self._stream(inputs.device)), "asg_full_backward")
         return gtr, gin
 
-    def aligned_forward(self, inputs, targets, transition, input_lengths, target_lengths, flags=0):
+    def aligned_forward(self, inputs, targets, transition, input_lengths, target_lengths, flags=0, tail_bytes=0):
         self._check(inputs, transition, targets, input_lengths, target_lengths)
         L = _lib.lib()
         with self._guard(inputs.device):
             p, keep = self._problem(inputs, transition, targets, input_lengths, target_lengths)
-            state = self._buf(self._bytes(p)[0], inputs.device)
+            state = self._buf(self._state_bytes(p) + tail_bytes, inputs.device)
             scores = torch.empty(inputs.shape[1], dtype=inputs.dtype, device=inputs.device)
             _lib.check(L.asg_aligned_forward(ctypes.byref(p), state.data_ptr(), state.numel(), scores.data_ptr(),
                                              flags, self._stream(inputs.device)), "asg_aligned_forward")
@@ -264,7 +275,7 @@ class HipBackend:
         return gtr, gin
 
     # -- fused (reference GPU fast route) --------------------------------------------------------
-    def forward(self, inputs, targets, transition, input_lengths, target_lengths, flags=_lib.FLAG_STREAMS):
+    def forward(self, inputs, targets, transition, input_lengths, target_lengths, flags=_lib.FLAG_STREAMS, tail_bytes=0):
         if inputs.shape[2] > 256:
             self.check_faults()          # (resident-slice route: a timed-out launch of an earlier call must not stay silent)
         self._check(inputs, transition, targets, input_lengths, target_lengths)
@@ -273,7 +284,7 @@ class HipBackend:
         k = 2 if flags & _lib.FLAG_ALPHA_SCORES else 1
         with self._guard(inputs.device):
             p, keep = self._problem(inputs, transition, targets, input_lengths, target_lengths)
-            state = self._buf(self._bytes(p)[0], inputs.device)
+            state = self._buf(self._state_bytes(p) + tail_bytes, inputs.device)
             scores = torch.empty(2, k * B, dtype=inputs.dtype, device=inputs.device)
             _lib.check(L.asg_forward(self._context(inputs.device), ctypes.byref(p), state.data_ptr(), state.numel(),
                                      scores[0].data_ptr(), scores[1].data_ptr(), flags,
@@ -318,6 +329,8 @@ class HipBackend:
                  flags=0):
         L = _lib.lib()
         T, B, N = inputs.shape
+        if N > 256:
+            self.check_faults()          # (the forward of THIS step may have been the launch that timed out: its gradients are NaN)
         with self._guard(inputs.device):
             p, keep = self._problem(inputs, transition, targets, input_lengths, target_lengths)
             g = torch.stack([grad_full.to(inputs.dtype), grad_aligned.to(inputs.dtype)]).contiguous()
@@ -466,6 +479,8 @@ class HipBackend:
         back (they may have travelled through saved-tensor hooks)."""
         L = _lib.lib()
         T, B, N = inputs.shape
+        if N > 256:
+            self.check_faults()          # (the forward of THIS step may have been the launch that timed out: its gradients are NaN)
         dev = inputs.device
         with self._guard(dev):
             p = saved.problem

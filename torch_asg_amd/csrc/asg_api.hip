@@ -6,6 +6,7 @@
 
 #include <hip/hip_runtime.h>
 #include <new>
+#include <atomic>
 #include <cstdlib>
 
 using namespace asg;
@@ -32,6 +33,34 @@ size_t bwd_scratch_bytes_small(int elem, int T, int B, int N, int S, int *chunk,
 }
 }  // namespace asg
 
+namespace asg {
+namespace {
+std::atomic<const Knobs *> g_knobs{nullptr};
+int env_int(const char *name) { const char *v = getenv(name); return v ? atoi(v) : -1; }
+const Knobs *read_knobs() {
+    Knobs *k = new Knobs();          // (a handful per process at most: never freed, readers may still hold the old one)
+    k->fork_in_capture = env_int("ASG_FORK_IN_CAPTURE");
+    k->pair_min_b = env_int("ASG_PAIR_MIN_B");
+    k->bwd_rowsum = env_int("ASG_BWD_ROWSUM");
+    k->no_cluster = env_int("ASG_NO_CLUSTER");
+    k->no_mid = env_int("ASG_NO_MID");
+    k->no_tile_step = env_int("ASG_NO_TILE_STEP");
+    const char *ak = getenv("ASG_ALIGNED_KERNEL");
+    k->aligned_kernel = ak ? ak[0] : 0;
+    return k;
+}
+}  // namespace
+const Knobs &knobs() {
+    const Knobs *k = g_knobs.load(std::memory_order_acquire);
+    if (!k) {
+        const Knobs *fresh = read_knobs();
+        if (g_knobs.compare_exchange_strong(k, fresh, std::memory_order_acq_rel)) k = fresh;
+        else delete fresh;
+    }
+    return *k;
+}
+}  // namespace asg
+
 // Host-side handles only (side stream + fork/join events of ASG_FLAG_STREAMS); no device memory, no per-call state:
 // everything a call mutates on the device lives in the caller-owned `state` buffer of that call.
 struct asg_ctx {
@@ -47,7 +76,7 @@ inline int hip_status(hipError_t e) { return e == hipSuccess ? ASG_OK : ASG_ERR_
 inline size_t align_up(size_t x) { return (x + 255) & ~(size_t) 255; }
 
 struct Layout {
-    size_t ah, bh, ab, bb, klog, ehat, fhat, rmax, cmax, etile, ftile, asu, asi, dbg, ticket, xflags, work, total;
+    size_t ah, bh, ab, bb, klog, ehat, fhat, rmax, cmax, etile, ftile, asu, asi, dbg, ticket, work, total;
     int npad;
 };
 
@@ -80,7 +109,6 @@ Layout make_layout(const asg_problem *p) {
     L.asi = off; off = align_up(off + B * S * 2 * sizeof(int));
     L.dbg = off; off = align_up(off + 512);      // developer timing stamps (ASG_PROBE builds only)
     L.ticket = off; off = align_up(off + 256);   // arrival ticket of the in-kernel loss reduction (zeroed per call)
-    if (small_full(p->N)) { L.xflags = off; off = align_up(off + 2 * B * sizeof(int)); }      // batched forward -> clean-up launch
     if (!small_full(p->N)) { L.work = off; off = align_up(off + fwd_work_bytes_generic((int) e, (int) T, (int) B, (int) N)); }
     L.total = off;
     return L;
@@ -133,7 +161,7 @@ State to_state(const asg_problem *p, const void *state) {
         W.dbg = base + L.dbg;
         W.ticket = (unsigned *) (base + L.ticket);
         if (!small_full(p->N)) W.work = base + L.work;
-        else { W.xflags = (int *) (base + L.xflags); W.klog = base + L.klog; }
+        else W.klog = base + L.klog;
     }
     W.npad = L.npad;
     return W;
@@ -156,8 +184,7 @@ int run_forward(asg_ctx *ctx, const asg_problem *p, void *state, void *full_scor
     // then 11 us before the backward launch): while capturing, the small path records its passes on the caller's stream.
     bool fork_ok = true;
     {
-        const char *ev = getenv("ASG_FORK_IN_CAPTURE");
-        const int mode = ev ? atoi(ev) : -1;             // -1: default policy
+        const int mode = knobs().fork_in_capture;        // -1: default policy
         if (mode == 0) fork_ok = !capturing(stream);
         else if (mode < 0) fork_ok = !(small_full(p->N) && small_aligned(p->S) && capturing(stream));
     }
@@ -218,11 +245,7 @@ int run_forward(asg_ctx *ctx, const asg_problem *p, void *state, void *full_scor
         return ASG_OK;
     }
     hipError_t e;
-    // large batches: the full-lattice chains run on the matrix cores (asg_batched.hip) and leave most of the VALU to the aligned
-    // chains, which are a launch of their own there anyway: the two overlap on two streams also in the default launch mode
-    const bool batched_two = (flags & ASG_FLAG_SINGLE_LAUNCH) && sizeof(R) == 4 && batched_forward_applies(P, W, mask) &&
-                             !(getenv("ASG_BATCHED_SEQ") && atoi(getenv("ASG_BATCHED_SEQ")) != 0);      // (developer A/B: one stream)
-    if (((flags & ASG_FLAG_STREAMS) || batched_two) && ctx && full_mask && ali_mask && fork_ok) {
+    if ((flags & ASG_FLAG_STREAMS) && ctx && full_mask && ali_mask && fork_ok) {
         // fork: aligned passes on the side stream, full passes on the caller's stream; join back.
         if ((e = hipEventRecord(ctx->fork, stream)) != hipSuccess) return hip_status(e);
         if ((e = hipStreamWaitEvent(ctx->side, ctx->fork, 0)) != hipSuccess) return hip_status(e);
@@ -291,6 +314,8 @@ const char *asg_hip_strerror(int status) {
 }
 
 unsigned asg_cluster_timeouts(void) { return cluster_timeouts(); }
+
+void asg_reload_env(void) { g_knobs.store(read_knobs(), std::memory_order_release); }
 
 int asg_ctx_create(asg_ctx **out) {
     if (!out) return ASG_ERR_INVALID;

@@ -1475,8 +1475,7 @@ __global__ void __launch_bounds__(kClNT) fwd_cluster_kernel(Problem P, StepBuf<f
 // the resident-slice route: fp32, 256 < N <= 2048 (ASG_NO_CLUSTER=1: the per-frame launches instead)
 static bool cluster_alphabet(const Problem &P, size_t elem) {
     if (elem != 4 || P.N <= 256 || P.N > 2048) return false;
-    const char *ev = getenv("ASG_NO_CLUSTER");
-    return !(ev && atoi(ev) != 0);
+    return !(knobs().no_cluster > 0);
 }
 constexpr size_t kClusterBytes = 8u << 20;       // exchange vectors of every cluster
 #ifndef ASG_X_TILE_MAX_N32
@@ -1490,8 +1489,7 @@ constexpr int kTileStepMaxN32 = ASG_X_TILE_MAX_N32;
 // the medium-alphabet route: fp32, 64 < N <= 256, 32-bit emission offsets (ASG_NO_MID=1: the per-frame launches instead)
 static bool mid_alphabet(const Problem &P, size_t elem) {
     if (P.N <= 64 || P.N > 256) return false;
-    const char *ev = getenv("ASG_NO_MID");
-    if (ev && atoi(ev) != 0) return false;
+    if (knobs().no_mid > 0) return false;
     const double fr = (double) (P.T - 1) * (double) P.is0 * (double) elem, ln = (double) (P.N - 1) * (double) P.is2 * (double) elem;
     return P.is0 >= 0 && P.is2 >= 0 && fr < 4294967296.0 && ln < 2147483648.0;
 }
@@ -3278,12 +3276,12 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
         const double fr = (double) (P.T - 1) * (double) P.is0 * sizeof(R), ln = (double) (P.N - 1) * (double) P.is2 * sizeof(R);
         const bool off32 = P.is0 >= 0 && P.is2 >= 0 && fr < 4294967296.0 && ln < 2147483648.0 &&
                            (double) P.T * P.S * sizeof(AlignedState) < 4294967296.0;
-        const char *ak = getenv("ASG_ALIGNED_KERNEL");        // developer A/B: "long" (K positions per lane), "wide" (barrier per frame)
-        const bool use_pipe = off32 && ((P.S > 256 && !(ak && (ak[0] == 'l' || ak[0] == 'w'))) || (ak && ak[0] == 'p'));
+        const char ak = knobs().aligned_kernel;        // developer A/B (ASG_ALIGNED_KERNEL): "long" (K positions per lane), "wide" (barrier per frame), "pipe"
+        const bool use_pipe = off32 && ((P.S > 256 && !(ak == 'l' || ak == 'w')) || ak == 'p');
         if (use_pipe) {
             if (store) hipLaunchKernelGGL((aligned_pipe_kernel<R, true>), grid, dim3(threads), 0, stream, P, W, O, ali_mask);
             else hipLaunchKernelGGL((aligned_pipe_kernel<R, false>), grid, dim3(threads), 0, stream, P, W, O, ali_mask);
-        } else if (!off32 || P.S > 512 || (ak && ak[0] == 'w')) {
+        } else if (!off32 || P.S > 512 || ak == 'w') {
             if (store) hipLaunchKernelGGL((aligned_wide_kernel<R, true>), grid, dim3(threads), 0, stream, P, W, O, ali_mask);
             else hipLaunchKernelGGL((aligned_wide_kernel<R, false>), grid, dim3(threads), 0, stream, P, W, O, ali_mask);
         } else if (P.S <= 128) {
@@ -3419,9 +3417,8 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
         {
             // below the streaming regime (and, fp32, where the resident-slice kernel did not take the problem): 16 x 16 tiles on the
             // matrix instruction of the problem's precision (ASG_NO_TILE_STEP=1: the kernels built for N = 10^4)
-            const char *ev = getenv("ASG_NO_TILE_STEP");
             const int tile_max_n = sizeof(R) == 8 ? 2048 : kTileStepMaxN32;
-            if (!stepped && P.N <= tile_max_n && !(ev && atoi(ev) != 0)) {
+            if (!stepped && P.N <= tile_max_n && !(knobs().no_tile_step > 0)) {
                 const int nbt = (P.N > 512 && P.B > 16) ? 2 : 1;
                 const dim3 dgrid((P.N + 15) / 16, (P.B + 16 * nbt - 1) / (16 * nbt), (do_a && do_b) ? 2 : 1);
                 for (int n = 0; n + 1 < P.T; ++n) {

@@ -46,8 +46,6 @@ struct State {
     int *asi;
     void *dbg;
     unsigned *ticket;   // 256 B, zeroed per call: arrival counter of the in-kernel loss reduction
-    int *xflags;        // small path: [2][B] full-lattice alpha | beta chains that the batched forward kernel (asg_batched.hip) hands
-                        // to the per-utterance kernel (a row sum left the safe range)
     void *work;      // generic path: forward work buffers (emission maxima, p vectors, normalisers, offsets)
     int npad;
 };
@@ -112,16 +110,19 @@ struct FusedArgs {
 enum ChainBits { kFullAlpha = 1, kFullBeta = 2, kAlignedAlpha = 4, kAlignedBeta = 8 };
 
 // ---- small path: N <= 64, S <= 64, one wavefront per chain -------------------------------
+// Developer / test switches, read from the environment once (asg_api.hip; asg_reload_env() reads them again).  -1 = not set.
+struct Knobs {
+    int fork_in_capture, pair_min_b, bwd_rowsum, no_cluster, no_mid, no_tile_step;
+    char aligned_kernel;          // first letter of ASG_ALIGNED_KERNEL, or 0
+};
+const Knobs &knobs();
+
 // chain_mask selects which of the four recursions this launch runs.
 template <typename R>
 hipError_t launch_fwd_small(const Problem &P, const State &W, const FwdOut &O, int chain_mask, bool store,
                             hipStream_t stream);
 template <typename R>
 hipError_t launch_bwd_small(const Problem &P, const State &W, const BwdArgs &A, int parts, hipStream_t stream);
-// large batches, fp32: the full-lattice chains sixteen utterances per workgroup on the matrix cores (asg_batched.hip); writes
-// W.xflags, which the per-utterance kernel's clean-up launch reads (launch_fwd_small does both)
-bool batched_forward_applies(const Problem &P, const State &W, int chain_mask);
-hipError_t launch_fwd_batched(const Problem &P, const State &W, const FwdOut &O, int chain_mask, hipStream_t stream);
 hipError_t launch_fused_forward(const Problem &P, const State &W, const FusedArgs &F, hipStream_t stream);
 hipError_t launch_fused_backward(const Problem &P, const State &W, const FusedArgs &F, hipStream_t stream);
 // loss[b] = full[b] - aligned[b], reduced: 0 = none ([B] out), 1 = sum, 2 = mean ([1] out); fixed-order tree

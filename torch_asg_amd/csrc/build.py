@@ -12,8 +12,8 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["asg_small_f32.hip", "asg_small_f64.hip", "asg_bwd_f32.hip", "asg_bwd_f64.hip", "asg_fused.hip", "asg_generic.hip",
-           "asg_batched.hip", "asg_viterbi.hip", "asg_api.hip"]
-HEADERS = ["asg_common.h", "asg_kernels.h", "asg_chains.h", "asg_batched.h", "asg_outer.h", "asg_assemble.h", "asg_small_impl.inc", "asg_bwd_impl.inc",
+           "asg_viterbi.hip", "asg_api.hip"]
+HEADERS = ["asg_common.h", "asg_kernels.h", "asg_chains.h", "asg_outer.h", "asg_assemble.h", "asg_small_impl.inc", "asg_bwd_impl.inc",
            os.path.join("..", "..", "include", "asg_hip.h")]
 OUT = os.path.join(HERE, "libasg_hip.so")
 ARCH = os.environ.get("ASG_HIP_ARCH", "gfx950")

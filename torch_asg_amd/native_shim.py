@@ -37,33 +37,62 @@ def _handle(like, *shape):
     return torch.empty(1, dtype=like.dtype, device=like.device).expand(*shape)
 
 
-def _pack(state, transition, lengths=None):
-    """[state | lengths (int64, optional) | transition] as ONE uint8 tensor (what asg.py saves as path_contrib)."""
-    parts = [state.reshape(-1).view(torch.uint8)]
+_MAGIC = 0x4153475F53544154          # "ASG_STAT": first word of the tail behind a state buffer this module allocated
+STRICT = False                       # True: _unpack also checks the magic word (a device -> host read: one synchronisation per backward)
+
+
+def _tail_bytes(like, num_batches, num_labels, with_lengths):
+    """Bytes behind the state: [magic, state bytes] (2 x int64) | lengths (int64 x B, optional) | transition (N x N of like.dtype), padded
+    to 8 bytes."""
+    n = 16 + (num_batches * 8 if with_lengths else 0) + num_labels * num_labels * like.element_size()
+    return (n + 7) // 8 * 8
+
+
+def _fill_tail(state, tail, like, transition, lengths=None):
+    """Write the tail of `state` (allocated with `tail` extra bytes by HipBackend.*forward(tail_bytes=...)) IN PLACE: the lattice state --
+    14.5 MB at T=400 B=64 N=40 -- is not copied, only these few kilobytes are.  Returns `state`: what asg.py saves as path_contrib."""
+    nstate = state.numel() - tail
+    t = state[nstate:]
+    t[:16].view(torch.int64).copy_(torch.tensor([_MAGIC, nstate], dtype=torch.int64), non_blocking=True)
+    off = 16
     if lengths is not None:
-        parts.append(lengths.to(device=state.device, dtype=torch.int64).contiguous().view(torch.uint8))
-    parts.append(transition.detach().contiguous().reshape(-1).view(torch.uint8))
-    return torch.cat(parts)
+        nl = lengths.numel() * 8
+        t[off:off + nl].view(torch.int64).copy_(lengths.to(dtype=torch.int64).reshape(-1), non_blocking=True)
+        off += nl
+    nt = transition.numel() * like.element_size()
+    t[off:off + nt].view(like.dtype).copy_(transition.detach().to(like.dtype).reshape(-1), non_blocking=True)
+    return state
 
 
 def _unpack(packed, like, num_batches, num_labels, with_lengths):
     """-> (state, transition [N,N], lengths [B] or None) as views of `packed`; `like` gives the dtype."""
-    nt, nl = num_labels * num_labels * like.element_size(), (num_batches * 8 if with_lengths else 0)
-    rest = (packed.numel() - nt - nl) if (packed.dtype == torch.uint8 and packed.dim() == 1) else -1
+    tail = _tail_bytes(like, num_batches, num_labels, with_lengths)
+    rest = (packed.numel() - tail) if (packed.dtype == torch.uint8 and packed.dim() == 1) else -1
     if rest <= 0 or rest % 256 != 0:       # (the state buffer is a whole number of 256-byte units)
         raise RuntimeError("torch_asg_native (HIP shim): path_contrib does not come from this module's forward functions")
-    lengths = packed[rest:rest + nl].view(torch.int64) if with_lengths else None
-    transition = packed[rest + nl:rest + nl + nt].view(like.dtype).view(num_labels, num_labels)
+    t = packed[rest:]
+    if STRICT:
+        head = t[:16].view(torch.int64).cpu()
+        if int(head[0]) != _MAGIC or int(head[1]) != rest:
+            raise RuntimeError("torch_asg_native (HIP shim): path_contrib does not come from this module's forward functions")
+    off = 16
+    lengths = None
+    if with_lengths:
+        lengths = t[off:off + num_batches * 8].view(torch.int64)
+        off += num_batches * 8
+    nt = num_labels * num_labels * like.element_size()
+    transition = t[off:off + nt].view(like.dtype).view(num_labels, num_labels)
     return packed[:rest], transition, lengths
 
 
 # ---- serial route (asg.py:7-55) -----------------------------------------------------------------------------------
 def fully_connected_forward(inputs, transition, input_lengths, batch_input_len, num_batches, num_labels):
     """-> (scores [B], alpha, beta, path_contrib)   (fully_connected_lattice.h:41-48)"""
-    scores, state = native().full_forward(inputs, transition, input_lengths)
+    tail = _tail_bytes(inputs, num_batches, num_labels, True)
+    scores, state = native().full_forward(inputs, transition, input_lengths, tail_bytes=tail)
     if input_lengths is None:
         input_lengths = torch.full((num_batches,), batch_input_len, dtype=torch.int64, device=inputs.device)
-    return scores, inputs, _handle(inputs, batch_input_len, num_batches, num_labels), _pack(state, transition, input_lengths)
+    return scores, inputs, _handle(inputs, batch_input_len, num_batches, num_labels), _fill_tail(state, tail, inputs, transition, input_lengths)
 
 
 def fully_connected_backward(grad_out, alpha, beta, path_contrib, batch_input_len, num_batches, num_labels):
@@ -75,8 +104,9 @@ def fully_connected_backward(grad_out, alpha, beta, path_contrib, batch_input_le
 def force_aligned_forward(inputs, outputs, transition, input_lengths, output_lengths, batch_input_len, num_batches,
                           num_labels, batch_output_len):
     """-> (scores [B], alpha, beta, path_contrib)   (force_aligned_lattice.h:42-53)"""
-    scores, state = native().aligned_forward(inputs, outputs, transition, input_lengths, output_lengths)
-    return scores, _handle(inputs, batch_input_len, num_batches, batch_output_len), inputs, _pack(state, transition)
+    tail = _tail_bytes(inputs, num_batches, num_labels, False)
+    scores, state = native().aligned_forward(inputs, outputs, transition, input_lengths, output_lengths, tail_bytes=tail)
+    return scores, _handle(inputs, batch_input_len, num_batches, batch_output_len), inputs, _fill_tail(state, tail, inputs, transition)
 
 
 def force_aligned_backward(grad_out, alpha, beta, path_contrib, outputs, input_lengths, output_lengths, batch_input_len,
@@ -97,9 +127,10 @@ def fast_asg_gpu_forward_only(inputs, outputs, transition, input_lengths, output
 def fast_asg_gpu_forward(inputs, outputs, transition, input_lengths, output_lengths, batch_input_len, num_batches,
                          num_labels, batch_output_len):
     """-> (full_scores, aligned_scores, full_gamma, aligned_gamma, full_path_contrib, aligned_path_contrib)"""
-    full, aligned, state = native().forward(inputs, outputs, transition, input_lengths, output_lengths, _lib.FLAG_SINGLE_LAUNCH)
+    tail = _tail_bytes(inputs, num_batches, num_labels, False)
+    full, aligned, state = native().forward(inputs, outputs, transition, input_lengths, output_lengths, _lib.FLAG_SINGLE_LAUNCH, tail_bytes=tail)
     return (full, aligned, inputs, _handle(inputs, batch_input_len, num_batches, batch_output_len),
-            _pack(state, transition), inputs.new_empty(0))
+            _fill_tail(state, tail, inputs, transition), inputs.new_empty(0))
 
 
 def fast_asg_gpu_backward(grad_out_full, grad_out_aligned, full_gamma, aligned_gamma, full_path_contrib,
