@@ -37,7 +37,7 @@ if os.environ.get("ASG_DBG"):
     al = lambda v: (v + 255) // 256 * 256
     S = L
     off = 0
-    for sz in (B * T * N * 4, B * T * N * 4, B * T * S * 4, B * T * S * 4, N * ((N + 7) // 8 * 8) * 4, N * 4, B * S * 2 * 4, B * S * 2 * 4):
+    for sz in (B * T * N * 4, B * T * N * 4, B * T * S * 4, B * T * S * 4, B * T * 2 * 4, N * ((N + 7) // 8 * 8) * 4, N * 4, B * S * 2 * 4, B * S * 2 * 4):      # (asg_api.hip make_layout: ah bh ab bb klog ehat rmax asu asi | dbg)
         off = al(off + sz)
     be.loss_forward(x, tg, tr, il, tl, "mean", _lib.FLAG_SINGLE_LAUNCH)
     l2, sv2 = be.loss_forward(x, tg, tr, il, tl, "mean", _lib.FLAG_SINGLE_LAUNCH)

@@ -17,7 +17,7 @@ torch.cuda.synchronize()
 ws, gin = saved.tensors; sc, stb, fs = saved.sizes
 al = lambda v: (v + 255) // 256 * 256
 S = L; off = 0
-for sz in (B * T * N * 4, B * T * N * 4, B * T * S * 4, B * T * S * 4, N * ((N + 7) // 8 * 8) * 4, N * 4, B * S * 2 * 4, B * S * 2 * 4):
+for sz in (B * T * N * 4, B * T * N * 4, B * T * S * 4, B * T * S * 4, B * T * 2 * 4, N * ((N + 7) // 8 * 8) * 4, N * 4, B * S * 2 * 4, B * S * 2 * 4):      # (asg_api.hip make_layout: ah bh ab bb klog ehat rmax asu asi | dbg)
     off = al(off + sz)
 d = ws[sc + off: sc + off + 512].view(torch.int64).cpu().numpy()
 end = d[40]

@@ -1069,6 +1069,23 @@ __device__ __forceinline__ void aligned_workgroup(int b, FusedShared<NP> &SH) {
         SH.score_ali = -1e300;
     }
     __syncthreads();
+    if (wave == 4 && b == 0) {
+        // normalised transition rows for the exact stand-alone code (asg_assemble.h reads them).  BEFORE the roles: this wavefront is a
+        // finisher, idle until the chains cross; behind its role (round 4) these ~3 k cycles sat between the end of utterance 0's
+        // aligned workgroup and the word its two full workgroups wait for -- 4 us of the launch at T = 150 (tools/fused_flags.py)
+        const State W = ld_state(kernarg_params());
+        const bool act = lane < N;
+        const int lc = act ? lane : 0;
+        V2<R> e2[NP / 2];
+        R Ri;
+        load_norm_row<R, NP>((const R *) P.transition + (int64_t) lc * P.ts0, P.ts1, N, act, e2, Ri);
+        if (act) {
+            V2<R> *erow = reinterpret_cast<V2<R> *>((R *) W.ehat + (int64_t) lane * W.npad);
+#pragma unroll
+            for (int j = 0; j < NP / 2; ++j) erow[j] = e2[j];
+            ((R *) W.rmax)[lane] = Ri;
+        }
+    }
     double sc2 = -1e300;
     if (fused) {
         const Problem P = ld_problem(kernarg_params());        // per role: see FusedParams
@@ -1093,21 +1110,6 @@ __device__ __forceinline__ void aligned_workgroup(int b, FusedShared<NP> &SH) {
             default: break;
         }
         if (wave == 1 && lane == 0) SH.score_ali = sc2;
-    }
-    if (wave == 4 && b == 0) {
-        // normalised transition rows for the exact stand-alone code (asg_assemble.h reads them)
-        const State W = ld_state(kernarg_params());
-        const bool act = lane < N;
-        const int lc = act ? lane : 0;
-        V2<R> e2[NP / 2];
-        R Ri;
-        load_norm_row<R, NP>((const R *) P.transition + (int64_t) lc * P.ts0, P.ts1, N, act, e2, Ri);
-        if (act) {
-            V2<R> *erow = reinterpret_cast<V2<R> *>((R *) W.ehat + (int64_t) lane * W.npad);
-#pragma unroll
-            for (int j = 0; j < NP / 2; ++j) erow[j] = e2[j];
-            ((R *) W.rmax)[lane] = Ri;
-        }
     }
     if (wave == 5 && b == 0 && lane != 1) F.ticket2[lane] = 0;        // for the backward launch (word 1: see the closing workgroup)
     __syncthreads();
