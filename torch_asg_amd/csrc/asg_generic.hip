@@ -834,6 +834,8 @@ __global__ void __launch_bounds__(256) fwd_step_kernel(Problem P, StepBuf<R> Sa,
                     b0 = b < b0 ? b : b0; b1 = b > b1 ? b : b1; p0 = pd < p0 ? pd : p0; p1 = pd > p1 ? pd : p1; e0 = e < e0 ? e : e0; e1 = e > e1 ? e : e1;
                     if (e - pd > 100) { ++ne; esum += e - pd; }
                 }
+                for (int w = 0; w < nwg && w < 1024; ++w)
+                    printf("[wg] %d %d %.1f %.1f %.1f\n", w % (int) gridDim.x, w / (int) gridDim.x, (g_step_probe[w * 4] - b0) / 100.0, (g_step_probe[w * 4 + 1] - b0) / 100.0, (g_step_probe[w * 4 + 2] - b0) / 100.0);
                 printf("[step probe] %d workgroups: begin %.1f .. %.1f us, product done %.1f .. %.1f us, end %.1f .. %.1f us; %d workgroups ran an epilogue, %.1f us each on average\n",
                        nwg, 0.0, (b1 - b0) / 100.0, (p0 - b0) / 100.0, (p1 - b0) / 100.0, (e0 - b0) / 100.0, (e1 - b0) / 100.0, ne, ne ? esum / 100.0 / ne : 0.0);
             }
@@ -2609,7 +2611,7 @@ __global__ void __launch_bounds__(256) bwd_gemm_mfma(const float *ehat, const fl
 // 16 x 32: 2.7x less matrix-pipe time at the accuracy of an fp32 product chain.  gemm3_pack_kernel splits the two operands ONCE
 // (each element is used by ~80 output tiles) into planes laid out [K/8][npadT][8]: a lane's eight consecutive k of one label are
 // 16 contiguous bytes -- the instruction's operand as it is, in memory, in LDS and in registers.
-constexpr int kG3TM = 256, kG3TN = 128;          // output tile of a workgroup (8 wavefronts, 64 x 64 each)
+constexpr int kG3TM = 256, kG3TN = 256;          // output tile of a workgroup (8 wavefronts, 64 x 128 each)
 __host__ __device__ inline int g3_npadT(int N) { return (N + kG3TM - 1) / kG3TM * kG3TM; }
 __host__ __device__ inline size_t g3_plane_elems(int K, int N) { return (size_t) ((K + 31) / 32 * 32) * g3_npadT(N); }
 
@@ -2641,13 +2643,23 @@ typedef float V16f __attribute__((ext_vector_type(16)));
 // grid = 8 x 32 x ceil(blocks / 8) workgroups (1-D), block = 512, dynamic LDS = 2 stages x 72 KB.
 // Workgroup id -> tile: id & 7 is the XCD the dispatcher puts it on; an XCD walks blocks of 4 x 8 tiles (1024 labels x 1024 labels of
 // output: its 32 resident workgroups share 4 row panels and 8 column panels through that XCD's L2).
+// grid = 8 x 32 x ceil(blocks / 8) workgroups (1-D), block = 512 (8 wavefronts, 64 x 128 of the 256 x 256 tile each), dynamic LDS =
+// 3 stages x 48 KB (16 k per stage: one v_mfma_f32_32x32x16_bf16 step).
+// Workgroup id -> tile: id & 7 is the XCD the dispatcher puts it on; an XCD walks blocks of 4 x 8 tiles (its 32 resident workgroups share
+// 4 row panels and 8 column panels through that XCD's L2).
+// What bounded the first form (256 x 128 tiles, 64 x 64 per wavefront, 32 k per stage: 49 ms at cfg 5 where the products alone take 34 and
+// the staging alone 25-32) was LDS traffic and transfer issue per matrix instruction: 24 fragment reads and 18 transfers per 48 products of
+// a wavefront.  A 64 x 128 wavefront tile reads 18 fragments per 48 products, and a 256 x 256 workgroup tile needs 12 transfers per loader
+// wavefront for them; three stages give a transfer two steps to land.
+constexpr int kG3Stage = 3 * 2 * (kG3TM + kG3TN);          // 16-byte units per stage: 3 planes x 2 k groups x (256 + 256) labels
+constexpr size_t kG3LdsBytes = (size_t) 3 * kG3Stage * 16;
 __global__ void __launch_bounds__(512) bwd_gemm_bf3_kernel(const unsigned short *Apl, const unsigned short *Bpl, size_t plane_elems,
                                                            const float *ehat, float *out, int N, int npad, int npadT, const int *kdev, int K,
                                                            int Mt, int Nt) {
     extern __shared__ __attribute__((aligned(16))) unsigned char g3_lds[];
     U4v *lds = reinterpret_cast<U4v *>(g3_lds);
-    constexpr int TM = kG3TM, TN = kG3TN, AU = 3 * 4 * TM, BU = 3 * 4 * TN, SU = AU + BU;      // 16-byte units per stage: 3072 + 1536
-    constexpr int NR = SU / 512;                                                                // 64-lane transfers per wavefront slot and stage: 9
+    constexpr int TM = kG3TM, TN = kG3TN, AU = 3 * 2 * TM, SU = kG3Stage;
+    constexpr int ND = SU / 64 / 4;                                  // transfers per loader wavefront and stage: 12
     if (kdev) K = __builtin_amdgcn_readfirstlane(*kdev);
     const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
     const int mblocks = (Mt + 3) / 4, nblocks = (Nt + 7) / 8;
@@ -2656,108 +2668,100 @@ __global__ void __launch_bounds__(512) bwd_gemm_bf3_kernel(const unsigned short 
     const int tm = (g % mblocks) * 4 + (r & 3), tn = (g / mblocks) * 8 + (r >> 2);
     if (tm >= Mt || tn >= Nt) return;
     const int m0 = tm * TM, n0 = tn * TN;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = (wave & 3) * 64, wn = (wave >> 2) * 64;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+    const int wm = (wave & 3) * 64, wn = (wave >> 2) * 128;
     const size_t pu = plane_elems / 8;
     const U4v *Au = reinterpret_cast<const U4v *>(Apl), *Bu = reinterpret_cast<const U4v *>(Bpl);
     // Staging is LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 bytes land lane-linear at a wave-uniform LDS address -- the planes'
     // [k group][label][8] order IS the stage's order, so no register or ds_write is involved), issued by wavefronts 0-3 only: each SIMD
-    // holds wavefronts w and w + 4; while w spends ~1000 cycles issuing its 18 transfers, w + 4 has the matrix pipe to itself, then both
-    // interleave.  Unit e = 512 q + 64 v + lane of a stage (q = 0 .. 8, v = 0 .. 7) -> (operand, plane, k group, label).
-#ifndef ASG_X_G3_LOADERS
-#define ASG_X_G3_LOADERS 4
-#endif
-    constexpr int NLW = ASG_X_G3_LOADERS, ND = NR * 8 / NLW;      // wavefronts that issue transfers (4: w only; 8: all), transfers per wavefront
+    // holds wavefronts w and w + 4; while w issues its transfers, w + 4 has the matrix pipe to itself, then both interleave (four more
+    // wavefronts that do nothing but transfers: measured slower, 60 against 55 ms).  Unit e of a stage -> (operand, plane, k group, label).
+    const bool loader = wave < 4;
     const U4v *src[ND];
-    const int wl = __builtin_amdgcn_readfirstlane(wave) & (NLW - 1);
-    auto slot = [&](int d) { return NLW == 8 ? 512 * d + 64 * wl : 512 * (d >> 1) + 64 * (wl + 4 * (d & 1)); };
 #pragma unroll
     for (int d = 0; d < ND; ++d) {
-        const int e = slot(d) + lane;
-        if (e < AU) { const int pl = e / (4 * TM), rem = e % (4 * TM); src[d] = Au + (size_t) pl * pu + (size_t) (rem / TM) * npadT + m0 + rem % TM; }
-        else { const int f = e - AU, pl = f / (4 * TN), rem = f % (4 * TN); src[d] = Bu + (size_t) pl * pu + (size_t) (rem / TN) * npadT + n0 + rem % TN; }
+        const int e = 256 * d + 64 * (wave & 3) + lane;
+        if (e < AU) { const int pl = e / (2 * TM), rem = e % (2 * TM); src[d] = Au + (size_t) pl * pu + (size_t) (rem / TM) * npadT + m0 + rem % TM; }
+        else { const int f = e - AU, pl = f / (2 * TN), rem = f % (2 * TN); src[d] = Bu + (size_t) pl * pu + (size_t) (rem / TN) * npadT + n0 + rem % TN; }
     }
-    const size_t kstride = (size_t) 4 * npadT;          // 16-byte units per 32 k
-    const int nkb = (K + 31) / 32;
-    V16f acc[2][2];
+    const size_t kstride = (size_t) 2 * npadT;          // 16-byte units per 16 k
+    const int nst = (K + 31) / 32 * 2;                  // steps of 16 k (the planes are zero-padded to whole 32-row blocks)
+    V16f acc[2][4];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+        for (int c = 0; c < 4; ++c)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[a][c][q] = 0.f;
-    const bool loader = __builtin_amdgcn_readfirstlane(wave) < NLW;
-    auto dma = [&](int kb) {
-        U4v *dst = lds + (kb & 1) * SU;
+    auto dma = [&](int st) {
         // (inline asm: hipcc counts a __builtin_amdgcn_global_load_lds against EVERY later LDS read -- s_waitcnt vmcnt(0) in front of the
-        // fragment reads of the stage being multiplied, which is not the stage being filled; the drain is the explicit one ahead of the barrier)
-        const unsigned base = (unsigned) (uintptr_t) (__attribute__((address_space(3))) void *) dst;
+        // fragment reads of the stage being multiplied, which is not the stage being filled; the drains are the explicit ones below)
+        const unsigned base = (unsigned) (uintptr_t) (__attribute__((address_space(3))) void *) (lds + (st % 3) * SU);
 #pragma unroll
         for (int d = 0; d < ND; ++d) {
-            const U4v *g = src[d] + (size_t) kb * kstride;
-            const unsigned l = __builtin_amdgcn_readfirstlane(base + 16u * slot(d));
+            const U4v *gp = src[d] + (size_t) st * kstride;
+            const unsigned l = __builtin_amdgcn_readfirstlane(base + 16u * (256 * d + 64 * (wave & 3)));
             unsigned keep;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(g), "s"(l) : "memory");
+                         : "=&s"(keep) : "v"(gp), "s"(l) : "memory");
         }
     };
-    struct Frags { BF8 a[2][3], b[2][3]; };
-    auto fetch = [&](Frags &F, const U4v *cur, int s) {
-        const int kg = 2 * s + (lane >> 5), ln = lane & 31;
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) F.a[a][pl] = __builtin_bit_cast(BF8, cur[pl * 4 * TM + kg * TM + wm + 32 * a + ln]);
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) F.b[c][pl] = __builtin_bit_cast(BF8, cur[AU + pl * 4 * TN + kg * TN + wn + 32 * c + ln]);
-    };
-    auto multiply = [&](const Frags &F) {
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                // (smallest terms first)
-                acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[a][2], F.b[c][0], acc[a][c], 0, 0, 0);
-                acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[a][0], F.b[c][2], acc[a][c], 0, 0, 0);
-                acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[a][1], F.b[c][1], acc[a][c], 0, 0, 0);
-                acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[a][1], F.b[c][0], acc[a][c], 0, 0, 0);
-                acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[a][0], F.b[c][1], acc[a][c], 0, 0, 0);
-                acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[a][0], F.b[c][0], acc[a][c], 0, 0, 0);
-            }
-    };
-    if (nkb > 0 && loader) dma(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (loader) {
+        if (nst > 0) dma(0);
+        if (nst > 1) dma(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
-    for (int kb = 0; kb < nkb; ++kb) {
-        const U4v *cur = lds + (kb & 1) * SU;
-        Frags F0, F1;
-        fetch(F0, cur, 0);
-        fetch(F1, cur, 1);
-        // (pinned: an asm statement orders memory operations only -- left alone, hipcc sinks the second fetch below the first product
-        // and lifts the drain + barrier above half of the MFMAs, which then wait for the transfers)
+    for (int st = 0; st < nst; ++st) {
+        const U4v *cur = lds + (st % 3) * SU;
+        const int kg = lane >> 5, ln = lane & 31;
+        BF8 af[2][3], bf[4][3];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) af[a][pl] = __builtin_bit_cast(BF8, cur[pl * 2 * TM + kg * TM + wm + 32 * a + ln]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) bf[c][pl] = __builtin_bit_cast(BF8, cur[AU + pl * 2 * TN + kg * TN + wn + 32 * c + ln]);
+        // (pinned: an asm statement orders memory operations only -- left alone, hipcc lifts the drain + barrier above half of the MFMAs)
         __builtin_amdgcn_sched_barrier(0);
-#if !(defined(ASG_X_G3_ABL) && ASG_X_G3_ABL == 1)
-        if (loader && kb + 1 < nkb) dma(kb + 1);        // into the stage every wavefront finished reading before the last barrier
+        // into the stage every wavefront finished reading before the last barrier
+#if defined(ASG_X_G3_ABL) && ASG_X_G3_ABL == 1          // (developer timing: no transfers inside the loop, wrong results)
+        const bool issue = false;
+#else
+        const bool issue = loader && st + 2 < nst;
 #endif
+        if (issue) dma(st + 2);
         __builtin_amdgcn_sched_barrier(0);
-#if !(defined(ASG_X_G3_ABL) && ASG_X_G3_ABL == 2)
-        multiply(F0);
-        multiply(F1);
+#if defined(ASG_X_G3_ABL) && ASG_X_G3_ABL == 2          // (developer timing: transfers and fragment reads only, wrong results)
+        if (st == 0)
+#elif defined(ASG_X_G3_ABL) && ASG_X_G3_ABL == 3        // (developer timing: a third of the products)
+        if (st % 3 == 0)
 #endif
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                // (smallest terms first)
+                acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][2], bf[c][0], acc[a][c], 0, 0, 0);
+                acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[c][2], acc[a][c], 0, 0, 0);
+                acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][1], bf[c][1], acc[a][c], 0, 0, 0);
+                acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][1], bf[c][0], acc[a][c], 0, 0, 0);
+                acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[c][1], acc[a][c], 0, 0, 0);
+                acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[c][0], acc[a][c], 0, 0, 0);
+            }
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wavefront's transfers have landed
+        // the NEXT step's stage has landed (the transfers issued in this step may still travel)
+        if (issue) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(ND) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-#if defined(ASG_X_G3_ABL) && ASG_X_G3_ABL == 2
-    { Frags F0; fetch(F0, lds, 0); multiply(F0); }
-#endif
-    // element (m = 32 a + 8 (q >> 2) + 4 (l >> 5) + (q & 3), n = 32 c + (l & 31)) of the wavefront's 64 x 64 sits in acc[a][c][q]
+    // element (m = 32 a + 8 (q >> 2) + 4 (l >> 5) + (q & 3), n = 32 c + (l & 31)) of the wavefront's 64 x 128 sits in acc[a][c][q]
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
+        for (int c = 0; c < 4; ++c) {
             const int gn = n0 + wn + 32 * c + (lane & 31);
             if (gn >= N) continue;
 #pragma unroll
@@ -3563,7 +3567,7 @@ hipError_t launch_bwd_generic(const Problem &P, const State &W, const BwdArgs &A
                 hipLaunchKernelGGL(gemm3_pack_kernel, pgrid, dim3(256), 0, stream, (const float *) Pm, npad, npadT, (const int *) (rowoff + P.B), K, bpl, pe);
                 const int Mt = npadT / kG3TM, Nt = (P.N + kG3TN - 1) / kG3TN;
                 const int blocks = ((Mt + 3) / 4) * ((Nt + 7) / 8);
-                const size_t lds = (size_t) 2 * (3 * 4 * (kG3TM + kG3TN)) * 16;
+                const size_t lds = kG3LdsBytes;
                 (void) hipFuncSetAttribute((const void *) bwd_gemm_bf3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
                 hipLaunchKernelGGL(bwd_gemm_bf3_kernel, dim3(8 * 32 * ((blocks + 7) / 8)), dim3(512), lds, stream, (const unsigned short *) apl,
                                    (const unsigned short *) bpl, pe, (const float *) W.ehat, (float *) gtr, P.N, npad, npadT,
