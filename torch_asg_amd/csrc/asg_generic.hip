@@ -2655,15 +2655,18 @@ constexpr int kG3Stage = 3 * 2 * (kG3TM + kG3TN);          // 16-byte units per 
 constexpr size_t kG3LdsBytes = (size_t) 3 * kG3Stage * 16;
 __global__ void __launch_bounds__(512) bwd_gemm_bf3_kernel(const unsigned short *Apl, const unsigned short *Bpl, size_t plane_elems,
                                                            const float *ehat, float *out, int N, int npad, int npadT, const int *kdev, int K,
-                                                           int Mt, int Nt) {
+                                                           int Mt, int Nt, int block0, int ks, float *partial) {
     extern __shared__ __attribute__((aligned(16))) unsigned char g3_lds[];
     U4v *lds = reinterpret_cast<U4v *>(g3_lds);
     constexpr int TM = kG3TM, TN = kG3TN, AU = 3 * 2 * TM, SU = kG3Stage;
     constexpr int ND = SU / 64 / 4;                                  // transfers per loader wavefront and stage: 12
     if (kdev) K = __builtin_amdgcn_readfirstlane(*kdev);
-    const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
+    // (the LAST, partial round of blocks is a launch of its own with the frame axis cut into ks slices, so that its few tiles occupy
+    // the whole device too: slice s of tile (g, r) leaves raw sums in partial[((g - block0) * 32 + r) * ks + s], gemm3_tail_kernel adds them)
+    const int slice = (int) blockIdx.x % ks, id = (int) blockIdx.x / ks, xcd = id & 7, j = id >> 3;
     const int mblocks = (Mt + 3) / 4, nblocks = (Nt + 7) / 8;
-    const int g = (j >> 5) * 8 + xcd, r = j & 31;
+    // (the sliced launch is compact: tile id of the tail = id, no workgroup without work)
+    const int g = ks > 1 ? block0 + (id >> 5) : block0 + (j >> 5) * 8 + xcd, r = ks > 1 ? (id & 31) : (j & 31);
     if (g >= mblocks * nblocks) return;
     const int tm = (g % mblocks) * 4 + (r & 3), tn = (g / mblocks) * 8 + (r >> 2);
     if (tm >= Mt || tn >= Nt) return;
@@ -2685,7 +2688,9 @@ __global__ void __launch_bounds__(512) bwd_gemm_bf3_kernel(const unsigned short 
         else { const int f = e - AU, pl = f / (2 * TN), rem = f % (2 * TN); src[d] = Bu + (size_t) pl * pu + (size_t) (rem / TN) * npadT + n0 + rem % TN; }
     }
     const size_t kstride = (size_t) 2 * npadT;          // 16-byte units per 16 k
-    const int nst = (K + 31) / 32 * 2;                  // steps of 16 k (the planes are zero-padded to whole 32-row blocks)
+    const int nall = (K + 31) / 32 * 2;                 // steps of 16 k (the planes are zero-padded to whole 32-row blocks)
+    const int per = (nall + ks - 1) / ks, first = min(slice * per, nall);
+    const int nst = min(first + per, nall) - first;     // this workgroup's steps: first .. first + nst
     V16f acc[2][4];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -2699,7 +2704,7 @@ __global__ void __launch_bounds__(512) bwd_gemm_bf3_kernel(const unsigned short 
         const unsigned base = (unsigned) (uintptr_t) (__attribute__((address_space(3))) void *) (lds + (st % 3) * SU);
 #pragma unroll
         for (int d = 0; d < ND; ++d) {
-            const U4v *gp = src[d] + (size_t) st * kstride;
+            const U4v *gp = src[d] + (size_t) (first + st) * kstride;
             const unsigned l = __builtin_amdgcn_readfirstlane(base + 16u * (256 * d + 64 * (wave & 3)));
             unsigned keep;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -2762,7 +2767,13 @@ __global__ void __launch_bounds__(512) bwd_gemm_bf3_kernel(const unsigned short 
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const int gn = n0 + wn + 32 * c + (lane & 31);
+            const int ln = wn + 32 * c + (lane & 31), gn = n0 + ln;
+            if (ks > 1) {
+                float *pt = partial + ((size_t) ((g - block0) * 32 + r) * ks + slice) * (TM * TN);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) pt[(size_t) (wm + 32 * a + 8 * (q >> 2) + 4 * (lane >> 5) + (q & 3)) * TN + ln] = acc[a][c][q];
+                continue;
+            }
             if (gn >= N) continue;
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
@@ -2770,6 +2781,23 @@ __global__ void __launch_bounds__(512) bwd_gemm_bf3_kernel(const unsigned short 
                 if (gm_ < N) out[(int64_t) gm_ * N + gn] = acc[a][c][q] * ehat[(int64_t) gm_ * npad + gn];
             }
         }
+}
+
+// the sliced tail tiles: out = ehat o (slice 0 + slice 1 + ...), ascending.  grid = (tail blocks * 32, TM * TN / 1024), block = 256 (float4 each)
+__global__ void __launch_bounds__(256) gemm3_tail_kernel(const float *partial, const float *ehat, float *out, int N, int npad, int Mt, int Nt,
+                                                         int block0, int ks) {
+    const int t = blockIdx.x, g = block0 + (t >> 5), r = t & 31;
+    const int mblocks = (Mt + 3) / 4;
+    const int tm = (g % mblocks) * 4 + (r & 3), tn = (g / mblocks) * 8 + (r >> 2);
+    if (tm >= Mt || tn >= Nt) return;
+    const int e = ((int) blockIdx.y * 256 + (int) threadIdx.x) * 4, row = e / kG3TN, col = e % kG3TN;
+    const int gm_ = tm * kG3TM + row, gn = tn * kG3TN + col;
+    if (gm_ >= N) return;
+    V4f sum = {0, 0, 0, 0};
+    for (int k = 0; k < ks; ++k) sum += *reinterpret_cast<const V4f *>(partial + ((size_t) t * ks + k) * (kG3TM * kG3TN) + e);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (gn + q < N) out[(int64_t) gm_ * N + gn + q] = sum[q] * ehat[(int64_t) gm_ * npad + gn + q];
 }
 
 // out[m][n] = ehat[m][n] * sum over the slices of partial[z][m][n], slices in ascending order.  grid = ceil(N^2 / 256).
@@ -3473,6 +3501,8 @@ static int gemm_slices(int N, int K) {
 #ifndef ASG_X_GEMM_BF3
 #define ASG_X_GEMM_BF3 1
 #endif
+constexpr int kG3TailSlices = 4;
+constexpr size_t kG3TailBytes = (size_t) 128 << 20;          // at most 128 tail tiles x 4 slices x 256 KB
 static size_t gemm3_plane_bytes(int elem, int T, int B, int N) {
     if (!(ASG_X_GEMM_BF3 && elem == 4 && StepUsesMfma<float>::v && N > 64 && gemm_slices(N, B * T) == 1)) return 0;
     return au(3 * g3_plane_elems(B * T, N) * sizeof(unsigned short));
@@ -3496,6 +3526,7 @@ size_t bwd_scratch_bytes_generic(int elem, int T, int B, int N, int S) {
     if (S > 1024 && tiles < au((size_t) N * N * 8)) tiles = au((size_t) N * N * 8);      // (very long targets: the same accumulator for any N <= 2048)
     if (N > 64) tiles += au((size_t) gemm_slices(N, B * T) * N * N * elem);       // split contraction: partial sums
     tiles += 2 * gemm3_plane_bytes(elem, T, B, N);                                  // bfloat16 planes of both operands (bwd_gemm_bf3_kernel)
+    if (gemm3_plane_bytes(elem, T, B, N)) tiles += kG3TailBytes;                    // ... and the sliced tiles of its last, partial round
     return 2 * au((size_t) B * T * npad * elem) + au((size_t) B * nch * 2 * S * elem) + 512 + au(((size_t) B + 1) * 4) + tiles;
 }
 
@@ -3569,9 +3600,23 @@ hipError_t launch_bwd_generic(const Problem &P, const State &W, const BwdArgs &A
                 const int blocks = ((Mt + 3) / 4) * ((Nt + 7) / 8);
                 const size_t lds = kG3LdsBytes;
                 (void) hipFuncSetAttribute((const void *) bwd_gemm_bf3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-                hipLaunchKernelGGL(bwd_gemm_bf3_kernel, dim3(8 * 32 * ((blocks + 7) / 8)), dim3(512), lds, stream, (const unsigned short *) apl,
+                // whole rounds of 8 blocks (one per XCD, 32 tiles each) in one launch; a partial last round that would leave most of
+                // the device idle for a whole tile time (cfg 5: 50 blocks = 6 rounds + 2 blocks) as a second launch, the frame axis sliced
+                int tail = blocks % 8, tks = 1;
+                if (tail * 32 * 2 <= 256 && tail > 0 && blocks > 8) tks = 256 / (tail * 32) > kG3TailSlices ? kG3TailSlices : 256 / (tail * 32);
+                if (tks < 2 || (size_t) tail * 32 * tks * kG3TM * kG3TN * sizeof(float) > kG3TailBytes) { tail = 0; tks = 1; }
+                const int mainb = blocks - tail;
+                float *tpart = (float *) ((char *) planes3 + 2 * pbytes);
+                hipLaunchKernelGGL(bwd_gemm_bf3_kernel, dim3(8 * 32 * ((mainb + 7) / 8)), dim3(512), lds, stream, (const unsigned short *) apl,
                                    (const unsigned short *) bpl, pe, (const float *) W.ehat, (float *) gtr, P.N, npad, npadT,
-                                   (const int *) (rowoff + P.B), K, Mt, Nt);
+                                   (const int *) (rowoff + P.B), K, Mt, Nt, 0, 1, (float *) nullptr);
+                if (tail) {
+                    hipLaunchKernelGGL(bwd_gemm_bf3_kernel, dim3(tail * 32 * tks), dim3(512), lds, stream, (const unsigned short *) apl,
+                                       (const unsigned short *) bpl, pe, (const float *) W.ehat, (float *) gtr, P.N, npad, npadT,
+                                       (const int *) (rowoff + P.B), K, Mt, Nt, mainb, tks, tpart);
+                    hipLaunchKernelGGL(gemm3_tail_kernel, dim3(tail * 32, kG3TM * kG3TN / 1024), dim3(256), 0, stream, (const float *) tpart,
+                                       (const float *) W.ehat, (float *) gtr, P.N, npad, Mt, Nt, mainb, tks);
+                }
             } else {
                 hipLaunchKernelGGL((bwd_gemm_mfma<1>), dim3((P.N + 127) / 128, (P.N + 127) / 128), dim3(256), 0, stream,
                                    (const float *) W.ehat, (const float *) Pm, (float *) Gm, (float *) gtr, P.N, npad, K, anybad,
