@@ -287,7 +287,7 @@ def measure_cfg5(steps, warmup):
     a_alg = 3 * (T5 - 1) * N5 * N5 * w + 2 * T5 * B5 * N5 * w      # alpha, beta and gradient passes over Tr
     ms_per_step = dt / steps * 1e3
     achieved = a_alg_step / (kern_ms * 1e-3) / 1e9
-    traffic5, traffic5_src = committed_traffic(("r04_pmc_cfg5.json", "r03_pmc_cfg5.json", "r02_pmc_cfg5.json"))
+    traffic5, traffic5_src = committed_traffic(("r05_pmc_cfg5.json", "r04_pmc_cfg5.json", "r03_pmc_cfg5.json", "r02_pmc_cfg5.json"))
     del x, tr, m
     torch.cuda.empty_cache()
     return {
@@ -611,7 +611,7 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         value = global_batch * args.steps / dt
         achieved = a_alg / (kern_ms_med * 1e-3) / 1e9
-        traffic, traffic_source = committed_traffic(("r04_pmc_cfg3.json", "r03_pmc_cfg3.json", "r02_pmc_cfg3.json")) if fused_step else (None, None)
+        traffic, traffic_source = committed_traffic(("r05_pmc_cfg3.json", "r04_pmc_cfg3.json", "r03_pmc_cfg3.json", "r02_pmc_cfg3.json")) if fused_step else (None, None)
         out = {
             "metric": "utterances/sec fwd+bwd, T=400 B=64 N=40; achieved HBM GB/s vs roofline",
             "value": value,
