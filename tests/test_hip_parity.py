@@ -383,8 +383,8 @@ def test_generic_edge_cases(T, B, N, L, il, tl):
 def test_unsupported_shapes_fail_loudly():
     A = _asg()
     m = A.ASGLoss(5).to(DEV)
-    x = torch.randn(4200, 1, 5, device=DEV)
-    tg = torch.zeros(1, 4097, dtype=torch.long, device=DEV)          # targets beyond 4096 positions
+    x = torch.randn(8300, 1, 5, device=DEV)
+    tg = torch.zeros(1, 8193, dtype=torch.long, device=DEV)          # targets beyond 8192 positions
     with pytest.raises(RuntimeError, match="unsupported"):
         m(x, tg)
     m2 = A.ASGLoss(2100).to(DEV)                                         # ... and beyond 1024 only up to 2048 labels
@@ -740,7 +740,8 @@ def _path_score(x, tr, tg, pos):
 @pytest.mark.parametrize("T,B,N,L,variable", [(6, 2, 7, 5, True), (23, 5, 9, 7, True), (150, 16, 30, 20, True),
                                               (400, 64, 40, 30, False), (70, 3, 64, 64, True), (1, 2, 4, 1, False),
                                               (150, 3, 30, 100, True), (300, 2, 12, 300, False), (1030, 1, 5, 1000, True),
-                                              (1600, 2, 9, 1500, True), (4200, 1, 6, 4096, False), (1100, 3, 40, 1025, True)])
+                                              (1600, 2, 9, 1500, True), (4200, 1, 6, 4096, False), (1100, 3, 40, 1025, True),
+                                              (8300, 1, 5, 8192, False), (5200, 2, 7, 5000, True)])
 def test_viterbi_vs_oracle(T, B, N, L, variable, dtype):
     A = _asg()
     tr, x, tg, il, tl = util.synth(T, B, N, L, 7, variable, dtype)
@@ -786,8 +787,8 @@ def test_viterbi_edge_cases_and_module_method():
     so, po = orc.viterbi(xt.numpy(), tg2[:, :6].numpy(), np.zeros((4, 4)), None, np.array([6, 6, 6]))
     assert np.array_equal(sc2.cpu().numpy(), so) and np.array_equal(pos2.cpu().numpy(), po)
     with pytest.raises(RuntimeError):
-        A.viterbi_align(torch.randn(4200, 1, 4, device=DEV), torch.zeros(1, 4097, dtype=torch.long, device=DEV),
-                        torch.zeros(4, 4, device=DEV))        # S > 4096: not supported, fails loudly
+        A.viterbi_align(torch.randn(8300, 1, 4, device=DEV), torch.zeros(1, 8193, dtype=torch.long, device=DEV),
+                        torch.zeros(4, 4, device=DEV))        # S > 8192: not supported, fails loudly
 
 
 def _stress():
@@ -1196,13 +1197,14 @@ def test_medium_alphabet_exact_path_and_eval_route():
     util.assert_close(ev.cpu().numpy(), o["loss"], 1e-4, "medium alphabet eval")
 
 
-# ------------------------------------------------------------------ very long targets (1024 < S <= 4096)
+# ------------------------------------------------------------------ very long targets (1024 < S <= 8192)
 @pytest.mark.gpu
 @pytest.mark.parametrize("T,B,N,L,dtype,rtol", [(1300, 2, 30, 1100, torch.float32, 1e-4), (1600, 3, 40, 1500, torch.float32, 1e-4),
                                                  (4200, 1, 28, 4096, torch.float32, 1e-4), (1100, 2, 12, 1025, torch.float64, 1e-9),
+                                                 (8300, 1, 20, 8192, torch.float32, 1e-4), (5100, 2, 9, 5000, torch.float64, 1e-9),
                                                  (1200, 2, 200, 1100, torch.float32, 1e-4), (1150, 2, 600, 1030, torch.float32, 1e-4)])
 def test_very_long_targets(T, B, N, L, dtype, rtol):
-    """1024 < S <= 4096 (the reference has no limit: force_aligned_lattice.cpp:84-154): strip-mined recursion (four positions per
+    """1024 < S <= 8192 (the reference has no limit: force_aligned_lattice.cpp:84-154): strip-mined recursion (four / eight positions per
     thread, the frame through LDS) and a frame-by-frame gradient kernel with a fixed-point label row; small, medium and
     resident-slice alphabets; variable lengths, one infeasible utterance when B >= 3; run-to-run determinism."""
     rng = np.random.default_rng(T + L)

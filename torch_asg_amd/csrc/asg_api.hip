@@ -123,7 +123,7 @@ int check_problem(const asg_problem *p, bool need_targets, bool allow_bf16 = fal
     if (!p->inputs || !p->transition) return ASG_ERR_INVALID;
     if (need_targets && (p->S < 1 || !p->targets)) return ASG_ERR_INVALID;
     if (p->T > (1 << 30) || p->B > (1 << 30) || p->N > (1 << 30) || p->S > (1 << 30)) return ASG_ERR_UNSUPPORTED;
-    if (p->S > 4096) return ASG_ERR_UNSUPPORTED;              // aligned kernels: at most four target positions per thread of a workgroup
+    if (p->S > 8192) return ASG_ERR_UNSUPPORTED;              // aligned kernels: at most eight target positions per thread of a workgroup, a frame's states in LDS
     if (p->S > 1024 && p->N > 2048) return ASG_ERR_UNSUPPORTED;   // ... and beyond 1024 the label scatter is one LDS row (bwd_aligned_strip_kernel)
     {
         // the kernels address state and gradient rows through 32-bit buffer offsets

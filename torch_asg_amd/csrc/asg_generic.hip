@@ -2063,7 +2063,8 @@ __global__ void __launch_bounds__(1024) aligned_wide_kernel(Problem P, State W, 
     }
 }
 
-// ------------------------------------------------------------------ aligned lattice, very long targets (1024 < S <= 4096)
+// ------------------------------------------------------------------ aligned lattice, very long targets (1024 < S <= 8192)
+constexpr int kMaxTargets = 8192;
 // The reference takes any target length (force_aligned_lattice.cpp:84-154 has no limit); the kernels above stop at one
 // position per thread of a 1024-thread workgroup.  Beyond that the same recursion is strip-mined: thread s owns positions
 // s, s + 1024, ... (KP of them), the whole frame's states travel through a double-buffered LDS row (one barrier per frame, as
@@ -2211,14 +2212,13 @@ __global__ void __launch_bounds__(1024) aligned_strip_kernel(Problem P, State W,
 }
 
 // Gradient of the same: grid = (B, nchunks), block = 256.  The workgroup walks the frames of its chunk ONE AT A TIME, thread tid owns
-// positions tid, tid + 256, ... (KQ = 16 of them: S <= 4096) with their edge-posterior sums in registers; per frame two
+// positions tid, tid + 256, ... (KQ = 16 of them: S <= 4096; 32: S <= 8192) with their edge-posterior sums in registers; per frame two
 // block reductions (maximum, sum: the reference's masked softmax over positions), the posteriors scattered to the labels
 // through ONE fixed-point LDS row (integer adds commute: deterministic, repeated labels included; N <= 2048), read back and
 // added to grad_inputs.  Edge posteriors per (b, chunk) go to gHD as from bwd_aligned_kernel (aligned_tr_scatter_fx_kernel follows).
 // Restates force_aligned_lattice.cpp:156-264.
-template <typename R>
+template <typename R, int KQ>
 __global__ void __launch_bounds__(256) bwd_aligned_strip_kernel(Problem P, State W, BwdArgs A, R *gHD, int add_to_inputs) {
-    constexpr int KQ = 16;
     typedef typename FrameFix<R>::T FX;
     __shared__ FX fxl[2048];
     __shared__ R red[4];
@@ -3291,14 +3291,22 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
     const int full_mask = chain_mask & (kFullAlpha | kFullBeta);
     const int ali_mask = chain_mask & (kAlignedAlpha | kAlignedBeta);
     if (ali_mask && P.S > 1024) {
-        // very long targets (up to 4096 positions): four positions per thread, the frame's states through LDS
-        if (P.S > 4096) return hipErrorInvalidValue;
+        // very long targets (up to 8192 positions): four / eight positions per thread, the frame's states through LDS (two rows of
+        // S + 2 doubles: 131 KB at S = 8192 -- what a compute unit's LDS holds is what bounds the target length here)
+        if (P.S > kMaxTargets) return hipErrorInvalidValue;
         dim3 grid(P.B, __builtin_popcount(ali_mask));
         const size_t dyn = (size_t) 2 * (P.S + 2) * sizeof(double);
-        (void) hipFuncSetAttribute((const void *) aligned_strip_kernel<R, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) dyn);
-        (void) hipFuncSetAttribute((const void *) aligned_strip_kernel<R, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) dyn);
-        if (store) hipLaunchKernelGGL((aligned_strip_kernel<R, true, 4>), grid, dim3(1024), dyn, stream, P, W, O, ali_mask);
-        else hipLaunchKernelGGL((aligned_strip_kernel<R, false, 4>), grid, dim3(1024), dyn, stream, P, W, O, ali_mask);
+        if (P.S <= 4096) {
+            (void) hipFuncSetAttribute((const void *) aligned_strip_kernel<R, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) dyn);
+            (void) hipFuncSetAttribute((const void *) aligned_strip_kernel<R, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) dyn);
+            if (store) hipLaunchKernelGGL((aligned_strip_kernel<R, true, 4>), grid, dim3(1024), dyn, stream, P, W, O, ali_mask);
+            else hipLaunchKernelGGL((aligned_strip_kernel<R, false, 4>), grid, dim3(1024), dyn, stream, P, W, O, ali_mask);
+        } else {
+            (void) hipFuncSetAttribute((const void *) aligned_strip_kernel<R, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) dyn);
+            (void) hipFuncSetAttribute((const void *) aligned_strip_kernel<R, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) dyn);
+            if (store) hipLaunchKernelGGL((aligned_strip_kernel<R, true, 8>), grid, dim3(1024), dyn, stream, P, W, O, ali_mask);
+            else hipLaunchKernelGGL((aligned_strip_kernel<R, false, 8>), grid, dim3(1024), dyn, stream, P, W, O, ali_mask);
+        }
     } else if (ali_mask) {
         const int threads = ((P.S + 63) / 64) * 64;
         if (threads > 1024) return hipErrorInvalidValue;
@@ -3642,7 +3650,7 @@ hipError_t launch_bwd_generic(const Problem &P, const State &W, const BwdArgs &A
         }
     }
     if (do_ali) {
-        if (P.S > 4096 || (P.S > 1024 && P.N > 2048)) return hipErrorInvalidValue;
+        if (P.S > kMaxTargets || (P.S > 1024 && P.N > 2048)) return hipErrorInvalidValue;
         if (!have_full) (void) hipMemsetAsync(A.grad_inputs, 0, (size_t) P.T * P.B * P.N * e, stream);
         unsigned long long *nofx = nullptr;
         if (P.S > 1024) {
@@ -3651,7 +3659,8 @@ hipError_t launch_bwd_generic(const Problem &P, const State &W, const BwdArgs &A
             unsigned long long *fx = (unsigned long long *) atiles;
             const int64_t n2 = (int64_t) P.N * P.N;
             if (!fx_cleared) (void) hipMemsetAsync(fx, 0, (size_t) n2 * 8, stream);
-            hipLaunchKernelGGL((bwd_aligned_strip_kernel<R>), dim3(P.B, A.nchunks), dim3(256), 0, stream, P, W, A, gHD, 1);
+            if (P.S <= 4096) hipLaunchKernelGGL((bwd_aligned_strip_kernel<R, 16>), dim3(P.B, A.nchunks), dim3(256), 0, stream, P, W, A, gHD, 1);
+            else hipLaunchKernelGGL((bwd_aligned_strip_kernel<R, 32>), dim3(P.B, A.nchunks), dim3(256), 0, stream, P, W, A, gHD, 1);
             hipLaunchKernelGGL((aligned_tr_scatter_fx_kernel<R>), dim3(P.B), dim3(256), 0, stream, P, W, A, (const R *) gHD, fx);
             hipLaunchKernelGGL((fx_to_grad_kernel<R>), dim3((unsigned) ((n2 + 255) / 256)), dim3(256), 0, stream,
                                (const unsigned long long *) fx, n2, gtr, have_full ? 1 : 0);

@@ -1,5 +1,5 @@
 // torch_asg_amd/csrc/asg_viterbi.hip -- best-path (Viterbi) force alignment on gfx950 (S <= 64: one wavefront per
-// utterance; S <= 4096: one workgroup per utterance, up to four positions per thread).
+// utterance; S <= 8192: one workgroup per utterance, up to eight positions per thread).
 //
 // The force-aligned lattice of /root/reference/torch_asg/native/force_aligned_lattice.cpp:84-111 in the tropical
 // semiring (max instead of log-sum-exp: doc/tech_report.tex:84-88; a TODO in the reference's README.md:33 -- the
@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(64) viterbi_small_kernel(Problem P, unsigned l
     }
 }
 
-// S up to 1024 (KP = 1) / 4096 (KP = 4): one workgroup per utterance, thread tid owns target positions tid + 1024 k, 64 positions
+// S up to 1024 (KP = 1) / 4096 (KP = 4) / 8192 (KP = 8): one workgroup per utterance, thread tid owns target positions tid + 1024 k, 64 positions
 // per mask word.  The left neighbour crosses thread boundaries through a double-buffered LDS line (one __syncthreads per
 // frame); every 64-position strip stores its own 64 back-pointer bits per frame (masks[b][t][strip]).  The backtrace runs
 // in wavefront 0, 64 frames at a time: within 64 frames the position moves by at most 64, so the two mask words a frame can
@@ -230,6 +230,9 @@ hipError_t launch_viterbi_small(const Problem &P, void *work, void *scores, void
                            (unsigned long long *) work, (R *) scores, (long long *) path);
     else if (P.S <= 4096)
         hipLaunchKernelGGL((viterbi_wide_kernel<R, 4>), dim3(P.B), dim3(1024), 0, stream, P,
+                           (unsigned long long *) work, (R *) scores, (long long *) path);
+    else if (P.S <= 8192)
+        hipLaunchKernelGGL((viterbi_wide_kernel<R, 8>), dim3(P.B), dim3(1024), 0, stream, P,
                            (unsigned long long *) work, (R *) scores, (long long *) path);
     else
         return hipErrorInvalidValue;
