@@ -14,6 +14,7 @@ bad = 0
 t_start = time.time()
 for c in range(ncases):
     kind = rng.integers(0, 5)
+    big = rng.random() < 0.12          # round 5: beyond 2048 labels (K-sliced streaming step, bfloat16 contraction and its sliced tail, fp64 streaming)
     if kind == 0:      # long targets, small alphabet
         N = int(rng.integers(2, 65)); S = int(rng.integers(65, 1025)); T = int(rng.integers(1, 700))
     elif kind == 1:    # medium alphabet, short targets
@@ -25,6 +26,9 @@ for c in range(ncases):
     else:              # boundaries
         N = int(rng.choice([64, 65, 128, 129, 192, 193, 256, 257])); S = int(rng.choice([64, 65, 128, 129, 256, 257, 512, 513])); T = int(rng.integers(2, 200))
     B = int(rng.integers(1, 5))
+    if big:
+        N = int(rng.integers(2049, 4600)); S = int(rng.integers(1, 40)); T = int(rng.integers(1, 7)); B = int(rng.choice([1, 2, 3, 33, 40]))
+    junk = torch.full((64 * 1024 * 1024,), float("nan"), device=dev); del junk          # what the allocator hands out next is NaN, not zeros
     dtype = torch.float32 if rng.random() < 0.8 else torch.float64
     tr, x, tg, _, _ = util.synth(T, B, N, S, int(rng.integers(0, 1 << 30)))
     scaled = rng.random() < 0.3
