@@ -3351,8 +3351,12 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
         // the p vectors are npad wide: their pad columns must be (and stay) zero
         // (... and the arrival counters of the one-launch route, at the very end of the work area)
         char *bar_area = (char *) W.work + fwd_work_bytes_generic((int) e, P.T, P.B, P.N) - 4096;
-        (void) hipMemsetAsync(wk, 0, 2 * (au(2 * (size_t) P.B * W.npad * e) + au(3 * (size_t) P.B * 4) + au((size_t) P.B * 8)), stream);
-        (void) hipMemsetAsync(bar_area, 0, 4096, stream);
+        // (per direction: a caller may run the two directions as two calls on two streams -- each clears only what is its own)
+        const bool want[2] = {(full_mask & kFullAlpha) != 0, (full_mask & kFullBeta) != 0};
+        const size_t dirblock = au(2 * (size_t) P.B * W.npad * e) + au(3 * (size_t) P.B * 4) + au((size_t) P.B * 8);
+        for (int dir = 0; dir < 2; ++dir)
+            if (want[dir]) (void) hipMemsetAsync(wk + dir * dirblock, 0, dirblock, stream);
+        (void) bar_area;
         StepBuf<R> Sd[2];
         for (int dir = 0; dir < 2; ++dir) {
             StepBuf<R> S{};
@@ -3370,10 +3374,10 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
             if (const size_t pbytes = step_ptile_bytes((int) e, P.B, P.N)) {
                 char *area = (char *) W.work + work_mulog_offset(e, P.T, P.B, W.npad) + au((size_t) P.T * P.B * e);
                 S.ptile = (R *) (area + dir * pbytes);
-                if (dir == 0) (void) hipMemsetAsync(S.ptile, 0, 2 * pbytes, stream);       // (pad positions stay zero)
+                if (want[dir]) (void) hipMemsetAsync(S.ptile, 0, pbytes, stream);       // (pad positions stay zero)
                 const size_t tb = step_ticket_bytes(P.B, P.N), sb = step_partial_bytes(P.B, P.N);
                 S.tickets = (unsigned *) (area + 2 * pbytes + dir * tb);
-                if (dir == 0) (void) hipMemsetAsync(S.tickets, 0, 2 * tb, stream);
+                if (want[dir]) (void) hipMemsetAsync(S.tickets, 0, tb, stream);
                 S.partial = (R *) (area + 2 * pbytes + 2 * tb + dir * sb);
             }
             Sd[dir] = S;
