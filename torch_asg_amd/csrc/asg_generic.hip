@@ -2675,19 +2675,27 @@ __global__ void __launch_bounds__(512) bwd_gemm_bf3_kernel(const unsigned short 
     const int wm = (wave & 3) * 64, wn = (wave >> 2) * 128;
     const size_t pu = plane_elems / 8;
     const U4v *Au = reinterpret_cast<const U4v *>(Apl), *Bu = reinterpret_cast<const U4v *>(Bpl);
-    // Staging is LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 bytes land lane-linear at a wave-uniform LDS address -- the planes'
-    // [k group][label][8] order IS the stage's order, so no register or ds_write is involved), issued by wavefronts 0-3 only: each SIMD
-    // holds wavefronts w and w + 4; while w issues its transfers, w + 4 has the matrix pipe to itself, then both interleave (four more
-    // wavefronts that do nothing but transfers: measured slower, 60 against 55 ms).  Unit e of a stage -> (operand, plane, k group, label).
+    // Staging is LDS-DMA (64 lanes x 16 bytes land lane-linear at a wave-uniform LDS address -- the planes' [k group][label][8] order IS
+    // the stage's order, so no register or ds_write is involved), issued by wavefronts 0-3 only: each SIMD holds wavefronts w and w + 4;
+    // while w issues its transfers, w + 4 has the matrix pipe to itself, then both interleave (four more wavefronts that do nothing but
+    // transfers: measured slower, 60 against 55 ms).  In-kernel probe (-DASG_X_G3_PROBE, cycles per 16-k step at cfg 5): fragment reads
+    // 330-580, transfers 660 (2055 as global_load_lds), the SIMD's 96 products 3043 = 31.7 apiece back to back, drain + barrier ~270: the
+    // matrix pipe is busy 78 % of the step; the rest is the LDS serving 144 KB of fragment reads to eight wavefronts at the step's start.
     const bool loader = wave < 4;
-    const U4v *src[ND];
+    // transfer d of a loader wavefront (12 per stage): operand d / 6, plane (d % 6) / 2, k group d % 2, labels 64 (wave & 3) + lane of the
+    // tile -- as RAW BUFFER loads (buffer_load_dwordx4 .. offen lds): one descriptor per (operand, plane) in scalar registers, the lane's byte
+    // offset in ONE vector register per operand for the whole kernel, the step's row offset a scalar.  (global_load_lds_dwordx4 needs a
+    // 64-bit address per lane and transfer: two vector adds, a readfirstlane and four scalar moves around every one of them, 171 cycles of
+    // issue per transfer by the in-kernel probe -- and the twelve transfers in front of a loader's products are the step's critical path.)
+    const unsigned rowbytes = (unsigned) npadT * 16u;          // one k group of one plane
+    const unsigned planebytes = (unsigned) (pu * 16);          // (the launcher takes this route only while a plane stays below 4 GB)
+    __amdgpu_buffer_rsrc_t rsA[3], rsB[3];
 #pragma unroll
-    for (int d = 0; d < ND; ++d) {
-        const int e = 256 * d + 64 * (wave & 3) + lane;
-        if (e < AU) { const int pl = e / (2 * TM), rem = e % (2 * TM); src[d] = Au + (size_t) pl * pu + (size_t) (rem / TM) * npadT + m0 + rem % TM; }
-        else { const int f = e - AU, pl = f / (2 * TN), rem = f % (2 * TN); src[d] = Bu + (size_t) pl * pu + (size_t) (rem / TN) * npadT + n0 + rem % TN; }
+    for (int pl = 0; pl < 3; ++pl) {
+        rsA[pl] = __builtin_amdgcn_make_buffer_rsrc((void *) (Au + (size_t) pl * pu), 0, planebytes, 0x00020000);
+        rsB[pl] = __builtin_amdgcn_make_buffer_rsrc((void *) (Bu + (size_t) pl * pu), 0, planebytes, 0x00020000);
     }
-    const size_t kstride = (size_t) 2 * npadT;          // 16-byte units per 16 k
+    const unsigned vA = (unsigned) (m0 + 64 * (wave & 3) + lane) * 16u, vB = (unsigned) (n0 + 64 * (wave & 3) + lane) * 16u;
     const int nall = (K + 31) / 32 * 2;                 // steps of 16 k (the planes are zero-padded to whole 32-row blocks)
     const int per = (nall + ks - 1) / ks, first = min(slice * per, nall);
     const int nst = min(first + per, nall) - first;     // this workgroup's steps: first .. first + nst
@@ -2699,16 +2707,17 @@ __global__ void __launch_bounds__(512) bwd_gemm_bf3_kernel(const unsigned short 
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[a][c][q] = 0.f;
     auto dma = [&](int st) {
-        // (inline asm: hipcc counts a __builtin_amdgcn_global_load_lds against EVERY later LDS read -- s_waitcnt vmcnt(0) in front of the
-        // fragment reads of the stage being multiplied, which is not the stage being filled; the drains are the explicit ones below)
-        const unsigned base = (unsigned) (uintptr_t) (__attribute__((address_space(3))) void *) (lds + (st % 3) * SU);
+        // (inline asm: hipcc counts an LDS-DMA builtin against EVERY later LDS read -- s_waitcnt vmcnt(0) in front of the fragment reads
+        // of the stage being multiplied, which is not the stage being filled; the drains are the explicit ones below.  M0 = LDS address.)
+        const unsigned base = (unsigned) (uintptr_t) (__attribute__((address_space(3))) void *) (lds + (st % 3) * SU) + 1024u * (unsigned) (wave & 3);
+        const unsigned srow = (unsigned) (first + st) * 2u * rowbytes;
 #pragma unroll
         for (int d = 0; d < ND; ++d) {
-            const U4v *gp = src[d] + (size_t) (first + st) * kstride;
-            const unsigned l = __builtin_amdgcn_readfirstlane(base + 16u * (256 * d + 64 * (wave & 3)));
-            unsigned keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(gp), "s"(l) : "memory");
+            // (readfirstlane: hipcc keeps the row offset in a vector register otherwise; s_nop 4: a scalar register written by the vector
+            // ALU needs five wait states before a buffer instruction reads it as soffset)
+            const unsigned l = __builtin_amdgcn_readfirstlane(base + 4096u * d), so = __builtin_amdgcn_readfirstlane(srow + (d & 1 ? rowbytes : 0u));
+            if (d < ND / 2) asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" :: "v"(vA), "s"(rsA[(d % 6) / 2]), "s"(l), "s"(so) : "memory", "m0");
+            else asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" :: "v"(vB), "s"(rsB[(d % 6) / 2]), "s"(l), "s"(so) : "memory", "m0");
         }
     };
     if (loader) {
@@ -2717,10 +2726,19 @@ __global__ void __launch_bounds__(512) bwd_gemm_bf3_kernel(const unsigned short 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
+#ifdef ASG_X_G3_PROBE
+    long long tq[5] = {0, 0, 0, 0, 0};          // fragment reads | transfer issue | products | drain | barrier
+#define G3_T(i, expr) { const long long _a = __builtin_readcyclecounter(); expr; tq[i] += (long long) __builtin_readcyclecounter() - _a; }
+#else
+#define G3_T(i, expr) { expr; }
+#endif
     for (int st = 0; st < nst; ++st) {
         const U4v *cur = lds + (st % 3) * SU;
         const int kg = lane >> 5, ln = lane & 31;
         BF8 af[2][3], bf[4][3];
+#ifdef ASG_X_G3_PROBE
+        const long long t_f0 = __builtin_readcyclecounter();
+#endif
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -2729,6 +2747,10 @@ __global__ void __launch_bounds__(512) bwd_gemm_bf3_kernel(const unsigned short 
         for (int c = 0; c < 4; ++c)
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) bf[c][pl] = __builtin_bit_cast(BF8, cur[AU + pl * 2 * TN + kg * TN + wn + 32 * c + ln]);
+#ifdef ASG_X_G3_PROBE
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        tq[0] += (long long) __builtin_readcyclecounter() - t_f0;
+#endif
         // (pinned: an asm statement orders memory operations only -- left alone, hipcc lifts the drain + barrier above half of the MFMAs)
         __builtin_amdgcn_sched_barrier(0);
         // into the stage every wavefront finished reading before the last barrier
@@ -2737,8 +2759,11 @@ __global__ void __launch_bounds__(512) bwd_gemm_bf3_kernel(const unsigned short 
 #else
         const bool issue = loader && st + 2 < nst;
 #endif
-        if (issue) dma(st + 2);
+        G3_T(1, if (issue) dma(st + 2);)
         __builtin_amdgcn_sched_barrier(0);
+#ifdef ASG_X_G3_PROBE
+        const long long t_m0 = __builtin_readcyclecounter();
+#endif
 #if defined(ASG_X_G3_ABL) && ASG_X_G3_ABL == 2          // (developer timing: transfers and fragment reads only, wrong results)
         if (st == 0)
 #elif defined(ASG_X_G3_ABL) && ASG_X_G3_ABL == 3        // (developer timing: a third of the products)
@@ -2757,11 +2782,19 @@ __global__ void __launch_bounds__(512) bwd_gemm_bf3_kernel(const unsigned short 
                 acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[c][0], acc[a][c], 0, 0, 0);
             }
         __builtin_amdgcn_sched_barrier(0);
+#ifdef ASG_X_G3_PROBE
+        asm volatile("s_nop 0" : "+v"(acc[1][3]));          // (the last product has issued)
+        tq[2] += (long long) __builtin_readcyclecounter() - t_m0;
+#endif
         // the NEXT step's stage has landed (the transfers issued in this step may still travel)
-        if (issue) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(ND) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        G3_T(3, if (issue) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(ND) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");)
+        G3_T(4, __syncthreads();)
     }
+#ifdef ASG_X_G3_PROBE
+    if (blockIdx.x == 17 && lane == 0 && ks == 1)
+        printf("[g3] wave %d: %d steps; cycles per step: fragments %lld, transfer issue %lld, products %lld, drain %lld, barrier %lld\n", wave, nst,
+               tq[0] / nst, tq[1] / nst, tq[2] / nst, tq[3] / nst, tq[4] / nst);
+#endif
     // element (m = 32 a + 8 (q >> 2) + 4 (l >> 5) + (q & 3), n = 32 c + (l & 31)) of the wavefront's 64 x 128 sits in acc[a][c][q]
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -3517,6 +3550,7 @@ constexpr int kG3TailSlices = 4;
 constexpr size_t kG3TailBytes = (size_t) 128 << 20;          // at most 128 tail tiles x 4 slices x 256 KB
 static size_t gemm3_plane_bytes(int elem, int T, int B, int N) {
     if (!(ASG_X_GEMM_BF3 && elem == 4 && StepUsesMfma<float>::v && N > 64 && gemm_slices(N, B * T) == 1)) return 0;
+    if ((double) g3_plane_elems(B * T, N) * 2.0 >= 4294967296.0) return 0;          // (a plane is addressed through one 32-bit buffer resource)
     return au(3 * g3_plane_elems(B * T, N) * sizeof(unsigned short));
 }
 static void generic_chunks(int T, int B, int *chunk, int *nchunks) {
