@@ -721,7 +721,9 @@ __device__ __forceinline__ void fwd_step_mfma(const Problem &P, const StepBuf<fl
     typedef float R;
     constexpr int MB = kStepMB;
     const int B = P.B, npad = S.npad;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (readfirstlane: the chunk index derives from the wavefront's number and has to be a scalar for the buffer loads' offsets --
+    // "threadIdx.x >> 6" alone is not provably uniform, and a vector offset turns every load into a waterfall loop)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
     const int bt = blockIdx.y / ks, slice = blockIdx.y % ks;          // batch tile of 32 utterances, slice of K
     const StepPre pre = step_prefetch<BETA>(P, S, n, bt);
     {
@@ -742,9 +744,27 @@ __device__ __forceinline__ void fwd_step_mfma(const Problem &P, const StepBuf<fl
 #pragma unroll
         for (int m = 0; m < MB; ++m) { acc[m][0] = zero4; acc[m][1] = zero4; }
         struct Stage { V4f e[MB][2], a[2], b[2]; };
+#ifndef ASG_X_STEP_BUFLOAD
+#define ASG_X_STEP_BUFLOAD 1          // 1: raw buffer loads (descriptor + chunk offset in scalar registers, the lane's 16 l bytes in ONE vector register)
+#endif
+        // this workgroup's matrix tile and this batch tile's vectors as buffer resources: a load then names a scalar chunk offset and the
+        // SAME vector register every time -- no 64-bit address per lane and load
+        __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc((void *) (et - lane), 0, (unsigned) (nchunks * (MB * 2 * 64) * 16), 0x00020000);
+        __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc((void *) (pt - lane), 0, (unsigned) (nchunks * 256 * 16), 0x00020000);
+        const unsigned vlane = (unsigned) lane * 16u;
+        typedef unsigned RawU4 __attribute__((ext_vector_type(4)));
         auto load = [&](Stage &st, int c) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
+                if (ASG_X_STEP_BUFLOAD) {
+                    const unsigned cp = (unsigned) c * 4096u, ce = (unsigned) c * (MB * 2 * 1024u);
+                    st.a[h] = __builtin_bit_cast(V4f, (RawU4) __builtin_amdgcn_raw_buffer_load_b128(rsP, vlane, cp + h * 1024u, 0));
+                    st.b[h] = __builtin_bit_cast(V4f, (RawU4) __builtin_amdgcn_raw_buffer_load_b128(rsP, vlane, cp + (2 + h) * 1024u, 0));
+#pragma unroll
+                    for (int m = 0; m < MB; ++m)          // (aux 2 = non-temporal: see below)
+                        st.e[m][h] = __builtin_bit_cast(V4f, (RawU4) __builtin_amdgcn_raw_buffer_load_b128(rsE, vlane, ce + (m * 2 + h) * 1024u, 2));
+                    continue;
+                }
                 st.a[h] = pt[((size_t) c * 4 + h) * 64];
                 st.b[h] = pt[((size_t) c * 4 + 2 + h) * 64];
 #pragma unroll
