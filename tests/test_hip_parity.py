@@ -1043,6 +1043,25 @@ def test_streaming_step_slices_of_k(T, B, N, L):
                 assert np.array_equal(first[k], r[k]), "run %d differs in %s" % (rep, k)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,B,N,L", [(5, 70, 2200, 2), (4, 64, 5000, 2), (6, 33, 2049, 3), (5, 128, 2300, 2)])
+def test_streaming_step_two_batch_tiles(T, B, N, L, monkeypatch):
+    """B > 64 (ASG_STEP_ONE_TILE=0: B > 32): a workgroup of the fp32 streaming step multiplies its matrix tile into TWO batch tiles of
+    32 utterances (the matrix streamed once for both).  An odd number of batch tiles (the last group's second tile does not exist), a
+    second tile of one utterance, four tiles; against the fp64 oracle and against one batch tile per workgroup (ASG_STEP_ONE_TILE=1)."""
+    tr, x, tg, il, tl = util.synth(T, B, N, L, N + B, True)
+    o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il.numpy(), tl.numpy(), "none")
+    util.setenv(monkeypatch, "ASG_STEP_ONE_TILE", 0)
+    r = run_hip(x, tg, tr, il, tl, "none")
+    for k in ("loss", "grad_inputs", "grad_transition"):
+        util.assert_close(r[k], o[k], 1e-4, "two batch tiles T%d B%d N%d %s" % (T, B, N, k))
+    util.setenv(monkeypatch, "ASG_STEP_ONE_TILE", 1)
+    r1 = run_hip(x, tg, tr, il, tl, "none")
+    for k in ("loss", "grad_inputs", "grad_transition"):
+        util.assert_close(r1[k], o[k], 1e-4, "one batch tile T%d B%d N%d %s" % (T, B, N, k))
+        util.assert_close(r1[k], r[k], 1e-5, "one vs two batch tiles T%d B%d N%d %s" % (T, B, N, k))
+
+
 # ------------------------------------------------------------------ long targets over a small alphabet (letter models)
 @pytest.mark.gpu
 @pytest.mark.parametrize("T,B,N,L", [(90, 3, 29, 65), (140, 2, 40, 128), (150, 3, 40, 129), (300, 2, 31, 200),

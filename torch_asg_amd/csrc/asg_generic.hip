@@ -599,9 +599,10 @@ __device__ __forceinline__ StepPre step_prefetch(const Problem &P, const StepBuf
 // thread in S.partial (write-through) and takes a ticket; the LAST one to arrive adds the slices in ascending order (its own from
 // registers, in its place: a fixed order whoever is last, so the result does not depend on the arrival order) and runs the epilogue.
 // Nobody waits for anybody.  Returns without doing anything in the workgroups that were not last.
-template <bool BETA>
-__device__ __forceinline__ void step_epilogue(const Problem &P, const StepBuf<float> &S, int n, const float (*red)[kStepMB * 8][64],
-                                              const StepPre &E, int bt, int slice, int ks) {
+// NB batch tiles per workgroup: red[w][j MB 8 + ...] is batch tile j's part; nbt = batch tiles of the problem.
+template <bool BETA, int NB>
+__device__ __forceinline__ void step_epilogue(const Problem &P, const StepBuf<float> &S, int n, const float (*red)[NB * kStepMB * 8][64], int j,
+                                              const StepPre &E, int bt, int nbt, int slice, int ks) {
     typedef float R;
     constexpr int MB = kStepMB;
     const int N = P.N, T = P.T, B = P.B, npad = S.npad;
@@ -612,12 +613,12 @@ __device__ __forceinline__ void step_epilogue(const Problem &P, const StepBuf<fl
 #pragma unroll
     for (int rr2 = 0; rr2 < 2 * MB; ++rr2) {
         const int row = 16 * (rr2 >> 1) + 2 * (threadIdx.x & 7) + (rr2 & 1);
-        const int sl = 16 * ((row & 15) >> 2) + (ut & 15), sq = 8 * (row >> 4) + (row & 3) + 4 * (ut >> 4);
+        const int sl = 16 * ((row & 15) >> 2) + (ut & 15), sq = j * (MB * 8) + 8 * (row >> 4) + (row & 3) + 4 * (ut >> 4);
         sums[rr2] = (red[0][sq][sl] + red[1][sq][sl]) + (red[2][sq][sl] + red[3][sq][sl]);
     }
     if (ks > 1) {
         __shared__ int last_arrival;
-        const size_t tile = (size_t) blockIdx.x * gridDim.y / ks + bt;          // (gridDim.y = batch tiles x ks)
+        const size_t tile = (size_t) blockIdx.x * nbt + bt;
         R *mine = S.partial + ((tile * ks + slice) * (2 * MB)) * 256 + threadIdx.x;
 #pragma unroll
         for (int rr2 = 0; rr2 < 2 * MB; ++rr2) __hip_atomic_store(mine + rr2 * 256, sums[rr2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -716,23 +717,27 @@ __device__ __forceinline__ void step_epilogue(const Problem &P, const StepBuf<fl
 #ifdef ASG_X_STEP_PROBE
 __device__ long long g_step_probe[4096];
 #endif
-template <bool BETA>
-__device__ __forceinline__ void fwd_step_mfma(const Problem &P, const StepBuf<float> &S, int n, float (*red)[kStepMB * 8][64], int ks) {
+// NB batch tiles of 32 utterances per workgroup: every element of the matrix tile read from memory multiplies NB * 32 utterances
+// (B >= 64: the matrix is streamed ONCE per frame and direction instead of once per batch tile).  nbt = batch tiles of the problem.
+template <bool BETA, int NB>
+__device__ __forceinline__ void fwd_step_mfma(const Problem &P, const StepBuf<float> &S, int n, float (*red)[NB * kStepMB * 8][64], int ks, int nbt) {
     typedef float R;
     constexpr int MB = kStepMB;
     const int B = P.B, npad = S.npad;
     // (readfirstlane: the chunk index derives from the wavefront's number and has to be a scalar for the buffer loads' offsets --
     // "threadIdx.x >> 6" alone is not provably uniform, and a vector offset turns every load into a waterfall loop)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
-    const int bt = blockIdx.y / ks, slice = blockIdx.y % ks;          // batch tile of 32 utterances, slice of K
-    const StepPre pre = step_prefetch<BETA>(P, S, n, bt);
+    const int bt0 = (int) (blockIdx.y / ks) * NB, slice = blockIdx.y % ks;          // first batch tile of 32 utterances, slice of K
+    StepPre pre[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) pre[j] = step_prefetch<BETA>(P, S, n, bt0 + j);
     {
         // lane l: row / utterance (l & 15), k sub-range 8 (l >> 4) .. +7 of every 32-k chunk: two float4 per operand, so a
         // row's whole 128-byte line goes to one wavefront at once
         const size_t nchunks = ((size_t) npad + 31) / 32;
         const V4f *et = reinterpret_cast<const V4f *>(S.etile) + (size_t) blockIdx.x * nchunks * (MB * 2 * 64) + lane;
-        // the vectors in operand order (step_ptile_index): kilobyte (chunk, utterance half, h) of this batch tile, position `lane`
-        const V4f *pt = reinterpret_cast<const V4f *>(S.ptile + (size_t) (n & 1) * step_ptile_floats(B, npad)) + (size_t) bt * nchunks * 256 + lane;
+        // the vectors in operand order (step_ptile_index): kilobyte (chunk, utterance half, h) of a batch tile, position `lane`
+        const V4f *pt = reinterpret_cast<const V4f *>(S.ptile + (size_t) (n & 1) * step_ptile_floats(B, npad)) + lane;
         // K in chunks of 32 (the matrix tile and the vectors are zero-padded to whole chunks: every load is unconditional -- a
         // bounds test per load makes hipcc wait for every load before the first MFMA): this workgroup's slice, a quarter of it per
         // wavefront, through a two-stage software pipeline
@@ -740,17 +745,26 @@ __device__ __forceinline__ void fwd_step_mfma(const Problem &P, const StepBuf<fl
         const int cpw = (s1 - s0 + 3) / 4;
         const int c0 = min(s0 + wave * cpw, s1), c1 = min(c0 + cpw, s1);
         const V4f zero4 = {0, 0, 0, 0};
-        V4f acc[MB][2];
+        V4f acc[NB][MB][2];
 #pragma unroll
-        for (int m = 0; m < MB; ++m) { acc[m][0] = zero4; acc[m][1] = zero4; }
-        struct Stage { V4f e[MB][2], a[2], b[2]; };
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int m = 0; m < MB; ++m) { acc[j][m][0] = zero4; acc[j][m][1] = zero4; }
+        struct Stage { V4f e[MB][2], a[NB][2], b[NB][2]; };
 #ifndef ASG_X_STEP_BUFLOAD
 #define ASG_X_STEP_BUFLOAD 1          // 1: raw buffer loads (descriptor + chunk offset in scalar registers, the lane's 16 l bytes in ONE vector register)
 #endif
-        // this workgroup's matrix tile and this batch tile's vectors as buffer resources: a load then names a scalar chunk offset and the
-        // SAME vector register every time -- no 64-bit address per lane and load
+        // this workgroup's matrix tile and its batch tiles' vectors as buffer resources: a load then names a scalar chunk offset and the
+        // SAME vector register every time -- no 64-bit address per lane and load.  (A batch tile past the last one: a resource of no
+        // records, whose loads return zeros.)
         __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc((void *) (et - lane), 0, (unsigned) (nchunks * (MB * 2 * 64) * 16), 0x00020000);
-        __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc((void *) (pt - lane), 0, (unsigned) (nchunks * 256 * 16), 0x00020000);
+        __amdgpu_buffer_rsrc_t rsP[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const bool there = bt0 + j < nbt;
+            rsP[j] = __builtin_amdgcn_make_buffer_rsrc((void *) (pt - lane + (size_t) (there ? bt0 + j : bt0) * nchunks * 256), 0,
+                                                       there ? (unsigned) (nchunks * 256 * 16) : 0u, 0x00020000);
+        }
         const unsigned vlane = (unsigned) lane * 16u;
         typedef unsigned RawU4 __attribute__((ext_vector_type(4)));
         auto load = [&](Stage &st, int c) {
@@ -758,15 +772,22 @@ __device__ __forceinline__ void fwd_step_mfma(const Problem &P, const StepBuf<fl
             for (int h = 0; h < 2; ++h) {
                 if (ASG_X_STEP_BUFLOAD) {
                     const unsigned cp = (unsigned) c * 4096u, ce = (unsigned) c * (MB * 2 * 1024u);
-                    st.a[h] = __builtin_bit_cast(V4f, (RawU4) __builtin_amdgcn_raw_buffer_load_b128(rsP, vlane, cp + h * 1024u, 0));
-                    st.b[h] = __builtin_bit_cast(V4f, (RawU4) __builtin_amdgcn_raw_buffer_load_b128(rsP, vlane, cp + (2 + h) * 1024u, 0));
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) {
+                        st.a[j][h] = __builtin_bit_cast(V4f, (RawU4) __builtin_amdgcn_raw_buffer_load_b128(rsP[j], vlane, cp + h * 1024u, 0));
+                        st.b[j][h] = __builtin_bit_cast(V4f, (RawU4) __builtin_amdgcn_raw_buffer_load_b128(rsP[j], vlane, cp + (2 + h) * 1024u, 0));
+                    }
 #pragma unroll
                     for (int m = 0; m < MB; ++m)          // (aux 2 = non-temporal: see below)
                         st.e[m][h] = __builtin_bit_cast(V4f, (RawU4) __builtin_amdgcn_raw_buffer_load_b128(rsE, vlane, ce + (m * 2 + h) * 1024u, 2));
                     continue;
                 }
-                st.a[h] = pt[((size_t) c * 4 + h) * 64];
-                st.b[h] = pt[((size_t) c * 4 + 2 + h) * 64];
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const V4f *ptj = pt + (size_t) min(bt0 + j, nbt - 1) * nchunks * 256;
+                    st.a[j][h] = ptj[((size_t) c * 4 + h) * 64];
+                    st.b[j][h] = ptj[((size_t) c * 4 + 2 + h) * 64];
+                }
 #pragma unroll
                 for (int m = 0; m < MB; ++m) {
                     // (non-temporal: every element of the matrix is used once per frame, and the lines it would displace in
@@ -779,16 +800,18 @@ __device__ __forceinline__ void fwd_step_mfma(const Problem &P, const StepBuf<fl
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int m = 0; m < MB; ++m) {
-                    acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(st.e[m][h].x, st.a[h].x, acc[m][0], 0, 0, 0);
-                    acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(st.e[m][h].x, st.b[h].x, acc[m][1], 0, 0, 0);
-                    acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(st.e[m][h].y, st.a[h].y, acc[m][0], 0, 0, 0);
-                    acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(st.e[m][h].y, st.b[h].y, acc[m][1], 0, 0, 0);
-                    acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(st.e[m][h].z, st.a[h].z, acc[m][0], 0, 0, 0);
-                    acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(st.e[m][h].z, st.b[h].z, acc[m][1], 0, 0, 0);
-                    acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(st.e[m][h].w, st.a[h].w, acc[m][0], 0, 0, 0);
-                    acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(st.e[m][h].w, st.b[h].w, acc[m][1], 0, 0, 0);
-                }
+                for (int m = 0; m < MB; ++m)
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) {
+                        acc[j][m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(st.e[m][h].x, st.a[j][h].x, acc[j][m][0], 0, 0, 0);
+                        acc[j][m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(st.e[m][h].x, st.b[j][h].x, acc[j][m][1], 0, 0, 0);
+                        acc[j][m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(st.e[m][h].y, st.a[j][h].y, acc[j][m][0], 0, 0, 0);
+                        acc[j][m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(st.e[m][h].y, st.b[j][h].y, acc[j][m][1], 0, 0, 0);
+                        acc[j][m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(st.e[m][h].z, st.a[j][h].z, acc[j][m][0], 0, 0, 0);
+                        acc[j][m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(st.e[m][h].z, st.b[j][h].z, acc[j][m][1], 0, 0, 0);
+                        acc[j][m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(st.e[m][h].w, st.a[j][h].w, acc[j][m][0], 0, 0, 0);
+                        acc[j][m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(st.e[m][h].w, st.b[j][h].w, acc[j][m][1], 0, 0, 0);
+                    }
         };
         if (c0 < c1) {
             // STG stages: STG - 1 chunks of loads in flight while one is multiplied.  (A compute unit holds one of these
@@ -812,17 +835,24 @@ __device__ __forceinline__ void fwd_step_mfma(const Problem &P, const StepBuf<fl
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        // element (row 16 m + 4 (l >> 4) + q, utterance (l & 15) [+ 16]) of the tile sits in register q of lane l
+        // element (row 16 m + 4 (l >> 4) + q, utterance (l & 15) [+ 16]) of batch tile j's tile sits in register q of lane l
 #pragma unroll
-        for (int m = 0; m < MB; ++m)
+        for (int j = 0; j < NB; ++j)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { red[wave][8 * m + q][lane] = acc[m][0][q]; red[wave][8 * m + 4 + q][lane] = acc[m][1][q]; }
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    red[wave][j * (MB * 8) + 8 * m + q][lane] = acc[j][m][0][q];
+                    red[wave][j * (MB * 8) + 8 * m + 4 + q][lane] = acc[j][m][1][q];
+                }
     }
     __syncthreads();
 #ifdef ASG_X_STEP_PROBE
     if (n == 20 && threadIdx.x == 0) { const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x; if (wg < 1024) g_step_probe[wg * 4 + 1] = wall_clock64(); }
 #endif
-    step_epilogue<BETA>(P, S, n, red, pre, bt, slice, ks);
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+        if (bt0 + j < nbt) step_epilogue<BETA, NB>(P, S, n, red, j, pre[j], bt0 + j, nbt, slice, ks);
 }
 
 template <typename R> struct StepUsesMfma { static constexpr bool v = false; };
@@ -832,15 +862,17 @@ template <> struct StepUsesMfma<float> { static constexpr bool v = true; };
 
 // blockIdx.z selects the direction, so the alpha and beta frames of one step share a launch (they are
 // independent chains): twice the workgroups in flight, half the launches.  fp32: blockIdx.y = batch tile x slice of K (ks slices).
-template <typename R>
+// NB (fp32): batch tiles of 32 utterances per workgroup; blockIdx.y = group of NB batch tiles x slice of K.
+template <typename R, int NB>
 __global__ void __launch_bounds__(256) fwd_step_kernel(Problem P, StepBuf<R> Sa, StepBuf<R> Sb, int n, int dir_base, int ks) {
     if constexpr (StepUsesMfma<R>::v) {
-        __shared__ float red[4][kStepMB * 8][64];
+        __shared__ float red[4][NB * kStepMB * 8][64];
+        const int nbt = (P.B + 31) / 32;
 #ifdef ASG_X_STEP_PROBE
         const long long t_begin = wall_clock64();
 #endif
-        if ((int) blockIdx.z + dir_base == 0) fwd_step_mfma<false>(P, Sa, n, red, ks);
-        else fwd_step_mfma<true>(P, Sb, n, red, ks);
+        if ((int) blockIdx.z + dir_base == 0) fwd_step_mfma<false, NB>(P, Sa, n, red, ks, nbt);
+        else fwd_step_mfma<true, NB>(P, Sb, n, red, ks, nbt);
 #ifdef ASG_X_STEP_PROBE
         {
             // frame 20: every workgroup stamps begin / product done / end (100 MHz ticks); frame 30: one thread prints the summary
@@ -3528,8 +3560,15 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
         if (!stepped) {
             // fp32: K split over ks workgroups per (row tile, batch tile) so that the grid fills the device: 160-row tiles halve the
             // vector traffic per byte of the matrix (at cfg 5: 63 row tiles x 2 directions x 2 slices = 252 workgroups)
-            int ks = 1;
+            // B > 64: two batch tiles of 32 utterances per workgroup -- the matrix streamed once per frame and direction for both.
+            // (T=400, N=3000, B=128: 99 us per frame against 122; B=96, N=5000: 150 against 182.  At B = 64 the same form LOSES --
+            // N=1500: 38 against 26 us, N=3000: 58 against 52, N=5000: 99 against 92: the two batch tiles' workgroups of a row tile
+            // run side by side and share the matrix lines in L2 already, the product is bound by the matrix instruction either way,
+            // and half the workgroups means twice the K slices and their exchange.  ASG_STEP_ONE_TILE=1/0 forces either form.)
+            int ks = 1, nb = 1;
             if constexpr (StepUsesMfma<R>::v) {
+                nb = (knobs().step_one_tile >= 0 ? (knobs().step_one_tile == 0 && P.B > 32) : P.B > 64) ? 2 : 1;
+                sgrid.y = (sgrid.y + nb - 1) / nb;
                 int dev = 0, cus = 0;
                 if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
                     cus = 256;
@@ -3539,8 +3578,11 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
 #endif
                 sgrid.y *= ks;
             }
-            for (int n = 0; n + 1 < P.T; ++n)
-                hipLaunchKernelGGL((fwd_step_kernel<R>), sgrid, dim3(256), 0, stream, P, Sd[0], Sd[1], n, do_a ? 0 : 1, ks);
+            for (int n = 0; n + 1 < P.T; ++n) {
+                if constexpr (StepUsesMfma<R>::v)
+                    if (nb == 2) { hipLaunchKernelGGL((fwd_step_kernel<R, 2>), sgrid, dim3(256), 0, stream, P, Sd[0], Sd[1], n, do_a ? 0 : 1, ks); continue; }
+                hipLaunchKernelGGL((fwd_step_kernel<R, 1>), sgrid, dim3(256), 0, stream, P, Sd[0], Sd[1], n, do_a ? 0 : 1, ks);
+            }
         }
         if (do_b)
             hipLaunchKernelGGL((fwd_score_kernel<R, true>), dim3(P.B), dim3(256), 0, stream, P, Sd[1], (R *) O.full_scores);
