@@ -13,7 +13,7 @@ def reserve(device, nbytes=0):
 
 
 def check_faults():
-    """Raise RuntimeError if a resident-slice forward launch (fp32, 256 < N <= 2048) of this process timed out since the last look --
+    """Raise RuntimeError if a resident-slice forward launch (256 < N <= 2048 in fp32, <= 1024 in fp64) of this process timed out since the last look --
     the step that contained it returned NaN scores and gradients and must be discarded (the library has already switched to kernels
     that need no co-residency, so repeating the step is sound).  ASGLoss checks at the start of every forward AND backward call with
     N > 256; a training loop that wants to know before `optimizer.step()` calls this after its own synchronisation point

@@ -58,7 +58,7 @@ class HipBackend:
         self.binding = _lib.binding(self)        # C++ fast path of ASGLossFunction, or None (csrc/binding.cpp)
 
     def check_faults(self):
-        """Raise if a resident-slice forward launch (fp32, 256 < N <= 2048) of this process has timed out since the last look:
+        """Raise if a resident-slice forward launch (256 < N <= 2048 in fp32, <= 1024 in fp64) of this process has timed out since the last look:
         that call's scores were NaN.  Host-pinned counter, no synchronisation; the library has already switched to the
         per-frame launches, so the NEXT call is sound."""
         n = int(_lib.lib().asg_cluster_timeouts())

@@ -1134,7 +1134,7 @@ __global__ void __launch_bounds__(64 * NW * SP) fwd_mid_kernel(Problem P, State 
     }
 }
 
-// ------------------------------------------------------------------ full lattice, 256 < N <= 2048 (fp32): resident slices
+// ------------------------------------------------------------------ full lattice, 256 < N <= 2048 (fp32) / 1024 (fp64): resident slices
 // Between the one-workgroup-per-chain kernel above (the row of a label fits its thread's registers up to N = 256) and
 // the streamed step (N ~ 10^4: 400 MB per frame) the matrix is 0.25 - 4 MB: too large for one compute unit, far too
 // small to be worth a launch per frame (fwd_step_kernel: 14 / 27 us per frame at N = 512 / 1024, a round of dependent
@@ -1160,13 +1160,22 @@ __global__ void __launch_bounds__(64 * NW * SP) fwd_mid_kernel(Problem P, State 
 //             (Measured against polling the data itself for a tag in the sign bit: 2.3 vs 5.5 us per frame at N = 512.)
 // Clusters are placed with the workgroup index as the slow coordinate (block = g * ncl + c), so a cluster's workgroups
 // land on ONE XCD whenever the cluster count is a multiple of 8 and the exchange stays in that XCD's L2.
+// fp64 (round 5; the text above describes fp32): the same kernel on v_mfma_f64_16x16x4_f64 with workgroups of 512 threads -- the 32 K
+// matrix elements of a workgroup are 128 registers per lane of its 8 wavefronts -- two accumulators, 8-byte exchange words, N <= 1024
+// (16 chains x N doubles in LDS).  Per frame at T=400 B=64 N=512 (cycles, ASG_X_CL_PROBE): product 8 500 (128 MFMAs per SIMD at 64
+// cycles; only 4 of the 16 chain columns exist at this shape), epilogue 2 700, acknowledge 770, flags 1 500, reload 3 350 = 7 us
+// against 11.7 us for a launch per frame (fwd_step_tile_kernel); the step 5.9 -> 4.1 ms, N=1024: 13.1 -> 7.7 ms, N=300: 4.1 -> 3.75.
 // All workgroups must be co-resident (they wait for each other): the launcher sizes the grid to the device's compute
 // units; a wait that runs out (2^22 polls) poisons the scores with NaN instead of hanging the device.
-constexpr int kClNB = 16, kClNT = 1024;        // chains per batch; threads per workgroup (four wavefronts per SIMD: see above)
+constexpr int kClNB = 16;                       // chains per batch
+// threads per workgroup: fp32 1024 (four wavefronts per SIMD: see above; 32 matrix registers per lane), fp64 512 (two per SIMD: the
+// same 32 K elements of the matrix per workgroup are 128 registers per lane, and a lane of a 1024-thread workgroup has 128 in all)
+template <typename R> struct ClusterThreads { static constexpr int v = sizeof(R) == 4 ? 1024 : 512; };
 constexpr unsigned kClSc1 = 16;   // buffer load aux bit: agent scope
 typedef unsigned ClU4 __attribute__((ext_vector_type(4)));
+typedef unsigned ClU2 __attribute__((ext_vector_type(2)));
 struct ClusterArgs {
-    float *xbuf;        // [ncl][2][npadL / 4][kClNB][4]   exp-domain vectors of the frame just produced (pad columns stay zero)
+    void *xbuf;         // [ncl][2][npadL / 4][kClNB][4]   exp-domain vectors of the frame just produced, in the problem's precision (pad columns stay zero)
     unsigned *xmax;     // [ncl][2][G][kClNB]             key(max q) over each workgroup's rows
     unsigned *flags;    // [ncl][G]                       frames published so far (zero on entry)
     unsigned *fault;    // host-mapped word (or nullptr): incremented when a bounded wait runs out (cluster_fault_word)
@@ -1199,9 +1208,12 @@ static ClusterFault &cluster_fault(bool create = true) {
 
 static __host__ __device__ inline size_t cluster_xbuf_floats(int ncl, int npadL) { return (size_t) ncl * 2 * kClNB * npadL; }
 
-__global__ void __launch_bounds__(kClNT) fwd_cluster_kernel(Problem P, StepBuf<float> Sa, StepBuf<float> Sb, ClusterArgs C, int dir_base) {
-    typedef float R;
-    extern __shared__ __attribute__((aligned(16))) float cl_lds[];
+extern __shared__ __attribute__((aligned(16))) unsigned char cl_lds_bytes[];
+template <typename R>
+__global__ void __launch_bounds__(ClusterThreads<R>::v) fwd_cluster_kernel(Problem P, StepBuf<R> Sa, StepBuf<R> Sb, ClusterArgs C, int dir_base) {
+    constexpr int kClNT = ClusterThreads<R>::v;
+    typedef TileOps<R> Ops;
+    R *cl_lds = reinterpret_cast<R *>(cl_lds_bytes);
     __shared__ unsigned pmax[kClNB], lmax[kClNB];
     __shared__ float mus[kClNB];
     __shared__ int lens[kClNB];
@@ -1211,11 +1223,11 @@ __global__ void __launch_bounds__(kClNT) fwd_cluster_kernel(Problem P, StepBuf<f
     const int c = (int) blockIdx.x % ncl, g = (int) blockIdx.x / ncl;
     const int dir = dir_base + c / C.ncd, cd = c % C.ncd;
     const bool BETA = dir == 1;
-    const StepBuf<float> &S = BETA ? Sb : Sa;
+    const StepBuf<R> &S = BETA ? Sb : Sa;
     const int N = P.N, T = P.T, B = P.B, npad = S.npad, RW = C.RW, npadL = C.npadL;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float *pl = cl_lds;                          // [npadL / 4][kClNB][4]: the B operand
-    float *red = cl_lds + kClNB * npadL;         // [NKH][RW][kClNB]
+    R *pl = cl_lds;                              // [npadL / 4][kClNB][4]: the B operand
+    R *red = cl_lds + kClNB * npadL;             // [NKH][RW][kClNB]
     const R L2E = Num<R>::log2e(), LZ = Num<R>::logzero(), NINF = Num<R>::ninf();
     const int MBW = RW / 16, NKH = (kClNT / 64) / MBW;      // row blocks per workgroup, K parts
     const int mb = wave % MBW, kh = wave / MBW;
@@ -1235,8 +1247,8 @@ __global__ void __launch_bounds__(kClNT) fwd_cluster_kernel(Problem P, StepBuf<f
             ea[s4] = v;
         }
     }
-    float *xb = C.xbuf + (size_t) c * 2 * kClNB * npadL;
-    __amdgpu_buffer_rsrc_t rxb = make_rsrc(xb, (unsigned) (2 * kClNB * npadL * 4));
+    R *xb = (R *) C.xbuf + (size_t) c * 2 * kClNB * npadL;
+    __amdgpu_buffer_rsrc_t rxb = make_rsrc(xb, (unsigned) (2 * kClNB * npadL * sizeof(R)));
     unsigned *fl = C.flags + (size_t) c * C.G;
     unsigned *xm = C.xmax + (size_t) c * 2 * C.G * kClNB;
     const R *tr = (const R *) P.transition;
@@ -1261,7 +1273,7 @@ __global__ void __launch_bounds__(kClNT) fwd_cluster_kernel(Problem P, StepBuf<f
 #ifdef ASG_X_CL_NO_FEW
         const bool few = false;                   // (developer A/B)
 #else
-        const bool few = nb <= 4;                 // the product on 4 x 4 blocks (below)
+        const bool few = sizeof(R) == 4 && nb <= 4;      // the product on 4 x 4 blocks (below; fp32 only)
 #endif
         R hm[IT];                                 // hmax of the rows this thread finishes
 #pragma unroll
@@ -1280,7 +1292,7 @@ __global__ void __launch_bounds__(kClNT) fwd_cluster_kernel(Problem P, StepBuf<f
         // the vectors of the first frame (fwd_init_kernel wrote them to pbuf[0]), transposed into the operand layout
         for (int idx = tid; idx < kClNB * npadL; idx += kClNT) {
             const int k = idx / kClNB, u = idx - k * kClNB;
-            pl[((k >> 2) * kClNB + u) * 4 + (k & 3)] = (u < nb && k < npad) ? S.pbuf[(int64_t) (rb + u) * npad + k] : 0.0f;
+            pl[((k >> 2) * kClNB + u) * 4 + (k & 3)] = (u < nb && k < npad) ? S.pbuf[(int64_t) (rb + u) * npad + k] : R(0);
         }
         __syncthreads();
         const int nsteps = smaxlen - 1;
@@ -1314,7 +1326,9 @@ __global__ void __launch_bounds__(kClNT) fwd_cluster_kernel(Problem P, StepBuf<f
             for (int it = 0; it < IT; ++it) { xe[it] = xn[it]; xw[it] = wn[it]; }
             if (tid < kClNB) { pmax[tid] = fkey(-__builtin_inff()); lmax[tid] = fkey(-__builtin_inff()); }
             // ---- product: 16 rows x 16 chains x this wavefront's K range
-            if (few) {
+            bool few_done = false;
+            if constexpr (sizeof(R) == 4) if (few) {
+                few_done = true;
                 // At most four chains (N = 512 at B = 64: 32 clusters, four chains each): the 16 x 16 x 4 instruction would spend
                 // 32 cycles on sixteen chain columns of which four exist.  v_mfma_f32_4x4x1_16B_f32 is sixteen INDEPENDENT 4 x 4
                 // outer products in 8 cycles; block (lane >> 2) = (row quad (lane >> 2) & 3, k slot lane >> 4) takes
@@ -1345,8 +1359,10 @@ __global__ void __launch_bounds__(kClNT) fwd_cluster_kernel(Problem P, StepBuf<f
                 float xs = a0 + a2, ys = a1 + a3;
                 swap_rows(xs, ys);
                 red[((size_t) kh * RW + 16 * mb + 4 * ((lane >> 2) & 3) + (lane >> 4)) * 4 + (lane & 3)] = xs + ys;
-            } else {
-                V4f acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0}, acc3 = {0, 0, 0, 0};     // (independent chains: the
+            }
+            if (!few_done) {
+                typedef typename Ops::Acc Acc;
+                Acc acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0}, acc3 = {0, 0, 0, 0};     // (independent chains: the
                                                                                               // matrix pipe never waits for a result)
                 const V4<R> *bp = reinterpret_cast<const V4<R> *>(pl) + (size_t) (kbase / 4 + (lane >> 4)) * kClNB + (lane & 15);
                 // operand reads two groups ahead of the matrix pipe, unconditional (clamped), so that they are not tied to the
@@ -1358,16 +1374,21 @@ __global__ void __launch_bounds__(kClNT) fwd_cluster_kernel(Problem P, StepBuf<f
                     b0 = b1;
                     b1 = bp[(size_t) min(s4 + 2, KS4 - 1) * 4 * kClNB];
                     if (s4 < KS4) {
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ea[s4].x, bv.x, acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ea[s4].y, bv.y, acc1, 0, 0, 0);
-                        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(ea[s4].z, bv.z, acc2, 0, 0, 0);
-                        acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(ea[s4].w, bv.w, acc3, 0, 0, 0);
+                        acc0 = Ops::mma(ea[s4].x, bv.x, acc0);
+                        acc1 = Ops::mma(ea[s4].y, bv.y, acc1);
+                        if constexpr (sizeof(R) == 4) {
+                            acc2 = Ops::mma(ea[s4].z, bv.z, acc2);
+                            acc3 = Ops::mma(ea[s4].w, bv.w, acc3);
+                        } else {          // (fp64: two accumulators -- 16 registers that the 128 of the matrix slice do not leave)
+                            acc0 = Ops::mma(ea[s4].z, bv.z, acc0);
+                            acc1 = Ops::mma(ea[s4].w, bv.w, acc1);
+                        }
                     }
                 }
-                const V4f acc = (acc0 + acc1) + (acc2 + acc3);
-                // element (row 16 mb + 4 (lane >> 4) + q, chain lane & 15) sits in register q
+                const Acc acc = (acc0 + acc1) + (acc2 + acc3);
+                // element (row 16 mb + Ops::row(lane, q), chain lane & 15) sits in register q (fp32: row 4 (lane >> 4) + q, fp64: (lane >> 4) + 4 q)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) red[((size_t) kh * RW + 16 * mb + 4 * (lane >> 4) + q) * kClNB + (lane & 15)] = acc[q];
+                for (int q = 0; q < 4; ++q) red[((size_t) kh * RW + 16 * mb + Ops::row(lane, q)) * kClNB + (lane & 15)] = acc[q];
             }
             __syncthreads();
 #ifdef ASG_X_CL_PROBE
@@ -1384,7 +1405,7 @@ __global__ void __launch_bounds__(kClNT) fwd_cluster_kernel(Problem P, StepBuf<f
                 R a = 0;
                 if (few) { for (int h = 0; h < NKH; ++h) a += red[((size_t) h * RW + rr_) * 4 + u]; }
                 else { for (int h = 0; h < NKH; ++h) a += red[((size_t) h * RW + rr_) * kClNB + u]; }
-                const R muprev = fmax(mus[u], LZ);
+                const R muprev = fmax((R) mus[u], LZ);
                 const R lg = Num<R>::log2(a);
                 R rr = hm[it] + lg;
                 if (!(fabs(lg) < Num<R>::lg_limit())) {
@@ -1430,8 +1451,9 @@ __global__ void __launch_bounds__(kClNT) fwd_cluster_kernel(Problem P, StepBuf<f
                 const int idx = tid + kClNT * it, u = idx & nbm, rr_ = idx >> nbs, i = i0 + rr_;
                 if (!(u < nb && rr_ < RW && i < N)) continue;
                 if (!(n < lens[u] - 1)) continue;
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(xe[it]), rxb,
-                                                      (unsigned) ((((size_t) par * (npadL / 4) + (i >> 2)) * kClNB + u) * 16 + (i & 3) * 4), 0u, kClSc1);
+                const unsigned off = (unsigned) (((((size_t) par * (npadL / 4) + (i >> 2)) * kClNB + u) * 4 + (i & 3)) * sizeof(R));
+                if constexpr (sizeof(R) == 4) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(xe[it]), rxb, off, 0u, kClSc1);
+                else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ClU2, xe[it]), rxb, off, 0u, kClSc1);
             }
 #ifdef ASG_X_CL_PROBE
             const unsigned long long c2 = __builtin_readcyclecounter();
@@ -1479,22 +1501,26 @@ __global__ void __launch_bounds__(kClNT) fwd_cluster_kernel(Problem P, StepBuf<f
             if (sfail) break;
             {
                 // (all of a thread's loads go out before the first of them is used: one memory latency, not sixteen)
-                const int total = n4 * nb;
-                constexpr int RL = 4;     // (8 / 16: +4 % at N = 1024, -7 / -15 % at N = 512 -- the matrix rows spill into AGPRs)
+                // (in 16-byte pieces: GR = 1 (fp32) or 2 (fp64) per chain and group of four k)
+                constexpr int GR = sizeof(R) / 4;
+                const int total = n4 * nb * GR;
+                // (fp32, 8 / 16: +4 % at N = 1024, -7 / -15 % at N = 512 -- the matrix rows spill into AGPRs; fp64, 8: the reload 10 300 -> 9 450
+                // cycles at N = 1024, 3 350 -> 4 000 at N = 512; 16: spills, 7 100 / 9 800)
+                constexpr int RL = 4;
                 for (int base = 0; base < total; base += kClNT * RL) {
                     ClU4 v[RL];
                     int dst[RL];
 #pragma unroll
                     for (int k = 0; k < RL; ++k) {
                         const int idx = base + tid + kClNT * k, ic = min(idx, total - 1);
-                        const int k4 = ic / nb, u = ic - k4 * nb;
-                        dst[k] = (idx < total && n < lens[u] - 1) ? (k4 * kClNB + u) * 4 : -1;
-                        const unsigned off = (unsigned) ((((size_t) par * (npadL / 4) + k4) * kClNB + u) * 16);
+                        const int piece = ic % GR, cu = ic / GR, k4 = cu / nb, u = cu - k4 * nb;
+                        dst[k] = (idx < total && n < lens[u] - 1) ? (k4 * kClNB + u) * (int) (4 * sizeof(R)) + 16 * piece : -1;       // (bytes)
+                        const unsigned off = (unsigned) ((((size_t) par * (npadL / 4) + k4) * kClNB + u) * (4 * sizeof(R)) + 16 * piece);
                         v[k] = __builtin_amdgcn_raw_buffer_load_b128(rxb, off, 0u, kClSc1);      // (agent scope: the line may sit, two frames old, in this XCD's L2)
                     }
 #pragma unroll
                     for (int k = 0; k < RL; ++k)
-                        if (dst[k] >= 0) *reinterpret_cast<ClU4 *>(pl + dst[k]) = v[k];
+                        if (dst[k] >= 0) *reinterpret_cast<ClU4 *>(reinterpret_cast<unsigned char *>(pl) + dst[k]) = v[k];
                 }
                 // the frame's normaliser: max q over the cluster's workgroups (keys: max is order-independent)
                 for (int idx = tid; idx < C.G * kClNB; idx += kClNT) {
@@ -1526,9 +1552,11 @@ __global__ void __launch_bounds__(kClNT) fwd_cluster_kernel(Problem P, StepBuf<f
     if (sfail && tid == 0 && C.fault) __hip_atomic_fetch_add(C.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// the resident-slice route: fp32, 256 < N <= 2048 (ASG_NO_CLUSTER=1: the per-frame launches instead)
+// the resident-slice route: 256 < N <= 2048 (fp32) / 1024 (fp64: the batch's vectors, 16 chains x N, have to fit the LDS beside the
+// K parts' partial sums -- 144 KB at N = 1024); ASG_NO_CLUSTER=1: the per-frame launches instead
+static constexpr int cluster_max_n(size_t elem) { return elem == 4 ? 2048 : 1024; }
 static bool cluster_alphabet(const Problem &P, size_t elem) {
-    if (elem != 4 || P.N <= 256 || P.N > 2048) return false;
+    if (P.N <= 256 || P.N > cluster_max_n(elem)) return false;
     return !(knobs().no_cluster > 0);
 }
 constexpr size_t kClusterBytes = 8u << 20;       // exchange vectors of every cluster
@@ -3363,7 +3391,7 @@ size_t fwd_work_bytes_generic(int elem, int T, int B, int N) {
     const size_t npad = (size_t) (N + 3) / 4 * 4;
     return au((size_t) T * B * elem) + 2 * au(2 * (size_t) B * npad * elem) + 2 * au(3 * (size_t) B * 4) + 2 * au((size_t) B * 8) +
            au((size_t) T * B * elem) + 2 * step_ptile_bytes(elem, B, N) +
-           (step_ptile_bytes(elem, B, N) ? 2 * (step_ticket_bytes(B, N) + step_partial_bytes(B, N)) : 0) + ((elem == 4 && N > 256 && N <= 2048) ? kClusterBytes : 0) + 4096;
+           (step_ptile_bytes(elem, B, N) ? 2 * (step_ticket_bytes(B, N) + step_partial_bytes(B, N)) : 0) + ((N > 256 && N <= cluster_max_n((size_t) elem)) ? kClusterBytes : 0) + 4096;
 }
 // offset of the alpha pass's per-frame normaliser log inside the work area (its last member)
 static size_t work_mulog_offset(size_t elem, int T, int B, int npad) {
@@ -3473,8 +3501,9 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
         const int srows = StepUsesMfma<R>::v ? 16 * kStepMB : 64;
         dim3 sgrid((P.N + srows - 1) / srows, (P.B + 31) / 32, (do_a && do_b) ? 2 : 1);
         bool stepped = false;
-        if constexpr (sizeof(R) == 4) {
+        {
             if (cluster_alphabet(P, e) && P.T >= 2) {
+                constexpr int kClNT = ClusterThreads<R>::v;
                 int dev = 0, cus = 0;
                 if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
                     cus = 256;
@@ -3501,13 +3530,13 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
                 C.ncd = (P.B + C.cpc - 1) / C.cpc;
                 const int ncl = C.ndirs * C.ncd;
                 char *ca = bar_area - kClusterBytes;
-                const size_t xb = au(cluster_xbuf_floats(ncl, C.npadL) * 4), xmb = au((size_t) ncl * 2 * C.G * kClNB * 4), flb = au((size_t) ncl * C.G * 4);
+                const size_t xb = au(cluster_xbuf_floats(ncl, C.npadL) * sizeof(R)), xmb = au((size_t) ncl * 2 * C.G * kClNB * 4), flb = au((size_t) ncl * C.G * 4);
                 // beyond 1024 labels a cluster is half the device (one per direction) and takes the batch 16 chains at a time:
                 // worth it up to three rounds (B <= 48), after that the launch per frame (32 us for ALL chains) is the faster one
                 const bool few_rounds = P.N <= 1024 || (C.cpc + kClNB - 1) / kClNB <= 3;
                 // (at least 84 KB of LDS: a compute unit then holds ONE of these workgroups -- two on one unit would share its
                 // matrix pipes and make their whole clusters wait, while other units stay empty)
-                size_t lds = ((size_t) kClNB * C.npadL + (size_t) (kClNT / 64) * 16 * kClNB) * 4;
+                size_t lds = ((size_t) kClNB * C.npadL + (size_t) (kClNT / 64) * 16 * kClNB) * sizeof(R);
                 if (lds < 84 * 1024) lds = 84 * 1024;
                 // The workgroups of a cluster wait for each other: the route is taken only if (a) no earlier launch of this process
                 // ever timed out (cluster_fault), (b) the kernel can have its LDS (per device and cheap: asked on every call) and the
@@ -3520,25 +3549,24 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
                     fprintf(stderr, "[torch_asg_amd] a resident-slice forward launch timed out earlier in this process (its scores were NaN): "
                                     "taking the per-frame launches from now on\n");
                 }
-                if (resident_ok && hipFuncSetAttribute((const void *) fwd_cluster_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) {
+                if (resident_ok && hipFuncSetAttribute((const void *) fwd_cluster_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) {
                     (void) hipGetLastError();
                     resident_ok = false;
                 }
                 if (resident_ok) {
                     int per_cu = 0;
-                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *) fwd_cluster_kernel, kClNT, lds) != hipSuccess || per_cu < 1) {
+                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *) fwd_cluster_kernel<R>, kClNT, lds) != hipSuccess || per_cu < 1) {
                         (void) hipGetLastError();
                         resident_ok = false;
                     }
                 }
                 if (resident_ok && few_rounds && ncl * C.G <= cus && xb + xmb + flb <= kClusterBytes) {
-                    C.xbuf = (float *) ca;
+                    C.xbuf = ca;
                     C.xmax = (unsigned *) (ca + xb);
                     C.flags = (unsigned *) (ca + xb + xmb);
                     C.fault = CF.dev;
                     (void) hipMemsetAsync(ca, 0, xb + xmb + flb, stream);
-                    StepBuf<float> A0 = Sd[0], B0 = Sd[1];
-                    hipLaunchKernelGGL(fwd_cluster_kernel, dim3(ncl * C.G), dim3(kClNT), lds, stream, P, A0, B0, C, do_a ? 0 : 1);
+                    hipLaunchKernelGGL((fwd_cluster_kernel<R>), dim3(ncl * C.G), dim3(kClNT), lds, stream, P, Sd[0], Sd[1], C, do_a ? 0 : 1);
                     stepped = true;
                 }
             }
