@@ -1,0 +1,19 @@
+#!/bin/bash
+# here (no GPU), after `gpurun -- 'bash tools/run_round_end.sh <tag>'` has merged gpurun_out/: turn the scratch output into the tracked
+# profiles/<tag>_* files (rocprofv3 summaries via tools/summarize_profiles.py, the rest copied under stable names)
+set -e
+cd "$(dirname "$0")/.."; TAG=${1:-r05}; O=gpurun_out/$TAG; P=profiles/$TAG
+python tools/summarize_profiles.py $TAG gpurun_out/profiles_$TAG
+cp $O/bench.json ${P}_bench_line.json
+cp $O/bench_cfg5.json ${P}_cfg5_bench_line.json
+cp $O/cfg5_kernel_stats.csv ${P}_cfg5_kernel_stats.csv
+cp $O/pmc_cfg5.json ${P}_pmc_cfg5.json
+cp $O/pmc_cfg5_FETCH_SIZE.txt ${P}_pmc_cfg5_fetch.txt
+cp $O/pmc_cfg5_WRITE_SIZE.txt ${P}_pmc_cfg5_write.txt
+cp $O/batch_sweep.txt ${P}_batch_sweep.txt
+grep -h "^T=" $O/shape_times.txt > ${P}_shape_times.txt
+grep -h "^T=" $O/shape_times_f64.txt > ${P}_shape_times_f64.txt
+cp $O/pmc_standalone.txt ${P}_pmc_standalone_B512.txt
+grep -v amdgpu.ids $O/fuzz_400.txt | tail -40 > ${P}_fuzz_400.txt
+tail -3 $O/pytest.log > ${P}_pytest_gpu_tail.txt
+ls -la profiles/ | grep " ${TAG}_" | wc -l

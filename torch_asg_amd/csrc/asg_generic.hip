@@ -721,7 +721,6 @@ __device__ long long g_step_probe[4096];
 // (B >= 64: the matrix is streamed ONCE per frame and direction instead of once per batch tile).  nbt = batch tiles of the problem.
 template <bool BETA, int NB>
 __device__ __forceinline__ void fwd_step_mfma(const Problem &P, const StepBuf<float> &S, int n, float (*red)[NB * kStepMB * 8][64], int ks, int nbt) {
-    typedef float R;
     constexpr int MB = kStepMB;
     const int B = P.B, npad = S.npad;
     // (readfirstlane: the chunk index derives from the wavefront's number and has to be a scalar for the buffer loads' offsets --
