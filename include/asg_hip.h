@@ -75,7 +75,7 @@ typedef struct asg_ctx asg_ctx;
 int asg_hip_version(void);
 const char *asg_hip_strerror(int status);
 
-/* Fault report (no reference counterpart): how many launches of the resident-slice forward kernel (fp32, 256 < N <= 2048:
+/* Fault report (no reference counterpart): how many launches of the resident-slice forward kernel (256 < N <= 2048 in fp32, <= 1024 in fp64:
  * a grid of co-resident workgroups that wait for each other) of THIS process ran out of their bounded waits -- part of the
  * grid never became resident.  Such a call returns NaN scores; from then on the library takes the per-frame launches (which need
  * no co-residency).  Read from host-pinned memory, no synchronisation; the count of a call is visible once that call has run. */
@@ -159,7 +159,7 @@ int asg_viterbi(asg_ctx *ctx, const asg_problem *p, void *work, size_t work_byte
 
 /* loss = reduce_b(full[b] - aligned[b]); `loss` is [B] (none) or [1]; `scores` is a [2][B] work buffer that
  * receives full_scores then aligned_scores.
- * Alphabets of 257 .. 1024 labels (.. 2048 while B <= 48), float32, in every forward entry point: the full-lattice
+ * Alphabets of 257 .. 1024 labels (float32: .. 2048 while B <= 48) in every forward entry point: the full-lattice
  * recursions of all frames are ONE launch whose workgroups wait for each other frame by frame (the transition matrix
  * stays in their registers), sized to the device's compute units.  It therefore wants the device to itself: another
  * kernel that keeps compute units for seconds (a second process running the same route, say) can keep part of the
