@@ -3518,7 +3518,12 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
                     }
                 }
                 ClusterArgs C{};
-                C.RW = P.N <= 512 ? 64 : P.N <= 1024 ? 32 : 16;
+                // (fp64 up to 512 labels: 32 rows per workgroup, not 64 -- at T=400 B=64 N=512 the product 8 500 -> 4 600 cycles per frame for
+                // +2 000 of epilogue, flags and reload with twice the peers: 16 600 -> 14 400 in all; 16 rows: 15 500)
+                C.RW = P.N <= 512 ? (sizeof(R) == 8 ? 32 : 64) : P.N <= 1024 ? 32 : 16;
+#ifdef ASG_DEV_PROBES
+                if (const char *ev = getenv("ASG_CL_RW")) C.RW = atoi(ev) == 16 || atoi(ev) == 32 || atoi(ev) == 64 ? atoi(ev) : C.RW;
+#endif
                 C.G = (P.N + C.RW - 1) / C.RW;
                 C.npadL = (W.npad + 255) / 256 * 256;
                 C.ndirs = (do_a && do_b) ? 2 : 1;
