@@ -1506,6 +1506,21 @@ __global__ void __launch_bounds__(ClusterThreads<R>::v) fwd_cluster_kernel(Probl
                 // (fp32, 8 / 16: +4 % at N = 1024, -7 / -15 % at N = 512 -- the matrix rows spill into AGPRs; fp64, 8: the reload 10 300 -> 9 450
                 // cycles at N = 1024, 3 350 -> 4 000 at N = 512; 16: spills, 7 100 / 9 800)
                 constexpr int RL = 4;
+                // fp64: the workgroups' maxima of q are requested FIRST and used last, their latency passes under the vectors' (step at
+                // T=400 B=64: N = 512 3.81 -> 3.72 ms, N = 1024 7.68 -> 7.46).  fp32 keeps them as a loop of its own after the copy: with
+                // 128 registers per lane the two more cost more than the round trip (N = 512 1.89 -> 1.94 ms, N = 1024 3.24 -> 3.28).
+                constexpr bool kMaxFirst = sizeof(R) == 8;
+                constexpr int XM = kMaxFirst ? 128 * kClNB / kClNT : 1;       // (G <= 128)
+                unsigned xk[XM];
+                if constexpr (kMaxFirst) {
+#pragma unroll
+                    for (int j = 0; j < XM; ++j) {
+                        const int idx = tid + kClNT * j, u = idx & (kClNB - 1);
+                        xk[j] = 0u;                           // (below every key)
+                        if (idx < C.G * kClNB && u < nb && n < lens[u] - 1)
+                            xk[j] = __hip_atomic_load(&xm[(size_t) par * C.G * kClNB + idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
                 for (int base = 0; base < total; base += kClNT * RL) {
                     ClU4 v[RL];
                     int dst[RL];
@@ -1522,10 +1537,17 @@ __global__ void __launch_bounds__(ClusterThreads<R>::v) fwd_cluster_kernel(Probl
                         if (dst[k] >= 0) *reinterpret_cast<ClU4 *>(reinterpret_cast<unsigned char *>(pl) + dst[k]) = v[k];
                 }
                 // the frame's normaliser: max q over the cluster's workgroups (keys: max is order-independent)
-                for (int idx = tid; idx < C.G * kClNB; idx += kClNT) {
-                    const int u = idx & (kClNB - 1);
-                    if (u < nb && n < lens[u] - 1)
-                        atomicMax(&pmax[u], __hip_atomic_load(&xm[(size_t) par * C.G * kClNB + idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                if constexpr (kMaxFirst) {
+#pragma unroll
+                    for (int j = 0; j < XM; ++j)
+                        if (xk[j] != 0u) atomicMax(&pmax[(tid + kClNT * j) & (kClNB - 1)], xk[j]);
+                } else {
+                    // (handing this loop to the LAST threads, which have no part of the copy at N = 512, measured slower: 1.90 -> 2.00 ms)
+                    for (int idx = tid; idx < C.G * kClNB; idx += kClNT) {
+                        const int u = idx & (kClNB - 1);
+                        if (u < nb && n < lens[u] - 1)
+                            atomicMax(&pmax[u], __hip_atomic_load(&xm[(size_t) par * C.G * kClNB + idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    }
                 }
             }
             __syncthreads();
