@@ -1066,6 +1066,30 @@ def test_streaming_step_two_batch_tiles(T, B, N, L, monkeypatch):
         util.assert_close(r1[k], r[k], 1e-5, "one vs two batch tiles T%d B%d N%d %s" % (T, B, N, k))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("mb", [3, 4, 5])
+@pytest.mark.parametrize("T,B,N,L", [(6, 3, 2100, 3), (5, 40, 2300, 2), (4, 70, 2600, 2), (5, 2, 4111, 2)])
+def test_streaming_step_tile_heights(T, B, N, L, mb, monkeypatch):
+    """The fp32 streaming step with 48-, 64- and 80-row tiles (ASG_STEP_ROW_BLOCKS; the library picks the height that fills the
+    device: step_row_blocks): the operand-order copies of the matrix, the K-slice exchange and the epilogue are laid out per
+    height.  One and several batch tiles, two tiles per workgroup (B = 70), a last row tile that is mostly padding; against the
+    fp64 oracle, and the evaluation route (one direction: a different slice count over the same layout)."""
+    tr, x, tg, il, tl = util.synth(T, B, N, L, N + mb, True)
+    o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il.numpy(), tl.numpy(), "none")
+    util.setenv(monkeypatch, "ASG_STEP_ROW_BLOCKS", mb)
+    r = run_hip(x, tg, tr, il, tl, "none")
+    for k in ("loss", "grad_inputs", "grad_transition"):
+        util.assert_close(r[k], o[k], 1e-4, "%d row blocks T%d B%d N%d %s" % (mb, T, B, N, k))
+    r2 = run_hip(x, tg, tr, il, tl, "none")
+    assert np.array_equal(r["grad_inputs"], r2["grad_inputs"]) and np.array_equal(r["loss"], r2["loss"])
+    A = _asg()
+    m = A.ASGLoss(N, reduction="none").to(DEV).eval()
+    with torch.no_grad():
+        m.transition.copy_(tr)
+        ev = m(x.to(DEV), tg.to(DEV), il.to(DEV), tl.to(DEV)).cpu().numpy()
+    util.assert_close(ev, o["loss"], 1e-4, "%d row blocks, evaluation route" % mb)
+
+
 # ------------------------------------------------------------------ long targets over a small alphabet (letter models)
 @pytest.mark.gpu
 @pytest.mark.parametrize("T,B,N,L", [(90, 3, 29, 65), (140, 2, 40, 128), (150, 3, 40, 129), (300, 2, 31, 200),

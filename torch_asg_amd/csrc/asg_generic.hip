@@ -527,30 +527,34 @@ typedef float V4f __attribute__((ext_vector_type(4)));
 #ifndef ASG_X_STEP_PF
 #define ASG_X_STEP_PF 1
 #endif
-#ifndef ASG_X_STEP_MB
-#define ASG_X_STEP_MB 5
-#endif
-constexpr int kStepMB = ASG_X_STEP_MB;      // 16-row blocks per workgroup: every workgroup reads the batch's whole vector
-                                            // set once (L2 traffic = row tiles x 1.3 MB), so tiles must not be too small
+constexpr int kStepMB = 5;                  // 16-row blocks per workgroup, at most: every workgroup reads the batch's whole vector
+                                            // set once (L2 traffic = row tiles x 1.3 MB), so tiles must not be too small.  3 or 4
+                                            // where that fills the device better (step_row_blocks: N = 3000 at B = 64 is 152 workgroups
+                                            // of 80 rows on 256 compute units, 252 of 48 rows)
 // The MFMA step's E operand, laid out so that every wavefront load is ONE contiguous kilobyte and a workgroup streams
 // its K quarter front to back: [row tile of 16 kStepMB rows][chunk of 32 k][row block m][half h][lane][4 floats], lane l =
 // row (l & 15) of the block, k = 32 chunk + 8 (l >> 4) + 4 h .. +3.  Row-major E handed the memory system 16 kStepMB x 4
 // interleaved 128-byte streams per workgroup (80 000 on the chip): 3 TB/s; zero-padded to whole tiles and chunks.
-__host__ __device__ inline size_t step_tile_floats(int N) {
+__host__ __device__ inline size_t step_tile_floats(int N, int mb) {
     const size_t npad = (size_t) (N + 3) / 4 * 4;
-    const size_t tiles = ((size_t) N + 16 * kStepMB - 1) / (16 * kStepMB), chunks = (npad + 31) / 32;
-    return tiles * chunks * kStepMB * 2 * 64 * 4;
+    const size_t tiles = ((size_t) N + 16 * mb - 1) / (16 * mb), chunks = (npad + 31) / 32;
+    return tiles * chunks * mb * 2 * 64 * 4;
 }
-__global__ void __launch_bounds__(256) tile_kernel(const float *src, int N, int npad, float *dst) {
+// (what the buffer is sized for: any tile height up to kStepMB)
+__host__ __device__ inline size_t step_tile_floats_max(int N) {
+    const size_t npad = (size_t) (N + 3) / 4 * 4;
+    return (((size_t) N + 15) / 16 + kStepMB) * ((npad + 31) / 32) * 2 * 64 * 4;
+}
+__global__ void __launch_bounds__(256) tile_kernel(const float *src, int N, int npad, int mb, float *dst) {
     const size_t chunks = ((size_t) npad + 31) / 32;
-    const size_t total = step_tile_floats(N) / 4;                 // float4 elements
+    const size_t total = step_tile_floats(N, mb) / 4;             // float4 elements
     for (size_t idx = (size_t) blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t) gridDim.x * 256) {
         const int lane = (int) (idx & 63);
         size_t rest = idx >> 6;
         const int h = (int) (rest & 1); rest >>= 1;
-        const int m = (int) (rest % kStepMB); rest /= kStepMB;
+        const int m = (int) (rest % mb); rest /= mb;
         const size_t c = rest % chunks, tile = rest / chunks;
-        const size_t row = tile * 16 * kStepMB + 16 * m + (lane & 15), k = 32 * c + 8 * (lane >> 4) + 4 * h;
+        const size_t row = tile * 16 * mb + 16 * m + (lane & 15), k = 32 * c + 8 * (lane >> 4) + 4 * h;
         V4f v = {0, 0, 0, 0};
         if (row < (size_t) N && k < (size_t) npad) v = *reinterpret_cast<const V4f *>(src + row * npad + k);
         reinterpret_cast<V4f *>(dst)[idx] = v;
@@ -560,18 +564,18 @@ __global__ void __launch_bounds__(256) tile_kernel(const float *src, int N, int 
 // What the frame's epilogue needs from memory, requested BEFORE the product: thread -> utterance 32 bt + (tid >> 3), rows
 // i0 + 16 (rr2 >> 1) + 2 (tid & 7) + (rr2 & 1).  (Loaded inside the epilogue, the 2 MB emission values of a thread -- each a miss all the
 // way to memory, behind a rarely taken branch hipcc will not load across -- cost the epilogue 7 of its 9 us at cfg 5.)
+template <int MB>
 struct StepPre {
     int b, len, t, tw;
     bool active;
     float muprev, emw;
-    float x[2 * kStepMB], hm[2 * kStepMB];          // raw emission at frame tw, hmax, of the thread's rows (0 where there is no row)
+    float x[2 * MB], hm[2 * MB];          // raw emission at frame tw, hmax, of the thread's rows (0 where there is no row)
 };
-template <bool BETA>
-__device__ __forceinline__ StepPre step_prefetch(const Problem &P, const StepBuf<float> &S, int n, int bt) {
-    constexpr int MB = kStepMB;
+template <bool BETA, int MB>
+__device__ __forceinline__ StepPre<MB> step_prefetch(const Problem &P, const StepBuf<float> &S, int n, int bt) {
     const int N = P.N, T = P.T, B = P.B;
     const int i0 = blockIdx.x * (16 * MB);
-    StepPre E;
+    StepPre<MB> E;
     E.b = bt * 32 + (int) (threadIdx.x >> 3);
     const bool bvalid = E.b < B;
     const int bc = bvalid ? E.b : 0;
@@ -600,11 +604,10 @@ __device__ __forceinline__ StepPre step_prefetch(const Problem &P, const StepBuf
 // registers, in its place: a fixed order whoever is last, so the result does not depend on the arrival order) and runs the epilogue.
 // Nobody waits for anybody.  Returns without doing anything in the workgroups that were not last.
 // NB batch tiles per workgroup: red[w][j MB 8 + ...] is batch tile j's part; nbt = batch tiles of the problem.
-template <bool BETA, int NB>
-__device__ __forceinline__ void step_epilogue(const Problem &P, const StepBuf<float> &S, int n, const float (*red)[NB * kStepMB * 8][64], int j,
-                                              const StepPre &E, int bt, int nbt, int slice, int ks) {
+template <bool BETA, int NB, int MB>
+__device__ __forceinline__ void step_epilogue(const Problem &P, const StepBuf<float> &S, int n, const float (*red)[NB * MB * 8][64], int j,
+                                              const StepPre<MB> &E, int bt, int nbt, int slice, int ks) {
     typedef float R;
-    constexpr int MB = kStepMB;
     const int N = P.N, T = P.T, B = P.B, npad = S.npad;
     const int i0 = blockIdx.x * (16 * MB);
     R *pnext = S.pbuf + (int64_t) ((n + 1) & 1) * B * npad;
@@ -719,17 +722,16 @@ __device__ long long g_step_probe[4096];
 #endif
 // NB batch tiles of 32 utterances per workgroup: every element of the matrix tile read from memory multiplies NB * 32 utterances
 // (B >= 64: the matrix is streamed ONCE per frame and direction instead of once per batch tile).  nbt = batch tiles of the problem.
-template <bool BETA, int NB>
-__device__ __forceinline__ void fwd_step_mfma(const Problem &P, const StepBuf<float> &S, int n, float (*red)[NB * kStepMB * 8][64], int ks, int nbt) {
-    constexpr int MB = kStepMB;
+template <bool BETA, int NB, int MB>
+__device__ __forceinline__ void fwd_step_mfma(const Problem &P, const StepBuf<float> &S, int n, float (*red)[NB * MB * 8][64], int ks, int nbt) {
     const int B = P.B, npad = S.npad;
     // (readfirstlane: the chunk index derives from the wavefront's number and has to be a scalar for the buffer loads' offsets --
     // "threadIdx.x >> 6" alone is not provably uniform, and a vector offset turns every load into a waterfall loop)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
     const int bt0 = (int) (blockIdx.y / ks) * NB, slice = blockIdx.y % ks;          // first batch tile of 32 utterances, slice of K
-    StepPre pre[NB];
+    StepPre<MB> pre[NB];
 #pragma unroll
-    for (int j = 0; j < NB; ++j) pre[j] = step_prefetch<BETA>(P, S, n, bt0 + j);
+    for (int j = 0; j < NB; ++j) pre[j] = step_prefetch<BETA, MB>(P, S, n, bt0 + j);
     {
         // lane l: row / utterance (l & 15), k sub-range 8 (l >> 4) .. +7 of every 32-k chunk: two float4 per operand, so a
         // row's whole 128-byte line goes to one wavefront at once
@@ -851,7 +853,7 @@ __device__ __forceinline__ void fwd_step_mfma(const Problem &P, const StepBuf<fl
 #endif
 #pragma unroll
     for (int j = 0; j < NB; ++j)
-        if (bt0 + j < nbt) step_epilogue<BETA, NB>(P, S, n, red, j, pre[j], bt0 + j, nbt, slice, ks);
+        if (bt0 + j < nbt) step_epilogue<BETA, NB, MB>(P, S, n, red, j, pre[j], bt0 + j, nbt, slice, ks);
 }
 
 template <typename R> struct StepUsesMfma { static constexpr bool v = false; };
@@ -861,17 +863,17 @@ template <> struct StepUsesMfma<float> { static constexpr bool v = true; };
 
 // blockIdx.z selects the direction, so the alpha and beta frames of one step share a launch (they are
 // independent chains): twice the workgroups in flight, half the launches.  fp32: blockIdx.y = batch tile x slice of K (ks slices).
-// NB (fp32): batch tiles of 32 utterances per workgroup; blockIdx.y = group of NB batch tiles x slice of K.
-template <typename R, int NB>
+// fp32: NB = batch tiles of 32 utterances per workgroup, MB = 16-row blocks per workgroup; blockIdx.y = group of NB batch tiles x slice of K.
+template <typename R, int NB, int MB>
 __global__ void __launch_bounds__(256) fwd_step_kernel(Problem P, StepBuf<R> Sa, StepBuf<R> Sb, int n, int dir_base, int ks) {
     if constexpr (StepUsesMfma<R>::v) {
-        __shared__ float red[4][NB * kStepMB * 8][64];
+        __shared__ float red[4][NB * MB * 8][64];
         const int nbt = (P.B + 31) / 32;
 #ifdef ASG_X_STEP_PROBE
         const long long t_begin = wall_clock64();
 #endif
-        if ((int) blockIdx.z + dir_base == 0) fwd_step_mfma<false, NB>(P, Sa, n, red, ks, nbt);
-        else fwd_step_mfma<true, NB>(P, Sb, n, red, ks, nbt);
+        if ((int) blockIdx.z + dir_base == 0) fwd_step_mfma<false, NB, MB>(P, Sa, n, red, ks, nbt);
+        else fwd_step_mfma<true, NB, MB>(P, Sb, n, red, ks, nbt);
 #ifdef ASG_X_STEP_PROBE
         {
             // frame 20: every workgroup stamps begin / product done / end (100 MHz ticks); frame 30: one thread prints the summary
@@ -3359,6 +3361,55 @@ unsigned cluster_timeouts() {
 }
 
 // ---------------------------------------------------------------------------------------------- host side
+static int device_cus() {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
+        (void) hipGetLastError();
+        cus = 256;
+    }
+    return cus;
+}
+// Shape of the fp32 streaming step's grid: MB 16-row blocks per workgroup (3 .. kStepMB) and ks slices of K (1 .. kStepMaxSlices, at least
+// ~8 chunks of 32 k each), chosen by a cost model fitted to measurements (tools/step_mb_time.sh, tools/step_ks_time.sh; T=400, B = 32 .. 128,
+// N = 1500 .. 7000): a frame costs
+//     rounds x (MB x chunks per slice x batch tiles per workgroup x 48 ns  +  (ks - 1) x 4.5 us),   rounds = ceil(workgroups / compute units)
+// -- the product of one workgroup, and the partial-sum exchange of its slices (write-through stores, a ticket, the last arriver's reads).
+// It orders every measured pair correctly: N = 3000 at B = 64 takes 48-row tiles (252 workgroups) instead of 80-row ones (152 on 256
+// compute units): 51.4 -> 42.4 us per frame; N = 2100: 48-row tiles WITHOUT slices beat 80-row tiles with two (33.0 against 36.9);
+// N = 3500 / 4000: 64-row tiles; N = 5000 and cfg 5: 80.
+constexpr int kStepMaxSlices = 8;
+static double step_cost(int N, int groups, int dirs, int nb, int mb, int ks, int cus) {
+    const int nchunks = ((N + 3) / 4 * 4 + 31) / 32;
+    const long wgs = (long) ((N + 16 * mb - 1) / (16 * mb)) * groups * dirs * ks, rounds = (wgs + cus - 1) / cus;
+    return (double) rounds * ((double) mb * ((nchunks + ks - 1) / ks) * nb * 0.048 + (ks - 1) * 4.5);
+}
+static int step_slices(int N, int groups, int dirs, int nb, int mb, int cus) {
+    const int nchunks = ((N + 3) / 4 * 4 + 31) / 32;
+    int best = 1;
+    double best_cost = step_cost(N, groups, dirs, nb, mb, 1, cus);
+    for (int ks = 2; ks <= kStepMaxSlices && ks <= nchunks / 8; ++ks) {
+        const double c = step_cost(N, groups, dirs, nb, mb, ks, cus);
+        if (c < best_cost) { best = ks; best_cost = c; }
+    }
+    return best;
+}
+// batch tiles of 32 utterances per workgroup of the fp32 streaming step: two when B > 64 (see launch_fwd_generic)
+static int step_batch_tiles(int B) {
+    return (knobs().step_one_tile >= 0 ? (knobs().step_one_tile == 0 && B > 32) : B > 64) ? 2 : 1;
+}
+// The tile height is a function of the problem's shape only: the operand-order copies of the matrix are laid out for it before the
+// recursion knows which directions it runs (priced for both; the evaluation route runs one and re-prices its slices).
+static int step_row_blocks(int N, int B, int cus) {
+    if (knobs().step_row_blocks >= 3 && knobs().step_row_blocks <= kStepMB) return knobs().step_row_blocks;
+    const int nb = step_batch_tiles(B), groups = ((B + 31) / 32 + nb - 1) / nb;
+    int best = kStepMB;
+    double best_cost = 0;
+    for (int mb = kStepMB; mb >= 3; --mb) {
+        const double c = step_cost(N, groups, 2, nb, mb, step_slices(N, groups, 2, nb, mb, cus), cus);
+        if (mb == kStepMB || c < best_cost) { best = mb; best_cost = c; }
+    }
+    return best;
+}
 template <typename R>
 hipError_t launch_prep_generic(const Problem &P, const State &W, hipStream_t stream) {
     hipLaunchKernelGGL((prep_kernel<R, false>), dim3(P.N), dim3(256), 0, stream, (const R *) P.transition, P.ts0, P.ts1,
@@ -3380,14 +3431,15 @@ hipError_t launch_prep_generic(const Problem &P, const State &W, hipStream_t str
     }
     if constexpr (StepUsesMfma<R>::v) {
         if (!W.etile || !W.ftile) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(tile_kernel, dim3(4096), dim3(256), 0, stream, (const float *) W.ehat, P.N, W.npad, (float *) W.etile);
-        hipLaunchKernelGGL(tile_kernel, dim3(4096), dim3(256), 0, stream, (const float *) W.fhat, P.N, W.npad, (float *) W.ftile);
+        const int mb = step_row_blocks(P.N, P.B, device_cus());
+        hipLaunchKernelGGL(tile_kernel, dim3(4096), dim3(256), 0, stream, (const float *) W.ehat, P.N, W.npad, mb, (float *) W.etile);
+        hipLaunchKernelGGL(tile_kernel, dim3(4096), dim3(256), 0, stream, (const float *) W.fhat, P.N, W.npad, mb, (float *) W.ftile);
     }
     return hipGetLastError();
 }
 
 size_t step_tile_bytes_generic(int elem, int N) {
-    return (elem == 4 && StepUsesMfma<float>::v) ? step_tile_floats(N) * sizeof(float) : 0;
+    return (elem == 4 && StepUsesMfma<float>::v) ? step_tile_floats_max(N) * sizeof(float) : 0;
 }
 
 // the vectors of the fp32 streaming step a second time, in operand order (step_ptile_index): two frames per direction, behind the
@@ -3396,17 +3448,12 @@ static size_t step_ptile_bytes(int elem, int B, int N) {
     if (!(elem == 4 && StepUsesMfma<float>::v)) return 0;
     return au(2 * step_ptile_floats(B, (N + 3) / 4 * 4) * sizeof(float));
 }
-// K slices of the fp32 streaming step (fwd_step_mfma): as many as fill the device, at least ~8 chunks of 32 k each, at most kStepMaxSlices
-constexpr int kStepMaxSlices = 8;
-static int step_slices(int workgroups, int nchunks, int cus) {
-    int ks = cus / (workgroups > 0 ? workgroups : 1);
-    if (ks > nchunks / 8) ks = nchunks / 8;
-    if (ks > kStepMaxSlices) ks = kStepMaxSlices;
-    return ks < 1 ? 1 : ks;
+// tickets and partial sums of the K slices, sized for any tile height: one ticket per (row tile, batch tile) -- most at 3 row blocks --
+// and 2 MB x 256 floats per slice and tile, row tiles x MB <= N / 16 + kStepMB
+static size_t step_ticket_bytes(int B, int N) { return au((size_t) ((N + 47) / 48) * ((B + 31) / 32) * sizeof(unsigned)); }
+static size_t step_partial_bytes(int B, int N) {
+    return au((size_t) ((N + 15) / 16 + kStepMB) * ((B + 31) / 32) * kStepMaxSlices * 2 * 256 * sizeof(float));
 }
-static size_t step_tiles(int B, int N) { return (size_t) ((N + 16 * kStepMB - 1) / (16 * kStepMB)) * ((B + 31) / 32); }
-static size_t step_ticket_bytes(int B, int N) { return au(step_tiles(B, N) * sizeof(unsigned)); }
-static size_t step_partial_bytes(int B, int N) { return au(step_tiles(B, N) * kStepMaxSlices * (2 * kStepMB) * 256 * sizeof(float)); }
 // forward work buffers live behind the saved state (see fwd_work_bytes_generic): emax, pbuf x2 dirs, mu, off
 size_t fwd_work_bytes_generic(int elem, int T, int B, int N) {
     const size_t npad = (size_t) (N + 3) / 4 * 4;
@@ -3612,30 +3659,36 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
             }
         }
         if (!stepped) {
-            // fp32: K split over ks workgroups per (row tile, batch tile) so that the grid fills the device: 160-row tiles halve the
-            // vector traffic per byte of the matrix (at cfg 5: 63 row tiles x 2 directions x 2 slices = 252 workgroups)
+            // fp32: row tiles of 48 / 64 / 80 rows and K split over ks workgroups per (row tile, batch tile), whichever grid the cost model
+            // prices lowest (step_cost; cfg 5: 125 row tiles of 80 rows x 2 directions, no slices = 250 workgroups).
             // B > 64: two batch tiles of 32 utterances per workgroup -- the matrix streamed once per frame and direction for both.
             // (T=400, N=3000, B=128: 99 us per frame against 122; B=96, N=5000: 150 against 182.  At B = 64 the same form LOSES --
             // N=1500: 38 against 26 us, N=3000: 58 against 52, N=5000: 99 against 92: the two batch tiles' workgroups of a row tile
             // run side by side and share the matrix lines in L2 already, the product is bound by the matrix instruction either way,
             // and half the workgroups means twice the K slices and their exchange.  ASG_STEP_ONE_TILE=1/0 forces either form.)
-            int ks = 1, nb = 1;
+            int ks = 1, nb = 1, mb = kStepMB;
             if constexpr (StepUsesMfma<R>::v) {
-                nb = (knobs().step_one_tile >= 0 ? (knobs().step_one_tile == 0 && P.B > 32) : P.B > 64) ? 2 : 1;
+                const int cus = device_cus();
+                nb = step_batch_tiles(P.B);
+                mb = step_row_blocks(P.N, P.B, cus);          // (the height launch_prep_generic laid the operand-order copies out for)
+                sgrid.x = (P.N + 16 * mb - 1) / (16 * mb);
                 sgrid.y = (sgrid.y + nb - 1) / nb;
-                int dev = 0, cus = 0;
-                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-                    cus = 256;
-                ks = step_slices((int) (sgrid.x * sgrid.y * sgrid.z), (W.npad + 31) / 32, cus);
+                ks = step_slices(P.N, (int) sgrid.y, (int) sgrid.z, nb, mb, cus);
 #ifdef ASG_DEV_PROBES
                 if (const char *ev = getenv("ASG_STEP_KS")) ks = atoi(ev) >= 1 && atoi(ev) <= kStepMaxSlices ? atoi(ev) : ks;
+                if (getenv("ASG_STEP_SHOW")) fprintf(stderr, "[step grid] N=%d B=%d: %d row blocks, %d batch tile(s) per workgroup, %d slice(s), %u workgroups\n", P.N, P.B, mb, nb, ks, sgrid.x * sgrid.y * ks * sgrid.z);
 #endif
                 sgrid.y *= ks;
             }
             for (int n = 0; n + 1 < P.T; ++n) {
-                if constexpr (StepUsesMfma<R>::v)
-                    if (nb == 2) { hipLaunchKernelGGL((fwd_step_kernel<R, 2>), sgrid, dim3(256), 0, stream, P, Sd[0], Sd[1], n, do_a ? 0 : 1, ks); continue; }
-                hipLaunchKernelGGL((fwd_step_kernel<R, 1>), sgrid, dim3(256), 0, stream, P, Sd[0], Sd[1], n, do_a ? 0 : 1, ks);
+                if constexpr (StepUsesMfma<R>::v) {
+#define ASG_STEP_LAUNCH(NB_, MB_) hipLaunchKernelGGL((fwd_step_kernel<R, NB_, MB_>), sgrid, dim3(256), 0, stream, P, Sd[0], Sd[1], n, do_a ? 0 : 1, ks)
+                    if (nb == 2) { if (mb == 3) ASG_STEP_LAUNCH(2, 3); else if (mb == 4) ASG_STEP_LAUNCH(2, 4); else ASG_STEP_LAUNCH(2, 5); }
+                    else { if (mb == 3) ASG_STEP_LAUNCH(1, 3); else if (mb == 4) ASG_STEP_LAUNCH(1, 4); else ASG_STEP_LAUNCH(1, 5); }
+#undef ASG_STEP_LAUNCH
+                } else {
+                    hipLaunchKernelGGL((fwd_step_kernel<R, 1, kStepMB>), sgrid, dim3(256), 0, stream, P, Sd[0], Sd[1], n, do_a ? 0 : 1, ks);
+                }
             }
         }
         if (do_b)
