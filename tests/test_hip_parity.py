@@ -1067,10 +1067,10 @@ def test_streaming_step_two_batch_tiles(T, B, N, L, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mb", [3, 4, 5])
+@pytest.mark.parametrize("mb", [2, 3, 4, 5])
 @pytest.mark.parametrize("T,B,N,L", [(6, 3, 2100, 3), (5, 40, 2300, 2), (4, 70, 2600, 2), (5, 2, 4111, 2)])
 def test_streaming_step_tile_heights(T, B, N, L, mb, monkeypatch):
-    """The fp32 streaming step with 48-, 64- and 80-row tiles (ASG_STEP_ROW_BLOCKS; the library picks the height that fills the
+    """The fp32 streaming step with 32-, 48-, 64- and 80-row tiles (ASG_STEP_ROW_BLOCKS; the library picks the height that fills the
     device: step_row_blocks): the operand-order copies of the matrix, the K-slice exchange and the epilogue are laid out per
     height.  One and several batch tiles, two tiles per workgroup (B = 70), a last row tile that is mostly padding; against the
     fp64 oracle, and the evaluation route (one direction: a different slice count over the same layout)."""

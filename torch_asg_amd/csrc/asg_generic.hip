@@ -3369,19 +3369,20 @@ static int device_cus() {
     }
     return cus;
 }
-// Shape of the fp32 streaming step's grid: MB 16-row blocks per workgroup (3 .. kStepMB) and ks slices of K (1 .. kStepMaxSlices, at least
+// Shape of the fp32 streaming step's grid: MB 16-row blocks per workgroup (kStepMBMin .. kStepMB) and ks slices of K (1 .. kStepMaxSlices, at least
 // ~8 chunks of 32 k each), chosen by a cost model fitted to measurements (tools/step_mb_time.sh, tools/step_ks_time.sh; T=400, B = 32 .. 128,
 // N = 1500 .. 7000): a frame costs
-//     rounds x (MB x chunks per slice x batch tiles per workgroup x 48 ns  +  (ks - 1) x 4.5 us),   rounds = ceil(workgroups / compute units)
-// -- the product of one workgroup, and the partial-sum exchange of its slices (write-through stores, a ticket, the last arriver's reads).
+//     rounds x ((MB x 48 ns + 20 ns) x chunks per slice x batch tiles per workgroup  +  (ks - 1) x 4.5 us),   rounds = ceil(workgroups / compute units)
+// -- the product of one workgroup over its rows, its read of the batch's vectors (whatever its height), and the partial-sum exchange of
+// its slices (write-through stores, a ticket, the last arriver's reads).
 // It orders every measured pair correctly: N = 3000 at B = 64 takes 48-row tiles (252 workgroups) instead of 80-row ones (152 on 256
 // compute units): 51.4 -> 42.4 us per frame; N = 2100: 48-row tiles WITHOUT slices beat 80-row tiles with two (33.0 against 36.9);
 // N = 3500 / 4000: 64-row tiles; N = 5000 and cfg 5: 80.
-constexpr int kStepMaxSlices = 8;
+constexpr int kStepMaxSlices = 8, kStepMBMin = 2;
 static double step_cost(int N, int groups, int dirs, int nb, int mb, int ks, int cus) {
     const int nchunks = ((N + 3) / 4 * 4 + 31) / 32;
     const long wgs = (long) ((N + 16 * mb - 1) / (16 * mb)) * groups * dirs * ks, rounds = (wgs + cus - 1) / cus;
-    return (double) rounds * ((double) mb * ((nchunks + ks - 1) / ks) * nb * 0.048 + (ks - 1) * 4.5);
+    return (double) rounds * (((double) mb * 0.048 + 0.02) * ((nchunks + ks - 1) / ks) * nb + (ks - 1) * 4.5);
 }
 static int step_slices(int N, int groups, int dirs, int nb, int mb, int cus) {
     const int nchunks = ((N + 3) / 4 * 4 + 31) / 32;
@@ -3400,11 +3401,11 @@ static int step_batch_tiles(int B) {
 // The tile height is a function of the problem's shape only: the operand-order copies of the matrix are laid out for it before the
 // recursion knows which directions it runs (priced for both; the evaluation route runs one and re-prices its slices).
 static int step_row_blocks(int N, int B, int cus) {
-    if (knobs().step_row_blocks >= 3 && knobs().step_row_blocks <= kStepMB) return knobs().step_row_blocks;
+    if (knobs().step_row_blocks >= kStepMBMin && knobs().step_row_blocks <= kStepMB) return knobs().step_row_blocks;
     const int nb = step_batch_tiles(B), groups = ((B + 31) / 32 + nb - 1) / nb;
     int best = kStepMB;
     double best_cost = 0;
-    for (int mb = kStepMB; mb >= 3; --mb) {
+    for (int mb = kStepMB; mb >= kStepMBMin; --mb) {
         const double c = step_cost(N, groups, 2, nb, mb, step_slices(N, groups, 2, nb, mb, cus), cus);
         if (mb == kStepMB || c < best_cost) { best = mb; best_cost = c; }
     }
@@ -3450,7 +3451,7 @@ static size_t step_ptile_bytes(int elem, int B, int N) {
 }
 // tickets and partial sums of the K slices, sized for any tile height: one ticket per (row tile, batch tile) -- most at 3 row blocks --
 // and 2 MB x 256 floats per slice and tile, row tiles x MB <= N / 16 + kStepMB
-static size_t step_ticket_bytes(int B, int N) { return au((size_t) ((N + 47) / 48) * ((B + 31) / 32) * sizeof(unsigned)); }
+static size_t step_ticket_bytes(int B, int N) { return au((size_t) ((N + 31) / 32) * ((B + 31) / 32) * sizeof(unsigned)); }
 static size_t step_partial_bytes(int B, int N) {
     return au((size_t) ((N + 15) / 16 + kStepMB) * ((B + 31) / 32) * kStepMaxSlices * 2 * 256 * sizeof(float));
 }
@@ -3683,8 +3684,8 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
             for (int n = 0; n + 1 < P.T; ++n) {
                 if constexpr (StepUsesMfma<R>::v) {
 #define ASG_STEP_LAUNCH(NB_, MB_) hipLaunchKernelGGL((fwd_step_kernel<R, NB_, MB_>), sgrid, dim3(256), 0, stream, P, Sd[0], Sd[1], n, do_a ? 0 : 1, ks)
-                    if (nb == 2) { if (mb == 3) ASG_STEP_LAUNCH(2, 3); else if (mb == 4) ASG_STEP_LAUNCH(2, 4); else ASG_STEP_LAUNCH(2, 5); }
-                    else { if (mb == 3) ASG_STEP_LAUNCH(1, 3); else if (mb == 4) ASG_STEP_LAUNCH(1, 4); else ASG_STEP_LAUNCH(1, 5); }
+                    if (nb == 2) { if (mb == 2) ASG_STEP_LAUNCH(2, 2); else if (mb == 3) ASG_STEP_LAUNCH(2, 3); else if (mb == 4) ASG_STEP_LAUNCH(2, 4); else ASG_STEP_LAUNCH(2, 5); }
+                    else { if (mb == 2) ASG_STEP_LAUNCH(1, 2); else if (mb == 3) ASG_STEP_LAUNCH(1, 3); else if (mb == 4) ASG_STEP_LAUNCH(1, 4); else ASG_STEP_LAUNCH(1, 5); }
 #undef ASG_STEP_LAUNCH
                 } else {
                     hipLaunchKernelGGL((fwd_step_kernel<R, 1, kStepMB>), sgrid, dim3(256), 0, stream, P, Sd[0], Sd[1], n, do_a ? 0 : 1, ks);
