@@ -159,7 +159,7 @@ int asg_viterbi(asg_ctx *ctx, const asg_problem *p, void *work, size_t work_byte
 
 /* loss = reduce_b(full[b] - aligned[b]); `loss` is [B] (none) or [1]; `scores` is a [2][B] work buffer that
  * receives full_scores then aligned_scores.
- * Alphabets of 257 .. 1024 labels (float32: .. 2048 while B <= 48) in every forward entry point: the full-lattice
+ * Alphabets of 257 .. 1024 labels (float32: .. 2048 while B <= 16) in every forward entry point: the full-lattice
  * recursions of all frames are ONE launch whose workgroups wait for each other frame by frame (the transition matrix
  * stays in their registers), sized to the device's compute units.  It therefore wants the device to itself: another
  * kernel that keeps compute units for seconds (a second process running the same route, say) can keep part of the

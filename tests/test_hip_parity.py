@@ -1130,7 +1130,7 @@ def test_long_targets_small_alphabet(T, B, N, L, dtype, rtol):
                                        (20, 3, 1025, 4), (16, 20, 1500, 3), (14, 2, 2048, 3), (8, 50, 2000, 2)])
 @pytest.mark.parametrize("dtype,rtol,cross", [(torch.float32, 1e-4, 3e-5), (torch.float64, 1e-9, 1e-11)])
 def test_resident_slice_alphabets(T, B, N, L, dtype, rtol, cross, monkeypatch):
-    """256 < N <= 2048 in fp32 (beyond 1024 labels: up to 48 utterances; (8, 50, 2000, 2) takes the launch per frame), 256 < N <= 1024 in
+    """256 < N <= 2048 in fp32 (beyond 1024 labels: up to 16 utterances; (16, 20, 1500, 3) and (8, 50, 2000, 2) take the launch per frame), 256 < N <= 1024 in
     fp64 (v_mfma_f64_16x16x4_f64, workgroups of 512 threads; beyond that the fp64 cases below run the launch per frame both times):
     all frames of the full-lattice recursions in ONE launch (fwd_cluster_kernel: the matrix
     stays in the registers of a cluster of workgroups that exchange the frame's vectors through write-through stores

@@ -3605,9 +3605,11 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
                 const int ncl = C.ndirs * C.ncd;
                 char *ca = bar_area - kClusterBytes;
                 const size_t xb = au(cluster_xbuf_floats(ncl, C.npadL) * sizeof(R)), xmb = au((size_t) ncl * 2 * C.G * kClNB * 4), flb = au((size_t) ncl * C.G * 4);
-                // beyond 1024 labels a cluster is half the device (one per direction) and takes the batch 16 chains at a time:
-                // worth it up to three rounds (B <= 48), after that the launch per frame (32 us for ALL chains) is the faster one
-                const bool few_rounds = P.N <= 1024 || (C.cpc + kClNB - 1) / kClNB <= 3;
+                // beyond 1024 labels a cluster is half the device (one per direction) and takes the batch 16 chains at a time: worth it
+                // for ONE round (B <= 16).  (Round 4: up to three; since the streaming step picks its tile height the launch per frame wins
+                // from two rounds on -- ms per step at T=400, cluster / launch per frame: N = 1500 B = 16 3.65 / 5.60, B = 32 6.97 / 6.32,
+                // B = 48 10.5 / 7.6; N = 2048 B = 16 4.15 / 6.95, B = 32 7.93 / 8.02, B = 48 11.96 / 8.72.)
+                const bool few_rounds = P.N <= 1024 || (C.cpc + kClNB - 1) / kClNB <= 1;
                 // (at least 84 KB of LDS: a compute unit then holds ONE of these workgroups -- two on one unit would share its
                 // matrix pipes and make their whole clusters wait, while other units stay empty)
                 size_t lds = ((size_t) kClNB * C.npadL + (size_t) (kClNT / 64) * 16 * kClNB) * sizeof(R);
