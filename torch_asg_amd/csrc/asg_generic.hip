@@ -527,6 +527,15 @@ typedef float V4f __attribute__((ext_vector_type(4)));
 #ifndef ASG_X_STEP_PF
 #define ASG_X_STEP_PF 1
 #endif
+#ifndef ASG_X_STEP_PF_MB2
+#define ASG_X_STEP_PF_MB2 1
+#endif
+#ifndef ASG_X_STEP_PF_MB3
+#define ASG_X_STEP_PF_MB3 1
+#endif
+#ifndef ASG_X_STEP_PF_MB4
+#define ASG_X_STEP_PF_MB4 1
+#endif
 constexpr int kStepMB = 5;                  // 16-row blocks per workgroup, at most: every workgroup reads the batch's whole vector
                                             // set once (L2 traffic = row tiles x 1.3 MB), so tiles must not be too small.  3 or 4
                                             // where that fills the device better (step_row_blocks: N = 3000 at B = 64 is 152 workgroups
@@ -817,7 +826,7 @@ __device__ __forceinline__ void fwd_step_mfma(const Problem &P, const StepBuf<fl
         if (c0 < c1) {
             // STG stages: STG - 1 chunks of loads in flight while one is multiplied.  (A compute unit holds one of these
             // workgroups = one wavefront per SIMD: the depth has to come from the pipeline.)
-            constexpr int STG = ASG_X_STEP_PF + 1;
+            constexpr int STG = (MB == 2 ? ASG_X_STEP_PF_MB2 : MB == 3 ? ASG_X_STEP_PF_MB3 : MB == 4 ? ASG_X_STEP_PF_MB4 : ASG_X_STEP_PF) + 1;
             Stage st[STG];
 #pragma unroll
             for (int u = 0; u < STG - 1; ++u) {
