@@ -367,6 +367,8 @@ def extras(args):
     # not a BASELINE config either: a word-piece sized alphabet (between cfg 3's 40 labels and cfg 5's 10^4) -- the matrix
     # stays in the registers of a cluster of workgroups for all frames (fwd_cluster_kernel)
     attempt("alphabet_512", lambda: time_small_config("512 labels (not a BASELINE config)", 400, 64, 512, 30, True, 10))
+    # and a sub-word sized one that takes a launch per frame (fwd_step_kernel: 48-row tiles here, 252 workgroups) -- verdict r4, Missing #4
+    attempt("alphabet_3000", lambda: time_small_config("3000 labels (not a BASELINE config)", 400, 64, 3000, 30, True, 4))
     attempt("cfg5", lambda: measure_cfg5(3, 1))
     return ex
 
