@@ -581,9 +581,9 @@ struct StepPre {
     float x[2 * MB], hm[2 * MB];          // raw emission at frame tw, hmax, of the thread's rows (0 where there is no row)
 };
 template <bool BETA, int MB>
-__device__ __forceinline__ StepPre<MB> step_prefetch(const Problem &P, const StepBuf<float> &S, int n, int bt) {
+__device__ __forceinline__ StepPre<MB> step_prefetch(const Problem &P, const StepBuf<float> &S, int n, int row_tile, int bt) {
     const int N = P.N, T = P.T, B = P.B;
-    const int i0 = blockIdx.x * (16 * MB);
+    const int i0 = row_tile * (16 * MB);
     StepPre<MB> E;
     E.b = bt * 32 + (int) (threadIdx.x >> 3);
     const bool bvalid = E.b < B;
@@ -615,10 +615,10 @@ __device__ __forceinline__ StepPre<MB> step_prefetch(const Problem &P, const Ste
 // NB batch tiles per workgroup: red[w][j MB 8 + ...] is batch tile j's part; nbt = batch tiles of the problem.
 template <bool BETA, int NB, int MB>
 __device__ __forceinline__ void step_epilogue(const Problem &P, const StepBuf<float> &S, int n, const float (*red)[NB * MB * 8][64], int j,
-                                              const StepPre<MB> &E, int bt, int nbt, int slice, int ks) {
+                                              const StepPre<MB> &E, int row_tile, int bt, int nbt, int slice, int ks) {
     typedef float R;
     const int N = P.N, T = P.T, B = P.B, npad = S.npad;
-    const int i0 = blockIdx.x * (16 * MB);
+    const int i0 = row_tile * (16 * MB);
     R *pnext = S.pbuf + (int64_t) ((n + 1) & 1) * B * npad;
     const int ut = threadIdx.x >> 3, b = E.b;
     R sums[2 * MB];
@@ -630,7 +630,7 @@ __device__ __forceinline__ void step_epilogue(const Problem &P, const StepBuf<fl
     }
     if (ks > 1) {
         __shared__ int last_arrival;
-        const size_t tile = (size_t) blockIdx.x * nbt + bt;
+        const size_t tile = (size_t) row_tile * nbt + bt;
         R *mine = S.partial + ((tile * ks + slice) * (2 * MB)) * 256 + threadIdx.x;
 #pragma unroll
         for (int rr2 = 0; rr2 < 2 * MB; ++rr2) __hip_atomic_store(mine + rr2 * 256, sums[rr2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -731,21 +731,24 @@ __device__ long long g_step_probe[4096];
 #endif
 // NB batch tiles of 32 utterances per workgroup: every element of the matrix tile read from memory multiplies NB * 32 utterances
 // (B >= 64: the matrix is streamed ONCE per frame and direction instead of once per batch tile).  nbt = batch tiles of the problem.
-template <bool BETA, int NB, int MB>
-__device__ __forceinline__ void fwd_step_mfma(const Problem &P, const StepBuf<float> &S, int n, float (*red)[NB * MB * 8][64], int ks, int nbt) {
+// NT: the matrix loads are non-temporal (the matrices do not fit the 256 MB memory-side cache and no other workgroup wants the same
+// tile) or take the default policy (they fit and stay there from frame to frame, or sibling workgroups share the tile through the L2).
+template <bool BETA, int NB, int MB, bool NT>
+__device__ __forceinline__ void fwd_step_mfma(const Problem &P, const StepBuf<float> &S, int n, float (*red)[NB * MB * 8][64], int ks, int nbt,
+                                              int row_tile, int group, int slice) {
     const int B = P.B, npad = S.npad;
     // (readfirstlane: the chunk index derives from the wavefront's number and has to be a scalar for the buffer loads' offsets --
     // "threadIdx.x >> 6" alone is not provably uniform, and a vector offset turns every load into a waterfall loop)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
-    const int bt0 = (int) (blockIdx.y / ks) * NB, slice = blockIdx.y % ks;          // first batch tile of 32 utterances, slice of K
+    const int bt0 = group * NB;          // first batch tile of 32 utterances
     StepPre<MB> pre[NB];
 #pragma unroll
-    for (int j = 0; j < NB; ++j) pre[j] = step_prefetch<BETA, MB>(P, S, n, bt0 + j);
+    for (int j = 0; j < NB; ++j) pre[j] = step_prefetch<BETA, MB>(P, S, n, row_tile, bt0 + j);
     {
         // lane l: row / utterance (l & 15), k sub-range 8 (l >> 4) .. +7 of every 32-k chunk: two float4 per operand, so a
         // row's whole 128-byte line goes to one wavefront at once
         const size_t nchunks = ((size_t) npad + 31) / 32;
-        const V4f *et = reinterpret_cast<const V4f *>(S.etile) + (size_t) blockIdx.x * nchunks * (MB * 2 * 64) + lane;
+        const V4f *et = reinterpret_cast<const V4f *>(S.etile) + (size_t) row_tile * nchunks * (MB * 2 * 64) + lane;
         // the vectors in operand order (step_ptile_index): kilobyte (chunk, utterance half, h) of a batch tile, position `lane`
         const V4f *pt = reinterpret_cast<const V4f *>(S.ptile + (size_t) (n & 1) * step_ptile_floats(B, npad)) + lane;
         // K in chunks of 32 (the matrix tile and the vectors are zero-padded to whole chunks: every load is unconditional -- a
@@ -789,7 +792,7 @@ __device__ __forceinline__ void fwd_step_mfma(const Problem &P, const StepBuf<fl
                     }
 #pragma unroll
                     for (int m = 0; m < MB; ++m)          // (aux 2 = non-temporal: see below)
-                        st.e[m][h] = __builtin_bit_cast(V4f, (RawU4) __builtin_amdgcn_raw_buffer_load_b128(rsE, vlane, ce + (m * 2 + h) * 1024u, 2));
+                        st.e[m][h] = __builtin_bit_cast(V4f, (RawU4) __builtin_amdgcn_raw_buffer_load_b128(rsE, vlane, ce + (m * 2 + h) * 1024u, NT ? 2 : 0));
                     continue;
                 }
 #pragma unroll
@@ -802,7 +805,7 @@ __device__ __forceinline__ void fwd_step_mfma(const Problem &P, const StepBuf<fl
                 for (int m = 0; m < MB; ++m) {
                     // (non-temporal: every element of the matrix is used once per frame, and the lines it would displace in
                     // L2 are the batch's vectors that all workgroups of the XCD read: 144.4 -> 137.9 us per frame at cfg 5)
-                    st.e[m][h] = __builtin_nontemporal_load(&et[((size_t) c * MB * 2 + m * 2 + h) * 64]);
+                    st.e[m][h] = NT ? __builtin_nontemporal_load(&et[((size_t) c * MB * 2 + m * 2 + h) * 64]) : et[((size_t) c * MB * 2 + m * 2 + h) * 64];
                 }
             }
         };
@@ -858,11 +861,11 @@ __device__ __forceinline__ void fwd_step_mfma(const Problem &P, const StepBuf<fl
     }
     __syncthreads();
 #ifdef ASG_X_STEP_PROBE
-    if (n == 20 && threadIdx.x == 0) { const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x; if (wg < 1024) g_step_probe[wg * 4 + 1] = wall_clock64(); }
+    if (n == 20 && threadIdx.x == 0) { const int wg = blockIdx.x; if (wg < 1024) g_step_probe[wg * 4 + 1] = wall_clock64(); }
 #endif
 #pragma unroll
     for (int j = 0; j < NB; ++j)
-        if (bt0 + j < nbt) step_epilogue<BETA, NB, MB>(P, S, n, red, j, pre[j], bt0 + j, nbt, slice, ks);
+        if (bt0 + j < nbt) step_epilogue<BETA, NB, MB>(P, S, n, red, j, pre[j], row_tile, bt0 + j, nbt, slice, ks);
 }
 
 template <typename R> struct StepUsesMfma { static constexpr bool v = false; };
@@ -870,29 +873,41 @@ template <typename R> struct StepUsesMfma { static constexpr bool v = false; };
 template <> struct StepUsesMfma<float> { static constexpr bool v = true; };
 #endif
 
-// blockIdx.z selects the direction, so the alpha and beta frames of one step share a launch (they are
-// independent chains): twice the workgroups in flight, half the launches.  fp32: blockIdx.y = batch tile x slice of K (ks slices).
-// fp32: NB = batch tiles of 32 utterances per workgroup, MB = 16-row blocks per workgroup; blockIdx.y = group of NB batch tiles x slice of K.
+// The alpha and beta frames of one step share a launch (they are independent chains): twice the workgroups in flight, half the launches.
+// fp64: blockIdx.z selects the direction.  fp32 (NB = batch tiles of 32 utterances per workgroup, MB = 16-row blocks per workgroup): a
+// one-dimensional grid of (row tile, slice of K, direction) units x `groups` batch tile groups, laid out so that the workgroups of one unit
+// -- which stream the SAME matrix tile -- sit on one XCD next to each other (workgroup L goes to XCD L mod 8): L = 8 (unit / 8 x groups +
+// group) + unit mod 8.  The last eight units are padded (a workgroup past the end returns).
 template <typename R, int NB, int MB>
-__global__ void __launch_bounds__(256) fwd_step_kernel(Problem P, StepBuf<R> Sa, StepBuf<R> Sb, int n, int dir_base, int ks) {
+__global__ void __launch_bounds__(256) fwd_step_kernel(Problem P, StepBuf<R> Sa, StepBuf<R> Sb, int n, int dir_base, int ks, int tiles, int groups, int ndirs, int nt) {
     if constexpr (StepUsesMfma<R>::v) {
         __shared__ float red[4][NB * MB * 8][64];
         const int nbt = (P.B + 31) / 32;
+        const int xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
+        const int unit = (within / groups) * 8 + xcd, group = within % groups;
+        if (unit >= tiles * ks * ndirs) return;
+        const int row_tile = unit % tiles, slice = (unit / tiles) % ks, dir = unit / (tiles * ks);
 #ifdef ASG_X_STEP_PROBE
         const long long t_begin = wall_clock64();
 #endif
-        if ((int) blockIdx.z + dir_base == 0) fwd_step_mfma<false, NB, MB>(P, Sa, n, red, ks, nbt);
-        else fwd_step_mfma<true, NB, MB>(P, Sb, n, red, ks, nbt);
+        if (nt) {
+            if (dir + dir_base == 0) fwd_step_mfma<false, NB, MB, true>(P, Sa, n, red, ks, nbt, row_tile, group, slice);
+            else fwd_step_mfma<true, NB, MB, true>(P, Sb, n, red, ks, nbt, row_tile, group, slice);
+        } else {
+            if (dir + dir_base == 0) fwd_step_mfma<false, NB, MB, false>(P, Sa, n, red, ks, nbt, row_tile, group, slice);
+            else fwd_step_mfma<true, NB, MB, false>(P, Sb, n, red, ks, nbt, row_tile, group, slice);
+        }
 #ifdef ASG_X_STEP_PROBE
         {
             // frame 20: every workgroup stamps begin / product done / end (100 MHz ticks); frame 30: one thread prints the summary
-            const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+            const int wg = blockIdx.x;
             if (n == 20 && threadIdx.x == 0 && wg < 1024) { g_step_probe[wg * 4 + 0] = t_begin; g_step_probe[wg * 4 + 2] = wall_clock64(); }
             if (n == 30 && wg == 0 && threadIdx.x == 0) {
-                const int nwg = gridDim.x * gridDim.y * gridDim.z;
+                const int nwg = gridDim.x;
                 long long b0 = 0x7fffffffffffffffll, b1 = 0, p0 = b0, p1 = 0, e0 = b0, e1 = 0; int ne = 0; long long esum = 0;
                 for (int w = 0; w < nwg && w < 1024; ++w) {
                     const long long b = g_step_probe[w * 4], pd = g_step_probe[w * 4 + 1], e = g_step_probe[w * 4 + 2];
+                    if (b == 0) continue;          // (a padding workgroup)
                     b0 = b < b0 ? b : b0; b1 = b > b1 ? b : b1; p0 = pd < p0 ? pd : p0; p1 = pd > p1 ? pd : p1; e0 = e < e0 ? e : e0; e1 = e > e1 ? e : e1;
                     if (e - pd > 100) { ++ne; esum += e - pd; }
                 }
@@ -3678,28 +3693,37 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
             // N=1500: 38 against 26 us, N=3000: 58 against 52, N=5000: 99 against 92: the two batch tiles' workgroups of a row tile
             // run side by side and share the matrix lines in L2 already, the product is bound by the matrix instruction either way,
             // and half the workgroups means twice the K slices and their exchange.  ASG_STEP_ONE_TILE=1/0 forces either form.)
-            int ks = 1, nb = 1, mb = kStepMB;
+            int ks = 1, nb = 1, mb = kStepMB, tiles = 0, groups = 1, ndirs = 1, nt = 1;
             if constexpr (StepUsesMfma<R>::v) {
                 const int cus = device_cus();
                 nb = step_batch_tiles(P.B);
                 mb = step_row_blocks(P.N, P.B, cus);          // (the height launch_prep_generic laid the operand-order copies out for)
-                sgrid.x = (P.N + 16 * mb - 1) / (16 * mb);
-                sgrid.y = (sgrid.y + nb - 1) / nb;
-                ks = step_slices(P.N, (int) sgrid.y, (int) sgrid.z, nb, mb, cus);
+                tiles = (P.N + 16 * mb - 1) / (16 * mb);
+                groups = ((int) sgrid.y + nb - 1) / nb;
+                ndirs = (int) sgrid.z;
+                ks = step_slices(P.N, groups, ndirs, nb, mb, cus);
 #ifdef ASG_DEV_PROBES
                 if (const char *ev = getenv("ASG_STEP_KS")) ks = atoi(ev) >= 1 && atoi(ev) <= kStepMaxSlices ? atoi(ev) : ks;
-                if (getenv("ASG_STEP_SHOW")) fprintf(stderr, "[step grid] N=%d B=%d: %d row blocks, %d batch tile(s) per workgroup, %d slice(s), %u workgroups\n", P.N, P.B, mb, nb, ks, sgrid.x * sgrid.y * ks * sgrid.z);
+                if (getenv("ASG_STEP_SHOW")) fprintf(stderr, "[step grid] N=%d B=%d: %d row blocks, %d batch tile(s) per workgroup, %d slice(s), %d workgroups\n", P.N, P.B, mb, nb, ks, tiles * groups * ks * ndirs);
 #endif
-                sgrid.y *= ks;
+                sgrid = dim3((unsigned) ((tiles * ks * ndirs + 7) / 8 * 8 * groups), 1, 1);
+                // matrix loads: non-temporal only when nobody else wants the tile (one batch tile group) and the directions' matrices do not
+                // fit the memory-side cache.  T=200, B=32, nt / default, ms per step: N = 4000 8.46 / 7.57, 6000 (288 MB) 13.66 / 13.06,
+                // 7000 (392 MB) 18.20 / 19.26, 8000 21.6 / 23.7, cfg 5 (800 MB) 133.9 / 140.1 us per frame; B = 64 (two groups sharing each
+                // tile through the L2): N = 6000 25.8 / 23.0, 7000 39.4 / 36.4.
+                nt = (groups == 1 && (double) ndirs * P.N * (double) W.npad * 4.0 > 320e6) ? 1 : 0;
+#ifdef ASG_DEV_PROBES
+                if (const char *ev = getenv("ASG_STEP_NT")) nt = atoi(ev) ? 1 : 0;
+#endif
             }
             for (int n = 0; n + 1 < P.T; ++n) {
                 if constexpr (StepUsesMfma<R>::v) {
-#define ASG_STEP_LAUNCH(NB_, MB_) hipLaunchKernelGGL((fwd_step_kernel<R, NB_, MB_>), sgrid, dim3(256), 0, stream, P, Sd[0], Sd[1], n, do_a ? 0 : 1, ks)
+#define ASG_STEP_LAUNCH(NB_, MB_) hipLaunchKernelGGL((fwd_step_kernel<R, NB_, MB_>), sgrid, dim3(256), 0, stream, P, Sd[0], Sd[1], n, do_a ? 0 : 1, ks, tiles, groups, ndirs, nt)
                     if (nb == 2) { if (mb == 2) ASG_STEP_LAUNCH(2, 2); else if (mb == 3) ASG_STEP_LAUNCH(2, 3); else if (mb == 4) ASG_STEP_LAUNCH(2, 4); else ASG_STEP_LAUNCH(2, 5); }
                     else { if (mb == 2) ASG_STEP_LAUNCH(1, 2); else if (mb == 3) ASG_STEP_LAUNCH(1, 3); else if (mb == 4) ASG_STEP_LAUNCH(1, 4); else ASG_STEP_LAUNCH(1, 5); }
 #undef ASG_STEP_LAUNCH
                 } else {
-                    hipLaunchKernelGGL((fwd_step_kernel<R, 1, kStepMB>), sgrid, dim3(256), 0, stream, P, Sd[0], Sd[1], n, do_a ? 0 : 1, ks);
+                    hipLaunchKernelGGL((fwd_step_kernel<R, 1, kStepMB>), sgrid, dim3(256), 0, stream, P, Sd[0], Sd[1], n, do_a ? 0 : 1, ks, 0, 1, 1, 1);
                 }
             }
         }
