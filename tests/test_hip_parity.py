@@ -1050,8 +1050,8 @@ def test_streaming_step_slices_of_k(T, B, N, L):
 @pytest.mark.gpu
 @pytest.mark.parametrize("T,B,N,L", [(5, 70, 2200, 2), (4, 64, 5000, 2), (6, 33, 2049, 3), (5, 128, 2300, 2)])
 def test_streaming_step_two_batch_tiles(T, B, N, L, monkeypatch):
-    """B > 64 (ASG_STEP_ONE_TILE=0: B > 32): a workgroup of the fp32 streaming step multiplies its matrix tile into TWO batch tiles of
-    32 utterances (the matrix streamed once for both).  An odd number of batch tiles (the last group's second tile does not exist), a
+    """Where the plan prices it lower (ASG_STEP_ONE_TILE=0: whenever B > 32) a workgroup of the fp32 streaming step multiplies its matrix tile
+    into TWO batch tiles of 32 utterances (the matrix streamed once for both).  An odd number of batch tiles (the last group's second tile does not exist), a
     second tile of one utterance, four tiles; against the fp64 oracle and against one batch tile per workgroup (ASG_STEP_ONE_TILE=1)."""
     tr, x, tg, il, tl = util.synth(T, B, N, L, N + B, True)
     o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il.numpy(), tl.numpy(), "none")

@@ -538,7 +538,7 @@ typedef float V4f __attribute__((ext_vector_type(4)));
 #endif
 constexpr int kStepMB = 5;                  // 16-row blocks per workgroup, at most: every workgroup reads the batch's whole vector
                                             // set once (L2 traffic = row tiles x 1.3 MB), so tiles must not be too small.  3 or 4
-                                            // where that fills the device better (step_row_blocks: N = 3000 at B = 64 is 152 workgroups
+                                            // where that fills the device better (step_plan: N = 3000 at B = 64 is 152 workgroups
                                             // of 80 rows on 256 compute units, 252 of 48 rows)
 // The MFMA step's E operand, laid out so that every wavefront load is ONE contiguous kilobyte and a workgroup streams
 // its K quarter front to back: [row tile of 16 kStepMB rows][chunk of 32 k][row block m][half h][lane][4 floats], lane l =
@@ -3406,7 +3406,7 @@ constexpr int kStepMaxSlices = 8, kStepMBMin = 2;
 static double step_cost(int N, int groups, int dirs, int nb, int mb, int ks, int cus) {
     const int nchunks = ((N + 3) / 4 * 4 + 31) / 32;
     const long wgs = (long) ((N + 16 * mb - 1) / (16 * mb)) * groups * dirs * ks, rounds = (wgs + cus - 1) / cus;
-    return (double) rounds * (((double) mb * 0.048 + 0.02) * ((nchunks + ks - 1) / ks) * nb + (ks - 1) * 4.5);
+    return (double) rounds * (((double) mb * 0.048 + 0.02) * ((nchunks + ks - 1) / ks) * (nb == 2 ? 1.9 : 1.0) + (ks - 1) * 4.5);
 }
 static int step_slices(int N, int groups, int dirs, int nb, int mb, int cus) {
     const int nchunks = ((N + 3) / 4 * 4 + 31) / 32;
@@ -3418,20 +3418,29 @@ static int step_slices(int N, int groups, int dirs, int nb, int mb, int cus) {
     }
     return best;
 }
-// batch tiles of 32 utterances per workgroup of the fp32 streaming step: two when B > 64 (see launch_fwd_generic)
-static int step_batch_tiles(int B) {
-    return (knobs().step_one_tile >= 0 ? (knobs().step_one_tile == 0 && B > 32) : B > 64) ? 2 : 1;
-}
-// The tile height is a function of the problem's shape only: the operand-order copies of the matrix are laid out for it before the
-// recursion knows which directions it runs (priced for both; the evaluation route runs one and re-prices its slices).
-static int step_row_blocks(int N, int B, int cus) {
-    if (knobs().step_row_blocks >= kStepMBMin && knobs().step_row_blocks <= kStepMB) return knobs().step_row_blocks;
-    const int nb = step_batch_tiles(B), groups = ((B + 31) / 32 + nb - 1) / nb;
-    int best = kStepMB;
-    double best_cost = 0;
-    for (int mb = kStepMB; mb >= kStepMBMin; --mb) {
-        const double c = step_cost(N, groups, 2, nb, mb, step_slices(N, groups, 2, nb, mb, cus), cus);
-        if (mb == kStepMB || c < best_cost) { best = mb; best_cost = c; }
+// Batch tiles of 32 utterances per workgroup (1 or 2) and tile height, priced together.  Two batch tiles per workgroup read the matrix
+// once for both (priced at 1.9 products instead of 2) but halve the workgroups; one per workgroup leaves the sharing to sibling workgroups on
+// one XCD.  Measured (T=400, ms per step, two / one): B = 96 N = 2500 24.5 / 17.5 (three batch tiles: the second group is half empty),
+// B = 128 N = 1500 12.6 / 10.3, B = 128 N = 3000 29.1 / 30.6, B = 256 N = 3000 (T=200) 32.8 / 36.7; at B = 64 one always (N = 3000: 21.7 / 15.8).
+// A function of the problem's shape only: the operand-order copies of the matrix are laid out for the height before the recursion knows
+// which directions it runs (priced for both; the evaluation route runs one and re-prices its slices).  ASG_STEP_ONE_TILE=1/0 and
+// ASG_STEP_ROW_BLOCKS force either.
+struct StepPlan { int nb, mb; };
+static StepPlan step_plan(int N, int B, int cus) {
+    const int nbt = (B + 31) / 32;
+    int nb_lo = 1, nb_hi = nbt > 1 ? 2 : 1;
+    if (knobs().step_one_tile == 1) nb_hi = 1;
+    else if (knobs().step_one_tile == 0 && nbt > 1) nb_lo = 2;
+    int mb_lo = kStepMBMin, mb_hi = kStepMB;
+    if (knobs().step_row_blocks >= kStepMBMin && knobs().step_row_blocks <= kStepMB) mb_lo = mb_hi = knobs().step_row_blocks;
+    StepPlan best{nb_lo, mb_hi};
+    double best_cost = -1;
+    for (int nb = nb_lo; nb <= nb_hi; ++nb) {
+        const int groups = (nbt + nb - 1) / nb;
+        for (int mb = mb_hi; mb >= mb_lo; --mb) {
+            const double c = step_cost(N, groups, 2, nb, mb, step_slices(N, groups, 2, nb, mb, cus), cus);
+            if (best_cost < 0 || c < best_cost) { best = StepPlan{nb, mb}; best_cost = c; }
+        }
     }
     return best;
 }
@@ -3456,7 +3465,7 @@ hipError_t launch_prep_generic(const Problem &P, const State &W, hipStream_t str
     }
     if constexpr (StepUsesMfma<R>::v) {
         if (!W.etile || !W.ftile) return hipErrorInvalidValue;
-        const int mb = step_row_blocks(P.N, P.B, device_cus());
+        const int mb = step_plan(P.N, P.B, device_cus()).mb;
         hipLaunchKernelGGL(tile_kernel, dim3(4096), dim3(256), 0, stream, (const float *) W.ehat, P.N, W.npad, mb, (float *) W.etile);
         hipLaunchKernelGGL(tile_kernel, dim3(4096), dim3(256), 0, stream, (const float *) W.fhat, P.N, W.npad, mb, (float *) W.ftile);
     }
@@ -3688,16 +3697,13 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
         if (!stepped) {
             // fp32: row tiles of 48 / 64 / 80 rows and K split over ks workgroups per (row tile, batch tile), whichever grid the cost model
             // prices lowest (step_cost; cfg 5: 125 row tiles of 80 rows x 2 directions, no slices = 250 workgroups).
-            // B > 64: two batch tiles of 32 utterances per workgroup -- the matrix streamed once per frame and direction for both.
-            // (T=400, N=3000, B=128: 99 us per frame against 122; B=96, N=5000: 150 against 182.  At B = 64 the same form LOSES --
-            // N=1500: 38 against 26 us, N=3000: 58 against 52, N=5000: 99 against 92: the two batch tiles' workgroups of a row tile
-            // run side by side and share the matrix lines in L2 already, the product is bound by the matrix instruction either way,
-            // and half the workgroups means twice the K slices and their exchange.  ASG_STEP_ONE_TILE=1/0 forces either form.)
+            // One or two batch tiles of 32 utterances per workgroup: step_plan.
             int ks = 1, nb = 1, mb = kStepMB, tiles = 0, groups = 1, ndirs = 1, nt = 1;
             if constexpr (StepUsesMfma<R>::v) {
                 const int cus = device_cus();
-                nb = step_batch_tiles(P.B);
-                mb = step_row_blocks(P.N, P.B, cus);          // (the height launch_prep_generic laid the operand-order copies out for)
+                const StepPlan plan = step_plan(P.N, P.B, cus);
+                nb = plan.nb;
+                mb = plan.mb;          // (the height launch_prep_generic laid the operand-order copies out for)
                 tiles = (P.N + 16 * mb - 1) / (16 * mb);
                 groups = ((int) sgrid.y + nb - 1) / nb;
                 ndirs = (int) sgrid.z;
