@@ -16,4 +16,5 @@ grep -h "^T=" $O/shape_times_f64.txt > ${P}_shape_times_f64.txt
 cp $O/pmc_standalone.txt ${P}_pmc_standalone_B512.txt
 grep -v amdgpu.ids $O/fuzz_400.txt | tail -40 > ${P}_fuzz_400.txt
 tail -3 $O/pytest.log > ${P}_pytest_gpu_tail.txt
+grep -v amdgpu.ids $O/step_grid.txt > ${P}_step_grid_at_head.txt
 ls -la profiles/ | grep " ${TAG}_" | wc -l

@@ -15,3 +15,5 @@ bash tools/pmc_standalone.sh > $O/pmc_standalone.txt 2>&1; for c in FETCH_SIZE W
 ASG_DTYPE=f64 timeout 300 python tools/shape_times.py 400,64,128,30 400,64,300,30 400,64,512,30 400,64,1024,30 400,64,2048,30 > $O/shape_times_f64.txt 2>&1; tail -5 $O/shape_times_f64.txt
 timeout 300 python tools/shape_times.py 400,128,3000,30 200,96,5000,30 >> $O/shape_times.txt 2>&1
 timeout 900 python tools/fuzz_routes.py 400 5 > $O/fuzz_400.txt 2>&1; tail -2 $O/fuzz_400.txt
+# (needs torch_asg_amd/csrc/variants/libprobes.so: tools/devbuild_generic.sh probes -DASG_DEV_PROBES)
+SHAPES="400,64,1500,30 400,64,3000,30 400,64,5000,30 400,32,3000,30 400,16,2100,30 400,128,3000,30" KS="1 2" timeout 900 bash tools/step_grid_time.sh > $O/step_grid.txt 2>&1; grep -c "mb=" $O/step_grid.txt
