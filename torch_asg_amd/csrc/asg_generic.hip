@@ -3625,7 +3625,9 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
                 // +2 000 of epilogue, flags and reload with twice the peers: 16 600 -> 14 400 in all; 16 rows: 15 500)
                 C.RW = P.N <= 512 ? (sizeof(R) == 8 ? 32 : 64) : P.N <= 1024 ? 32 : 16;
 #ifdef ASG_DEV_PROBES
-                if (const char *ev = getenv("ASG_CL_RW")) C.RW = atoi(ev) == 16 || atoi(ev) == 32 || atoi(ev) == 64 ? atoi(ev) : C.RW;
+                // (a workgroup's registers hold 32 K matrix elements: more rows than that allows would silently drop part of K)
+                if (const char *ev = getenv("ASG_CL_RW"))
+                    if ((atoi(ev) == 16 || atoi(ev) == 32 || atoi(ev) == 64) && (size_t) atoi(ev) * ((W.npad + 255) / 256 * 256) <= 32768) C.RW = atoi(ev);
 #endif
                 C.G = (P.N + C.RW - 1) / C.RW;
                 C.npadL = (W.npad + 255) / 256 * 256;
