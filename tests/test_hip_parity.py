@@ -1090,6 +1090,23 @@ def test_streaming_step_tile_heights(T, B, N, L, mb, monkeypatch):
     util.assert_close(ev, o["loss"], 1e-4, "%d row blocks, evaluation route" % mb)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,B,N,L", [(6, 16, 2100, 3), (5, 3, 3300, 2), (5, 17, 2100, 2)])
+def test_streaming_step_half_tile(T, B, N, L, monkeypatch):
+    """Batches of at most 16 utterances: the fp32 streaming step leaves out the second half of its 32-utterance tile (vector loads and
+    matrix instructions).  Against the fp64 oracle and bit-identical to the full tile (ASG_STEP_FULL_TILE=1: the first half's
+    accumulators see the same products in the same order); B = 17 takes the full tile either way."""
+    tr, x, tg, il, tl = util.synth(T, B, N, L, N + B, True)
+    o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il.numpy(), tl.numpy(), "none")
+    r = run_hip(x, tg, tr, il, tl, "none")
+    for k in ("loss", "grad_inputs", "grad_transition"):
+        util.assert_close(r[k], o[k], 1e-4, "half tile T%d B%d N%d %s" % (T, B, N, k))
+    util.setenv(monkeypatch, "ASG_STEP_FULL_TILE", 1)
+    r1 = run_hip(x, tg, tr, il, tl, "none")
+    for k in ("loss", "grad_inputs", "grad_transition"):
+        assert np.array_equal(r[k], r1[k]), "half vs full tile differ in %s" % k
+
+
 # ------------------------------------------------------------------ long targets over a small alphabet (letter models)
 @pytest.mark.gpu
 @pytest.mark.parametrize("T,B,N,L", [(90, 3, 29, 65), (140, 2, 40, 128), (150, 3, 40, 129), (300, 2, 31, 200),

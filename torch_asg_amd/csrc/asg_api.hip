@@ -47,6 +47,7 @@ const Knobs *read_knobs() {
     k->no_tile_step = env_int("ASG_NO_TILE_STEP");
     k->step_one_tile = env_int("ASG_STEP_ONE_TILE");
     k->step_row_blocks = env_int("ASG_STEP_ROW_BLOCKS");
+    k->step_full_tile = env_int("ASG_STEP_FULL_TILE");
     const char *ak = getenv("ASG_ALIGNED_KERNEL");
     k->aligned_kernel = ak ? ak[0] : 0;
     return k;

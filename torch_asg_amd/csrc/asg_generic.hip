@@ -733,7 +733,9 @@ __device__ long long g_step_probe[4096];
 // (B >= 64: the matrix is streamed ONCE per frame and direction instead of once per batch tile).  nbt = batch tiles of the problem.
 // NT: the matrix loads are non-temporal (the matrices do not fit the 256 MB memory-side cache and no other workgroup wants the same
 // tile) or take the default policy (they fit and stay there from frame to frame, or sibling workgroups share the tile through the L2).
-template <bool BETA, int NB, int MB, bool NT>
+// HALF: the batch has at most 16 utterances -- the second half of the 32-utterance tile does not exist, its vector loads and matrix
+// instructions are not issued (the epilogue's threads of those utterances are inactive anyway).
+template <bool BETA, int NB, int MB, bool NT, bool HALF>
 __device__ __forceinline__ void fwd_step_mfma(const Problem &P, const StepBuf<float> &S, int n, float (*red)[NB * MB * 8][64], int ks, int nbt,
                                               int row_tile, int group, int slice) {
     const int B = P.B, npad = S.npad;
@@ -788,7 +790,7 @@ __device__ __forceinline__ void fwd_step_mfma(const Problem &P, const StepBuf<fl
 #pragma unroll
                     for (int j = 0; j < NB; ++j) {
                         st.a[j][h] = __builtin_bit_cast(V4f, (RawU4) __builtin_amdgcn_raw_buffer_load_b128(rsP[j], vlane, cp + h * 1024u, 0));
-                        st.b[j][h] = __builtin_bit_cast(V4f, (RawU4) __builtin_amdgcn_raw_buffer_load_b128(rsP[j], vlane, cp + (2 + h) * 1024u, 0));
+                        if (!HALF) st.b[j][h] = __builtin_bit_cast(V4f, (RawU4) __builtin_amdgcn_raw_buffer_load_b128(rsP[j], vlane, cp + (2 + h) * 1024u, 0));
                     }
 #pragma unroll
                     for (int m = 0; m < MB; ++m)          // (aux 2 = non-temporal: see below)
@@ -799,7 +801,7 @@ __device__ __forceinline__ void fwd_step_mfma(const Problem &P, const StepBuf<fl
                 for (int j = 0; j < NB; ++j) {
                     const V4f *ptj = pt + (size_t) min(bt0 + j, nbt - 1) * nchunks * 256;
                     st.a[j][h] = ptj[((size_t) c * 4 + h) * 64];
-                    st.b[j][h] = ptj[((size_t) c * 4 + 2 + h) * 64];
+                    if (!HALF) st.b[j][h] = ptj[((size_t) c * 4 + 2 + h) * 64];
                 }
 #pragma unroll
                 for (int m = 0; m < MB; ++m) {
@@ -817,13 +819,13 @@ __device__ __forceinline__ void fwd_step_mfma(const Problem &P, const StepBuf<fl
 #pragma unroll
                     for (int j = 0; j < NB; ++j) {
                         acc[j][m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(st.e[m][h].x, st.a[j][h].x, acc[j][m][0], 0, 0, 0);
-                        acc[j][m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(st.e[m][h].x, st.b[j][h].x, acc[j][m][1], 0, 0, 0);
+                        if (!HALF) acc[j][m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(st.e[m][h].x, st.b[j][h].x, acc[j][m][1], 0, 0, 0);
                         acc[j][m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(st.e[m][h].y, st.a[j][h].y, acc[j][m][0], 0, 0, 0);
-                        acc[j][m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(st.e[m][h].y, st.b[j][h].y, acc[j][m][1], 0, 0, 0);
+                        if (!HALF) acc[j][m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(st.e[m][h].y, st.b[j][h].y, acc[j][m][1], 0, 0, 0);
                         acc[j][m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(st.e[m][h].z, st.a[j][h].z, acc[j][m][0], 0, 0, 0);
-                        acc[j][m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(st.e[m][h].z, st.b[j][h].z, acc[j][m][1], 0, 0, 0);
+                        if (!HALF) acc[j][m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(st.e[m][h].z, st.b[j][h].z, acc[j][m][1], 0, 0, 0);
                         acc[j][m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(st.e[m][h].w, st.a[j][h].w, acc[j][m][0], 0, 0, 0);
-                        acc[j][m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(st.e[m][h].w, st.b[j][h].w, acc[j][m][1], 0, 0, 0);
+                        if (!HALF) acc[j][m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(st.e[m][h].w, st.b[j][h].w, acc[j][m][1], 0, 0, 0);
                     }
         };
         if (c0 < c1) {
@@ -878,7 +880,7 @@ template <> struct StepUsesMfma<float> { static constexpr bool v = true; };
 // one-dimensional grid of (row tile, slice of K, direction) units x `groups` batch tile groups, laid out so that the workgroups of one unit
 // -- which stream the SAME matrix tile -- sit on one XCD next to each other (workgroup L goes to XCD L mod 8): L = 8 (unit / 8 x groups +
 // group) + unit mod 8.  The last eight units are padded (a workgroup past the end returns).
-template <typename R, int NB, int MB>
+template <typename R, int NB, int MB, bool HALF>
 __global__ void __launch_bounds__(256) fwd_step_kernel(Problem P, StepBuf<R> Sa, StepBuf<R> Sb, int n, int dir_base, int ks, int tiles, int groups, int ndirs, int nt) {
     if constexpr (StepUsesMfma<R>::v) {
         __shared__ float red[4][NB * MB * 8][64];
@@ -891,11 +893,11 @@ __global__ void __launch_bounds__(256) fwd_step_kernel(Problem P, StepBuf<R> Sa,
         const long long t_begin = wall_clock64();
 #endif
         if (nt) {
-            if (dir + dir_base == 0) fwd_step_mfma<false, NB, MB, true>(P, Sa, n, red, ks, nbt, row_tile, group, slice);
-            else fwd_step_mfma<true, NB, MB, true>(P, Sb, n, red, ks, nbt, row_tile, group, slice);
+            if (dir + dir_base == 0) fwd_step_mfma<false, NB, MB, true, HALF>(P, Sa, n, red, ks, nbt, row_tile, group, slice);
+            else fwd_step_mfma<true, NB, MB, true, HALF>(P, Sb, n, red, ks, nbt, row_tile, group, slice);
         } else {
-            if (dir + dir_base == 0) fwd_step_mfma<false, NB, MB, false>(P, Sa, n, red, ks, nbt, row_tile, group, slice);
-            else fwd_step_mfma<true, NB, MB, false>(P, Sb, n, red, ks, nbt, row_tile, group, slice);
+            if (dir + dir_base == 0) fwd_step_mfma<false, NB, MB, false, HALF>(P, Sa, n, red, ks, nbt, row_tile, group, slice);
+            else fwd_step_mfma<true, NB, MB, false, HALF>(P, Sb, n, red, ks, nbt, row_tile, group, slice);
         }
 #ifdef ASG_X_STEP_PROBE
         {
@@ -3701,6 +3703,7 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
             // prices lowest (step_cost; cfg 5: 125 row tiles of 80 rows x 2 directions, no slices = 250 workgroups).
             // One or two batch tiles of 32 utterances per workgroup: step_plan.
             int ks = 1, nb = 1, mb = kStepMB, tiles = 0, groups = 1, ndirs = 1, nt = 1;
+            const bool half = P.B <= 16 && !(knobs().step_full_tile > 0);          // (at most 16 utterances: half of the 32-utterance tile)
             if constexpr (StepUsesMfma<R>::v) {
                 const int cus = device_cus();
                 const StepPlan plan = step_plan(P.N, P.B, cus);
@@ -3726,12 +3729,13 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
             }
             for (int n = 0; n + 1 < P.T; ++n) {
                 if constexpr (StepUsesMfma<R>::v) {
-#define ASG_STEP_LAUNCH(NB_, MB_) hipLaunchKernelGGL((fwd_step_kernel<R, NB_, MB_>), sgrid, dim3(256), 0, stream, P, Sd[0], Sd[1], n, do_a ? 0 : 1, ks, tiles, groups, ndirs, nt)
-                    if (nb == 2) { if (mb == 2) ASG_STEP_LAUNCH(2, 2); else if (mb == 3) ASG_STEP_LAUNCH(2, 3); else if (mb == 4) ASG_STEP_LAUNCH(2, 4); else ASG_STEP_LAUNCH(2, 5); }
-                    else { if (mb == 2) ASG_STEP_LAUNCH(1, 2); else if (mb == 3) ASG_STEP_LAUNCH(1, 3); else if (mb == 4) ASG_STEP_LAUNCH(1, 4); else ASG_STEP_LAUNCH(1, 5); }
+#define ASG_STEP_LAUNCH(NB_, MB_, HALF_) hipLaunchKernelGGL((fwd_step_kernel<R, NB_, MB_, HALF_>), sgrid, dim3(256), 0, stream, P, Sd[0], Sd[1], n, do_a ? 0 : 1, ks, tiles, groups, ndirs, nt)
+                    if (nb == 2) { if (mb == 2) ASG_STEP_LAUNCH(2, 2, false); else if (mb == 3) ASG_STEP_LAUNCH(2, 3, false); else if (mb == 4) ASG_STEP_LAUNCH(2, 4, false); else ASG_STEP_LAUNCH(2, 5, false); }
+                    else if (half) { if (mb == 2) ASG_STEP_LAUNCH(1, 2, true); else if (mb == 3) ASG_STEP_LAUNCH(1, 3, true); else if (mb == 4) ASG_STEP_LAUNCH(1, 4, true); else ASG_STEP_LAUNCH(1, 5, true); }
+                    else { if (mb == 2) ASG_STEP_LAUNCH(1, 2, false); else if (mb == 3) ASG_STEP_LAUNCH(1, 3, false); else if (mb == 4) ASG_STEP_LAUNCH(1, 4, false); else ASG_STEP_LAUNCH(1, 5, false); }
 #undef ASG_STEP_LAUNCH
                 } else {
-                    hipLaunchKernelGGL((fwd_step_kernel<R, 1, kStepMB>), sgrid, dim3(256), 0, stream, P, Sd[0], Sd[1], n, do_a ? 0 : 1, ks, 0, 1, 1, 1);
+                    hipLaunchKernelGGL((fwd_step_kernel<R, 1, kStepMB, false>), sgrid, dim3(256), 0, stream, P, Sd[0], Sd[1], n, do_a ? 0 : 1, ks, 0, 1, 1, 1);
                 }
             }
         }

@@ -112,7 +112,7 @@ enum ChainBits { kFullAlpha = 1, kFullBeta = 2, kAlignedAlpha = 4, kAlignedBeta 
 // ---- small path: N <= 64, S <= 64, one wavefront per chain -------------------------------
 // Developer / test switches, read from the environment once (asg_api.hip; asg_reload_env() reads them again).  -1 = not set.
 struct Knobs {
-    int fork_in_capture, pair_min_b, bwd_rowsum, no_cluster, no_mid, no_tile_step, step_one_tile, step_row_blocks;
+    int fork_in_capture, pair_min_b, bwd_rowsum, no_cluster, no_mid, no_tile_step, step_one_tile, step_row_blocks, step_full_tile;
     char aligned_kernel;          // first letter of ASG_ALIGNED_KERNEL, or 0
 };
 const Knobs &knobs();
