@@ -3774,7 +3774,7 @@ static int gemm_slices(int N, int K) {
 #define ASG_X_GEMM_BF3 1
 #endif
 constexpr int kG3TailSlices = 4;
-constexpr size_t kG3TailBytes = (size_t) 128 << 20;          // at most 128 tail tiles x 4 slices x 256 KB
+constexpr size_t kG3TailBytes = (size_t) 208 << 20;          // 128 tail tiles x 4 slices x 256 KB; or a whole single round (8 blocks x 32 tiles) x 3 slices
 static size_t gemm3_plane_bytes(int elem, int T, int B, int N) {
     if (!(ASG_X_GEMM_BF3 && elem == 4 && StepUsesMfma<float>::v && N > 64 && gemm_slices(N, B * T) == 1)) return 0;
     if ((double) g3_plane_elems(B * T, N) * 2.0 >= 4294967296.0) return 0;          // (a plane is addressed through one 32-bit buffer resource)
@@ -3876,13 +3876,26 @@ hipError_t launch_bwd_generic(const Problem &P, const State &W, const BwdArgs &A
                 // whole rounds of 8 blocks (one per XCD, 32 tiles each) in one launch; a partial last round that would leave most of
                 // the device idle for a whole tile time (cfg 5: 50 blocks = 6 rounds + 2 blocks) as a second launch, the frame axis sliced
                 int tail = blocks % 8, tks = 1;
-                if (tail * 32 * 2 <= 256 && tail > 0 && blocks > 8) tks = 256 / (tail * 32) > kG3TailSlices ? kG3TailSlices : 256 / (tail * 32);
+                if (blocks <= 8) {
+                    // a single, partial round (N = 3000: 144 tiles on 256 compute units): the whole product goes the sliced way when that
+                    // takes fewer tile times -- rounds of the sliced grid / slices (N = 3000: 3 slices, 432 workgroups = 2 rounds of a third)
+                    tail = blocks;
+                    const int real = Mt * Nt;
+                    double best = (double) ((real + 255) / 256);
+                    for (int t = 2; t <= kG3TailSlices; ++t) {
+                        const double c = (double) ((real * t + 255) / 256) / t;
+                        if (c < best - 0.05 && (size_t) tail * 32 * t * kG3TM * kG3TN * sizeof(float) <= kG3TailBytes) { best = c; tks = t; }
+                    }
+                } else if (tail * 32 * 2 <= 256 && tail > 0) {
+                    tks = 256 / (tail * 32) > kG3TailSlices ? kG3TailSlices : 256 / (tail * 32);
+                }
                 if (tks < 2 || (size_t) tail * 32 * tks * kG3TM * kG3TN * sizeof(float) > kG3TailBytes) { tail = 0; tks = 1; }
                 const int mainb = blocks - tail;
                 float *tpart = (float *) ((char *) planes3 + 2 * pbytes);
-                hipLaunchKernelGGL(bwd_gemm_bf3_kernel, dim3(8 * 32 * ((mainb + 7) / 8)), dim3(512), lds, stream, (const unsigned short *) apl,
-                                   (const unsigned short *) bpl, pe, (const float *) W.ehat, (float *) gtr, P.N, npad, npadT,
-                                   (const int *) (rowoff + P.B), K, Mt, Nt, 0, 1, (float *) nullptr);
+                if (mainb > 0)
+                    hipLaunchKernelGGL(bwd_gemm_bf3_kernel, dim3(8 * 32 * ((mainb + 7) / 8)), dim3(512), lds, stream, (const unsigned short *) apl,
+                                       (const unsigned short *) bpl, pe, (const float *) W.ehat, (float *) gtr, P.N, npad, npadT,
+                                       (const int *) (rowoff + P.B), K, Mt, Nt, 0, 1, (float *) nullptr);
                 if (tail) {
                     hipLaunchKernelGGL(bwd_gemm_bf3_kernel, dim3(tail * 32 * tks), dim3(512), lds, stream, (const unsigned short *) apl,
                                        (const unsigned short *) bpl, pe, (const float *) W.ehat, (float *) gtr, P.N, npad, npadT,
