@@ -3773,10 +3773,16 @@ static int gemm_slices(int N, int K) {
 #ifndef ASG_X_GEMM_BF3
 #define ASG_X_GEMM_BF3 1
 #endif
-constexpr int kG3TailSlices = 4;
+constexpr int kG3TailSlices = 4, kG3WholeSlices = 8;      // slices of a partial last round / of a grid that is a single partial round
 constexpr size_t kG3TailBytes = (size_t) 208 << 20;          // 128 tail tiles x 4 slices x 256 KB; or a whole single round (8 blocks x 32 tiles) x 3 slices
+#ifndef ASG_X_G3_MIN_N
+#define ASG_X_G3_MIN_N 1024
+#endif
+constexpr int kG3MinN = ASG_X_G3_MIN_N;
 static size_t gemm3_plane_bytes(int elem, int T, int B, int N) {
-    if (!(ASG_X_GEMM_BF3 && elem == 4 && StepUsesMfma<float>::v && N > 64 && gemm_slices(N, B * T) == 1)) return 0;
+    // (beyond 1024 labels; round 5 first took it only where the fp32 contraction ran unsliced, N >= ~2900 -- below that the grid is a
+    // single partial round of 256 x 256 tiles, which the sliced launch now fills: N = 1500 36 tiles x 7 slices)
+    if (!(ASG_X_GEMM_BF3 && elem == 4 && StepUsesMfma<float>::v && N > kG3MinN)) return 0;
     if ((double) g3_plane_elems(B * T, N) * 2.0 >= 4294967296.0) return 0;          // (a plane is addressed through one 32-bit buffer resource)
     return au(3 * g3_plane_elems(B * T, N) * sizeof(unsigned short));
 }
@@ -3854,14 +3860,15 @@ hipError_t launch_bwd_generic(const Problem &P, const State &W, const BwdArgs &A
             // (no row-sum contraction: bwd_post_kernel<.., true> derived the row sums from the stored state)
             const int tiles1 = ((P.N + 127) / 128) * ((P.N + 127) / 128);
             const int nsl = gemm_slices(P.N, K);
-            if (nsl > 1) {
+            const size_t pbytes3 = gemm3_plane_bytes((int) e, P.T, P.B, P.N);
+            if (nsl > 1 && !pbytes3) {
                 const int kslice = ((K + nsl - 1) / nsl + ASG_X_GEMM_BK - 1) / ASG_X_GEMM_BK * ASG_X_GEMM_BK;
                 hipLaunchKernelGGL((bwd_gemm_mfma<1>), dim3((P.N + 127) / 128, (P.N + 127) / 128, nsl), dim3(256), 0, stream,
                                    (const float *) W.ehat, (const float *) Pm, (float *) Gm, (float *) gtr, P.N, npad, K, anybad,
                                    (const int *) (rowoff + P.B), kslice, (float *) gpart);
                 hipLaunchKernelGGL((gemm_combine_kernel<float>), dim3((P.N * P.N + 255) / 256), dim3(256), 0, stream, (const float *) gpart,
                                    nsl, (const float *) W.ehat, P.N, npad, (float *) gtr);
-            } else if (const size_t pbytes = gemm3_plane_bytes((int) e, P.T, P.B, P.N)) {
+            } else if (const size_t pbytes = pbytes3) {
                 // large alphabets: both operands split into bfloat16 planes once, the product on v_mfma_f32_32x32x16_bf16
                 const int npadT = g3_npadT(P.N);
                 const size_t pe = g3_plane_elems(K, P.N);
@@ -3882,7 +3889,7 @@ hipError_t launch_bwd_generic(const Problem &P, const State &W, const BwdArgs &A
                     tail = blocks;
                     const int real = Mt * Nt;
                     double best = (double) ((real + 255) / 256);
-                    for (int t = 2; t <= kG3TailSlices; ++t) {
+                    for (int t = 2; t <= kG3WholeSlices; ++t) {
                         const double c = (double) ((real * t + 255) / 256) / t;
                         if (c < best - 0.05 && (size_t) tail * 32 * t * kG3TM * kG3TN * sizeof(float) <= kG3TailBytes) { best = c; tks = t; }
                     }
