@@ -143,7 +143,7 @@ int asg_backward(asg_ctx *ctx, const asg_problem *p, const void *state, size_t s
  * doc/tech_report.tex:84-88).  scores[B] (dtype of inputs) = score of the best alignment, path[B][T] int64 = the
  * target POSITION occupied at each frame (-1 for frames >= input_lengths[b], and everywhere when the utterance has
  * no finite alignment: score -inf).  Tied comparisons keep "stay" (so among tied paths the one that advances
- * earliest is returned).  S <= 8192 like the other aligned-lattice entry points (beyond 1024 positions: N <= 2048).
+ * earliest is returned).  S <= 8192 like the other aligned-lattice entry points (beyond 1024 positions: N <= 38 400 in float32, 19 200 in float64).
  * `work` holds B*T*ceil(S/64) 64-bit back-pointer masks (asg_viterbi_work_bytes). */
 size_t asg_viterbi_work_bytes(const asg_problem *p);
 int asg_viterbi(asg_ctx *ctx, const asg_problem *p, void *work, size_t work_bytes, void *scores, int64_t *path,

@@ -127,7 +127,7 @@ int check_problem(const asg_problem *p, bool need_targets, bool allow_bf16 = fal
     if (need_targets && (p->S < 1 || !p->targets)) return ASG_ERR_INVALID;
     if (p->T > (1 << 30) || p->B > (1 << 30) || p->N > (1 << 30) || p->S > (1 << 30)) return ASG_ERR_UNSUPPORTED;
     if (p->S > 8192) return ASG_ERR_UNSUPPORTED;              // aligned kernels: at most eight target positions per thread of a workgroup, a frame's states in LDS
-    if (p->S > 1024 && p->N > 2048) return ASG_ERR_UNSUPPORTED;   // ... and beyond 1024 the label scatter is one LDS row (bwd_aligned_strip_kernel)
+    if (p->S > 1024 && (double) p->N * (p->dtype == ASG_DTYPE_F64 ? 8.0 : 4.0) > 150.0 * 1024.0) return ASG_ERR_UNSUPPORTED;   // ... and beyond 1024 the label scatter is one LDS row of N words (bwd_aligned_strip_kernel)
     {
         // the kernels address state and gradient rows through 32-bit buffer offsets
         const double e = p->dtype == ASG_DTYPE_F64 ? 8.0 : 4.0;

@@ -2343,13 +2343,14 @@ __global__ void __launch_bounds__(1024) aligned_strip_kernel(Problem P, State W,
 // Gradient of the same: grid = (B, nchunks), block = 256.  The workgroup walks the frames of its chunk ONE AT A TIME, thread tid owns
 // positions tid, tid + 256, ... (KQ = 16 of them: S <= 4096; 32: S <= 8192) with their edge-posterior sums in registers; per frame two
 // block reductions (maximum, sum: the reference's masked softmax over positions), the posteriors scattered to the labels
-// through ONE fixed-point LDS row (integer adds commute: deterministic, repeated labels included; N <= 2048), read back and
-// added to grad_inputs.  Edge posteriors per (b, chunk) go to gHD as from bwd_aligned_kernel (aligned_tr_scatter_fx_kernel follows).
-// Restates force_aligned_lattice.cpp:156-264.
+// through ONE fixed-point LDS row of N words (dynamic LDS; integer adds commute: deterministic, repeated labels included), read back and
+// added to grad_inputs.  Edge posteriors per (b, chunk) go to gHD as from bwd_aligned_kernel (aligned_tr_scatter_fx_kernel follows, or
+// beyond 2048 labels the hash-table scatter aligned_tr_scatter_kernel).  Restates force_aligned_lattice.cpp:156-264.
+extern __shared__ __attribute__((aligned(16))) unsigned char strip_row_bytes[];
 template <typename R, int KQ>
 __global__ void __launch_bounds__(256) bwd_aligned_strip_kernel(Problem P, State W, BwdArgs A, R *gHD, int add_to_inputs) {
     typedef typename FrameFix<R>::T FX;
-    __shared__ FX fxl[2048];
+    FX *fxl = reinterpret_cast<FX *>(strip_row_bytes);
     __shared__ R red[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x, chunk = blockIdx.y;
@@ -2361,7 +2362,7 @@ __global__ void __launch_bounds__(256) bwd_aligned_strip_kernel(Problem P, State
     const R ga = (A.grad_aligned || !A.neg_aligned) ? g0 : -g0;
     const int2 *asi = reinterpret_cast<const int2 *>(W.asi) + (int64_t) b * S;
     const V2<R> *asu = reinterpret_cast<const V2<R> *>(W.asu) + (int64_t) b * S;
-    for (int q = tid; q < 2048; q += 256) fxl[q] = 0;
+    for (int q = tid; q < N; q += 256) fxl[q] = 0;
     R H2[KQ], Dp[KQ], accH[KQ], accD[KQ];
     int tgt[KQ];
     bool act[KQ];
@@ -3802,7 +3803,7 @@ size_t bwd_scratch_bytes_generic(int elem, int T, int B, int N, int S) {
     generic_chunks(T, B, &ch, &nch);
     size_t tiles = N <= 64 ? au((size_t) B * nch * N * N * elem) : 0;             // bwd_aligned_long_kernel
     if (N > 64 && N <= 2048) tiles = au((size_t) N * N * 8);                      // aligned_tr_scatter_fx_kernel
-    if (S > 1024 && tiles < au((size_t) N * N * 8)) tiles = au((size_t) N * N * 8);      // (very long targets: the same accumulator for any N <= 2048)
+    if (S > 1024 && N <= 2048 && tiles < au((size_t) N * N * 8)) tiles = au((size_t) N * N * 8);      // (very long targets: the same accumulator for any N <= 2048)
     if (N > 64) tiles += au((size_t) gemm_slices(N, B * T) * N * N * elem);       // split contraction: partial sums
     tiles += 2 * gemm3_plane_bytes(elem, T, B, N);                                  // bfloat16 planes of both operands (bwd_gemm_bf3_kernel)
     if (gemm3_plane_bytes(elem, T, B, N)) tiles += kG3TailBytes;                    // ... and the sliced tiles of its last, partial round
@@ -3824,7 +3825,7 @@ hipError_t launch_bwd_generic(const Problem &P, const State &W, const BwdArgs &A
     R *atiles = (R *) sc;
     {
         size_t tb = P.N <= 64 ? au((size_t) P.B * A.nchunks * P.N * P.N * e) : (P.N <= 2048 ? au((size_t) P.N * P.N * 8) : 0);
-        if (P.S > 1024 && tb < au((size_t) P.N * P.N * 8)) tb = au((size_t) P.N * P.N * 8);      // (as bwd_scratch_bytes_generic)
+        if (P.S > 1024 && P.N <= 2048 && tb < au((size_t) P.N * P.N * 8)) tb = au((size_t) P.N * P.N * 8);      // (as bwd_scratch_bytes_generic)
         sc += tb;
     }
     R *gpart = (R *) sc;
@@ -3935,20 +3936,31 @@ hipError_t launch_bwd_generic(const Problem &P, const State &W, const BwdArgs &A
         }
     }
     if (do_ali) {
-        if (P.S > kMaxTargets || (P.S > 1024 && P.N > 2048)) return hipErrorInvalidValue;
+        if (P.S > kMaxTargets) return hipErrorInvalidValue;
         if (!have_full) (void) hipMemsetAsync(A.grad_inputs, 0, (size_t) P.T * P.B * P.N * e, stream);
         unsigned long long *nofx = nullptr;
         if (P.S > 1024) {
-            // very long targets (N <= 2048): frame-by-frame workgroups, label scatter through a fixed-point LDS row; the edge
-            // posteriors into the 64-bit fixed-point accumulator, as for the medium alphabets
-            unsigned long long *fx = (unsigned long long *) atiles;
-            const int64_t n2 = (int64_t) P.N * P.N;
-            if (!fx_cleared) (void) hipMemsetAsync(fx, 0, (size_t) n2 * 8, stream);
-            if (P.S <= 4096) hipLaunchKernelGGL((bwd_aligned_strip_kernel<R, 16>), dim3(P.B, A.nchunks), dim3(256), 0, stream, P, W, A, gHD, 1);
-            else hipLaunchKernelGGL((bwd_aligned_strip_kernel<R, 32>), dim3(P.B, A.nchunks), dim3(256), 0, stream, P, W, A, gHD, 1);
-            hipLaunchKernelGGL((aligned_tr_scatter_fx_kernel<R>), dim3(P.B), dim3(256), 0, stream, P, W, A, (const R *) gHD, fx);
-            hipLaunchKernelGGL((fx_to_grad_kernel<R>), dim3((unsigned) ((n2 + 255) / 256)), dim3(256), 0, stream,
-                               (const unsigned long long *) fx, n2, gtr, have_full ? 1 : 0);
+            // very long targets: frame-by-frame workgroups, label scatter through a fixed-point LDS row of N words; the edge posteriors
+            // into the 64-bit fixed-point accumulator, as for the medium alphabets (N <= 2048), or through the hash-table scatter
+            const size_t row = ((size_t) P.N * sizeof(typename FrameFix<R>::T) + 255) & ~(size_t) 255;
+            if (row > 150 * 1024) return hipErrorInvalidValue;          // (N beyond ~19 000 / 38 000 labels with targets beyond 1024 positions)
+            if (P.S <= 4096) {
+                (void) hipFuncSetAttribute((const void *) bwd_aligned_strip_kernel<R, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) row);
+                hipLaunchKernelGGL((bwd_aligned_strip_kernel<R, 16>), dim3(P.B, A.nchunks), dim3(256), row, stream, P, W, A, gHD, 1);
+            } else {
+                (void) hipFuncSetAttribute((const void *) bwd_aligned_strip_kernel<R, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) row);
+                hipLaunchKernelGGL((bwd_aligned_strip_kernel<R, 32>), dim3(P.B, A.nchunks), dim3(256), row, stream, P, W, A, gHD, 1);
+            }
+            if (P.N <= 2048) {
+                unsigned long long *fx = (unsigned long long *) atiles;
+                const int64_t n2 = (int64_t) P.N * P.N;
+                if (!fx_cleared) (void) hipMemsetAsync(fx, 0, (size_t) n2 * 8, stream);
+                hipLaunchKernelGGL((aligned_tr_scatter_fx_kernel<R>), dim3(P.B), dim3(256), 0, stream, P, W, A, (const R *) gHD, fx);
+                hipLaunchKernelGGL((fx_to_grad_kernel<R>), dim3((unsigned) ((n2 + 255) / 256)), dim3(256), 0, stream,
+                                   (const unsigned long long *) fx, n2, gtr, have_full ? 1 : 0);
+            } else {
+                hipLaunchKernelGGL((aligned_tr_scatter_kernel<R>), dim3(1), dim3(1024), 0, stream, P, W, A, gHD, gtr, have_full ? 1 : 0);
+            }
         } else if (P.N <= 64 && P.S > 64 && P.S <= 1024) {
             dim3 grid(P.B, A.nchunks);
             if (P.S <= 128) hipLaunchKernelGGL((bwd_aligned_long_kernel<R, 2, 64, AlignedState>), grid, dim3(256), 0, stream, P, W, A, atiles, 1, nofx);
