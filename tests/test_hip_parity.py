@@ -488,6 +488,28 @@ def test_fcc_fac_functions_direct():
     util.assert_close(xd3.grad.cpu().numpy(), o["grad_inputs_aligned"], 1e-4, "gin aligned only")
 
 
+def test_fac_alone_over_a_large_alphabet():
+    """The force-aligned criterion on its own beyond 2048 labels: grad_transition starts from a memset and receives the edge posteriors
+    through the hash-table scatter (no full-lattice gradient before it).  Against the oracle's aligned parts."""
+    A = _asg()
+    T, B, N, L = 12, 3, 2100, 5
+    tr, x, tg, il, tl = util.synth(T, B, N, L, 21, True)
+    o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il.numpy(), tl.numpy(), "none")
+    xd = x.to(DEV).requires_grad_(True)
+    trd = tr.to(DEV).requires_grad_(True)
+    ali = A.FAC.apply(trd, xd, tg.to(DEV), il, tl)
+    util.assert_close(ali.detach().cpu().numpy(), o["aligned_scores"], 1e-5, "FAC, 2100 labels")
+    (-ali).sum().backward()
+    util.assert_close(xd.grad.cpu().numpy(), o["grad_inputs_aligned"], 1e-4, "gin aligned only, 2100 labels")
+    g = trd.grad.cpu().numpy()
+    assert np.isfinite(g).all()
+    # the aligned part of grad_transition = total - full part: take the full part from FCC alone
+    xd2 = x.to(DEV).requires_grad_(True)
+    trd2 = tr.to(DEV).requires_grad_(True)
+    A.FCC.apply(trd2, xd2, tg.to(DEV), il, tl).sum().backward()
+    util.assert_close(trd2.grad.cpu().numpy() + g, o["grad_transition"], 1e-4, "gtr = full part + aligned part")
+
+
 def test_determinism_and_mode_equality():
     tr, x, tg, il, tl = util.synth(150, 16, 30, 20, 0, True)
     base = run_hip(x, tg, tr, il, tl, "mean")

@@ -3959,7 +3959,9 @@ hipError_t launch_bwd_generic(const Problem &P, const State &W, const BwdArgs &A
                 hipLaunchKernelGGL((fx_to_grad_kernel<R>), dim3((unsigned) ((n2 + 255) / 256)), dim3(256), 0, stream,
                                    (const unsigned long long *) fx, n2, gtr, have_full ? 1 : 0);
             } else {
-                hipLaunchKernelGGL((aligned_tr_scatter_kernel<R>), dim3(1), dim3(1024), 0, stream, P, W, A, gHD, gtr, have_full ? 1 : 0);
+                // (without a full-lattice part before it the gradient starts from zero: a memset, not one workgroup walking N x N elements)
+                if (!have_full) (void) hipMemsetAsync(gtr, 0, (size_t) P.N * P.N * e, stream);
+                hipLaunchKernelGGL((aligned_tr_scatter_kernel<R>), dim3(1), dim3(1024), 0, stream, P, W, A, gHD, gtr, 1);
             }
         } else if (P.N <= 64 && P.S > 64 && P.S <= 1024) {
             dim3 grid(P.B, A.nchunks);
@@ -3996,8 +3998,8 @@ hipError_t launch_bwd_generic(const Problem &P, const State &W, const BwdArgs &A
                 hipLaunchKernelGGL((fx_to_grad_kernel<R>), dim3((unsigned) ((n2 + 255) / 256)), dim3(256), 0, stream,
                                    (const unsigned long long *) fx, n2, gtr, have_full ? 1 : 0);
             } else {
-                hipLaunchKernelGGL((aligned_tr_scatter_kernel<R>), dim3(1), dim3(1024), 0, stream, P, W, A, gHD, gtr,
-                                   have_full ? 1 : 0);
+                if (!have_full) (void) hipMemsetAsync(gtr, 0, (size_t) P.N * P.N * e, stream);
+                hipLaunchKernelGGL((aligned_tr_scatter_kernel<R>), dim3(1), dim3(1024), 0, stream, P, W, A, gHD, gtr, 1);
             }
         }
     }
