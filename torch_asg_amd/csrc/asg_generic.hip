@@ -513,13 +513,14 @@ __global__ void __launch_bounds__(256) fwd_step_tile_kernel(Problem P, StepBuf<R
 // direction pair at N = 10^4).  The LDS-staged VALU body above reaches a fifth of either (LDS operand traffic: one
 // ds_read_b64 + one ds_read_b128 per 8 FMAs).  v_mfma_f32_16x16x4_f32 is exact fp32 (a k-ordered fmaf chain) at the
 // vector peak rate and takes its operands straight from the registers the global loads fill:
-//   workgroup = 16 kStepMB rows of E x 32 utterances, K split over its 4 wavefronts (partial sums meet in LDS)
+//   workgroup = 16 MB rows of E (MB = 2 .. kStepMB row blocks) x 32 utterances, K split over its 4 wavefronts (partial sums meet in LDS)
 //   lane l of a wavefront loads E[row i0 + (l & 15)][k + 8 (l >> 4) .. +7] (two float4; a row's 128 contiguous bytes per
 //   32 k) and V[utterance (l & 15) (+16)][same k]; component c of one of those float4 is the A / B operand of one MFMA:
 //   A[m = l & 15][kk = l >> 4], B[kk = l >> 4][n = l & 15] -- the four k of an instruction are {c, 8+c, 16+c, 24+c}
 //   (+4 for the second float4), the same set on both sides, which is all the contraction needs.
-// grid = (ceil(N / (16 kStepMB)), ceil(B/32), directions).  Tile height decides two things: every workgroup reads the
-// batch's whole vector set (1.3 MB, from L2), and the workgroup count has to divide evenly over 256 compute units.
+// grid = row tiles x slices of K x directions x batch tile groups, one-dimensional and XCD-aware (fwd_step_kernel; the shape is
+// step_plan's and step_slices' choice).  Tile height decides two things: every workgroup reads the batch's whole vector set
+// (1.3 MB at cfg 5, from L2), and the workgroup count has to divide evenly over 256 compute units.
 // Measured at cfg 5 (us per frame, both directions; tools/cfg5_fwd_time.py): 16 rows 356 (1250 workgroups, 3.2 GB of
 // vectors per frame) - 48 rows 213 (418 workgroups = 1.6 per compute unit: half the chip waits for the other half) -
 // 80 rows 151 (250 workgroups, one per compute unit) - 96 rows 161.  The VALU body above: 509 (314 workgroups).
@@ -537,7 +538,7 @@ typedef float V4f __attribute__((ext_vector_type(4)));
 #define ASG_X_STEP_PF_MB4 1
 #endif
 constexpr int kStepMB = 5;                  // 16-row blocks per workgroup, at most: every workgroup reads the batch's whole vector
-                                            // set once (L2 traffic = row tiles x 1.3 MB), so tiles must not be too small.  3 or 4
+                                            // set once (L2 traffic = row tiles x 1.3 MB), so tiles must not be too small.  2 .. 4
                                             // where that fills the device better (step_plan: N = 3000 at B = 64 is 152 workgroups
                                             // of 80 rows on 256 compute units, 252 of 48 rows)
 // The MFMA step's E operand, laid out so that every wavefront load is ONE contiguous kilobyte and a workgroup streams
@@ -730,7 +731,8 @@ __device__ __forceinline__ void step_epilogue(const Problem &P, const StepBuf<fl
 __device__ long long g_step_probe[4096];
 #endif
 // NB batch tiles of 32 utterances per workgroup: every element of the matrix tile read from memory multiplies NB * 32 utterances
-// (B >= 64: the matrix is streamed ONCE per frame and direction instead of once per batch tile).  nbt = batch tiles of the problem.
+// (the matrix is streamed ONCE per frame and direction for both; whether that beats one batch tile per workgroup -- whose siblings share
+// the tile through the L2 -- is step_plan's pricing).  nbt = batch tiles of the problem.
 // NT: the matrix loads are non-temporal (the matrices do not fit the 256 MB memory-side cache and no other workgroup wants the same
 // tile) or take the default policy (they fit and stay there from frame to frame, or sibling workgroups share the tile through the L2).
 // HALF: the batch has at most 16 utterances -- the second half of the 32-utterance tile does not exist, its vector loads and matrix
