@@ -205,8 +205,8 @@ def time_small_config(name, T_, B_, N_, L_, variable, steps, eval_route=False, e
             one_step()
         group = one_step
     else:
-        g = capture_steps(one_step, gsteps)
-        group = g.replay
+        # the public helper: `gsteps` consecutive module(...) + loss.backward() recorded into one hipGraph
+        group = torch_asg_amd.graphed(m, (x, tg, il, tl), steps=gsteps).graph.replay
     for _ in range(3):
         group()
     blocks = timed_blocks(group, steps // gsteps, torch.cuda.synchronize, target_s=0.12)
@@ -449,7 +449,9 @@ def main():
             os.write(real_stdout, (json.dumps({"dry_run": True, "world": world, "gpus": args.gpus, "steps": args.steps,
                                                "warmup": args.warmup, "mode": args.mode, "steps_per_graph": gs,
                                                "global_batch": B * world, "uses_dist": world > 1 or args.force_dist,
-                                               "ranks_joined": joined,
+                                               "ranks_joined": joined, "n_gpus": joined,
+                                               "collective": ("rccl all_reduce(transition.grad), %d rank(s)" % world)
+                                                             if (world > 1 or args.force_dist) else "none (one process)",
                                                "self_launched": os.environ.get("ASG_BENCH_SELF_LAUNCHED") == "1",
                                                "master": os.environ.get("MASTER_ADDR", "127.0.0.1")}) + "\n").encode())
         return
@@ -500,17 +502,20 @@ def main():
             torch.cuda.synchronize()
             sync_grads()                  # the communicator exists (and has run once) before anything is captured
             torch.cuda.synchronize()
+            # torch_asg_amd.graphed IS the captured step (the same helper a user calls): static buffers, the 1/world factor
+            # as the gradient handed to backward, G consecutive steps per hipGraph
             if use_dist and gsteps > 1:
                 try:                     # the all-reduce inside the graph, so that G steps stay one replay
                     # thread_local: RCCL's watchdog thread polls events while this thread captures
-                    graph = capture_steps(one_step, gsteps, after_step=sync_grads, relaxed=True)
+                    graph = torch_asg_amd.graphed(loss_mod, (x, tg, il, tl), steps=gsteps, grad_scale=gscale,
+                                                  after_step=sync_grads, capture_error_mode="thread_local")
                     graph_has_collective = True
                 except Exception as e:
                     sys.stderr.write("[bench] could not capture the all-reduce (%s); one step per graph\n" % (e,))
                     gsteps = 1
                     graph = None
             if graph is None:
-                graph = capture_steps(one_step, gsteps)
+                graph = torch_asg_amd.graphed(loss_mod, (x, tg, il, tl), steps=gsteps, grad_scale=gscale)
         except Exception as e:           # capture unsupported in this environment: fall back, say so
             sys.stderr.write("[bench] hipGraph capture failed (%s); running eager\n" % (e,))
             graph = None
@@ -519,7 +524,7 @@ def main():
 
     def step_group():                    # gsteps steps
         if graph is not None:
-            graph.replay()
+            graph()                      # GraphedStep.__call__: nothing to copy in, one hipGraph replay
             if not graph_has_collective:
                 sync_grads()
         else:
@@ -632,7 +637,7 @@ def main():
                                                             "; global batch %d sharded over %d GPUs, one RCCL "
                                                             "all-reduce of transition.grad per step" % (global_batch, world)),
                        "global_batch": global_batch, "per_gpu_batch": B, "T": T, "N": N, "L": L,
-                       "step_mode": mode if mode != "graph" else "graph (%d consecutive steps per hipGraph replay)" % gsteps,
+                       "step_mode": mode if mode != "graph" else "graph (torch_asg_amd.graphed: %d consecutive steps per hipGraph replay)" % gsteps,
                        "launch_mode": args.launch,
                        "overlap": {"single": "one launch: the four recursions of every utterance (full alpha / beta on two workgroups, both aligned "
                                              "chains on a third) run concurrently on three compute units, gradient assembly inside the "

@@ -6,7 +6,7 @@ import subprocess
 
 import pytest
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.subprocess_only]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 

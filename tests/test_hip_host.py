@@ -232,11 +232,12 @@ def test_input_is_logits_exception_for_infeasible_utterances():
     assert torch.allclose(ga[:5, 1] - gb[:5, 1], sm[:5, 1], atol=1e-5)
 
 
-@pytest.mark.parametrize("shape", [(60, 6, 28, 9), (50, 100, 28, 9), (40, 3, 80, 70), (30, 4, 300, 6)])
+@pytest.mark.parametrize("shape", [(60, 6, 28, 9), (50, 100, 28, 9), (90, 3, 80, 70), (30, 4, 300, 6)])
 @pytest.mark.parametrize("reduction", ["mean", "none"])
-def test_cpp_fast_path_and_python_path_are_the_same_call(shape, reduction):
-    """csrc/binding.cpp does in C++ what HipBackend.loss_forward / loss_backward do in Python: same buffers, same entry
-    points, same arguments -- so the results must be bit-identical on every route (fused step, stand-alone kernels,
+def test_cpp_node_python_function_and_python_path_are_the_same_call(shape, reduction):
+    """csrc/binding.cpp does in C++ what ASGLossFunction + HipBackend.loss_forward / loss_backward do in Python: same
+    buffers, same entry points, same arguments -- so the three host routes (C++ autograd node; Python Function around the
+    C++ calls; Python statements + ctypes) must be bit-identical on every kernel route (fused step, stand-alone kernels,
     long targets, large alphabet)."""
     from torch_asg_amd import asg as A
     be = A.native()
@@ -246,40 +247,110 @@ def test_cpp_fast_path_and_python_path_are_the_same_call(shape, reduction):
     tr, x, tg, il, tl = util.synth(T, B, N, L, 11, True)
     m = _module(N, tr, reduction=reduction)
     tgd, ild, tld = tg.to(DEV), il.to(DEV), tl.to(DEV)
-    calls = {"n": 0}
-    real = be.binding.try_loss_forward
+    calls = {"apply": 0, "fwd": 0}
+    bd = be.binding
 
     class Spy:
         def __getattr__(self, k):
             return getattr(bd, k)
 
-        def try_loss_forward(self, *a):
-            r = real(*a)
-            calls["n"] += r is not None
+        def loss_apply(self, *a):
+            r = bd.loss_apply(*a)
+            calls["apply"] += r is not None
             return r
-    bd = be.binding
-    out = []
-    for use in (True, False):
-        be.binding = Spy() if use else None
+
+        def try_loss_forward(self, *a):
+            r = bd.try_loss_forward(*a)
+            calls["fwd"] += r is not None
+            return r
+    out, names = [], []
+    old_node = A._CPP_NODE
+    for route in ("node", "function", "python"):
+        be.binding = None if route == "python" else Spy()
+        A._CPP_NODE = route == "node"
         try:
             xd = x.to(DEV).requires_grad_(True)
             m.transition.grad = None
             loss = m(xd, tgd, ild, tld)
+            names.append(loss.grad_fn.name())
             g = torch.ones_like(loss) * 0.5
             loss.backward(g)
             torch.cuda.synchronize()
             out.append((loss.detach().clone(), xd.grad.clone(), m.transition.grad.clone()))
         finally:
             be.binding = bd
-    assert calls["n"] == 1, "the C++ path declined a plain call"
+            A._CPP_NODE = old_node
+    assert calls == {"apply": 1, "fwd": 1}, "the C++ path declined a plain call: %s" % calls
+    assert names[0] == "AsgLossBackward" and names[1] == names[2] == "ASGLossFunctionBackward", names
     deterministic = B <= 80 and N <= 64          # stand-alone / generic routes use atomics-free but order-stable sums too
-    for a, b in zip(*out):
-        if deterministic:
-            assert torch.equal(a, b)
-        else:
-            assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+    for other in out[1:]:
+        for a, b in zip(out[0], other):
+            if deterministic:
+                assert torch.equal(a, b)
+            else:
+                assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
     o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il.numpy(), tl.numpy(), reduction)
     assert np.allclose(out[0][0].cpu().numpy(), o["loss"], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("shape", [(60, 6, 28, 9), (50, 100, 28, 9)])
+def test_cpp_node_under_the_autograd_engine(shape):
+    """What the engine may ask of a grad_fn, asked of AsgLossBackward: a second pass through a retained graph (the fused
+    step is recomputed), an error after the buffers were released, only one of the two inputs requiring a gradient, no
+    graph under no_grad, an incoming gradient of another dtype / layout, torch.autograd.grad with allow_unused."""
+    from torch_asg_amd import asg as A
+    be = A.native()
+    if be.binding is None or not A._CPP_NODE:
+        pytest.skip("C++ autograd node not in use")
+    T, B, N, L = shape
+    tr, x, tg, il, tl = util.synth(T, B, N, L, 21, True)
+    o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il.numpy(), tl.numpy(), "none")
+    w = torch.linspace(0.5, 1.5, B, dtype=torch.float64)
+    ow = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il.numpy(), tl.numpy(), "none", grad_out=w.numpy())
+    m = _module(N, tr, reduction="none")
+    tgd, ild, tld = tg.to(DEV), il.to(DEV), tl.to(DEV)
+    xd = x.to(DEV).requires_grad_(True)
+    loss = m(xd, tgd, ild, tld)
+    assert loss.grad_fn.name() == "AsgLossBackward" and loss.requires_grad
+    assert [e[0].name() for e in loss.grad_fn.next_functions] == ["torch::autograd::AccumulateGrad"] * 2
+    # a float64, non-contiguous incoming gradient
+    g64 = torch.stack([w, w], 1).to(DEV)[:, 0]
+    loss.backward(g64, retain_graph=True)
+    util.assert_close(xd.grad.cpu().numpy(), ow["grad_inputs"], 1e-4, "grad_inputs, weighted")
+    util.assert_close(m.transition.grad.cpu().numpy(), ow["grad_transition"], 1e-4, "grad_transition, weighted")
+    xd.grad = None
+    m.transition.grad = None
+    loss.sum().backward()                          # second pass through the retained graph
+    util.assert_close(xd.grad.cpu().numpy(), o["grad_inputs"], 1e-4, "grad_inputs, second pass")
+    util.assert_close(m.transition.grad.cpu().numpy(), o["grad_transition"], 1e-4, "grad_transition, second pass")
+    with pytest.raises(RuntimeError, match="second time|already been freed"):
+        loss.sum().backward()
+    # only the transition matrix requires a gradient
+    x2 = x.to(DEV)
+    m.transition.grad = None
+    l2 = m(x2, tgd, ild, tld)
+    assert l2.grad_fn is not None
+    l2.sum().backward()
+    util.assert_close(m.transition.grad.cpu().numpy(), o["grad_transition"], 1e-4, "grad_transition alone")
+    # only the emissions do
+    m.transition.requires_grad_(False)
+    try:
+        x3 = x.to(DEV).requires_grad_(True)
+        (gx,) = torch.autograd.grad(m(x3, tgd, ild, tld).sum(), [x3])
+        util.assert_close(gx.cpu().numpy(), o["grad_inputs"], 1e-4, "grad_inputs alone")
+        assert m(x2, tgd, ild, tld).grad_fn is None
+    finally:
+        m.transition.requires_grad_(True)
+    with torch.no_grad():
+        l4 = m(xd, tgd, ild, tld)
+    assert l4.grad_fn is None and not l4.requires_grad
+    util.assert_close(l4.cpu().numpy(), o["loss"], 1e-4, "loss under no_grad")
+    # the node sits in a larger graph
+    x5 = x.to(DEV).requires_grad_(True)
+    l5 = (m(x5 * 1.0, tgd, ild, tld) * 2.0).sum()
+    gx, gt = torch.autograd.grad(l5, [x5, m.transition], allow_unused=True)
+    util.assert_close(gx.cpu().numpy(), 2.0 * o["grad_inputs"], 1e-4, "grad_inputs through mul")
+    util.assert_close(gt.cpu().numpy(), 2.0 * o["grad_transition"], 1e-4, "grad_transition through mul")
 
 
 def test_cpp_fast_path_declines_what_python_converts():
@@ -296,4 +367,11 @@ def test_cpp_fast_path_declines_what_python_converts():
     assert be.binding.try_loss_forward(xd, trd, tg.to(DEV), il2, tl.to(DEV), 2, 2) is None          # strided lengths
     assert be.binding.try_loss_forward(xd, trd.double(), tg.to(DEV), None, None, 2, 2) is None      # dtype mismatch
     assert be.binding.try_loss_forward(xd, trd, tg.to(DEV), None, None, 2, 2) is not None
+    # the C++ node declines the same, and what ASGLoss.forward settles before the Function: missing lengths, S > T
+    assert be.binding.loss_apply(xd, trd, tg, il.to(DEV), tl.to(DEV), 2, 2) is None
+    assert be.binding.loss_apply(xd, trd, tg.to(DEV), il2, tl.to(DEV), 2, 2) is None
+    assert be.binding.loss_apply(xd, trd, tg.to(DEV), None, None, 2, 2) is None
+    long_tg = torch.zeros(4, 41, dtype=torch.int64, device=DEV)
+    assert be.binding.loss_apply(xd, trd, long_tg, il.to(DEV), tl.to(DEV), 2, 2) is None
+    assert be.binding.loss_apply(xd, trd, tg.to(DEV), il.to(DEV), tl.to(DEV), 2, 2) is not None
     torch.cuda.synchronize()

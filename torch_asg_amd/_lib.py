@@ -97,7 +97,7 @@ def check(status, what):
 # what the C++ fast path of ASGLossFunction (csrc/binding.cpp) calls, in the order its init() expects
 BINDING_SYMBOLS = ["asg_state_bytes", "asg_scratch_bytes", "asg_loss_fused_scratch_bytes", "asg_loss_fused_sync_bytes",
                    "asg_loss_fused_supported", "asg_stream_capture_id", "asg_hip_strerror", "asg_loss_forward",
-                   "asg_loss_backward", "asg_loss_fused_forward", "asg_loss_fused_backward"]
+                   "asg_loss_backward", "asg_loss_fused_forward", "asg_loss_fused_backward", "asg_cluster_timeouts"]
 BINDING_PATH = os.path.join(_HERE, "_binding.so")
 
 

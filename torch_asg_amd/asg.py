@@ -12,6 +12,7 @@ All numerical work happens in hand-written HIP kernels behind the C ABI of inclu
 CPU tensors are rejected: this package has no CPU fallback by design.
 """
 import ctypes
+import os
 import threading
 
 import torch
@@ -513,6 +514,20 @@ class HipBackend:
         return gtr, gin
 
 
+    def loss_backward_tensors(self, mode, sc_bytes, state_bytes, fs, red, buf0, buf1, grad_loss, inputs, transition, targets,
+                              input_lengths, target_lengths):
+        """Backward of a step whose forward ran in csrc/binding.cpp (AsgLossNode) when what autograd handed back is not the
+        plain case any more (saved-tensor hooks that return CPU or strided tensors): convert, then the same entry points."""
+        dev = transition.device
+        inputs = inputs.to(dev)
+        targets, input_lengths, target_lengths = self.device_args(dev, targets, input_lengths, target_lengths)
+        saved = _Saved("fused" if mode else "split", None, None, None, (sc_bytes, state_bytes, fs))
+        tensors = (buf0.to(dev), buf1.to(dev)) if mode else (buf0.to(dev),)
+        reduction = [k for k, v in self._RED.items() if v == red][0]
+        return self.loss_backward(saved, tensors, grad_loss.to(dev), inputs, targets, transition, input_lengths, target_lengths,
+                                  reduction)
+
+
 class _Saved:
     """Host-side record of one loss_forward call: which route ran, the device buffers it filled, the C problem block."""
     __slots__ = ("mode", "tensors", "problem", "keep", "sizes", "consumed", "rec")
@@ -524,6 +539,9 @@ class _Saved:
 
 
 _backend = None
+# ASG_NO_CPP_NODE=1: keep the autograd node in Python (ASGLossFunction) -- the A/B switch of tools/host_pieces2.py and of
+# tests/test_hip_host.py::test_cpp_node_python_function_and_python_path_are_the_same_call
+_CPP_NODE = os.environ.get("ASG_NO_CPP_NODE", "0") in ("", "0")
 
 
 def native():
@@ -668,6 +686,8 @@ class ASGLossFunction(torch.autograd.Function):
     def backward(ctx, grad_loss):
         inputs, outputs, input_lengths, output_lengths, transition, *tensors = ctx.saved_tensors
         be = native()
+        if inputs.shape[2] > 256:
+            be.check_faults()            # (the forward of THIS step may have been the launch that timed out: its gradients are NaN)
         saved = ctx.saved
         if saved.consumed and saved.mode == "fused":
             # backward through a retained graph a second time: the gradient buffers of the first pass were handed to
@@ -830,6 +850,18 @@ class ASGLoss(nn.Module):
         return ASGLossFunction.apply(inputs, self.transition, *args, 'none', self._flags())
 
     def forward(self, inputs, targets, input_lengths=None, target_lengths=None):
+        if (_CPP_NODE and self.training and input_lengths is not None and target_lengths is not None
+                and self.scale_mode == 'none' and not (self.gpu_no_stream_impl or self.forward_only)):
+            # the plain training step: forward, autograd node and backward in C++ (csrc/binding.cpp: Fast.loss_apply); None =
+            # not the plain case (CPU or strided arguments, S > T, a batch to split, bf16 off the fused route ...), and
+            # the statements below take it
+            red = HipBackend._RED.get(self.reduction)
+            bd = getattr(_backend or native(), "binding", None)
+            if red is not None and bd is not None:
+                loss = bd.loss_apply(inputs, self.transition, targets, input_lengths, target_lengths, red,
+                                     self._LAUNCH_FLAGS[self.launch_mode])
+                if loss is not None:
+                    return loss
         if inputs.dtype == torch.bfloat16 and not self._bf16_direct(inputs, targets):
             inputs = inputs.to(self.transition.dtype)
         targets, input_lengths, target_lengths = self._canonical(inputs, targets, input_lengths, target_lengths)

@@ -177,6 +177,8 @@ inline bool capturing(hipStream_t stream) {
     return st == hipStreamCaptureStatusActive;
 }
 
+__global__ void __launch_bounds__(64) zero_ticket_kernel(unsigned *ticket) { ticket[threadIdx.x] = 0u; }
+
 template <typename R>
 int run_forward(asg_ctx *ctx, const asg_problem *p, void *state, void *full_scores, void *aligned_scores,
                 int mask, bool store, int flags, hipStream_t stream, void *loss = nullptr, int reduction = 0) {
@@ -202,7 +204,11 @@ int run_forward(asg_ctx *ctx, const asg_problem *p, void *state, void *full_scor
         O.counter = W.ticket;
         O.reduction = reduction;
         O.expected = 2 * (int) p->B;
-        hipError_t me = hipMemsetAsync(W.ticket, 0, 256, stream);
+        // (a kernel, not hipMemsetAsync: recorded into a hipGraph, ROCm 7.2 replays that 256-byte memset node with garbage
+        // -- host pointers -- instead of zeros, the count never reached `expected` and a replayed step kept its first loss;
+        // tests/test_hip_graphed.py::test_the_stand_alone_route_and_a_large_alphabet_replay_too)
+        hipLaunchKernelGGL(zero_ticket_kernel, dim3(1), dim3(64), 0, stream, W.ticket);
+        hipError_t me = hipGetLastError();
         if (me != hipSuccess) return hip_status(me);
     }
     if ((flags & ASG_FLAG_ALPHA_SCORES) && store) {

@@ -31,21 +31,31 @@ def shard_batch(inputs, targets, input_lengths=None, target_lengths=None, rank=N
     return inputs[:, lo:hi], targets[lo:hi], il, tl
 
 
+def _unwrap(loss_module):
+    return getattr(loss_module, "module", loss_module) if not hasattr(loss_module, "transition") else loss_module
+
+
 def sharded_asg_loss(loss_module, inputs, targets, input_lengths=None, target_lengths=None,
                      global_batch=None, reduction=None):
     """Loss of this rank's shard, scaled so that summing over ranks gives the global-batch loss.
+
+    Two ways to the same `transition.grad`: call `allreduce_transition_grad` after backward (a SUM: the
+    gradient of the global-batch loss on every rank), or wrap the module in `DistributedDataParallel` and pass the
+    wrapper here -- DDP then all-reduces and AVERAGES, so every rank holds 1/world of it
+    (tests/test_distributed_cpu.py::test_ddp_wrapped_module_averages_what_the_sum_route_adds).
 
     `loss_module` must be an ASGLoss-like module; it is evaluated with reduction 'none' and reduced here:
     'mean' divides by the GLOBAL batch size so local gradients are already correctly scaled and the
     all-reduce of transition.grad is a plain SUM (no post-division, exact for unequal shards too).
     """
-    reduction = reduction or loss_module.reduction
-    old = loss_module.reduction
-    loss_module.reduction = 'none'
+    inner = _unwrap(loss_module)            # DistributedDataParallel(ASGLoss): the settings live on .module, the call goes through the wrapper
+    reduction = reduction or inner.reduction
+    old = inner.reduction
+    inner.reduction = 'none'
     try:
         per_utt = loss_module(inputs, targets, input_lengths, target_lengths)
     finally:
-        loss_module.reduction = old
+        inner.reduction = old
     if reduction == 'none':
         return per_utt
     total = per_utt.sum()
@@ -63,7 +73,7 @@ def allreduce_transition_grad(loss_module, group=None, async_op=False, force=Fal
     """The single collective of the step: all-reduce(SUM) of transition.grad across ranks.
     A one-rank group has nothing to add and is skipped; `force=True` issues the collective anyway (tests that want the
     RCCL call itself to run on a one-GPU box)."""
-    g = loss_module.transition.grad
+    g = _unwrap(loss_module).transition.grad
     if g is None:
         raise RuntimeError("transition.grad is None: call backward() first")
     if not (dist.is_available() and dist.is_initialized()):

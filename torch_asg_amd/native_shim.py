@@ -53,7 +53,11 @@ def _fill_tail(state, tail, like, transition, lengths=None):
     14.5 MB at T=400 B=64 N=40 -- is not copied, only these few kilobytes are.  Returns `state`: what asg.py saves as path_contrib."""
     nstate = state.numel() - tail
     t = state[nstate:]
-    t[:16].view(torch.int64).copy_(torch.tensor([_MAGIC, nstate], dtype=torch.int64), non_blocking=True)
+    # (written on the device: a copy from a pageable host tensor would stall the host behind everything queued on the stream, and
+    # is illegal while the stream is being captured)
+    head = t[:16].view(torch.int64)
+    head[0].fill_(_MAGIC)
+    head[1].fill_(nstate)
     off = 16
     if lengths is not None:
         nl = lengths.numel() * 8
