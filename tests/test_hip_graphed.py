@@ -99,21 +99,33 @@ def test_missing_lengths_and_the_evaluation_route():
     util.assert_close(ev().item(), o["loss"], 1e-4, "evaluation route")
 
 
-def test_the_stand_alone_route_and_a_large_alphabet_replay_too():
-    """B > 80 leaves the fused step (recursion kernels + assembly launches), N > 64 takes the generic kernels: both
-    record and replay; their sums are order-stable but not bit-pinned against the eager call's allocation pattern."""
+@pytest.mark.parametrize("shape,env", [((60, 100, 28, 9), None), ((30, 4, 300, 6), None), ((30, 4, 300, 6), "ASG_NO_CLUSTER"),
+                                       ((40, 6, 100, 8), None), ((90, 3, 28, 70), None), ((24, 3, 1200, 5), None)])
+def test_every_other_route_replays_too(shape, env, monkeypatch):
+    """B > 80 leaves the fused step (recursion kernels + assembly launches), 64 < N <= 256 takes the medium-alphabet kernels, N > 256 the
+    resident-slice kernel (or, ASG_NO_CLUSTER=1 / beyond 1024 labels, a launch per frame), S > 64 the long-target kernels: all of them
+    record and replay, REPEATEDLY -- every region these routes need zeroed is zeroed by a kernel node (a memset node stops writing zeros at
+    the second replay on ROCm 7.2: asg_common.h::zero_async; this test is what found it, through a stand-alone step whose replays kept
+    their first loss).  Their sums are order-stable but not bit-pinned against the eager call's allocation pattern: 1e-4 vs the oracle,
+    1e-6 vs the eager call."""
     A = _asg()
-    for (T, B, N, L) in ((60, 100, 28, 9), (30, 4, 300, 6)):
-        tr, x, tg, il, tl = util.synth(T, B, N, L, 38, True)
-        m = _module(N, tr)
-        step = A.graphed(m, (x.to(DEV), tg.to(DEV), il.to(DEV), tl.to(DEV)))
-        _, x2, tg2, il2, tl2 = util.synth(T, B, N, L, 39, True)
+    if env:
+        util.setenv(monkeypatch, env, "1")
+    T, B, N, L = shape
+    tr, x, tg, il, tl = util.synth(T, B, N, L, 38, True)
+    m = _module(N, tr)
+    step = A.graphed(m, (x.to(DEV), tg.to(DEV), il.to(DEV), tl.to(DEV)))
+    for seed in (39, 40, 41, 42):
+        _, x2, tg2, il2, tl2 = util.synth(T, B, N, L, seed, True)
         loss = step(x2.to(DEV), tg2.to(DEV), il2.to(DEV), tl2.to(DEV))
         torch.cuda.synchronize()
         o = orc.asg_loss(x2.double().numpy(), tg2.numpy(), tr.double().numpy(), il2.numpy(), tl2.numpy(), "mean")
-        util.assert_close(loss.item(), o["loss"], 1e-4, "loss")
-        util.assert_close(step.inputs_grad.cpu().numpy(), o["grad_inputs"], 1e-4, "grad_inputs")
-        util.assert_close(m.transition.grad.cpu().numpy(), o["grad_transition"], 1e-4, "grad_transition")
+        util.assert_close(loss.item(), o["loss"], 1e-4, "loss, replay with seed %d" % seed)
+        util.assert_close(step.inputs_grad.cpu().numpy(), o["grad_inputs"], 1e-4, "grad_inputs, seed %d" % seed)
+        util.assert_close(m.transition.grad.cpu().numpy(), o["grad_transition"], 1e-4, "grad_transition, seed %d" % seed)
+        le, gx, gt = _eager(N, tr, x2, tg2, il2, tl2)
+        assert torch.allclose(loss, le, rtol=1e-6, atol=1e-6)
+        assert torch.allclose(step.inputs_grad, gx, rtol=1e-5, atol=1e-6) and torch.allclose(m.transition.grad, gt, rtol=1e-5, atol=1e-5)
 
 
 def test_make_graphed_callables_takes_the_module():

@@ -3,6 +3,7 @@
 // No torch, no pybind: plain HIP runtime calls only.
 #include "../../include/asg_hip.h"
 #include "asg_kernels.h"
+#include "asg_common.h"
 
 #include <hip/hip_runtime.h>
 #include <new>
@@ -177,8 +178,6 @@ inline bool capturing(hipStream_t stream) {
     return st == hipStreamCaptureStatusActive;
 }
 
-__global__ void __launch_bounds__(64) zero_ticket_kernel(unsigned *ticket) { ticket[threadIdx.x] = 0u; }
-
 template <typename R>
 int run_forward(asg_ctx *ctx, const asg_problem *p, void *state, void *full_scores, void *aligned_scores,
                 int mask, bool store, int flags, hipStream_t stream, void *loss = nullptr, int reduction = 0) {
@@ -204,11 +203,8 @@ int run_forward(asg_ctx *ctx, const asg_problem *p, void *state, void *full_scor
         O.counter = W.ticket;
         O.reduction = reduction;
         O.expected = 2 * (int) p->B;
-        // (a kernel, not hipMemsetAsync: recorded into a hipGraph, ROCm 7.2 replays that 256-byte memset node with garbage
-        // -- host pointers -- instead of zeros, the count never reached `expected` and a replayed step kept its first loss;
-        // tests/test_hip_graphed.py::test_the_stand_alone_route_and_a_large_alphabet_replay_too)
-        hipLaunchKernelGGL(zero_ticket_kernel, dim3(1), dim3(64), 0, stream, W.ticket);
-        hipError_t me = hipGetLastError();
+        // (a kernel, not hipMemsetAsync: asg_common.h::zero_async says why)
+        hipError_t me = zero_async(W.ticket, 256, stream);
         if (me != hipSuccess) return hip_status(me);
     }
     if ((flags & ASG_FLAG_ALPHA_SCORES) && store) {

@@ -17,6 +17,32 @@ namespace asg {
 constexpr int kWave = 64;
 constexpr double kLn2 = 0.6931471805599453;
 
+// ---- zero-fill on a stream ---------------------------------------------------------------------------------
+// Never hipMemsetAsync: a memset node recorded into a hipGraph writes its value at the FIRST replay only -- from the second replay on it
+// writes its own node parameters (word count, a constant, a host pointer) instead -- on ROCm 7.2 / torch 2.10, any size, either API
+// (tools/memset_in_graph_probe.py, profiles/r06_memset_in_graph.txt; found through a replayed stand-alone step that kept its first loss).
+// A kernel node replays as recorded.  `p` 4-byte aligned, `bytes` a multiple of 4.
+static __global__ void __launch_bounds__(256) zero_fill_kernel(unsigned *p, size_t nwords) {
+    size_t head = ((16u - (unsigned) ((uintptr_t) p & 15u)) & 15u) / 4u;      // words up to the first 16-byte boundary
+    if (head > nwords) head = nwords;
+    const size_t tid = (size_t) blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t) gridDim.x * blockDim.x;
+    if (tid < head) p[tid] = 0u;
+    uint4 *q = reinterpret_cast<uint4 *>(p + head);
+    const size_t n16 = (nwords - head) / 4;
+    for (size_t i = tid; i < n16; i += nth) q[i] = make_uint4(0u, 0u, 0u, 0u);
+    const size_t tail0 = head + 4 * n16;
+    if (tid < nwords - tail0) p[tail0 + tid] = 0u;
+}
+static inline hipError_t zero_async(void *p, size_t bytes, hipStream_t stream) {
+    if (bytes == 0) return hipSuccess;
+    const size_t nwords = (bytes + 3) / 4;
+    size_t blocks = (nwords / 4 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned) blocks), dim3(256), 0, stream, (unsigned *) p, nwords);
+    return hipGetLastError();
+}
+
 template <typename R> using V2 = R __attribute__((ext_vector_type(2)));
 template <typename R> using V4 = R __attribute__((ext_vector_type(4)));
 

@@ -3471,7 +3471,7 @@ hipError_t launch_prep_generic(const Problem &P, const State &W, hipStream_t str
         // which nothing uses before the recursion's own set-up kernels run (later on this stream); it is >= 16 B npad bytes
         unsigned long long *keys = (unsigned long long *) W.work;
         if (!keys) return hipErrorInvalidValue;
-        hipError_t me = hipMemsetAsync(keys, 0, (size_t) P.N * sizeof(unsigned long long), stream);      // 0 < key(-inf)
+        hipError_t me = zero_async(keys, (size_t) P.N * sizeof(unsigned long long), stream);      // 0 < key(-inf)
         if (me != hipSuccess) return me;
         hipLaunchKernelGGL((colmax_kernel<R>), dim3((P.N + 63) / 64, (P.N + 255) / 256), dim3(256), 0, stream,
                            (const R *) P.transition, P.ts0, P.ts1, P.N, keys);
@@ -3585,7 +3585,7 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
         const bool want[2] = {(full_mask & kFullAlpha) != 0, (full_mask & kFullBeta) != 0};
         const size_t dirblock = au(2 * (size_t) P.B * W.npad * e) + au(3 * (size_t) P.B * 4) + au((size_t) P.B * 8);
         for (int dir = 0; dir < 2; ++dir)
-            if (want[dir]) (void) hipMemsetAsync(wk + dir * dirblock, 0, dirblock, stream);
+            if (want[dir]) (void) zero_async(wk + dir * dirblock, dirblock, stream);
         (void) bar_area;
         StepBuf<R> Sd[2];
         for (int dir = 0; dir < 2; ++dir) {
@@ -3604,10 +3604,10 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
             if (const size_t pbytes = step_ptile_bytes((int) e, P.B, P.N)) {
                 char *area = (char *) W.work + work_mulog_offset(e, P.T, P.B, W.npad) + au((size_t) P.T * P.B * e);
                 S.ptile = (R *) (area + dir * pbytes);
-                if (want[dir]) (void) hipMemsetAsync(S.ptile, 0, pbytes, stream);       // (pad positions stay zero)
+                if (want[dir]) (void) zero_async(S.ptile, pbytes, stream);       // (pad positions stay zero)
                 const size_t tb = step_ticket_bytes(P.B, P.N), sb = step_partial_bytes(P.B, P.N);
                 S.tickets = (unsigned *) (area + 2 * pbytes + dir * tb);
-                if (want[dir]) (void) hipMemsetAsync(S.tickets, 0, tb, stream);
+                if (want[dir]) (void) zero_async(S.tickets, tb, stream);
                 S.partial = (R *) (area + 2 * pbytes + 2 * tb + dir * sb);
             }
             Sd[dir] = S;
@@ -3691,7 +3691,7 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
                     C.xmax = (unsigned *) (ca + xb);
                     C.flags = (unsigned *) (ca + xb + xmb);
                     C.fault = CF.dev;
-                    (void) hipMemsetAsync(ca, 0, xb + xmb + flb, stream);
+                    (void) zero_async(ca, xb + xmb + flb, stream);
                     hipLaunchKernelGGL((fwd_cluster_kernel<R>), dim3(ncl * C.G), dim3(kClNT), lds, stream, P, Sd[0], Sd[1], C, do_a ? 0 : 1);
                     stepped = true;
                 }
@@ -3842,7 +3842,7 @@ hipError_t launch_bwd_generic(const Problem &P, const State &W, const BwdArgs &A
         // one clear for the flag word and, when the aligned part follows with its fixed-point scatter buffer (64 < N <= 2048), for
         // that buffer too: only the row-offset table lies between them, and it is written later on this stream
         fx_cleared = do_ali && P.N > 64 && P.N <= 2048;
-        (void) hipMemsetAsync(anybad, 0, fx_cleared ? (size_t) ((char *) atiles - (char *) anybad) + (size_t) P.N * P.N * 8 : sizeof(int), stream);
+        (void) zero_async(anybad, fx_cleared ? (size_t) ((char *) atiles - (char *) anybad) + (size_t) P.N * P.N * 8 : sizeof(int), stream);
         const R *emax = (const R *) W.work;
         const R *mulog = (const R *) ((const char *) W.work + work_mulog_offset(e, P.T, P.B, npad));
         // (medium alphabets, fwd_mid_kernel, log the same per-frame normaliser as the streamed step since round 3: one branch)
@@ -3939,7 +3939,7 @@ hipError_t launch_bwd_generic(const Problem &P, const State &W, const BwdArgs &A
     }
     if (do_ali) {
         if (P.S > kMaxTargets) return hipErrorInvalidValue;
-        if (!have_full) (void) hipMemsetAsync(A.grad_inputs, 0, (size_t) P.T * P.B * P.N * e, stream);
+        if (!have_full) (void) zero_async(A.grad_inputs, (size_t) P.T * P.B * P.N * e, stream);
         unsigned long long *nofx = nullptr;
         if (P.S > 1024) {
             // very long targets: frame-by-frame workgroups, label scatter through a fixed-point LDS row of N words; the edge posteriors
@@ -3956,13 +3956,13 @@ hipError_t launch_bwd_generic(const Problem &P, const State &W, const BwdArgs &A
             if (P.N <= 2048) {
                 unsigned long long *fx = (unsigned long long *) atiles;
                 const int64_t n2 = (int64_t) P.N * P.N;
-                if (!fx_cleared) (void) hipMemsetAsync(fx, 0, (size_t) n2 * 8, stream);
+                if (!fx_cleared) (void) zero_async(fx, (size_t) n2 * 8, stream);
                 hipLaunchKernelGGL((aligned_tr_scatter_fx_kernel<R>), dim3(P.B), dim3(256), 0, stream, P, W, A, (const R *) gHD, fx);
                 hipLaunchKernelGGL((fx_to_grad_kernel<R>), dim3((unsigned) ((n2 + 255) / 256)), dim3(256), 0, stream,
                                    (const unsigned long long *) fx, n2, gtr, have_full ? 1 : 0);
             } else {
                 // (without a full-lattice part before it the gradient starts from zero: a memset, not one workgroup walking N x N elements)
-                if (!have_full) (void) hipMemsetAsync(gtr, 0, (size_t) P.N * P.N * e, stream);
+                if (!have_full) (void) zero_async(gtr, (size_t) P.N * P.N * e, stream);
                 hipLaunchKernelGGL((aligned_tr_scatter_kernel<R>), dim3(1), dim3(1024), 0, stream, P, W, A, gHD, gtr, 1);
             }
         } else if (P.N <= 64 && P.S > 64 && P.S <= 1024) {
@@ -3980,7 +3980,7 @@ hipError_t launch_bwd_generic(const Problem &P, const State &W, const BwdArgs &A
             dim3 grid(P.B, A.nchunks);
             unsigned long long *fx = (unsigned long long *) atiles;
             const int64_t n2 = (int64_t) P.N * P.N;
-            if (!fx_cleared) (void) hipMemsetAsync(fx, 0, (size_t) n2 * 8, stream);
+            if (!fx_cleared) (void) zero_async(fx, (size_t) n2 * 8, stream);
             // (S <= 64: the states are the one-wavefront chains' (asg_chains.h), stored in the problem's type)
             if (P.S <= 64) hipLaunchKernelGGL((bwd_aligned_long_kernel<R, 2, 256, R>), grid, dim3(256), 0, stream, P, W, A, (R *) nullptr, 1, fx);
             else if (P.S <= 128) hipLaunchKernelGGL((bwd_aligned_long_kernel<R, 2, 256, AlignedState>), grid, dim3(256), 0, stream, P, W, A, (R *) nullptr, 1, fx);
@@ -3995,12 +3995,12 @@ hipError_t launch_bwd_generic(const Problem &P, const State &W, const BwdArgs &A
             if (P.N > 64 && P.N <= 2048) {
                 unsigned long long *fx = (unsigned long long *) atiles;
                 const int64_t n2 = (int64_t) P.N * P.N;
-                if (!fx_cleared) (void) hipMemsetAsync(fx, 0, (size_t) n2 * 8, stream);
+                if (!fx_cleared) (void) zero_async(fx, (size_t) n2 * 8, stream);
                 hipLaunchKernelGGL((aligned_tr_scatter_fx_kernel<R>), dim3(P.B), dim3(256), 0, stream, P, W, A, (const R *) gHD, fx);
                 hipLaunchKernelGGL((fx_to_grad_kernel<R>), dim3((unsigned) ((n2 + 255) / 256)), dim3(256), 0, stream,
                                    (const unsigned long long *) fx, n2, gtr, have_full ? 1 : 0);
             } else {
-                if (!have_full) (void) hipMemsetAsync(gtr, 0, (size_t) P.N * P.N * e, stream);
+                if (!have_full) (void) zero_async(gtr, (size_t) P.N * P.N * e, stream);
                 hipLaunchKernelGGL((aligned_tr_scatter_kernel<R>), dim3(1), dim3(1024), 0, stream, P, W, A, gHD, gtr, 1);
             }
         }
