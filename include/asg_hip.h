@@ -75,10 +75,14 @@ typedef struct asg_ctx asg_ctx;
 int asg_hip_version(void);
 const char *asg_hip_strerror(int status);
 
-/* Fault report (no reference counterpart): how many launches of the resident-slice forward kernel (256 < N <= 2048 in fp32, <= 1024 in fp64:
- * a grid of co-resident workgroups that wait for each other) of THIS process ran out of their bounded waits -- part of the
- * grid never became resident.  Such a call returns NaN scores; from then on the library takes the per-frame launches (which need
- * no co-residency).  Read from host-pinned memory, no synchronisation; the count of a call is visible once that call has run. */
+/* Fault report (no reference counterpart): how many launches of the resident-slice forward kernel (256 < N <= 2048 in fp32, <= 1024 in
+ * fp64: a grid of co-resident workgroups that wait for each other) of THIS process ran out of their bounded waits -- part of the grid
+ * never became resident.  Such a call is REPAIRED IN STREAM: the launch raises a word in the call's own work area, and a repair kernel
+ * that the same call enqueued behind it redoes the full-lattice recursion with no dependence between workgroups (exact; tens of
+ * milliseconds; a no-op of ~2 us when nothing timed out) before the scores are computed -- the call's results are right, no NaN, no
+ * error at a later call.  From then on the library takes the per-frame launches (no co-residency needed, 2-3x slower): this count is
+ * what tells a caller that the fast route is gone.  Read from host-pinned memory, no synchronisation; the count of a call is visible once
+ * that call has run. */
 unsigned asg_cluster_timeouts(void);
 
 /* Developer / test switches (ASG_FORK_IN_CAPTURE, ASG_PAIR_MIN_B, ASG_BWD_ROWSUM, ASG_NO_CLUSTER, ASG_NO_MID, ASG_NO_TILE_STEP, ASG_STEP_ONE_TILE, ASG_STEP_ROW_BLOCKS, ASG_STEP_FULL_TILE,
@@ -163,8 +167,9 @@ int asg_viterbi(asg_ctx *ctx, const asg_problem *p, void *work, size_t work_byte
  * recursions of all frames are ONE launch whose workgroups wait for each other frame by frame (the transition matrix
  * stays in their registers), sized to the device's compute units.  It therefore wants the device to itself: another
  * kernel that keeps compute units for seconds (a second process running the same route, say) can keep part of the
- * grid from starting, and a wait that runs out (~2^22 polls) makes the affected SCORES NaN -- never a wrong number,
- * never a hang.  ASG_NO_CLUSTER=1 in the environment selects the launch-per-frame kernels instead (2-3x slower,
+ * grid from starting.  A wait that runs out (~2^22 polls) ends the launch early and the repair kernel enqueued behind it by the
+ * same call redoes the recursion without co-residency (asg_cluster_timeouts above): never a wrong number, never a NaN, never
+ * a hang.  ASG_NO_CLUSTER=1 in the environment selects the launch-per-frame kernels from the start (2-3x slower,
  * no co-residency needed). */
 int asg_loss_forward(asg_ctx *ctx, const asg_problem *p, void *state, size_t state_bytes, int reduction,
                      void *loss, void *scores, int flags, void *stream);

@@ -88,51 +88,80 @@ def test_late_workgroups_time_out_into_the_exact_redo_without_hanging():
 
 
 STALL_SCRIPT = r'''
-import sys, time
+import sys, time, warnings
 import numpy as np, torch
 sys.path.insert(0, "tests")
 import util
 import torch_asg_amd
 from torch_asg_amd import _lib
+from oracle import asg_oracle as orc
 assert "stall" in _lib.LIB_PATH
 T, B, N, L = 30, 5, 400, 6
 tr, x, tg, il, tl = util.synth(T, B, N, L, 31, True)
+o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il.numpy(), tl.numpy(), "none")
 m = torch_asg_amd.ASGLoss(N, reduction="none").to("cuda:0")
 with torch.no_grad():
     m.transition.copy_(tr)
 t0 = time.time()
 xd = x.to("cuda:0").requires_grad_(True)
 loss = m(xd, tg.to("cuda:0"), il.to("cuda:0"), tl.to("cuda:0"))
+loss.sum().backward()
 torch.cuda.synchronize()
 dt = time.time() - t0
 assert dt < 30.0, "the waits are bounded: %.1f s" % dt
-assert torch.isnan(loss).all(), "a cluster that cannot complete must poison every score it owns: %s" % loss
-# ... and must not stay silent: the library counts the time-out in host-pinned memory, the next call of this route raises,
-# and the call after that takes the per-frame launches (no co-residency needed) and is right
-assert _lib.lib().asg_cluster_timeouts() >= 1
-try:
-    m(xd, tg.to("cuda:0"), il.to("cuda:0"), tl.to("cuda:0"))
-    raise SystemExit("the time-out was not reported")
-except RuntimeError as e:
-    assert "timed out" in str(e), e
-from oracle import asg_oracle as orc
-o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il.numpy(), tl.numpy(), "none")
+# the launch timed out (workgroup 1 of every cluster never publishes a frame in this build) -- and THIS call is right all the same:
+# the repair kernel behind it on the stream redid the recursion
+assert _lib.lib().asg_cluster_timeouts() >= 1, "the stall variant did not stall"
+assert torch.isfinite(loss).all(), loss
+util.assert_close(loss.detach().cpu().numpy(), o["loss"], 1e-4, "loss of the call whose launch timed out")
+util.assert_close(xd.grad.cpu().numpy(), o["grad_inputs"], 1e-4, "grad_inputs of that call")
+util.assert_close(m.transition.grad.cpu().numpy(), o["grad_transition"], 1e-4, "grad_transition of that call")
+# the next call says that the resident route is gone (a warning, not an error) and takes the per-frame launches
+m.transition.grad = None
 xd = x.to("cuda:0").requires_grad_(True)
-loss = m(xd, tg.to("cuda:0"), il.to("cuda:0"), tl.to("cuda:0"))
+with warnings.catch_warnings(record=True) as w:
+    warnings.simplefilter("always")
+    loss = m(xd, tg.to("cuda:0"), il.to("cuda:0"), tl.to("cuda:0"))
+assert any("timed out" in str(v.message) for v in w), [str(v.message) for v in w]
+n_before = _lib.lib().asg_cluster_timeouts()
 loss.sum().backward()
 torch.cuda.synchronize()
+assert _lib.lib().asg_cluster_timeouts() == n_before, "the resident route was taken again"
 util.assert_close(loss.detach().cpu().numpy(), o["loss"], 1e-4, "loss after the fallback")
 util.assert_close(xd.grad.cpu().numpy(), o["grad_inputs"], 1e-4, "grad_inputs after the fallback")
 util.assert_close(m.transition.grad.cpu().numpy(), o["grad_transition"], 1e-4, "grad_transition after the fallback")
-# small alphabets do not go through that kernel: the same library still answers them
-tr2, x2, tg2, il2, tl2 = util.synth(40, 4, 20, 6, 3, True)
-m2 = torch_asg_amd.ASGLoss(20).to("cuda:0")
-v = m2(x2.to("cuda:0"), tg2.to("cuda:0"), il2.to("cuda:0"), tl2.to("cuda:0"))
-assert torch.isfinite(v)
+# double precision and the evaluation route repair themselves the same way (a fresh process each: the count is per process)
 print("STALL-OK")
 '''
 
+STALL_SCRIPT_F64 = r'''
+import sys
+import numpy as np, torch
+sys.path.insert(0, "tests")
+import util
+import torch_asg_amd
+from torch_asg_amd import _lib
+from oracle import asg_oracle as orc
+T, B, N, L = 24, 20, 300, 5
+tr, x, tg, il, tl = util.synth(T, B, N, L, 32, True, torch.float64)
+o = orc.asg_loss(x.numpy(), tg.numpy(), tr.numpy(), il.numpy(), tl.numpy(), "mean")
+m = torch_asg_amd.ASGLoss(N).double().to("cuda:0")
+with torch.no_grad():
+    m.transition.copy_(tr)
+m.eval()
+with torch.no_grad():
+    ev = m(x.to("cuda:0"), tg.to("cuda:0"), il.to("cuda:0"), tl.to("cuda:0"))
+torch.cuda.synchronize()
+assert _lib.lib().asg_cluster_timeouts() >= 1
+util.assert_close(ev.item(), o["loss"], 1e-9, "evaluation route, fp64, launch timed out")
+print("STALL64-OK")
+'''
 
-def test_a_cluster_that_cannot_complete_returns_nan_is_reported_and_recovers():
-    out = _run(["-c", STALL_SCRIPT], _lib("stall"), 120)
+
+def test_a_cluster_that_cannot_complete_is_repaired_in_the_same_call():
+    """VERDICT r5 item 5: never NaN-then-raise-later.  The call whose resident-slice launch runs out of its waits returns the exact
+    result (fwd_repair_kernel behind it on the stream), the next call warns and takes the launch-per-frame kernels."""
+    out = _run(["-c", STALL_SCRIPT], _lib("stall"), 180)
     assert "STALL-OK" in out, out[-2000:]
+    out = _run(["-c", STALL_SCRIPT_F64], _lib("stall"), 180)
+    assert "STALL64-OK" in out, out[-2000:]

@@ -14,11 +14,11 @@ def reserve(device, nbytes=0):
 
 
 def check_faults():
-    """Raise RuntimeError if a resident-slice forward launch (256 < N <= 2048 in fp32, <= 1024 in fp64) of this process timed out since the last look --
-    the step that contained it returned NaN scores and gradients and must be discarded (the library has already switched to kernels
-    that need no co-residency, so repeating the step is sound).  ASGLoss checks at the start of every forward AND backward call with
-    N > 256; a training loop that wants to know before `optimizer.step()` calls this after its own synchronisation point
-    (`loss.item()`): it reads one host-pinned word, no device synchronisation of its own."""
+    """Number of resident-slice forward launches (256 < N <= 2048 in fp32, <= 1024 in fp64) of this process that timed out since the
+    last look (a RuntimeWarning says so).  Results are NOT affected: the call that contained the launch repaired itself in stream
+    (`fwd_repair_kernel`, exact, tens of milliseconds) before its scores were read, and later calls take kernels that need no
+    co-residency (2-3x slower).  ASGLoss looks at the start of every forward call with N > 256; reads one host-pinned word, no
+    device synchronisation."""
     from .asg import native
     return native().check_faults()
 

@@ -59,15 +59,20 @@ class HipBackend:
         self.binding = _lib.binding(self)        # C++ fast path of ASGLossFunction, or None (csrc/binding.cpp)
 
     def check_faults(self):
-        """Raise if a resident-slice forward launch (256 < N <= 2048 in fp32, <= 1024 in fp64) of this process has timed out since the last look:
-        that call's scores were NaN.  Host-pinned counter, no synchronisation; the library has already switched to the
-        per-frame launches, so the NEXT call is sound."""
+        """How many resident-slice forward launches (256 < N <= 2048 in fp32, <= 1024 in fp64) of this process have run out of
+        their bounded waits since the last look; a RuntimeWarning says so once per look.  Nothing is wrong with the results: the
+        call that contained such a launch repaired itself in stream (fwd_repair_kernel redoes the recursion without
+        co-residency, tens of milliseconds), and the library takes the launch-per-frame kernels from then on (2-3x slower than
+        the resident route) -- the warning is about speed.  Host-pinned counter, no synchronisation."""
         n = int(_lib.lib().asg_cluster_timeouts())
-        if n != self._faults:
+        new = n - self._faults
+        if new:
             self._faults = n
-            raise RuntimeError("torch_asg_amd: a resident-slice forward launch timed out (part of its grid never became resident: "
-                               "another process on the device, a CU-masked stream?); that call returned NaN scores.  The library "
-                               "takes the per-frame launches from now on; repeat the step.")
+            import warnings
+            warnings.warn("torch_asg_amd: %d resident-slice forward launch(es) timed out (part of the grid never became resident: "
+                          "another process on the device, a CU-masked stream?).  The affected call(s) were repaired in stream and "
+                          "are exact; the library takes the launch-per-frame kernels from now on (slower)." % new, RuntimeWarning)
+        return new
 
     def _cu_count(self, idx):
         cus = self._cus.get(idx)
@@ -223,7 +228,7 @@ class HipBackend:
     # -- granular (reference "serial" route) ---------------------------------------------------
     def full_forward(self, inputs, transition, input_lengths, flags=0, tail_bytes=0):
         if inputs.shape[2] > 256:
-            self.check_faults()          # (resident-slice route: a timed-out launch of an earlier call must not stay silent)
+            self.check_faults()          # (resident-slice route: a launch that timed out was repaired in stream; say that the route is gone)
         self._check(inputs, transition, None, input_lengths, None)
         L = _lib.lib()
         with self._guard(inputs.device):
@@ -237,8 +242,6 @@ class HipBackend:
     def full_backward(self, state, grad_out, inputs, transition, input_lengths):
         L = _lib.lib()
         T, B, N = inputs.shape
-        if N > 256:
-            self.check_faults()          # (the forward of THIS step may have been the launch that timed out: its gradients are NaN)
         with self._guard(inputs.device):
             p, keep = self._problem(inputs, transition, None, input_lengths, None)
             g = grad_out.to(inputs.dtype).contiguous()
@@ -278,7 +281,7 @@ class HipBackend:
     # -- fused (reference GPU fast route) --------------------------------------------------------
     def forward(self, inputs, targets, transition, input_lengths, target_lengths, flags=_lib.FLAG_STREAMS, tail_bytes=0):
         if inputs.shape[2] > 256:
-            self.check_faults()          # (resident-slice route: a timed-out launch of an earlier call must not stay silent)
+            self.check_faults()          # (resident-slice route: a launch that timed out was repaired in stream; say that the route is gone)
         self._check(inputs, transition, targets, input_lengths, target_lengths)
         L = _lib.lib()
         B = inputs.shape[1]
@@ -294,7 +297,7 @@ class HipBackend:
 
     def forward_only(self, inputs, targets, transition, input_lengths, target_lengths, flags=_lib.FLAG_STREAMS):
         if inputs.shape[2] > 256:
-            self.check_faults()          # (resident-slice route: a timed-out launch of an earlier call must not stay silent)
+            self.check_faults()          # (resident-slice route: a launch that timed out was repaired in stream; say that the route is gone)
         self._check(inputs, transition, targets, input_lengths, target_lengths)
         L = _lib.lib()
         T, B, N = inputs.shape
@@ -330,8 +333,6 @@ class HipBackend:
                  flags=0):
         L = _lib.lib()
         T, B, N = inputs.shape
-        if N > 256:
-            self.check_faults()          # (the forward of THIS step may have been the launch that timed out: its gradients are NaN)
         with self._guard(inputs.device):
             p, keep = self._problem(inputs, transition, targets, input_lengths, target_lengths)
             g = torch.stack([grad_full.to(inputs.dtype), grad_aligned.to(inputs.dtype)]).contiguous()
@@ -438,7 +439,7 @@ class HipBackend:
         L = _lib.lib()
         T, B, N = inputs.shape
         if N > 256:
-            self.check_faults()          # (resident-slice route: a timed-out launch of an earlier call must not stay silent)
+            self.check_faults()          # (resident-slice route: a launch that timed out was repaired in stream; say that the route is gone)
         red = self._RED[reduction]
         dev = inputs.device
         with self._guard(dev):
@@ -480,8 +481,6 @@ class HipBackend:
         back (they may have travelled through saved-tensor hooks)."""
         L = _lib.lib()
         T, B, N = inputs.shape
-        if N > 256:
-            self.check_faults()          # (the forward of THIS step may have been the launch that timed out: its gradients are NaN)
         dev = inputs.device
         with self._guard(dev):
             p = saved.problem
@@ -658,7 +657,7 @@ class ASGLossFunction(torch.autograd.Function):
         r = None
         bd = getattr(be, "binding", None)
         if inputs.dim() == 3 and inputs.shape[2] > 256:
-            be.check_faults()            # (resident-slice route: a timed-out launch of an earlier call must not stay silent)
+            be.check_faults()            # (resident-slice route: a launch that timed out was repaired in stream; say that the route is gone)
         if bd is not None:
             # the plain case (everything on the device, contiguous lengths) entirely in C++; None = not that case
             r = bd.try_loss_forward(inputs, transition, outputs, input_lengths, output_lengths,
@@ -686,8 +685,6 @@ class ASGLossFunction(torch.autograd.Function):
     def backward(ctx, grad_loss):
         inputs, outputs, input_lengths, output_lengths, transition, *tensors = ctx.saved_tensors
         be = native()
-        if inputs.shape[2] > 256:
-            be.check_faults()            # (the forward of THIS step may have been the launch that timed out: its gradients are NaN)
         saved = ctx.saved
         if saved.consumed and saved.mode == "fused":
             # backward through a retained graph a second time: the gradient buffers of the first pass were handed to

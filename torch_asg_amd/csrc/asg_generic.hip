@@ -187,8 +187,7 @@ __host__ __device__ inline size_t step_ptile_index(int b, int i, int npad) {
 
 // init: alpha at frame 0 / beta at frame len-1.  grid = B, block = 256.
 template <typename R, bool BETA>
-__global__ void __launch_bounds__(256) fwd_init_kernel(Problem P, StepBuf<R> S) {
-    const int b = blockIdx.x;
+__device__ __forceinline__ void fwd_init_body(const Problem &P, const StepBuf<R> &S, int b) {
     const int N = P.N, T = P.T;
     const int len = P.in_len ? gclampi(P.in_len[b], 0, T) : T;
     const R L2E = Num<R>::log2e();
@@ -215,6 +214,8 @@ __global__ void __launch_bounds__(256) fwd_init_kernel(Problem P, StepBuf<R> S) 
     }
     if (threadIdx.x == 0) S.off[b] = (double) em;
 }
+template <typename R, bool BETA>
+__global__ void __launch_bounds__(256) fwd_init_kernel(Problem P, StepBuf<R> S) { fwd_init_body<R, BETA>(P, S, (int) blockIdx.x); }
 
 // One frame of the recursion for all utterances.  grid = (ceil(N/64), ceil(B/32)), block = 256.
 // Thread (r = tid & 63, ug = tid >> 6) owns row i = 64*bx + r and the eight utterances 32*by + 8*ug .. +7, so with
@@ -381,7 +382,7 @@ template <> struct TileOps<float> {
 // NBT = utterance tiles per workgroup (16 NBT utterances share every element of E that is loaded: 2 from N > 512, where the
 // matrix no longer sits in the L2 and B / 16 readers per row cost more than the workgroups they add)
 template <typename R, bool BETA, int NBT>
-__device__ __forceinline__ void fwd_step_tile(const Problem &P, const StepBuf<R> &S, int n) {
+__device__ __forceinline__ void fwd_step_tile(const Problem &P, const StepBuf<R> &S, int n, int tile_x, int tile_y) {
     typedef TileOps<R> Ops;
     typedef typename Ops::Ld Ld;
     typedef typename Ops::Acc Acc;
@@ -391,7 +392,7 @@ __device__ __forceinline__ void fwd_step_tile(const Problem &P, const StepBuf<R>
     const int N = P.N, T = P.T, B = P.B, npad = S.npad;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 15, kq = lane >> 4;
-    const int i0 = blockIdx.x * 16, b0 = blockIdx.y * 16 * NBT;
+    const int i0 = tile_x * 16, b0 = tile_y * 16 * NBT;
     const R *pcur = S.pbuf + (int64_t) (n & 1) * B * npad;
     R *pnext = S.pbuf + (int64_t) ((n + 1) & 1) * B * npad;
     const int KL = ((npad + 15) / 16 + EPL - 1) / EPL * EPL;   // elements per lane group (whole 16-byte loads)
@@ -503,8 +504,40 @@ __device__ __forceinline__ void fwd_step_tile(const Problem &P, const StepBuf<R>
 }
 template <typename R, int NBT>
 __global__ void __launch_bounds__(256) fwd_step_tile_kernel(Problem P, StepBuf<R> Sa, StepBuf<R> Sb, int n, int dir_base) {
-    if ((int) blockIdx.z + dir_base == 0) fwd_step_tile<R, false, NBT>(P, Sa, n);
-    else fwd_step_tile<R, true, NBT>(P, Sb, n);
+    if ((int) blockIdx.z + dir_base == 0) fwd_step_tile<R, false, NBT>(P, Sa, n, (int) blockIdx.x, (int) blockIdx.y);
+    else fwd_step_tile<R, true, NBT>(P, Sb, n, (int) blockIdx.x, (int) blockIdx.y);
+}
+
+// ---- in-stream repair of a resident-slice launch that timed out (round 6) -------------------------------------------------
+// fwd_cluster_kernel's workgroups wait for each other; a wait that runs out used to poison the scores with NaN and the error surfaced at
+// the NEXT call -- after an optimizer may have stepped.  Now the launch that timed out raises a per-call word in its own work area, and
+// this kernel, enqueued behind it on the same stream by the same call, reads that word: zero (every launch but a faulted one) and it
+// returns at once (~2 us per call of a >= 1.8 ms route); non-zero and it REDOES the whole full-lattice recursion of the call with no
+// dependence between workgroups -- one workgroup per 16 utterances and direction, initial state as fwd_init_kernel, then frame after frame
+// the 16 x 16 tile step of the launch-per-frame route (fwd_step_tile: the same arithmetic, states and scale log the gradient pass reads)
+// over all row tiles, agent-scope release / acquire around a barrier between frames.  Slow (tens of milliseconds) and exact; the
+// process-wide count (asg_cluster_timeouts) still makes later calls take the launch-per-frame kernels.
+template <typename R>
+__global__ void __launch_bounds__(256) fwd_repair_kernel(Problem P, StepBuf<R> Sa, StepBuf<R> Sb, const unsigned *callfault, int dir_base) {
+    if (__hip_atomic_load(callfault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
+    const bool beta = (int) blockIdx.y + dir_base != 0;
+    const StepBuf<R> &S = beta ? Sb : Sa;
+    const int by = (int) blockIdx.x, tiles = (P.N + 15) / 16;
+    for (int u = 0; u < 16; ++u) {
+        const int b = by * 16 + u;
+        if (b >= P.B) break;
+        if (beta) fwd_init_body<R, true>(P, S, b);
+        else fwd_init_body<R, false>(P, S, b);
+    }
+    for (int n = 0; n + 1 < P.T; ++n) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        for (int x = 0; x < tiles; ++x) {
+            if (beta) fwd_step_tile<R, true, 1>(P, S, n, x, by);
+            else fwd_step_tile<R, false, 1>(P, S, n, x, by);
+        }
+    }
 }
 
 // ---- the same frame on the matrix cores (fp32 only) ------------------------------------------------------------
@@ -1208,6 +1241,7 @@ struct ClusterArgs {
     unsigned *xmax;     // [ncl][2][G][kClNB]             key(max q) over each workgroup's rows
     unsigned *flags;    // [ncl][G]                       frames published so far (zero on entry)
     unsigned *fault;    // host-mapped word (or nullptr): incremented when a bounded wait runs out (cluster_fault_word)
+    unsigned *callfault;   // device word of THIS call (zero on entry): raised with it -- fwd_repair_kernel, enqueued behind the launch, reads it
     int G, RW, npadL, ncd, cpc, ndirs;
 };
 
@@ -1600,7 +1634,10 @@ __global__ void __launch_bounds__(ClusterThreads<R>::v) fwd_cluster_kernel(Probl
 #endif
     if (sfail && g == 0 && tid < kClNB)
         for (int b = cb0 + tid; b < cb1; b += kClNB) S.off[b] = __builtin_nan("");      // (never hang, never return a wrong number quietly)
-    if (sfail && tid == 0 && C.fault) __hip_atomic_fetch_add(C.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (sfail && tid == 0) {
+        if (C.callfault) __hip_atomic_store(C.callfault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (C.fault) __hip_atomic_fetch_add(C.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // the resident-slice route: 256 < N <= 2048 (fp32) / 1024 (fp64: the batch's vectors, 16 chains x N, have to fit the LDS beside the
@@ -3686,13 +3723,17 @@ hipError_t launch_fwd_generic(const Problem &P, const State &W, const FwdOut &O,
                         resident_ok = false;
                     }
                 }
-                if (resident_ok && few_rounds && ncl * C.G <= cus && xb + xmb + flb <= kClusterBytes) {
+                if (resident_ok && few_rounds && ncl * C.G <= cus && xb + xmb + flb + 256 <= kClusterBytes) {
                     C.xbuf = ca;
                     C.xmax = (unsigned *) (ca + xb);
                     C.flags = (unsigned *) (ca + xb + xmb);
+                    C.callfault = (unsigned *) (ca + xb + xmb + flb);
                     C.fault = CF.dev;
-                    (void) zero_async(ca, xb + xmb + flb, stream);
+                    (void) zero_async(ca, xb + xmb + flb + 256, stream);
                     hipLaunchKernelGGL((fwd_cluster_kernel<R>), dim3(ncl * C.G), dim3(kClNT), lds, stream, P, Sd[0], Sd[1], C, do_a ? 0 : 1);
+                    // ... and, behind it, the repair of THIS call should one of its waits have run out (returns at once otherwise)
+                    hipLaunchKernelGGL((fwd_repair_kernel<R>), dim3((P.B + 15) / 16, C.ndirs), dim3(256), 0, stream, P, Sd[0], Sd[1],
+                                       (const unsigned *) C.callfault, do_a ? 0 : 1);
                     stepped = true;
                 }
             }
