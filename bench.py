@@ -287,7 +287,7 @@ def measure_cfg5(steps, warmup):
     a_alg = 3 * (T5 - 1) * N5 * N5 * w + 2 * T5 * B5 * N5 * w      # alpha, beta and gradient passes over Tr
     ms_per_step = dt / steps * 1e3
     achieved = a_alg_step / (kern_ms * 1e-3) / 1e9
-    traffic5, traffic5_src = committed_traffic(("r05_pmc_cfg5.json", "r04_pmc_cfg5.json", "r03_pmc_cfg5.json", "r02_pmc_cfg5.json"))
+    traffic5, traffic5_src = committed_traffic(("r06_pmc_cfg5.json", "r05_pmc_cfg5.json"))
     del x, tr, m
     torch.cuda.empty_cache()
     return {
@@ -310,18 +310,108 @@ def measure_cfg5(steps, warmup):
     }
 
 
+def csrc_sha16():
+    """Fingerprint of the kernel sources a counter reading belongs to: sha256 over csrc/*.hip|*.h|*.inc and include/asg_hip.h
+    (names and contents, sorted) -- .git does not travel to the GPU box, file contents do."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "torch_asg_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "torch_asg_amd", "csrc", "*.h")) +
+                   glob.glob(os.path.join(ROOT, "torch_asg_amd", "csrc", "*.inc")) + [os.path.join(ROOT, "include", "asg_hip.h")])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def committed_traffic(names, key="dominant_kernel_hbm_bytes_per_launch"):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc needs its own runs:
-    profiles/*_summary.md).  NOT measured in this run: the file is named so that a stale number is detectable."""
+    """HBM bytes per launch of the dominant kernel from a committed PMC collection (profiles/<tag>_pmc_*.json), and where it came from.
+    A file that records the sources it was taken at (`csrc_sha16`) is only used when they are THIS tree's sources: a stale number
+    is returned as None with the reason in the source string, never silently."""
+    here = csrc_sha16()
     for name in names:
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             try:
                 with open(path) as f:
-                    return float(json.load(f)[key]), "profiles/" + name
+                    d = json.load(f)
+                sha, commit = d.get("csrc_sha16"), d.get("commit")
+                tag = "profiles/%s (csrc %s%s)" % (name, sha or "unrecorded", ", commit %s" % commit if commit else "")
+                if sha is not None and sha != here:
+                    return None, tag + " -- STALE: this tree's csrc is %s; re-collect with `python bench.py --pmc-only`" % here
+                return float(d[key]), tag
             except Exception:
                 pass
     return None, None
+
+
+PMC_KERNELS = (("fused_fwd_kernel", "dominant_kernel"), ("fused_bwd_kernel", "backward_kernel"))
+
+
+def collect_pmc_traffic(timeout_s=170):
+    """roofline.traffic measured where it is reported: the two counter passes MI355X_MICROARCH.md prescribes -- `rocprofv3 --pmc FETCH_SIZE`
+    and `rocprofv3 --pmc WRITE_SIZE`, separate runs, --kernel-trace only -- over tools/pmc_probe.py (a 256 MiB device copy for calibration,
+    then 10 eager cfg-3 steps), per launch of the two fused kernels, with the guide's gfx950 correction (FETCH_SIZE x2; the copy of the
+    same run is reported so that the factor can be checked).  Returns the dict that also goes to profiles/<tag>_pmc_cfg3.json, or raises."""
+    import collections
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        raise RuntimeError("rocprofv3 not found")
+    raw = {}
+    cal = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="asg_pmc_", dir="/tmp")
+        try:
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run([rocprof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--",
+                                sys.executable, os.path.join(ROOT, "tools", "pmc_probe.py")], cwd="/tmp", env=env,
+                               stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout_s / 2)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                raise RuntimeError("rocprofv3 --pmc %s failed (exit %d): %s" % (counter, r.returncode, r.stderr.decode()[-300:]))
+            per = collections.defaultdict(list)
+            with open(files[0]) as fh:
+                for row in csv.DictReader(fh):
+                    if row["Counter_Name"] == counter:
+                        per[row["Kernel_Name"]].append(float(row["Counter_Value"]))
+            for key, label in PMC_KERNELS:
+                v = [x for k, vals in per.items() if key in k for x in vals]
+                if not v:
+                    raise RuntimeError("no %s launch in the %s pass" % (key, counter))
+                raw[(label, counter)] = (sum(v) / len(v), len(v))
+            c = [x for k, vals in per.items() if "copyBuffer" in k for x in vals]
+            cal[counter] = max(c) if c else None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    out = {"csrc_sha16": csrc_sha16(), "collected_unix": int(time.time()),
+           "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) -- python tools/pmc_probe.py "
+                     "(10 eager cfg-3 steps; averages per launch); collected by bench.py::collect_pmc_traffic",
+           "note": "FETCH_SIZE doubled (gfx950 counts 128-B requests as 64 B: MI355X_MICROARCH.md, HBM); WRITE_SIZE as read; both in KB",
+           "calibration_copy_256MiB_raw_kb": {"FETCH_SIZE": cal.get("FETCH_SIZE"), "WRITE_SIZE": cal.get("WRITE_SIZE"), "expected": 262144.0}}
+    for _, label in PMC_KERNELS:
+        fr, n = raw[(label, "FETCH_SIZE")]
+        wr, _ = raw[(label, "WRITE_SIZE")]
+        out[label + "_fetch_bytes"] = fr * 2 * 1024
+        out[label + "_write_bytes"] = wr * 1024
+        out[label + "_hbm_bytes_per_launch"] = fr * 2 * 1024 + wr * 1024
+        out[label + "_launches_averaged"] = n
+    a = algorithmic_bytes(T, B, N, L)
+    out["step_hbm_bytes"] = out["dominant_kernel_hbm_bytes_per_launch"] + out["backward_kernel_hbm_bytes_per_launch"]
+    out["algorithmic_bytes_per_step"] = a
+    out["step_traffic_over_algorithmic"] = out["step_hbm_bytes"] / a
+    try:                                   # scratch copy that `gpurun` merges back (tools/collect_profiles.sh files it under profiles/)
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "pmc_cfg3.json"), "w") as fh:
+            json.dump(out, fh, indent=1)
+    except OSError:
+        pass
+    return out
 
 
 def run_cfg5(args, real_stdout):
@@ -406,6 +496,10 @@ def main():
     ap.add_argument("--graph-steps", type=int, default=0, help="steps per captured hipGraph (0 = largest divisor of --steps <= 10)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the `extra` object (the other configurations)")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="do not run the two rocprofv3 counter passes that measure roofline.traffic (N=1 only; ~40 s); the committed "
+                         "collection is used if it belongs to this tree's sources")
+    ap.add_argument("--pmc-only", action="store_true", help="run only those two passes, print their JSON (-> profiles/<tag>_pmc_cfg3.json)")
     ap.add_argument("--force-dist", action="store_true", help="init the process group even with one rank (testing)")
     ap.add_argument("--dry-run", action="store_true",
                     help="parse the arguments and the launcher's environment, print the plan as JSON, touch no GPU (tests)")
@@ -417,6 +511,9 @@ def main():
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
+    if args.pmc_only:
+        os.write(real_stdout, (json.dumps(collect_pmc_traffic(), indent=1) + "\n").encode())
+        return
     if args.config == "cfg5":
         if "--steps" not in sys.argv:
             args.steps = 3
@@ -618,7 +715,17 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         value = global_batch * args.steps / dt
         achieved = a_alg / (kern_ms_med * 1e-3) / 1e9
-        traffic, traffic_source = committed_traffic(("r05_pmc_cfg3.json", "r04_pmc_cfg3.json", "r03_pmc_cfg3.json", "r02_pmc_cfg3.json")) if fused_step else (None, None)
+        traffic, traffic_source, traffic_live, pmc = None, None, False, None
+        if fused_step and world == 1 and not args.no_pmc:
+            try:
+                pmc = collect_pmc_traffic()
+                traffic, traffic_live = pmc["dominant_kernel_hbm_bytes_per_launch"], True
+                traffic_source = ("measured by this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (two passes of tools/pmc_probe.py) "
+                                  "at csrc %s" % pmc["csrc_sha16"])
+            except Exception as e:
+                sys.stderr.write("[bench] counter passes failed (%s: %s); falling back to the committed collection\n" % (type(e).__name__, e))
+        if fused_step and traffic is None:
+            traffic, traffic_source = committed_traffic(("r06_pmc_cfg3.json", "r05_pmc_cfg3.json"))
         out = {
             "metric": "utterances/sec fwd+bwd, T=400 B=64 N=40; achieved HBM GB/s vs roofline",
             "value": value,
@@ -658,7 +765,10 @@ def main():
                        "total_timed_s": sum(blocks)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                         "traffic_measured_in_run": False,
+                         "traffic_measured_in_run": traffic_live,
+                         "traffic_detail": None if pmc is None else {k: pmc[k] for k in (
+                             "dominant_kernel_fetch_bytes", "dominant_kernel_write_bytes", "backward_kernel_hbm_bytes_per_launch",
+                             "step_hbm_bytes", "step_traffic_over_algorithmic", "calibration_copy_256MiB_raw_kb")},
                          "kernel": "fused_fwd_kernel (all four recursions of every utterance AND the gradient assembly in "
                                    "one launch: three workgroups per utterance)"
                                    if fused_step else "asg_forward launches (recursion kernels)",

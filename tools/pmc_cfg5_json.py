@@ -30,6 +30,12 @@ if st:
     out["dominant_kernel_hbm_bytes_per_launch"] = out[st[0]]["hbm_bytes_per_launch"]
 else:
     sys.stderr.write("pmc_cfg5_json: no fwd_step_kernel row in %s/FETCH_SIZE.txt\n" % R)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+try:
+    import bench
+    out["csrc_sha16"] = bench.csrc_sha16()          # the sources this reading belongs to (bench.py::committed_traffic refuses another tree's)
+except Exception as e:
+    sys.stderr.write("pmc_cfg5_json: no source fingerprint (%s)\n" % e)
 json.dump(out, open(os.path.join(R, "pmc_cfg5.json"), "w"), indent=1)
 print(json.dumps(out, indent=1)[:1800])
 sys.exit(0 if st else 1)
