@@ -236,7 +236,7 @@ CFG5 = dict(T=2000, B=32, N=10000, L=60)      # BASELINE.json configs[4]: large 
 
 
 def measure_cfg5(steps, warmup):
-    """The large-alphabet workload on the generic kernels (csrc/asg_generic.hip).  A step is ASGLoss forward + backward
+    """The large-alphabet workload on the generic kernels (csrc/asg_generic_step.hip, asg_generic_grad.hip).  A step is ASGLoss forward + backward
     on one batch (eager: a step is ~0.4 s of GPU time, launch overhead is nothing).
     The reference cannot run this size at all: fully_connected_lattice.cpp:77 allocates a [T-1,B,N,N] tensor = 25.6 TB."""
     import torch_asg_amd

@@ -11,9 +11,9 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["asg_small_f32.hip", "asg_small_f64.hip", "asg_bwd_f32.hip", "asg_bwd_f64.hip", "asg_fused.hip", "asg_generic.hip",
+SOURCES = ["asg_small_f32.hip", "asg_small_f64.hip", "asg_bwd_f32.hip", "asg_bwd_f64.hip", "asg_fused.hip", "asg_generic.hip", "asg_generic_step.hip", "asg_generic_aligned.hip", "asg_generic_grad.hip",
            "asg_viterbi.hip", "asg_api.hip"]
-HEADERS = ["asg_common.h", "asg_kernels.h", "asg_chains.h", "asg_outer.h", "asg_assemble.h", "asg_small_impl.inc", "asg_bwd_impl.inc",
+HEADERS = ["asg_common.h", "asg_kernels.h", "asg_generic_common.h", "asg_chains.h", "asg_outer.h", "asg_assemble.h", "asg_small_impl.inc", "asg_bwd_impl.inc",
            os.path.join("..", "..", "include", "asg_hip.h")]
 OUT = os.path.join(HERE, "libasg_hip.so")
 ARCH = os.environ.get("ASG_HIP_ARCH", "gfx950")
@@ -75,7 +75,7 @@ VARIANTS = {
     "delay": ("asg_fused.hip", ["ASG_X_TEST_DELAY=60000", "ASG_X_CAPSHIFT=7"]),
     # workgroup 1 of every cluster of fwd_cluster_kernel never publishes a frame: its peers' bounded waits must run out
     # (2^16 polls in this build) and poison the scores with NaN -- no hang, no wrong number
-    "stall": ("asg_generic.hip", ["ASG_X_CL_TEST_STALL", "ASG_X_CL_SPINMAX=65536"]),
+    "stall": ("asg_generic_step.hip", ["ASG_X_CL_TEST_STALL", "ASG_X_CL_SPINMAX=65536"]),
 }
 VAR_DIR = os.path.join(HERE, "var_libs")
 
