@@ -375,3 +375,23 @@ def test_cpp_fast_path_declines_what_python_converts():
     assert be.binding.loss_apply(xd, trd, long_tg, il.to(DEV), tl.to(DEV), 2, 2) is None
     assert be.binding.loss_apply(xd, trd, tg.to(DEV), il.to(DEV), tl.to(DEV), 2, 2) is not None
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(60, 6, 28, 9), (50, 100, 28, 9), (30, 4, 300, 6)])
+def test_sixteen_bit_emissions_are_widened_where_no_kernel_reads_them(dtype, shape):
+    """float16 emissions (always) and bfloat16 emissions off the fused training step are widened to the dtype of `transition` inside
+    ASGLoss.forward: the result is the float32 result on the same 16-bit-representable values, and inputs.grad has the emissions' dtype."""
+    T, B, N, L = shape
+    tr, x, tg, il, tl = util.synth(T, B, N, L, 51, True)
+    x16 = x.to(dtype)
+    o = orc.asg_loss(x16.double().numpy(), tg.numpy(), tr.double().numpy(), il.numpy(), tl.numpy(), "mean")
+    m = _module(N, tr)
+    xd = x16.to(DEV).requires_grad_(True)
+    loss = m(xd, tg.to(DEV), il.to(DEV), tl.to(DEV))
+    loss.backward()
+    assert loss.dtype == torch.float32 and xd.grad.dtype == dtype and m.transition.grad.dtype == torch.float32
+    util.assert_close(loss.item(), o["loss"], 1e-4, "loss")
+    util.assert_close(m.transition.grad.cpu().numpy(), o["grad_transition"], 1e-4, "grad_transition")
+    tol = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7          # (the gradient is rounded to the emissions' dtype on the way out)
+    util.assert_close(xd.grad.float().cpu().numpy(), o["grad_inputs"], tol, "grad_inputs")

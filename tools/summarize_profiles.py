@@ -87,6 +87,15 @@ def main():
         summary["step_traffic_over_algorithmic"] = summary["step_hbm_bytes"] / 8221440.0
         lines += ["Step traffic (sum of the kernels of one step) = %.0f bytes = %.2fx the algorithmic 8 221 440 bytes (SURVEY.md 8d)."
                   % (summary["step_hbm_bytes"], summary["step_traffic_over_algorithmic"]), ""]
+        # the sources and the commit this collection belongs to: bench.py::committed_traffic refuses a collection taken at other sources
+        try:
+            sys.path.insert(0, ROOT)
+            import bench
+            summary["csrc_sha16"] = bench.csrc_sha16()
+            import subprocess
+            summary["commit"] = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+        except Exception as e:
+            sys.stderr.write("summarize_profiles: no source fingerprint (%s)\n" % e)
         json.dump(summary, open(os.path.join(prof, "%s_pmc_cfg3.json" % tag), "w"), indent=1)
     open(os.path.join(prof, "%s_summary.md" % tag), "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))

@@ -740,7 +740,8 @@ class ASGLoss(nn.Module):
                    upstream gradient g, not to 0), so for that utterance d loss / d logits differs from what autograd
                    through log_softmax would give by softmax * g (tests/test_hip_host.py pins this).
     bfloat16 `inputs` (with the float32 `transition`): "bf16 in, fp32 accumulate"  -- the fused training step
-    reads them as they are and returns a bfloat16 `inputs.grad`; every other route widens them first.  The loss and
+    reads them as they are and returns a bfloat16 `inputs.grad`; every other route widens them first.  float16 `inputs` are
+    always widened to the dtype of `transition` (and `inputs.grad` comes back as float16 through autograd's cast).  The loss and
     `transition.grad` are float32 and match a float32 run on the same (bf16-representable) values to 1e-4; `inputs.grad`
     is rounded to bfloat16 on store (8 bits of mantissa: 4e-3 relative).
     `gpu_no_stream_impl=True` selects the reference's "serial" route (separate FAC and FCC Functions).
@@ -847,11 +848,16 @@ class ASGLoss(nn.Module):
         return ASGLossFunction.apply(inputs, self.transition, *args, 'none', self._flags())
 
     def forward(self, inputs, targets, input_lengths=None, target_lengths=None):
+        dt = inputs.dtype
+        if dt is torch.float16 or (dt is torch.bfloat16 and not self._bf16_direct(inputs, targets)):
+            # 16-bit emissions the kernels do not read as they are: widened here (autograd casts the gradient back).  bfloat16 on the
+            # fused training step is read directly (_bf16_direct); float16 always widens -- its 5-bit exponent cannot hold log-probabilities
+            # below -65504 ("log zero" masks), so a direct route would buy nothing a caller can rely on
+            inputs = inputs.to(self.transition.dtype)
         if (_CPP_NODE and self.training and input_lengths is not None and target_lengths is not None
                 and self.scale_mode == 'none' and not (self.gpu_no_stream_impl or self.forward_only)):
             # the plain training step: forward, autograd node and backward in C++ (csrc/binding.cpp: Fast.loss_apply); None =
-            # not the plain case (CPU or strided arguments, S > T, a batch to split, bf16 off the fused route ...), and
-            # the statements below take it
+            # not the plain case (CPU or strided arguments, S > T, a batch to split ...), and the statements below take it
             red = HipBackend._RED.get(self.reduction)
             bd = getattr(_backend or native(), "binding", None)
             if red is not None and bd is not None:
@@ -859,8 +865,6 @@ class ASGLoss(nn.Module):
                                      self._LAUNCH_FLAGS[self.launch_mode])
                 if loss is not None:
                     return loss
-        if inputs.dtype == torch.bfloat16 and not self._bf16_direct(inputs, targets):
-            inputs = inputs.to(self.transition.dtype)
         targets, input_lengths, target_lengths = self._canonical(inputs, targets, input_lengths, target_lengths)
         weights = self._utterance_weights(inputs, input_lengths, target_lengths)
         chunk = self._batch_chunk(inputs, targets) if inputs.dim() == 3 else 0
