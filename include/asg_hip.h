@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define ASG_HIP_VERSION 220
+#define ASG_HIP_VERSION 230
 
 #define ASG_DTYPE_F32 0
 #define ASG_DTYPE_F64 1
@@ -173,6 +173,16 @@ int asg_viterbi(asg_ctx *ctx, const asg_problem *p, void *work, size_t work_byte
  * no co-residency needed). */
 int asg_loss_forward(asg_ctx *ctx, const asg_problem *p, void *state, size_t state_bytes, int reduction,
                      void *loss, void *scores, int flags, void *stream);
+
+/* The evaluation route as ONE call: loss = reduce_b(full[b] - aligned[b]) from the beta recursions alone, nothing stored, no gradient
+ * -- asg_forward_only (fast_asg_gpu_forward_only, streamlined_fast_gpu.cpp:24-94) with the `full - aligned` and the reduction of
+ * asg.py:62-64,137-142 folded into the kernels, as asg_loss_forward does for the training route (small alphabets: the last beta
+ * pass to finish reduces; large ones: one small reduction launch).  `scores`: asg_loss_forward_only_scores_bytes(p) bytes of work
+ * space ([2][B] scores + 256 bytes for the arrival ticket).  `state` as for asg_forward_only (scratch of the large-alphabet path;
+ * may be NULL when N <= 64 and S <= 64). */
+size_t asg_loss_forward_only_scores_bytes(const asg_problem *p);
+int asg_loss_forward_only(asg_ctx *ctx, const asg_problem *p, void *state, size_t state_bytes, int reduction,
+                          void *loss, void *scores, size_t scores_bytes, int flags, void *stream);
 
 /* gradients of the reduced loss: grad_loss is [B] (none) or [1]. */
 int asg_loss_backward(asg_ctx *ctx, const asg_problem *p, const void *state, size_t state_bytes, int reduction,

@@ -148,6 +148,25 @@ int main() {
             CK(hipStreamSynchronize(st));
             CK(hipMemcpy(f.data(), dfull, B * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(a.data(), dali, B * 4, hipMemcpyDeviceToHost));
             for (int64_t b = 0; b < B; ++b) worst = fmax(worst, fmax(fabs(f[b] - fs[b]) / mf, fabs(a[b] - as[b]) / ma));
+            // ... and the same route as ONE call with the loss reduced inside the kernels (asg_loss_forward_only), every reduction
+            {
+                asg_problem q = p;
+                const size_t wb = asg_loss_forward_only_scores_bytes(&q);
+                void *dwork; float *dl;
+                CK(hipMalloc(&dwork, wb)); CK(hipMalloc(&dl, B * 4));
+                for (int red = 0; red <= 2; ++red) {
+                    AK(asg_loss_forward_only(ctx, &q, nullptr, 0, red, dl, dwork, wb, flags, st));
+                    CK(hipStreamSynchronize(st));
+                    std::vector<float> lv(B);
+                    CK(hipMemcpy(lv.data(), dl, (red == 0 ? B : 1) * 4, hipMemcpyDeviceToHost));
+                    double want = 0, scale = 1;
+                    for (int64_t b = 0; b < B; ++b) { want += fs[b] - as[b]; scale = fmax(scale, fabs(fs[b] - as[b])); }
+                    if (red == 0) { for (int64_t b = 0; b < B; ++b) worst = fmax(worst, fabs(lv[b] - (fs[b] - as[b])) / scale); }
+                    else worst = fmax(worst, fabs(lv[0] - (red == 2 ? want / B : want)) / fmax(1.0, fabs(red == 2 ? want / B : want)));
+                }
+                if (asg_loss_forward_only(ctx, &q, nullptr, 0, 2, dl, dwork, wb - 1, flags, st) != ASG_ERR_WORKSPACE) { fprintf(stderr, "short work buffer accepted\n"); return 12; }
+                CK(hipFree(dwork)); CK(hipFree(dl));
+            }
         }
         // serial pair of each lattice (fully_connected_forward/backward, force_aligned_forward/backward)
         AK(asg_full_forward(&p, dstate, sb, dfull, 0, st));

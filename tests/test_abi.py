@@ -30,7 +30,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in _declared_symbols():
         assert hasattr(L, name), name
     assert sorted(_lib.SYMBOLS) == _declared_symbols()
-    assert _lib.lib().asg_hip_version() == _lib.ABI_VERSION == 220
+    assert _lib.lib().asg_hip_version() == _lib.ABI_VERSION == 230
 
 
 def test_sizes_and_argument_validation_without_gpu():

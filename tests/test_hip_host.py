@@ -395,3 +395,37 @@ def test_sixteen_bit_emissions_are_widened_where_no_kernel_reads_them(dtype, sha
     util.assert_close(m.transition.grad.cpu().numpy(), o["grad_transition"], 1e-4, "grad_transition")
     tol = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7          # (the gradient is rounded to the emissions' dtype on the way out)
     util.assert_close(xd.grad.float().cpu().numpy(), o["grad_inputs"], tol, "grad_inputs")
+
+
+@pytest.mark.parametrize("shape", [(60, 6, 28, 9), (50, 100, 28, 9), (90, 3, 80, 70), (30, 4, 300, 6), (90, 5, 28, 70)])
+@pytest.mark.parametrize("reduction", ["mean", "sum", "none"])
+def test_evaluation_route_in_one_call_equals_the_python_route(shape, reduction):
+    """module.eval() / forward_only=True: csrc/binding.cpp::Fast.eval_apply runs the beta recursions with `full - aligned` and the
+    reduction inside the kernels (asg_loss_forward_only: one launch on the small path); the Python route (ASGGPUFastForwardOnly +
+    torch's subtraction and reduction) must give the same numbers, and both the oracle's.  No autograd graph either way."""
+    from torch_asg_amd import asg as A
+    be = A.native()
+    if be.binding is None:
+        pytest.skip("torch_asg_amd/_binding.so not built (or ASG_NO_BINDING=1)")
+    T, B, N, L = shape
+    tr, x, tg, il, tl = util.synth(T, B, N, L, 61, True)
+    o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il.numpy(), tl.numpy(), reduction, need_grad=False)
+    outs = []
+    old = A._CPP_NODE
+    for kw, train in ((dict(), False), (dict(forward_only=True), True)):
+        m = _module(N, tr, reduction=reduction, **kw)
+        m.train(train)
+        xd = x.to(DEV).requires_grad_(True)
+        for cpp in (True, False):
+            A._CPP_NODE = cpp
+            try:
+                v = m(xd, tg.to(DEV), il.to(DEV), tl.to(DEV))
+            finally:
+                A._CPP_NODE = old
+            assert not v.requires_grad and v.grad_fn is None
+            outs.append(v.detach().cpu().numpy())
+    for v in outs:
+        util.assert_close(v, o["loss"], 1e-4, "evaluation route vs oracle")
+    for v in outs[1:]:
+        assert np.allclose(v, outs[0], rtol=2e-6, atol=1e-5), "C++ one-call route vs Python route"
+    assert np.array_equal(outs[0], outs[2]), "eval() and forward_only=True are the same call"

@@ -18,8 +18,8 @@ SYMBOLS = ["asg_hip_version", "asg_hip_strerror", "asg_ctx_create", "asg_ctx_des
            "asg_aligned_backward", "asg_forward", "asg_forward_only", "asg_backward", "asg_loss_forward",
            "asg_loss_backward", "asg_viterbi_work_bytes", "asg_viterbi", "asg_loss_fused_supported",
            "asg_loss_fused_scratch_bytes", "asg_loss_fused_sync_bytes", "asg_loss_fused_forward",
-           "asg_loss_fused_backward", "asg_cluster_timeouts", "asg_reload_env"]
-ABI_VERSION = 220        # include/asg_hip.h: ASG_HIP_VERSION this package was written against
+           "asg_loss_fused_backward", "asg_cluster_timeouts", "asg_reload_env", "asg_loss_forward_only", "asg_loss_forward_only_scores_bytes"]
+ABI_VERSION = 230        # include/asg_hip.h: ASG_HIP_VERSION this package was written against
 
 
 class AsgProblem(ctypes.Structure):
@@ -72,6 +72,9 @@ def lib():
     L.asg_backward.argtypes = [vp, pp, vp, sz, vp, vp, vp, sz, vp, vp, ci, vp]
     L.asg_loss_forward.argtypes = [vp, pp, vp, sz, ci, vp, vp, ci, vp]
     L.asg_loss_backward.argtypes = [vp, pp, vp, sz, ci, vp, vp, sz, vp, vp, ci, vp]
+    L.asg_loss_forward_only_scores_bytes.restype = sz
+    L.asg_loss_forward_only_scores_bytes.argtypes = [pp]
+    L.asg_loss_forward_only.argtypes = [vp, pp, vp, sz, ci, vp, vp, sz, ci, vp]
     L.asg_viterbi_work_bytes.restype = sz
     L.asg_viterbi_work_bytes.argtypes = [pp]
     L.asg_viterbi.argtypes = [vp, pp, vp, sz, vp, vp, ci, vp]
@@ -97,7 +100,8 @@ def check(status, what):
 # what the C++ fast path of ASGLossFunction (csrc/binding.cpp) calls, in the order its init() expects
 BINDING_SYMBOLS = ["asg_state_bytes", "asg_scratch_bytes", "asg_loss_fused_scratch_bytes", "asg_loss_fused_sync_bytes",
                    "asg_loss_fused_supported", "asg_stream_capture_id", "asg_hip_strerror", "asg_loss_forward",
-                   "asg_loss_backward", "asg_loss_fused_forward", "asg_loss_fused_backward", "asg_cluster_timeouts"]
+                   "asg_loss_backward", "asg_loss_fused_forward", "asg_loss_fused_backward", "asg_cluster_timeouts",
+                   "asg_loss_forward_only"]
 BINDING_PATH = os.path.join(_HERE, "_binding.so")
 
 

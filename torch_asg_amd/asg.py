@@ -854,7 +854,18 @@ class ASGLoss(nn.Module):
             # fused training step is read directly (_bf16_direct); float16 always widens -- its 5-bit exponent cannot hold log-probabilities
             # below -65504 ("log zero" masks), so a direct route would buy nothing a caller can rely on
             inputs = inputs.to(self.transition.dtype)
-        if (_CPP_NODE and self.training and input_lengths is not None and target_lengths is not None
+        if (_CPP_NODE and input_lengths is not None and target_lengths is not None and self.scale_mode == 'none'
+                and not self.gpu_no_stream_impl and (self.forward_only or not self.training)):
+            # the evaluation route as one C++ call and one launch: beta recursions, `full - aligned` and the reduction inside the
+            # kernels, no autograd graph (asg.py:129-131, 58-68: ASGGPUFastForwardOnly marks its result non-differentiable)
+            red = HipBackend._RED.get(self.reduction)
+            bd = getattr(_backend or native(), "binding", None)
+            if red is not None and bd is not None:
+                loss = bd.eval_apply(inputs, self.transition, targets, input_lengths, target_lengths, red,
+                                     self._LAUNCH_FLAGS[self.launch_mode])
+                if loss is not None:
+                    return loss
+        elif (_CPP_NODE and self.training and input_lengths is not None and target_lengths is not None
                 and self.scale_mode == 'none' and not (self.gpu_no_stream_impl or self.forward_only)):
             # the plain training step: forward, autograd node and backward in C++ (csrc/binding.cpp: Fast.loss_apply); None =
             # not the plain case (CPU or strided arguments, S > T, a batch to split ...), and the statements below take it

@@ -180,7 +180,8 @@ inline bool capturing(hipStream_t stream) {
 
 template <typename R>
 int run_forward(asg_ctx *ctx, const asg_problem *p, void *state, void *full_scores, void *aligned_scores,
-                int mask, bool store, int flags, hipStream_t stream, void *loss = nullptr, int reduction = 0) {
+                int mask, bool store, int flags, hipStream_t stream, void *loss = nullptr, int reduction = 0,
+                unsigned *ticket = nullptr) {
     Problem P = to_problem(p);
     // Two streams (fork / join through ctx) only help when the two lattices' kernels really run side by side.  Recorded into a
     // hipGraph, ROCm 7.2 replays the two branches of the SHORT kernels one after the other with ~12 us per cross-queue edge
@@ -200,11 +201,11 @@ int run_forward(asg_ctx *ctx, const asg_problem *p, void *state, void *full_scor
         // the last beta pass to finish reduces the loss; its arrival ticket is part of THIS call's state buffer
         // and is zeroed on the launch stream ahead of the kernels (a memset node under graph capture)
         O.loss = loss;
-        O.counter = W.ticket;
+        O.counter = ticket ? ticket : W.ticket;           // (the evaluation route has no state buffer: its caller lends 256 bytes)
         O.reduction = reduction;
         O.expected = 2 * (int) p->B;
         // (a kernel, not hipMemsetAsync: asg_common.h::zero_async says why)
-        hipError_t me = zero_async(W.ticket, 256, stream);
+        hipError_t me = zero_async(O.counter, 256, stream);
         if (me != hipSuccess) return hip_status(me);
     }
     if ((flags & ASG_FLAG_ALPHA_SCORES) && store) {
@@ -361,6 +362,11 @@ size_t asg_state_bytes(const asg_problem *p) {
     return make_layout(&q).total;
 }
 
+size_t asg_loss_forward_only_scores_bytes(const asg_problem *p) {
+    if (!p || p->B < 1) return 0;
+    return align_up(2 * (size_t) p->B * (p->dtype == ASG_DTYPE_F64 ? 8 : 4)) + 256;
+}
+
 size_t asg_scratch_bytes(const asg_problem *p) {
     if (!p || p->T < 1 || p->B < 1 || p->N < 1) return 0;
     const int e = p->dtype == ASG_DTYPE_F64 ? 8 : 4;
@@ -496,6 +502,33 @@ int asg_loss_forward(asg_ctx *ctx, const asg_problem *p, void *state, size_t sta
     rc = ASG_DISPATCH(p,
         run_forward<float>(ctx, p, state, full, ali, 15, true, flags, (hipStream_t) stream, loss, reduction),
         run_forward<double>(ctx, p, state, full, ali, 15, true, flags, (hipStream_t) stream, loss, reduction));
+    if (rc || in_kernel) return rc;
+    return hip_status(ASG_DISPATCH(p,
+        launch_loss_reduce<float>(full, ali, (int) p->B, reduction, loss, (hipStream_t) stream),
+        launch_loss_reduce<double>(full, ali, (int) p->B, reduction, loss, (hipStream_t) stream)));
+}
+
+int asg_loss_forward_only(asg_ctx *ctx, const asg_problem *p, void *state, size_t state_bytes, int reduction,
+                          void *loss, void *scores, size_t scores_bytes, int flags, void *stream) {
+    if (reduction < 0 || reduction > 2 || !loss || !scores) return ASG_ERR_INVALID;
+    int rc = check_problem(p, true);
+    if (rc) return rc;
+    const size_t e = p->dtype == ASG_DTYPE_F64 ? 8 : 4;
+    if (scores_bytes < asg_loss_forward_only_scores_bytes(p)) return ASG_ERR_WORKSPACE;
+    const bool in_kernel = small_full(p->N) && small_aligned(p->S);
+    if (!in_kernel) {
+        if (!state) return ASG_ERR_INVALID;
+        if (state_bytes < asg_state_bytes(p)) return ASG_ERR_WORKSPACE;
+    } else {
+        state = nullptr;
+    }
+    char *sc = (char *) scores;
+    void *full = sc, *ali = sc + (size_t) p->B * e;
+    unsigned *ticket = (unsigned *) (sc + align_up(2 * (size_t) p->B * e));
+    flags &= ~ASG_FLAG_ALPHA_SCORES;
+    rc = ASG_DISPATCH(p,
+        run_forward<float>(ctx, p, state, full, ali, kFullBeta | kAlignedBeta, false, flags, (hipStream_t) stream, loss, reduction, ticket),
+        run_forward<double>(ctx, p, state, full, ali, kFullBeta | kAlignedBeta, false, flags, (hipStream_t) stream, loss, reduction, ticket));
     if (rc || in_kernel) return rc;
     return hip_status(ASG_DISPATCH(p,
         launch_loss_reduce<float>(full, ali, (int) p->B, reduction, loss, (hipStream_t) stream),

@@ -20,6 +20,8 @@
 //       the whole step: forward + an AsgLossNode (torch::autograd::Node) attached to the loss.  The node keeps what
 //       backward needs in SavedVariables (saved-tensor hooks see them), runs without the GIL on the engine's thread,
 //       recomputes the fused step when a retained graph is walked a second time.
+//   Fast.eval_apply(same arguments) -> loss | None
+//       the evaluation route (beta recursions, no gradient) as one call: asg_loss_forward_only.
 //   Fast.try_loss_forward / try_loss_backward
 //       the same two calls for the Python ASGLossFunction (kept as the route for whatever loss_apply declines and
 //       for ASG_NO_CPP_NODE=1): tuples in, tuples out.
@@ -54,6 +56,7 @@ struct Api {
     int (*fused_backward)(const asg_problem *, void *, size_t, int, const void *, void *, size_t, void *, void *, int,
                           void *);
     unsigned (*cluster_timeouts)(void);
+    int (*loss_forward_only)(asg_ctx *, const asg_problem *, void *, size_t, int, void *, void *, size_t, int, void *);
 };
 constexpr int kSingleLaunch = ASG_FLAG_SINGLE_LAUNCH, kAlphaScores = ASG_FLAG_ALPHA_SCORES;
 
@@ -100,7 +103,7 @@ void reset() {
 }
 
 Fast(const std::vector<uint64_t> &a, py::handle backend) {
-    TORCH_CHECK(a.size() == 12, "torch_asg_amd._binding.Fast: 12 addresses expected");
+    TORCH_CHECK(a.size() == 13, "torch_asg_amd._binding.Fast: 13 addresses expected");
     size_t i = 0;
     auto next = [&]() { return reinterpret_cast<void *>(a[i++]); };
     api.state_bytes = (fn_bytes) next();
@@ -115,6 +118,7 @@ Fast(const std::vector<uint64_t> &a, py::handle backend) {
     api.fused_forward = (decltype(api.fused_forward)) next();
     api.fused_backward = (decltype(api.fused_backward)) next();
     api.cluster_timeouts = (decltype(api.cluster_timeouts)) next();
+    api.loss_forward_only = (decltype(api.loss_forward_only)) next();
     host = backend;
     faults_seen = api.cluster_timeouts();
 }
@@ -346,6 +350,45 @@ py::object try_loss_backward(const std::tuple<int, int64_t, int64_t, int64_t, in
 py::object loss_apply(const at::Tensor &x, const at::Tensor &tr, const at::Tensor &tg, const c10::optional<at::Tensor> &il,
                       const c10::optional<at::Tensor> &tl, int red, int flags);
 
+// what ASGLoss.forward settles in Python before any native call and these entry points do not: missing lengths (defaults: an allocation +
+// fill), S > T (truncation), batches beyond the 32-bit offsets of the small path (split)
+static bool plain_call(const at::Tensor &x, const at::Tensor &tg, const c10::optional<at::Tensor> &il, const c10::optional<at::Tensor> &tl) {
+    if (!il.has_value() || !tl.has_value() || !il->defined() || !tl->defined()) return false;
+    if (x.dim() != 3 || tg.dim() != 2 || tg.size(1) > x.size(0)) return false;
+    if (x.size(2) <= 64) {
+        const double w = x.scalar_type() == at::kDouble ? 8.0 : 4.0;
+        if ((double) x.size(0) * (double) std::max(x.size(2), tg.size(1)) * w * (double) x.size(1) >= 4294967296.0) return false;
+    }
+    return true;
+}
+
+// The evaluation route (module.eval() or forward_only=True; asg.py:129-131 -> ASGGPUFastForwardOnly, asg.py:58-68): beta recursions
+// only, nothing saved, no autograd graph -- one call, the `full - aligned` and the reduction inside the kernels (asg_loss_forward_only).
+// -> loss | None
+py::object eval_apply(const at::Tensor &x, const at::Tensor &tr, const at::Tensor &tg, const c10::optional<at::Tensor> &il,
+                      const c10::optional<at::Tensor> &tl, int red, int flags) {
+    if (!plain_call(x, tg, il, tl)) return py::none();
+    asg_problem p;
+    if (red < 0 || red > 2 || !problem(p, x, tr, tg, il, tl) || p.inputs_dtype) return py::none();
+    at::AutoGradMode no_grad(false);
+    const at::Device dev = x.device();
+    const int idx = dev.index();
+    check_faults(p.N);
+    void *stream = c10::hip::getCurrentHIPStream(idx).stream();
+    const auto fopt = tr.options().requires_grad(false);
+    const auto bopt = fopt.dtype(at::kByte);
+    at::Tensor loss = red == 0 ? at::empty({p.B}, fopt) : at::empty({}, fopt);
+    const int64_t e = p.dtype == ASG_DTYPE_F64 ? 8 : 4;
+    const int64_t sbytes = (2 * p.B * e + 255) / 256 * 256 + 256;
+    at::Tensor scores = at::empty({sbytes}, bopt), state;
+    if (p.N > 64 || p.S > 64) state = at::empty({std::max<int64_t>(shape_info(p).state_bytes, 256)}, bopt);
+    check(api.loss_forward_only((asg_ctx *) context(idx, stream, dev), &p, state.defined() ? state.data_ptr() : nullptr,
+                                state.defined() ? (size_t) state.numel() : 0, red, loss.data_ptr(), scores.data_ptr(), (size_t) sbytes,
+                                flags & ~kAlphaScores, stream),
+          "asg_loss_forward_only");
+    return py::cast(loss);
+}
+
 };  // struct Fast
 
 // ---- the autograd node --------------------------------------------------------------------------------------------
@@ -413,14 +456,7 @@ struct AsgLossNode : public torch::autograd::Node {
 
 py::object Fast::loss_apply(const at::Tensor &x, const at::Tensor &tr, const at::Tensor &tg, const c10::optional<at::Tensor> &il,
                             const c10::optional<at::Tensor> &tl, int red, int flags) {
-    // what ASGLoss.forward does before the Function in the general case and this call does not: missing lengths get
-    // defaults (an allocation + fill), S > T truncates, batches beyond the 32-bit offsets are split -> not the plain case
-    if (!il.has_value() || !tl.has_value() || !il->defined() || !tl->defined()) return py::none();
-    if (x.dim() != 3 || tg.dim() != 2 || tg.size(1) > x.size(0)) return py::none();
-    if (x.size(2) <= 64) {
-        const double w = x.scalar_type() == at::kDouble ? 8.0 : 4.0;
-        if ((double) x.size(0) * (double) std::max(x.size(2), tg.size(1)) * w * (double) x.size(1) >= 4294967296.0) return py::none();
-    }
+    if (!plain_call(x, tg, il, tl)) return py::none();
     Step r;
     {
         at::AutoGradMode no_grad(false);
@@ -452,6 +488,7 @@ PYBIND11_MODULE(_binding, m) {
         .def(py::init<const std::vector<uint64_t> &, py::handle>())
         .def("reset", &Fast::reset)
         .def("loss_apply", &Fast::loss_apply)
+        .def("eval_apply", &Fast::eval_apply)
         .def("try_loss_forward", &Fast::try_loss_forward)
         .def("try_loss_backward", &Fast::try_loss_backward);
 }
