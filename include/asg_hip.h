@@ -85,7 +85,7 @@ const char *asg_hip_strerror(int status);
  * that call has run. */
 unsigned asg_cluster_timeouts(void);
 
-/* Developer / test switches (ASG_FORK_IN_CAPTURE, ASG_PAIR_MIN_B, ASG_BWD_ROWSUM, ASG_NO_CLUSTER, ASG_NO_MID, ASG_NO_TILE_STEP, ASG_STEP_ONE_TILE, ASG_STEP_ROW_BLOCKS, ASG_STEP_FULL_TILE,
+/* Developer / test switches (ASG_FORK_IN_CAPTURE, ASG_PAIR_MIN_B, ASG_BWD_ROWSUM, ASG_NO_CLUSTER, ASG_NO_MID, ASG_NO_TILE_STEP, ASG_STEP_ONE_TILE, ASG_STEP_ROW_BLOCKS, ASG_STEP_FULL_TILE, ASG_STEP_NO_BF3, ASG_STEP_BF3_MIN_B,
  * ASG_ALIGNED_KERNEL) are read from the environment ONCE, at the first call that needs one -- no getenv on the per-call path.
  * A process that changes them afterwards (the test-suite does) calls this to have them read again.  No reference counterpart. */
 void asg_reload_env(void);

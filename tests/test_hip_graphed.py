@@ -100,7 +100,7 @@ def test_missing_lengths_and_the_evaluation_route():
 
 
 @pytest.mark.parametrize("shape,env", [((60, 100, 28, 9), None), ((30, 4, 300, 6), None), ((30, 4, 300, 6), "ASG_NO_CLUSTER"),
-                                       ((40, 6, 100, 8), None), ((90, 3, 28, 70), None), ((24, 3, 1200, 5), None)])
+                                       ((40, 6, 100, 8), None), ((90, 3, 28, 70), None), ((24, 3, 1200, 5), None), ((12, 70, 1100, 4), None)])
 def test_every_other_route_replays_too(shape, env, monkeypatch):
     """B > 80 leaves the fused step (recursion kernels + assembly launches), 64 < N <= 256 takes the medium-alphabet kernels, N > 256 the
     resident-slice kernel (or, ASG_NO_CLUSTER=1 / beyond 1024 labels, a launch per frame), S > 64 the long-target kernels: all of them

@@ -1336,3 +1336,41 @@ def test_very_long_targets(T, B, N, L, dtype, rtol):
         m.transition.copy_(tr.to(dtype))
         ev = m(x.to(DEV, dtype), tg.to(DEV), torch.as_tensor(il).to(DEV), torch.as_tensor(tl).to(DEV))
     util.assert_close(ev.cpu().numpy(), o["loss"], rtol, "very long targets, evaluation route")
+
+
+@pytest.mark.parametrize("shape", [(10, 70, 1300, 4), (8, 100, 2100, 4), (7, 130, 1100, 3)])
+def test_streaming_step_on_the_bf16_pipe(shape, monkeypatch):
+    """More than 64 utterances over a large alphabet: the per-frame step multiplies on v_mfma_f32_16x16x32_bf16 with every float of the
+    matrix and of the vectors as three bfloat16 planes (fwd_step_bf3: six partial products, fp32 accumulation).  Must be fp32-equivalent:
+    1e-4 against the fp64 oracle like every route, AND within 2e-6 (scaled) of the same step on the exact fp32 matrix instruction
+    (ASG_STEP_NO_BF3=1); 8-nat transitions, variable lengths, an utterance with no alignment, the evaluation route."""
+    A = _asg()
+    T, B, N, L = shape
+    tr, x, tg, il, tl = util.synth(T, B, N, L, 77, True)
+    tr = tr * 8.0
+    il[1], tl[1] = 2, L                              # target longer than the input: no alignment (+inf loss, finite gradients)
+    o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il.numpy(), tl.numpy(), "none")
+    res = {}
+    for name, env in (("bf3", None), ("fp32", "1")):
+        util.setenv(monkeypatch, "ASG_STEP_NO_BF3", env)
+        m = A.ASGLoss(N, reduction="none").to(DEV)
+        with torch.no_grad():
+            m.transition.copy_(tr)
+        xd = x.to(DEV).requires_grad_(True)
+        loss = m(xd, tg.to(DEV), il.to(DEV), tl.to(DEV))
+        fin = torch.isfinite(loss)
+        loss[fin].sum().backward()
+        m.eval()
+        with torch.no_grad():
+            ev = m(xd, tg.to(DEV), il.to(DEV), tl.to(DEV))
+        res[name] = (loss.detach().cpu().numpy(), xd.grad.cpu().numpy(), m.transition.grad.cpu().numpy(), ev.cpu().numpy())
+    assert np.isinf(o["loss"][1]) and np.isinf(res["bf3"][0][1])
+    g = np.isfinite(o["loss"]).astype(np.float64)
+    og = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il.numpy(), tl.numpy(), "none", grad_out=g)
+    for name in ("bf3", "fp32"):
+        util.assert_close(res[name][0], o["loss"], 1e-4, name + " loss")
+        util.assert_close(res[name][3], o["loss"], 1e-4, name + " evaluation route")
+        util.assert_close(res[name][1], og["grad_inputs"], 1e-4, name + " grad_inputs")
+        util.assert_close(res[name][2], og["grad_transition"], 1e-4, name + " grad_transition")
+    for a, b_, what in zip(res["bf3"], res["fp32"], ("loss", "grad_inputs", "grad_transition", "evaluation")):
+        util.assert_close(a, b_, 2e-6, what + ": bf16 pipe vs fp32 matrix instruction")

@@ -49,6 +49,8 @@ const Knobs *read_knobs() {
     k->step_one_tile = env_int("ASG_STEP_ONE_TILE");
     k->step_row_blocks = env_int("ASG_STEP_ROW_BLOCKS");
     k->step_full_tile = env_int("ASG_STEP_FULL_TILE");
+    k->step_no_bf3 = env_int("ASG_STEP_NO_BF3");
+    k->step_bf3_min_b = env_int("ASG_STEP_BF3_MIN_B");
     const char *ak = getenv("ASG_ALIGNED_KERNEL");
     k->aligned_kernel = ak ? ak[0] : 0;
     return k;
@@ -105,7 +107,7 @@ Layout make_layout(const asg_problem *p) {
     if (!small_full(p->N)) {
         L.fhat = off; off = align_up(off + N * L.npad * e);
         L.cmax = off; off = align_up(off + N * e);
-        const size_t tb = step_tile_bytes_generic((int) e, (int) N);
+        const size_t tb = step_tile_bytes_generic((int) e, (int) N, (int) B);
         L.etile = off; off = align_up(off + tb);
         L.ftile = off; off = align_up(off + tb);
     }

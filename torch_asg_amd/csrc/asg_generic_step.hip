@@ -105,6 +105,7 @@ struct StepBuf {
     R *partial;       // fp32 streaming step, K split over several workgroups: [row tile][batch tile][slice][2 MB][256] partial row sums
     unsigned *tickets;   // ... and one arrival counter per (row tile, batch tile), zero at the start of a forward call
     int npad;
+    int bf3;             // fp32 streaming step on the bfloat16 pipe (fwd_step_bf3): etile / ptile hold three bfloat16 planes per float
 };
 
 // The vectors of the fp32 streaming step in operand order: [batch tile of 32][chunk of 32 k][utterance half u][h][lane][4], lane =
@@ -116,6 +117,29 @@ __host__ __device__ inline size_t step_ptile_index(int b, int i, int npad) {
     const size_t nch = ((size_t) npad + 31) / 32;
     const int c = i >> 5, kq = (i >> 3) & 3, h = (i >> 2) & 1, u = (b >> 4) & 1;
     return ((((size_t) (b >> 5) * nch + c) * 2 + u) * 2 + h) * 256 + (size_t) (kq * 16 + (b & 15)) * 4 + (i & 3);
+}
+
+// ... and as three bfloat16 planes (fwd_step_bf3): [batch tile of 32][chunk of 32 k][utterance half u][plane][lane][8], lane = 16 (k sub-range kq)
+// + (utterance & 15), k = 32 chunk + 8 kq + component: the 16 bytes of lane l are the A / B operand of one v_mfma_f32_16x16x32_bf16.
+__host__ __device__ inline size_t step_ptile3_elems(int B, int npad) { return (size_t) ((B + 31) / 32) * ((npad + 31) / 32) * 2 * 3 * 64 * 8; }
+__host__ __device__ inline size_t step_ptile3_index(int b, int i, int npad, int plane) {
+    const size_t nch = ((size_t) npad + 31) / 32;
+    const int c = i >> 5, kq = (i >> 3) & 3, u = (b >> 4) & 1;
+    return (((((size_t) (b >> 5) * nch + c) * 2 + u) * 3 + plane) * 64 + (size_t) (kq * 16 + (b & 15))) * 8 + (i & 7);
+}
+// one float as the exact sum of three bfloat16 (split3x2 for a single value)
+__device__ __forceinline__ void split3(float x, unsigned short &h, unsigned short &m, unsigned short &l) {
+    unsigned a, b, c;
+    split3x2(x, 0.f, a, b, c);
+    h = (unsigned short) (a & 0xffffu); m = (unsigned short) (b & 0xffffu); l = (unsigned short) (c & 0xffffu);
+}
+__device__ __forceinline__ void store_ptile3(float *ptile, size_t frame_elems_offset, int b, int i, int npad, float pv) {
+    unsigned short h, m, l;
+    split3(pv, h, m, l);
+    unsigned short *pp = reinterpret_cast<unsigned short *>(ptile) + frame_elems_offset;
+    pp[step_ptile3_index(b, i, npad, 0)] = h;
+    pp[step_ptile3_index(b, i, npad, 1)] = m;
+    pp[step_ptile3_index(b, i, npad, 2)] = l;
 }
 
 // init: alpha at frame 0 / beta at frame len-1.  grid = B, block = 256.
@@ -140,7 +164,10 @@ __device__ __forceinline__ void fwd_init_body(const Problem &P, const StepBuf<R>
             R q = in[(int64_t) i * P.is2] * L2E - em;          // max over i is exactly 0
             st[i] = BETA ? R(0) : q;
             pb[i] = Num<R>::exp2(q);
-            if (S.ptile) S.ptile[step_ptile_index(b, i, S.npad)] = pb[i];      // (frame 0's buffer; pad positions were zeroed by the launcher)
+            if (S.ptile) {      // (frame 0's buffer; pad positions were zeroed by the launcher)
+                if (S.bf3) store_ptile3((float *) S.ptile, 0, b, i, S.npad, (float) pb[i]);
+                else S.ptile[step_ptile_index(b, i, S.npad)] = pb[i];
+            }
         } else {
             pb[i] = 0;
         }
@@ -536,6 +563,43 @@ __global__ void __launch_bounds__(256) tile_kernel(const float *src, int N, int 
     }
 }
 
+
+// The same operand for the bfloat16 pipe (fwd_step_bf3): every float as three bfloat16 planes (exact: 8 + 8 + 8 significant bits), [row
+// tile][chunk of 32 k][row block m][plane][lane][8 bfloat16], lane l = row (l & 15) of the block, k = 32 chunk + 8 (l >> 4) .. +7 -- the 16
+// bytes of a lane are the A operand of one v_mfma_f32_16x16x32_bf16; 1.5x the bytes of the fp32 tile.
+__host__ __device__ inline size_t step_tile3_units(int N, int mb) {          // 16-byte units
+    const size_t npad = (size_t) (N + 3) / 4 * 4;
+    const size_t tiles = ((size_t) N + 16 * mb - 1) / (16 * mb), chunks = (npad + 31) / 32;
+    return tiles * chunks * mb * 3 * 64;
+}
+__host__ __device__ inline size_t step_tile3_units_max(int N) {
+    const size_t npad = (size_t) (N + 3) / 4 * 4;
+    return (((size_t) N + 15) / 16 + kStepMB) * ((npad + 31) / 32) * 3 * 64;
+}
+__global__ void __launch_bounds__(256) tile3_kernel(const float *src, int N, int npad, int mb, U4v *dst) {
+    const size_t chunks = ((size_t) npad + 31) / 32;
+    const size_t total = step_tile3_units(N, mb) / 3;             // (tile, chunk, m, lane) quadruples: three units each
+    for (size_t idx = (size_t) blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t) gridDim.x * 256) {
+        const int lane = (int) (idx & 63);
+        size_t rest = idx >> 6;
+        const int m = (int) (rest % mb); rest /= mb;
+        const size_t c = rest % chunks, tile = rest / chunks;
+        const size_t row = tile * 16 * mb + 16 * m + (lane & 15), k = 32 * c + 8 * (lane >> 4);
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = (row < (size_t) N && k + q < (size_t) npad) ? src[row * npad + k + q] : 0.f;
+        U4v h, md, l;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned a, b_, c_;
+            split3x2(v[2 * q], v[2 * q + 1], a, b_, c_);
+            h[q] = a; md[q] = b_; l[q] = c_;
+        }
+        U4v *o = dst + (((tile * chunks + c) * mb + m) * 3) * 64 + lane;
+        o[0] = h; o[64] = md; o[128] = l;
+    }
+}
+
 // What the frame's epilogue needs from memory, requested BEFORE the product: thread -> utterance 32 bt + (tid >> 3), rows
 // i0 + 16 (rr2 >> 1) + 2 (tid & 7) + (rr2 & 1).  (Loaded inside the epilogue, the 2 MB emission values of a thread -- each a miss all the
 // way to memory, behind a rarely taken branch hipcc will not load across -- cost the epilogue 7 of its 9 us at cfg 5.)
@@ -672,7 +736,8 @@ __device__ __forceinline__ void step_epilogue(const Problem &P, const StepBuf<fl
         const R pv = Num<R>::exp2(q);
         S.state[((int64_t) b * T + tw) * N + i] = stv;
         pnext[(int64_t) b * npad + i] = pv;
-        S.ptile[(size_t) ((n + 1) & 1) * step_ptile_floats(B, npad) + step_ptile_index(b, i, npad)] = pv;
+        if (S.bf3) store_ptile3(S.ptile, (size_t) ((n + 1) & 1) * step_ptile3_elems(B, npad), b, i, npad, pv);
+        else S.ptile[(size_t) ((n + 1) & 1) * step_ptile_floats(B, npad) + step_ptile_index(b, i, npad)] = pv;
         qkey = fmaxf(qkey, (float) q);
         if (i == 0) {
             S.off[b] += (double) muprev + (double) emw;
@@ -837,6 +902,135 @@ __device__ __forceinline__ void fwd_step_mfma(const Problem &P, const StepBuf<fl
         if (bt0 + j < nbt) step_epilogue<BETA, NB, MB>(P, S, n, red, j, pre[j], row_tile, bt0 + j, nbt, slice, ks);
 }
 
+
+
+// ---- the same frame on the BFLOAT16 matrix pipe at fp32 accuracy (round 6) ---------------------------------------------------------
+// v_mfma_f32_16x16x4_f32 is exact but runs at the vector rate: from 48 utterances up the fp32 step is bound by the issue of its matrix
+// instructions (49 cycles apiece fed from memory), not by the matrix stream.  Every float is the exact sum of three bfloat16 (8 + 8 + 8
+// significant bits); six partial products hh, hm, mh, hl, lh, mm on v_mfma_f32_16x16x32_bf16 (fp32 accumulation; what is dropped is below
+// 2^-24 of the product: the arithmetic of the gradient contraction bwd_gemm_bf3_kernel) do the work of eight fp32 instructions in ~a
+// third of the cycles.  The matrix is split ONCE per call (tile3_kernel: 1.5x the bytes), the frame's vectors are written as planes by the
+// epilogue that produces them -- no conversion instruction sits in the product loop (round 5's bf16x3 step converted the fp32 matrix in
+// registers every frame and lost to its own conversions: tools/experiments/README.md).  Same work split (a quarter of K per wavefront, partial
+// tiles meet in `red`), same accumulator layout, same epilogue as fwd_step_mfma.
+template <bool BETA, int NB, int MB, bool NT>
+__device__ __forceinline__ void fwd_step_bf3(const Problem &P, const StepBuf<float> &S, int n, float (*red)[NB * MB * 8][64], int ks, int nbt,
+                                             int row_tile, int group, int slice) {
+    const int B = P.B, npad = S.npad;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+    const int bt0 = group * NB;
+    StepPre<MB> pre[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) pre[j] = step_prefetch<BETA, MB>(P, S, n, row_tile, bt0 + j);
+    {
+        const size_t nchunks = ((size_t) npad + 31) / 32;
+        const U4v *et = reinterpret_cast<const U4v *>(S.etile) + (size_t) row_tile * nchunks * (MB * 3 * 64);
+        const U4v *pt = reinterpret_cast<const U4v *>(reinterpret_cast<const unsigned short *>(S.ptile) + (size_t) (n & 1) * step_ptile3_elems(B, npad));
+        const int per = ((int) nchunks + ks - 1) / ks, s0 = min(slice * per, (int) nchunks), s1 = min(s0 + per, (int) nchunks);
+        const int cpw = (s1 - s0 + 3) / 4;
+        const int c0 = min(s0 + wave * cpw, s1), c1 = min(c0 + cpw, s1);
+        const V4f zero4 = {0, 0, 0, 0};
+        V4f acc[NB][MB][2];
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int m = 0; m < MB; ++m) { acc[j][m][0] = zero4; acc[j][m][1] = zero4; }
+        struct Stage { BF8 e[MB][3], a[NB][3], b[NB][3]; };
+        __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc((void *) et, 0, (unsigned) (nchunks * (MB * 3 * 64) * 16), 0x00020000);
+        __amdgpu_buffer_rsrc_t rsP[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const bool there = bt0 + j < nbt;
+            rsP[j] = __builtin_amdgcn_make_buffer_rsrc((void *) (pt + (size_t) (there ? bt0 + j : bt0) * nchunks * (2 * 3 * 64)), 0,
+                                                       there ? (unsigned) (nchunks * (2 * 3 * 64) * 16) : 0u, 0x00020000);
+        }
+        const unsigned vlane = (unsigned) lane * 16u;
+        typedef unsigned RawU4 __attribute__((ext_vector_type(4)));
+        auto load = [&](Stage &st, int c) {
+            const unsigned cp = (unsigned) c * (2 * 3 * 1024u), ce = (unsigned) c * (MB * 3 * 1024u);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    st.a[j][pl] = __builtin_bit_cast(BF8, (RawU4) __builtin_amdgcn_raw_buffer_load_b128(rsP[j], vlane, cp + pl * 1024u, 0));
+                    st.b[j][pl] = __builtin_bit_cast(BF8, (RawU4) __builtin_amdgcn_raw_buffer_load_b128(rsP[j], vlane, cp + (3 + pl) * 1024u, 0));
+                }
+#pragma unroll
+                for (int m = 0; m < MB; ++m)
+                    st.e[m][pl] = __builtin_bit_cast(BF8, (RawU4) __builtin_amdgcn_raw_buffer_load_b128(rsE, vlane, ce + (m * 3 + pl) * 1024u, NT ? 2 : 0));
+            }
+        };
+        auto multiply = [&](const Stage &st) {
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    // (smallest terms first)
+#define ASG_BF3_SIX(ACC, V) \
+                    ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(st.e[m][2], V[0], ACC, 0, 0, 0); \
+                    ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(st.e[m][0], V[2], ACC, 0, 0, 0); \
+                    ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(st.e[m][1], V[1], ACC, 0, 0, 0); \
+                    ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(st.e[m][1], V[0], ACC, 0, 0, 0); \
+                    ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(st.e[m][0], V[1], ACC, 0, 0, 0); \
+                    ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(st.e[m][0], V[0], ACC, 0, 0, 0);
+                    ASG_BF3_SIX(acc[j][m][0], st.a[j])
+                    ASG_BF3_SIX(acc[j][m][1], st.b[j])
+#undef ASG_BF3_SIX
+                }
+        };
+        if (c0 < c1) {
+            constexpr int STG = 3;          // two chunks of loads in flight while one is multiplied
+            Stage st[STG];
+#pragma unroll
+            for (int u = 0; u < STG - 1; ++u) {
+                __builtin_amdgcn_sched_barrier(0);
+                load(st[u], min(c0 + u, c1 - 1));
+            }
+            for (int c = c0; c < c1; c += STG) {
+#pragma unroll
+                for (int u = 0; u < STG; ++u) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    load(st[(u + STG - 1) % STG], min(c + u + STG - 1, c1 - 1));
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (c + u < c1) multiply(st[u]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // element (row 16 m + 4 (l >> 4) + q, utterance (l & 15) [+ 16]) of batch tile j's tile sits in register q of lane l: as fwd_step_mfma
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    red[wave][j * (MB * 8) + 8 * m + q][lane] = acc[j][m][0][q];
+                    red[wave][j * (MB * 8) + 8 * m + 4 + q][lane] = acc[j][m][1][q];
+                }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+        if (bt0 + j < nbt) step_epilogue<BETA, NB, MB>(P, S, n, red, j, pre[j], row_tile, bt0 + j, nbt, slice, ks);
+}
+// grid and unit -> (row tile, slice, direction) mapping: fwd_step_kernel's
+template <int NB, int MB>
+__global__ void __launch_bounds__(256) fwd_step_bf3_kernel(Problem P, StepBuf<float> Sa, StepBuf<float> Sb, int n, int dir_base, int ks, int tiles, int groups,
+                                                           int ndirs, int nt) {
+    __shared__ float red[4][NB * MB * 8][64];
+    const int nbt = (P.B + 31) / 32;
+    const int xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
+    const int unit = (within / groups) * 8 + xcd, group = within % groups;
+    if (unit >= tiles * ks * ndirs) return;
+    const int row_tile = unit % tiles, slice = (unit / tiles) % ks, dir = unit / (tiles * ks);
+    if (nt) {
+        if (dir + dir_base == 0) fwd_step_bf3<false, NB, MB, true>(P, Sa, n, red, ks, nbt, row_tile, group, slice);
+        else fwd_step_bf3<true, NB, MB, true>(P, Sb, n, red, ks, nbt, row_tile, group, slice);
+    } else {
+        if (dir + dir_base == 0) fwd_step_bf3<false, NB, MB, false>(P, Sa, n, red, ks, nbt, row_tile, group, slice);
+        else fwd_step_bf3<true, NB, MB, false>(P, Sb, n, red, ks, nbt, row_tile, group, slice);
+    }
+}
 
 // The alpha and beta frames of one step share a launch (they are independent chains): twice the workgroups in flight, half the launches.
 // fp64: blockIdx.z selects the direction.  fp32 (NB = batch tiles of 32 utterances per workgroup, MB = 16-row blocks per workgroup): a
@@ -1689,6 +1883,16 @@ static StepPlan step_plan(int N, int B, int cus) {
     }
     return best;
 }
+// The streaming step on the bfloat16 pipe (fwd_step_bf3): fp32 problems of more than 64 utterances (three batch tiles of 32 or more).  Up to
+// 64 the frame is bound by what a compute unit can load (its matrix tile + the batch tile's vectors), and three planes are 1.5x the bytes
+// of a float: measured T=400, bf3 / fp32 ms per step, B = 48 N = 2048 8.9 / 7.8, B = 64 N = 1500 7.5 / 7.3, N = 3000 14.4 / 14.2, N = 5000
+// 38.0 / 31.4.  From three batch tiles on the matrix instructions take over and the bfloat16 pipe wins: B = 96 N = 3000 17.7 / 20.4,
+// B = 128 N = 2048 12.5 / 13.2, N = 3000 21.7 / 26.0, N = 5000 52.2 / 59.1, B = 192 N = 2500 (T=200) 12.4 / 15.3, B = 256 N = 1500 8.0 / 9.0,
+// N = 3000 19.1 / 29.9 (tools/shape_times.py, ASG_STEP_NO_BF3=1 for the fp32 instruction; profiles/r06_step_bf3_ab.txt).
+// A function of the shape (the buffers are sized by it); ASG_STEP_NO_BF3=1 keeps the fp32 instruction (tests, A/B).
+static bool step_bf3_shape(int elem, int B) { return elem == 4 && StepUsesMfma<float>::v && B > (knobs().step_bf3_min_b > 0 ? knobs().step_bf3_min_b - 1 : 64); }
+static bool step_bf3(int elem, int B) { return step_bf3_shape(elem, B) && !(knobs().step_no_bf3 > 0); }
+
 template <typename R>
 hipError_t launch_prep_generic(const Problem &P, const State &W, hipStream_t stream) {
     hipLaunchKernelGGL((prep_kernel<R, false>), dim3(P.N), dim3(256), 0, stream, (const R *) P.transition, P.ts0, P.ts1,
@@ -1711,21 +1915,30 @@ hipError_t launch_prep_generic(const Problem &P, const State &W, hipStream_t str
     if constexpr (StepUsesMfma<R>::v) {
         if (!W.etile || !W.ftile) return hipErrorInvalidValue;
         const int mb = step_plan(P.N, P.B, device_cus()).mb;
-        hipLaunchKernelGGL(tile_kernel, dim3(4096), dim3(256), 0, stream, (const float *) W.ehat, P.N, W.npad, mb, (float *) W.etile);
-        hipLaunchKernelGGL(tile_kernel, dim3(4096), dim3(256), 0, stream, (const float *) W.fhat, P.N, W.npad, mb, (float *) W.ftile);
+        if (step_bf3((int) sizeof(R), P.B)) {
+            hipLaunchKernelGGL(tile3_kernel, dim3(4096), dim3(256), 0, stream, (const float *) W.ehat, P.N, W.npad, mb, (U4v *) W.etile);
+            hipLaunchKernelGGL(tile3_kernel, dim3(4096), dim3(256), 0, stream, (const float *) W.fhat, P.N, W.npad, mb, (U4v *) W.ftile);
+        } else {
+            hipLaunchKernelGGL(tile_kernel, dim3(4096), dim3(256), 0, stream, (const float *) W.ehat, P.N, W.npad, mb, (float *) W.etile);
+            hipLaunchKernelGGL(tile_kernel, dim3(4096), dim3(256), 0, stream, (const float *) W.fhat, P.N, W.npad, mb, (float *) W.ftile);
+        }
     }
     return hipGetLastError();
 }
 
-size_t step_tile_bytes_generic(int elem, int N) {
-    return (elem == 4 && StepUsesMfma<float>::v) ? step_tile_floats_max(N) * sizeof(float) : 0;
+size_t step_tile_bytes_generic(int elem, int N, int B) {
+    if (!(elem == 4 && StepUsesMfma<float>::v)) return 0;
+    const size_t f32 = step_tile_floats_max(N) * sizeof(float), b3 = step_bf3_shape(elem, B) ? step_tile3_units_max(N) * 16 : 0;
+    return f32 > b3 ? f32 : b3;
 }
 
 // the vectors of the fp32 streaming step a second time, in operand order (step_ptile_index): two frames per direction, behind the
 // normaliser log
 static size_t step_ptile_bytes(int elem, int B, int N) {
     if (!(elem == 4 && StepUsesMfma<float>::v)) return 0;
-    return au(2 * step_ptile_floats(B, (N + 3) / 4 * 4) * sizeof(float));
+    const size_t f32 = au(2 * step_ptile_floats(B, (N + 3) / 4 * 4) * sizeof(float));
+    const size_t b3 = step_bf3_shape(elem, B) ? au(2 * step_ptile3_elems(B, (N + 3) / 4 * 4) * sizeof(unsigned short)) : 0;
+    return f32 > b3 ? f32 : b3;
 }
 // tickets and partial sums of the K slices, sized for any tile height: one ticket per (row tile, batch tile) -- most at 3 row blocks --
 // and 2 MB x 256 floats per slice and tile, row tiles x MB <= N / 16 + kStepMB
@@ -1778,6 +1991,7 @@ hipError_t launch_fwd_full_generic(const Problem &P, const State &W, const FwdOu
             S.etile = (const R *) (beta ? W.ftile : W.etile);
             S.hmax = (const R *) (beta ? W.cmax : W.rmax);
             S.mulog = beta ? nullptr : (R *) ((char *) W.work + work_mulog_offset(e, P.T, P.B, W.npad));
+            S.bf3 = step_bf3((int) e, P.B) ? 1 : 0;
             if (const size_t pbytes = step_ptile_bytes((int) e, P.B, P.N)) {
                 char *area = (char *) W.work + work_mulog_offset(e, P.T, P.B, W.npad) + au((size_t) P.T * P.B * e);
                 S.ptile = (R *) (area + dir * pbytes);
@@ -1916,12 +2130,23 @@ hipError_t launch_fwd_full_generic(const Problem &P, const State &W, const FwdOu
                 // fit the memory-side cache.  T=200, B=32, nt / default, ms per step: N = 4000 8.46 / 7.57, 6000 (288 MB) 13.66 / 13.06,
                 // 7000 (392 MB) 18.20 / 19.26, 8000 21.6 / 23.7, cfg 5 (800 MB) 133.9 / 140.1 us per frame; B = 64 (two groups sharing each
                 // tile through the L2): N = 6000 25.8 / 23.0, 7000 39.4 / 36.4.
-                nt = (groups == 1 && (double) ndirs * P.N * (double) W.npad * 4.0 > 320e6) ? 1 : 0;
+                nt = (groups == 1 && (double) ndirs * P.N * (double) W.npad * (step_bf3((int) e, P.B) ? 6.0 : 4.0) > 320e6) ? 1 : 0;
 #ifdef ASG_DEV_PROBES
                 if (const char *ev = getenv("ASG_STEP_NT")) nt = atoi(ev) ? 1 : 0;
 #endif
             }
-            for (int n = 0; n + 1 < P.T; ++n) {
+            if constexpr (StepUsesMfma<R>::v) {
+                if (step_bf3((int) e, P.B)) {
+                    for (int n = 0; n + 1 < P.T; ++n) {
+#define ASG_BF3_LAUNCH(NB_, MB_) hipLaunchKernelGGL((fwd_step_bf3_kernel<NB_, MB_>), sgrid, dim3(256), 0, stream, P, Sd[0], Sd[1], n, do_a ? 0 : 1, ks, tiles, groups, ndirs, nt)
+                        if (nb == 2) { if (mb == 2) ASG_BF3_LAUNCH(2, 2); else if (mb == 3) ASG_BF3_LAUNCH(2, 3); else if (mb == 4) ASG_BF3_LAUNCH(2, 4); else ASG_BF3_LAUNCH(2, 5); }
+                        else { if (mb == 2) ASG_BF3_LAUNCH(1, 2); else if (mb == 3) ASG_BF3_LAUNCH(1, 3); else if (mb == 4) ASG_BF3_LAUNCH(1, 4); else ASG_BF3_LAUNCH(1, 5); }
+#undef ASG_BF3_LAUNCH
+                    }
+                    stepped = true;
+                }
+            }
+            for (int n = 0; !stepped && n + 1 < P.T; ++n) {
                 if constexpr (StepUsesMfma<R>::v) {
 #define ASG_STEP_LAUNCH(NB_, MB_, HALF_) hipLaunchKernelGGL((fwd_step_kernel<R, NB_, MB_, HALF_>), sgrid, dim3(256), 0, stream, P, Sd[0], Sd[1], n, do_a ? 0 : 1, ks, tiles, groups, ndirs, nt)
                     if (nb == 2) { if (mb == 2) ASG_STEP_LAUNCH(2, 2, false); else if (mb == 3) ASG_STEP_LAUNCH(2, 3, false); else if (mb == 4) ASG_STEP_LAUNCH(2, 4, false); else ASG_STEP_LAUNCH(2, 5, false); }

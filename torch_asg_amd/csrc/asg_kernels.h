@@ -112,7 +112,7 @@ enum ChainBits { kFullAlpha = 1, kFullBeta = 2, kAlignedAlpha = 4, kAlignedBeta 
 // ---- small path: N <= 64, S <= 64, one wavefront per chain -------------------------------
 // Developer / test switches, read from the environment once (asg_api.hip; asg_reload_env() reads them again).  -1 = not set.
 struct Knobs {
-    int fork_in_capture, pair_min_b, bwd_rowsum, no_cluster, no_mid, no_tile_step, step_one_tile, step_row_blocks, step_full_tile;
+    int fork_in_capture, pair_min_b, bwd_rowsum, no_cluster, no_mid, no_tile_step, step_one_tile, step_row_blocks, step_full_tile, step_no_bf3, step_bf3_min_b;
     char aligned_kernel;          // first letter of ASG_ALIGNED_KERNEL, or 0
 };
 const Knobs &knobs();
@@ -149,6 +149,6 @@ unsigned cluster_timeouts();
 size_t bwd_scratch_bytes_small(int elem, int T, int B, int N, int S, int *chunk, int *nchunks);
 size_t bwd_scratch_bytes_generic(int elem, int T, int B, int N, int S);
 size_t fwd_work_bytes_generic(int elem, int T, int B, int N);
-size_t step_tile_bytes_generic(int elem, int N);      // one tiled copy of the normalised transition matrix (0: not used)
+size_t step_tile_bytes_generic(int elem, int N, int B);      // one operand-order copy of the normalised transition matrix (0: not used)
 
 }  // namespace asg
