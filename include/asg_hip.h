@@ -87,7 +87,11 @@ unsigned asg_cluster_timeouts(void);
 
 /* Developer / test switches (ASG_FORK_IN_CAPTURE, ASG_PAIR_MIN_B, ASG_BWD_ROWSUM, ASG_NO_CLUSTER, ASG_NO_MID, ASG_NO_TILE_STEP, ASG_STEP_ONE_TILE, ASG_STEP_ROW_BLOCKS, ASG_STEP_FULL_TILE, ASG_STEP_NO_BF3, ASG_STEP_BF3_MIN_B,
  * ASG_ALIGNED_KERNEL) are read from the environment ONCE, at the first call that needs one -- no getenv on the per-call path.
- * A process that changes them afterwards (the test-suite does) calls this to have them read again.  No reference counterpart. */
+ * A process that changes them afterwards (the test-suite does) calls this to have them read again.  No reference counterpart.
+ * NOT for use while another thread is inside a call of this library: a forward call reads the switches more than once (the layout of
+ * the operand-order matrices is chosen when they are built and again when they are read), and a reload between the two with another
+ * ASG_STEP_* setting would make them disagree.  Each call keeps the previous block of switches alive (readers may still hold it): a few
+ * dozen bytes per reload, never freed. */
 void asg_reload_env(void);
 
 int asg_ctx_create(asg_ctx **out);
