@@ -30,7 +30,7 @@ def _env():
 
 def _bench(extra):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--no-extra",
-                        "--no-cpu-baseline"] + extra, capture_output=True, text=True, timeout=900, env=_env())
+                        "--no-cpu-baseline", "--no-pmc"] + extra, capture_output=True, text=True, timeout=900, env=_env())
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout

@@ -10,7 +10,7 @@ OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- \
-    python "$R/bench.py" --steps 100 --warmup 10 --no-cpu-baseline > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.log"
+    python "$R/bench.py" --steps 100 --warmup 10 --no-cpu-baseline --no-pmc > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.log"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -o p -- \
     python "$R/tools/pmc_probe.py" > "$OUT/pmc_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -o p -- \

@@ -31,7 +31,7 @@ def main():
         for r in csv.DictReader(open(trace)):
             d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
             agg.setdefault(r["Kernel_Name"], []).append(d)
-        lines += ["## `rocprofv3 --kernel-trace --stats -- python bench.py --steps 100 --warmup 10 --no-cpu-baseline`", "",
+        lines += ["## `rocprofv3 --kernel-trace --stats -- python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-pmc`", "",
                   "| kernel | calls | avg us | min us | max us | total ms |", "|---|---|---|---|---|---|"]
         for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
             lines.append("| `%s` | %d | %.2f | %.2f | %.2f | %.3f |" % (k[:110], len(v), sum(v) / len(v), min(v), max(v), sum(v) / 1e3))
