@@ -294,7 +294,7 @@ def measure_cfg5(steps, warmup):
         "workload": "cfg5: T=%d B=%d N=%d L=%d fp32, variable input/target lengths, ASGLoss(reduction=mean) "
                     "forward+backward on the generic (large-alphabet) kernels" % (T5, B5, N5, L5),
         "step_mode": "eager", "steps": steps, "warmup": max(warmup, 1),
-        "ms_per_step": ms_per_step, "utt_s": B5 * steps / dt, "loss": float(loss),
+        "ms_per_step": ms_per_step, "utt_s": B5 * steps / dt, "loss": float(loss.detach()),
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic5, "traffic_source": traffic5_src, "traffic_measured_in_run": False,
                      "kernel": "the full-lattice recursion, one frame of alpha AND beta for the whole batch per step: the "
