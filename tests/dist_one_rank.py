@@ -47,6 +47,24 @@ def main():
             ok[k] = util.tol_ok(v, o[k], 1e-4)[1]
         out["cases"].append({"shape": [T, B, N, L], "reduction": red, "scaled_err": ok,
                              "allreduce_bit_identical": bool(torch.equal(before, m.transition.grad))})
+    # DistributedDataParallel around the module (`transition` is a Parameter, DDP all-reduces its gradient): the C++ autograd
+    # node under DDP's hooks on the real kernels, one rank, nccl -- the averaged gradient of a one-rank group is the gradient
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    T, B, N, L = 150, 16, 30, 20
+    tr, x, tg, il, tl = util.synth(T, B, N, L, 4, True)
+    m = torch_asg_amd.ASGLoss(N, reduction="mean").to(dev)
+    with torch.no_grad():
+        m.transition.copy_(tr)
+    ddp = DDP(m, device_ids=[0])
+    xd = x.to(dev).requires_grad_(True)
+    loss = torch_asg_amd.sharded_asg_loss(ddp, xd, tg.to(dev), il.to(dev), tl.to(dev), global_batch=B)
+    out["ddp_grad_fn"] = loss.grad_fn.name() if loss.grad_fn is not None else None
+    loss.backward()
+    torch.cuda.synchronize()
+    o = orc.asg_loss(x.double().numpy(), tg.numpy(), tr.double().numpy(), il.numpy(), tl.numpy(), "mean")
+    out["ddp_scaled_err"] = {"loss": util.tol_ok(loss.detach().cpu().numpy(), o["loss"], 1e-4)[1],
+                             "grad_inputs": util.tol_ok(xd.grad.cpu().numpy(), o["grad_inputs"], 1e-4)[1],
+                             "grad_transition": util.tol_ok(m.transition.grad.cpu().numpy(), o["grad_transition"], 1e-4)[1]}
     # the collective on a tensor of cfg 5's gradient size (400 MB) too: one rank, so still the identity
     big = torch.randn(10000, 10000, device=dev)
     ref = big.clone()

@@ -65,3 +65,7 @@ def test_hip_backend_under_a_one_rank_nccl_group():
         assert c["allreduce_bit_identical"], c
         assert all(v <= 1e-4 for v in c["scaled_err"].values()), c
     assert d["big_allreduce_bit_identical"]
+    # DistributedDataParallel(ASGLoss) on the real kernels (reduction 'none' inside sharded_asg_loss: the Python Function or the C++ node,
+    # whichever the call takes, under DDP's gradient hooks)
+    assert d["ddp_grad_fn"] is not None
+    assert all(v <= 1e-4 for v in d["ddp_scaled_err"].values()), d["ddp_scaled_err"]
