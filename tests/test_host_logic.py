@@ -150,3 +150,19 @@ def test_fused_route_policy_and_new_options(asg):
         assert be.fused_preferred(p, dev) is want
     m = torch_asg_amd.ASGLoss(5, input_is_logits=True)
     assert m.input_is_logits is True and torch_asg_amd.ASGLoss(5).input_is_logits is False
+
+
+def test_graphed_refuses_what_it_cannot_record():
+    """torch_asg_amd.graphed validates before it touches a device: an ASGLoss module, steps >= 1, a sample that lives on a ROCm device
+    (this package has no CPU implementation of the path: a CPU sample is refused like a CPU tensor is by ASGLoss itself)."""
+    import pytest
+    import torch_asg_amd
+    m = torch_asg_amd.ASGLoss(5)
+    x, tg = torch.randn(4, 2, 5), torch.zeros(2, 3, dtype=torch.int64)
+    with pytest.raises(TypeError, match="ASGLoss"):
+        torch_asg_amd.graphed(torch.nn.Linear(2, 2), (x, tg))
+    with pytest.raises(ValueError, match="steps"):
+        torch_asg_amd.graphed(m, (x, tg), steps=0)
+    with pytest.raises(RuntimeError, match="ROCm device"):
+        torch_asg_amd.graphed(m, (x, tg))
+    assert torch_asg_amd.GraphedStep.replay is torch_asg_amd.GraphedStep.__call__
